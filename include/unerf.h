@@ -1,0 +1,223 @@
+/*
+ * libunerf -- C ABI of the MI355X (gfx950) uncertainty-rendering hot path.
+ *
+ * The reference (AaltoML/uncertainty-nerf-gs) is pure Python and has no FFI of its
+ * own: every number on its hot path is produced by nerfstudio 1.1.0 torch ops,
+ * tiny-cuda-nn and gsplat 0.1.11 CUDA kernels that it *calls*.  Each entry point
+ * below therefore replaces a call site of the reference (cited per function,
+ * paths relative to /root/reference/nerfuncertainty) and is what a maintainer
+ * would bind from the reference's Model/Field classes (INTEGRATION.md shows the
+ * ctypes stubs).
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer unless it says "host";
+ *     the library never allocates, frees or retains caller memory
+ *     (exception: unerf_splat_sort_workspace_bytes + caller-provided workspace);
+ *   - `stream` is the caller's hipStream_t (NULL = default stream); no hidden sync;
+ *   - all functions return 0 on success, <0 on error; unerf_last_error() gives
+ *     a thread-local message;
+ *   - fp32 everywhere; row-major; rays are in image row-major order;
+ *   - there is NO CPU implementation behind these symbols.
+ */
+#ifndef UNERF_H
+#define UNERF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNERF_OK 0
+#define UNERF_ERR_ARG -1     /* bad argument / unsupported shape */
+#define UNERF_ERR_HIP -2     /* HIP runtime error (launch, no device) */
+
+const char* unerf_last_error(void);
+/* Library/ABI version (major*1000+minor). */
+int unerf_version(void);
+/* Number of visible HIP devices (<=0: none -> every other call fails with UNERF_ERR_HIP). */
+int unerf_device_count(void);
+
+/* ------------------------------------------------------------------ rays --
+ * Replaces Cameras.generate_rays(camera_indices=0, keep_shape=True) + row-major
+ * slicing used by get_outputs_for_camera (scripts/eval_uncertainty.py:1097,1127;
+ * models/laplace/laplace_model.py:269-297, 403-415).
+ * c2w: HOST pointer to 12 floats (3x4 row-major).  Rays [ray_start, ray_start+count)
+ * of the H*W row-major image.  pixel_area may be NULL. */
+int unerf_generate_rays(const float* c2w_host, float fx, float fy, float cx, float cy, int H, int W,
+                        int64_t ray_start, int64_t count, float* origins, float* directions,
+                        float* pixel_area, void* stream);
+
+/* ------------------------------------------------------------- hash grid --
+ * Replaces HashEncoding(implementation="torch").forward called at
+ * models/activenerfacto/activenerfacto_field.py:140-147,
+ * models/mcdropout/mcdropout_fields.py:115-122, models/laplace/laplace_field.py:129-136.
+ * xyz [N,3] in [0,1]; table [L<<log2T, 2]; scalings [L]; out [N, 2L].
+ * out_idx (may be NULL) receives the 8 table-row indices per level, [N,L,8] int32,
+ * corner order ccc,cfc,ffc,fcc,ccf,cff,fff,fcf (bit-exact bookkeeping check). */
+int unerf_hashgrid_fwd(const float* xyz, const float* table, const float* scalings, int64_t N, int L,
+                       int log2T, float* out, int32_t* out_idx, void* stream);
+
+/* hash grid + small MLP (torch nn.Linear weights pre-transposed to [in][out]). */
+typedef struct {
+    const float* table;      /* [L<<log2T][2] */
+    const float* scalings;   /* [L] */
+    int L, log2T;
+    const float* w0t;        /* [2L][hidden] */
+    const float* b0;         /* [hidden] */
+    const float* w1t;        /* [hidden][1] */
+    const float* b1;         /* [1] */
+    int hidden;              /* 16 (nerfacto proposal nets) or 64 */
+} unerf_density_net;
+
+/* -------------------------------------------------- proposal density --
+ * Replaces HashMLPDensityField.density_fn as invoked by ProposalNetworkSampler
+ * (call site models/activenerfacto/activenerfacto_model.py:89,
+ * models/laplace/laplace_model.py:210,459).  Sample i of ray r sits at the mid-point of
+ * spacing bins [i, i+1] (converted to euclidean with the piecewise-linear-in-disparity
+ * spacing fn and near/far).  sbins: [R, n+1] with row stride `sbins_stride`
+ * (0 = one shared row, the initial uniform bins).  density_out [R,n]. */
+int unerf_proposal_density(const float* origins, const float* directions, const float* sbins,
+                           int64_t sbins_stride, int64_t R, int n, float near_plane, float far_plane,
+                           const unerf_density_net* net /* host struct of device ptrs */,
+                           float average_init_density, float* density_out, void* stream);
+
+/* ------------------------------------------- weights + PDF resampling --
+ * Replaces RaySamples.get_weights + PDFSampler.generate_ray_samples (eval branch) inside
+ * ProposalNetworkSampler, and DepthRenderer("median") for prop_depth_i
+ * (models/activenerfacto/activenerfacto_model.py:150-151).
+ * u: [m+1] = linspace(0,1-1/(m+1),m+1)+1/(2(m+1)) (host computes it the torch way).
+ * sbins_out [R,m+1]; prop_depth_out [R] (may be NULL); weights_out [R,n] (may be NULL).
+ * clip_minmax (may be NULL): [ceil(R_total/chunk_rays)][2] floats, pre-set to {+inf,0};
+ * receives per-chunk min/max of the NEW samples' mid-points (the bounds
+ * DepthRenderer("expected") clips to); ray_offset = index of ray 0 inside the frame. */
+int unerf_weights_pdf_resample(const float* density, const float* sbins, int64_t sbins_stride, int64_t R,
+                               int n, float near_plane, float far_plane, const float* u, int m,
+                               float histogram_padding, float eps, float* sbins_out, float* prop_depth_out,
+                               float* weights_out, float* clip_minmax, int64_t ray_offset,
+                               int64_t chunk_rays, void* stream);
+
+/* ------------------------------------------------------- main field --
+ * Replaces, per mode:
+ *  ACTIVE    ActiveNerfactoField.get_density + NerfactoField.get_outputs
+ *            (models/activenerfacto/activenerfacto_field.py:162-215)
+ *  MCDROPOUT NerfactoMCDropoutField.get_density + create_mlp heads, K stochastic passes
+ *            (models/mcdropout/mcdropout_fields.py:110-174, mcdropout_models.py:116-119,
+ *            utils.py:6-43); K=0 means dropout off, one pass.
+ *  LAPLACE   NerfactoLaplaceField.forward_unc with is_inference=True
+ *            (models/laplace/laplace_field.py:279-362, 365-485, 528-568): ws_* are the
+ *            n_lap sampled last-layer parameter rows mu+randn*std ([out,in] row-major, bias).
+ */
+#define UNERF_FIELD_ACTIVE 0
+#define UNERF_FIELD_MCDROPOUT 1
+#define UNERF_FIELD_LAPLACE 2
+
+typedef struct {
+    int mode;
+    /* hash grid (L=16 levels, F=2) */
+    const float* table; const float* scalings; int L, log2T;
+    /* trunk: w0t [32][64], b0[64]; w1t [64][out1], b1[out1]
+       out1 = 17 ACTIVE (density, geo15, beta) | 16 MCDROPOUT | 15 LAPLACE (mlp_hidden) */
+    const float* w0t; const float* b0; const float* w1t; const float* b1; int out1;
+    /* colour head with the constant eval appearance embedding folded into the first bias:
+       h0t [31][64] (rows: SH16 then geo15), hb0[64]; h1t [64][64], hb1[64]; h2t [64][3], hb2[3] */
+    const float* h0t; const float* hb0; const float* h1t; const float* hb1; const float* h2t; const float* hb2;
+    float average_init_density, beta_min;
+    int sh_remap;            /* 0: SH on (d+1)/2 as the torch SHEncoding does; 1: tcnn ([-1,1]) */
+    /* MCDROPOUT */
+    int K; uint32_t seed; float p_drop;
+    /* LAPLACE */
+    const float* ws_density;  /* [n_lap][65]  */
+    const float* ws_rgb;      /* [n_lap][195] */
+    int n_lap;
+} unerf_field_params;
+
+/* outputs: B = max(K,1) passes
+ *   density [B,R,S]; rgb [B,R,S,3];
+ *   aux     ACTIVE: beta [R,S] | LAPLACE: density_var [R,S] | else NULL
+ *   aux2    LAPLACE: rgb_var [R,S] (relu, channel mean) | else NULL
+ * sbins [R,S+1] spacing-domain bins of the final samples; ray_offset keys the dropout RNG. */
+int unerf_field_fwd(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
+                    float near_plane, float far_plane, int64_t ray_offset,
+                    const unerf_field_params* p /* host struct */, float* density, float* rgb, float* aux,
+                    float* aux2, void* stream);
+
+/* Laplace depth path: models/laplace/laplace_model.py:486-507.  mean over D draws of
+ * get_weights(relu(mu + max(sqrt(var),1e-10) * eps)).  noise [D,R,S] or NULL (then the
+ * built-in counter RNG with `seed`).  weights_out [R,S]. */
+int unerf_laplace_depth_weights(const float* density_mu, const float* density_var, const float* sbins,
+                                int64_t R, int S, float near_plane, float far_plane, const float* noise, int D,
+                                uint32_t seed, int64_t ray_offset, float* weights_out, void* stream);
+
+/* ------------------------------------------------- composite + variance --
+ * Replaces RaySamples.get_weights + RGB/Accumulation/Depth(median,expected)/Uncertainty
+ * renderers + the depth-variance sum at models/activenerfacto/activenerfacto_model.py:94-112
+ * and models/laplace/laplace_model.py:471-521.
+ * density [B,R,S], rgb [B,R,S,3], beta [B? no: R,S] (NULL -> rgb_var = 0);
+ * weights_alt [R,S] (NULL or the laplace mean sampled weights: then accumulation, depth,
+ * expected depth and depth_var use it while rgb and rgb_var use get_weights(density)).
+ * clip_minmax as produced by unerf_weights_pdf_resample.
+ * out [B,R,8] = rgb(3), accumulation, depth(median), expected_depth, rgb_var, depth_var(+1e-5). */
+int unerf_composite_var(const float* density, const float* rgb, const float* beta, const float* weights_alt,
+                        const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane,
+                        const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, float* out,
+                        void* stream);
+
+/* ------------------------------------------------------ moments over K --
+ * Replaces torch.stack(...).mean(0) / .std(0) / .var(0) over MC passes
+ * (models/mcdropout/mcdropout_models.py:121-126) and over ensemble members
+ * (models/ensemble/ensemble_pipeline.py:159-189).  x [K,N,C] -> mean [N,C],
+ * var [N,C] (unbiased, K-1; NULL ok).  Two-pass in fp32 like torch. */
+int unerf_moments(const float* x, int K, int64_t N, int C, float* mean, float* var, void* stream);
+
+/* ================================================================ splats ==
+ * gsplat 0.1.11 call sites in models/activesplatfacto/activesplatfacto_model.py. */
+
+/* :221-234 project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, 16).
+ * viewmat_host: 12 or 16 floats row-major (first 3 rows used).  Outputs as gsplat:
+ * xys[N,2], depths[N], radii[N] i32, conics[N,3], compensation[N], num_tiles_hit[N] i32, cov3d[N,6]. */
+int unerf_splat_project(const float* means3d, const float* scales, float glob_scale, const float* quats,
+                        const float* viewmat_host, float fx, float fy, float cx, float cy, int H, int W,
+                        int block_width, float clip_thresh, int64_t N, float* xys, float* depths, int32_t* radii,
+                        float* conics, float* compensation, int32_t* num_tiles_hit, float* cov3d, void* stream);
+
+/* :245-246 spherical_harmonics(degree, viewdirs, coeffs[N,16,3]) then clamp(+0.5, min 0);
+ * and :286 softplus(log_unc)+beta_min.  cam_pos_host: 3 floats.  colors_out [N,3], beta_out [N]. */
+int unerf_splat_sh_colors(int degree, const float* means3d, const float* cam_pos_host, const float* sh_coeffs,
+                          const float* log_unc, float beta_min, int64_t N, float* colors_out, float* beta_out,
+                          void* stream);
+
+/* bin-and-sort done ONCE per frame (the reference repeats it inside each of its four
+ * rasterize_gaussians calls :260,:289,:306,:343).  cum_tiles_hit [N] i32 (inclusive scan,
+ * output), isect_ids [I] i64 + gaussian_ids [I] i32 sorted outputs, tile_bins [tiles,2] i32.
+ * Two-step use: call unerf_splat_count_intersects (async; writes the scan and *num_intersects
+ * on device), read it back, size the buffers, then unerf_splat_bin_sort. */
+int64_t unerf_splat_sort_workspace_bytes(int64_t N, int64_t num_intersects);
+int unerf_splat_count_intersects(const int32_t* num_tiles_hit, int64_t N, int32_t* cum_tiles_hit,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
+int unerf_splat_bin_sort(const float* xys, const float* depths, const int32_t* radii,
+                         const int32_t* cum_tiles_hit, int64_t N, int64_t num_intersects, int H, int W,
+                         int block_width, int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted,
+                         int32_t* tile_bins, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* rasterize_forward / nd_rasterize_forward: C channels blended in one pass.
+ * colors [N,C] (C<=8), opacities [N], background [C] DEVICE (NULL = zeros),
+ * out_img [H,W,C], final_T [H,W], final_idx [H,W] i32 (may be NULL). */
+int unerf_splat_rasterize(const int32_t* gaussian_ids_sorted, const int32_t* tile_bins, const float* xys,
+                          const float* conics, const float* colors, const float* opacities,
+                          const float* background, int C, int H, int W, int block_width, float* out_img,
+                          float* final_T, int32_t* final_idx, void* stream);
+
+/* :319 / :356  img = where(alpha>0, img/alpha, max(img)) with alpha = 1-final_T, applied IN PLACE
+ * to channel `ch` of an interleaved image [HW, stride]; scratch_max = 1 device float. */
+int unerf_splat_alpha_normalize(float* img, int stride, int ch, const float* final_T, int64_t HW,
+                                float* scratch_max, void* stream);
+/* :325-341 per-splat (z_i - depth[floor(xy_i)])^2, bounds test with the reference's strict ">0";
+ * depth image = channel `ch` of [H,W,stride].  sq_diff_out [N]. */
+int unerf_splat_depth_sqdiff(const float* xys, const float* depths, const float* depth_img, int stride, int ch,
+                             int H, int W, int64_t N, float* sq_diff_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNERF_H */

@@ -1,0 +1,686 @@
+"""CPU (torch fp32) restatement of the NeRF half of the hot path.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.
+
+Two kinds of functions live here, tagged in their docstrings:
+
+  [REF file:line]         restates code that is under /root/reference
+  [UPSTREAM nerfstudio]   restates nerfstudio==1.1.0 (README.md:23 of the
+                          reference pins it); not vendored, not installed ->
+                          "parity unpinned" for these.
+
+Everything is written as plain functions over tensors so that each HIP kernel
+has a same-shaped counterpart.  fp32 throughout (the canonical precision of
+this build; the reference's autocast fp16/bf16 for MC-dropout,
+mcdropout_models.py:86-92, is documented as a divergence in DESIGN.md).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# L0.1  HashEncoding (torch path)                         [UPSTREAM nerfstudio]
+# --------------------------------------------------------------------------
+
+HASH_PRIMES = (1, 2654435761, 805459861)
+
+
+def hash_scalings(num_levels: int, min_res: int, max_res: int) -> torch.Tensor:
+    """scalings[l] = floor(min_res * growth**l), evaluated the way upstream does:
+    numpy float64 growth factor raised to an int64 *torch* tensor -> float32 pow.
+    (This is why the last level of a 16..2048 grid comes out as 2047.)"""
+    levels = torch.arange(num_levels)
+    growth = np.exp((np.log(max_res) - np.log(min_res)) / (num_levels - 1)) if num_levels > 1 else 1
+    return torch.floor(min_res * growth ** levels).to(torch.float32)
+
+
+def hash_fn(coords: torch.Tensor, log2_T: int, num_levels: int) -> torch.Tensor:
+    """coords [..., L, 3] int32 -> table row index [..., L] (int64), level offset included."""
+    c = coords.to(torch.int64) * torch.tensor(HASH_PRIMES, dtype=torch.int64)
+    x = torch.bitwise_xor(c[..., 0], c[..., 1])
+    x = torch.bitwise_xor(x, c[..., 2])
+    x = x % (1 << log2_T)
+    x = x + torch.arange(num_levels, dtype=torch.int64) * (1 << log2_T)
+    return x
+
+
+# corner order of upstream pytorch_fwd: (x,y,z) pick ceil 'c' or floor 'f'
+_CORNERS = ("ccc", "cfc", "ffc", "fcc", "ccf", "cff", "fff", "fcf")
+
+
+def hash_indices(x: torch.Tensor, scalings: torch.Tensor, log2_T: int):
+    """x [N,3] in [0,1] -> (idx [N,L,8] int64, offset [N,L,3] fp32)."""
+    L = scalings.numel()
+    scaled = x[..., None, :] * scalings.view(-1, 1)
+    sc = torch.ceil(scaled).to(torch.int32)
+    sf = torch.floor(scaled).to(torch.int32)
+    offset = scaled - sf
+    idx = []
+    for pat in _CORNERS:
+        comps = [(sc if pat[a] == "c" else sf)[..., a:a + 1] for a in range(3)]
+        idx.append(hash_fn(torch.cat(comps, dim=-1), log2_T, L))
+    return torch.stack(idx, dim=-1), offset
+
+
+def hash_encode(x: torch.Tensor, table: torch.Tensor, scalings: torch.Tensor, log2_T: int) -> torch.Tensor:
+    """x [N,3] -> [N, L*F]; blend order f03,f12,f56,f47 -> y -> z as upstream."""
+    idx, o = hash_indices(x, scalings, log2_T)
+    f = [table[idx[..., k]] for k in range(8)]  # each [N,L,F]
+    ox, oy, oz = o[..., 0:1], o[..., 1:2], o[..., 2:3]
+    f03 = f[0] * ox + f[3] * (1 - ox)
+    f12 = f[1] * ox + f[2] * (1 - ox)
+    f56 = f[5] * ox + f[6] * (1 - ox)
+    f47 = f[4] * ox + f[7] * (1 - ox)
+    f0312 = f03 * oy + f12 * (1 - oy)
+    f4756 = f47 * oy + f56 * (1 - oy)
+    enc = f0312 * oz + f4756 * (1 - oz)
+    return torch.flatten(enc, start_dim=-2)
+
+
+# --------------------------------------------------------------------------
+# L0.2-L0.5 small pieces                                  [UPSTREAM nerfstudio]
+# --------------------------------------------------------------------------
+
+def mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor],
+                out_activation: Optional[str] = None) -> torch.Tensor:
+    """nerfstudio MLP.pytorch_fwd: ReLU on all but the last layer."""
+    n = len(weights)
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        x = F.linear(x, w, b)
+        if i < n - 1:
+            x = F.relu(x)
+    if out_activation == "sigmoid":
+        x = torch.sigmoid(x)
+    elif out_activation == "relu":
+        x = F.relu(x)
+    return x
+
+
+SH_C = dict(
+    c0=0.28209479177387814, c1=0.4886025119029199, c2a=1.0925484305920792, c2b=0.9461746957575601,
+    c2c=0.31539156525251999, c2d=0.5462742152960396, c3a=0.5900435899266435, c3b=2.890611442640554,
+    c3c=0.4570457994644658, c3d=0.3731763325901154, c3e=1.445305721320277,
+)
+
+
+def sh16(d: torch.Tensor) -> torch.Tensor:
+    """components_from_spherical_harmonics(levels=4).  `d` is used AS GIVEN: the torch
+    SHEncoding receives get_normalized_directions(d) = (d+1)/2 (laplace_field.py:379)
+    and does not map it back to [-1,1] (tcnn does) -- a torch/tcnn divergence."""
+    x, y, z = d[..., 0], d[..., 1], d[..., 2]
+    xx, yy, zz = x ** 2, y ** 2, z ** 2
+    c = SH_C
+    comps = [
+        torch.full_like(x, c["c0"]),
+        c["c1"] * y, c["c1"] * z, c["c1"] * x,
+        c["c2a"] * x * y, c["c2a"] * y * z, c["c2b"] * zz - c["c2c"], c["c2a"] * x * z, c["c2d"] * (xx - yy),
+        c["c3a"] * y * (3 * xx - yy), c["c3b"] * x * y * z, c["c3c"] * y * (5 * zz - 1),
+        c["c3d"] * z * (5 * zz - 3), c["c3c"] * x * (5 * zz - 1), c["c3e"] * z * (xx - yy),
+        c["c3a"] * x * (xx - 3 * yy),
+    ]
+    return torch.stack(comps, dim=-1)
+
+
+def contract_inf(x: torch.Tensor) -> torch.Tensor:
+    """SceneContraction(order=inf): x if |x|_inf<1 else (2-1/m) * (x/m)."""
+    mag = torch.linalg.norm(x, ord=float("inf"), dim=-1)[..., None]
+    return torch.where(mag < 1, x, (2 - (1 / mag)) * (x / mag))
+
+
+def normalized_positions(positions: torch.Tensor):
+    """[REF activenerfacto_field.py:164-172] contraction -> (x+2)/4 -> selector mask."""
+    p = contract_inf(positions)
+    p = (p + 2.0) / 4.0
+    selector = ((p > 0.0) & (p < 1.0)).all(dim=-1)
+    p = p * selector[..., None]
+    return p, selector
+
+
+# --------------------------------------------------------------------------
+# L0.9 camera rays                                        [UPSTREAM nerfstudio]
+# --------------------------------------------------------------------------
+
+def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int):
+    """Cameras.generate_rays(keep_shape=True) for a distortion-free perspective camera.
+    Returns origins [H,W,3], directions [H,W,3], pixel_area [H,W,1]."""
+    c2w = c2w.to(torch.float32)
+    ii, jj = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    y = ii + 0.5
+    x = jj + 0.5
+    fx, fy, cx, cy = (torch.tensor(v, dtype=torch.float32) for v in (fx, fy, cx, cy))
+    coord = torch.stack([(x - cx) / fx, -(y - cy) / fy], -1)
+    coord_x = torch.stack([(x - cx + 1) / fx, -(y - cy) / fy], -1)
+    coord_y = torch.stack([(x - cx) / fx, -(y - cy + 1) / fy], -1)
+    cs = torch.stack([coord, coord_x, coord_y], dim=0)
+    ds = torch.cat([cs, -torch.ones_like(cs[..., :1])], dim=-1)  # [3,H,W,3]
+    rot = c2w[:3, :3]
+    ds = torch.sum(ds[..., None, :] * rot, dim=-1)
+    norm = torch.maximum(torch.linalg.vector_norm(ds, dim=-1, keepdim=True), torch.tensor([1e-7]))
+    ds = ds / norm
+    directions = ds[0]
+    dx = torch.sqrt(torch.sum((directions - ds[1]) ** 2, dim=-1))
+    dy = torch.sqrt(torch.sum((directions - ds[2]) ** 2, dim=-1))
+    pixel_area = (dx * dy)[..., None]
+    origins = c2w[:3, 3].expand(H, W, 3).contiguous()
+    return origins, directions, pixel_area
+
+
+# --------------------------------------------------------------------------
+# L0.6 samplers                                           [UPSTREAM nerfstudio]
+# --------------------------------------------------------------------------
+
+def spacing_fn(x: torch.Tensor) -> torch.Tensor:
+    return torch.where(x < 1, x / 2, 1 - 1 / (2 * x))
+
+
+def spacing_fn_inv(x: torch.Tensor) -> torch.Tensor:
+    return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
+
+
+def spacing_to_euclidean(bins: torch.Tensor, near: float, far: float) -> torch.Tensor:
+    s_near = spacing_fn(torch.tensor(near, dtype=torch.float32))
+    s_far = spacing_fn(torch.tensor(far, dtype=torch.float32))
+    return spacing_fn_inv(bins * s_far + (1 - bins) * s_near)
+
+
+def initial_spacing_bins(num_samples: int) -> torch.Tensor:
+    return torch.linspace(0.0, 1.0, num_samples + 1)
+
+
+def pdf_u(num_samples: int) -> torch.Tensor:
+    nb = num_samples + 1
+    u = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb)
+    return u + 1.0 / (2 * nb)
+
+
+def get_weights(density: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
+    """RaySamples.get_weights; verbatim twin in the reference at laplace_model.py:47-62.
+    density, deltas: [R,S]."""
+    dd = deltas * density
+    alphas = 1 - torch.exp(-dd)
+    trans = torch.cumsum(dd[..., :-1], dim=-1)
+    trans = torch.cat([torch.zeros_like(trans[..., :1]), trans], dim=-1)
+    trans = torch.exp(-trans)
+    return torch.nan_to_num(alphas * trans)
+
+
+def pdf_resample(weights: torch.Tensor, spacing_bins: torch.Tensor, num_samples: int,
+                 histogram_padding: float = 0.01, eps: float = 1e-5) -> torch.Tensor:
+    """PDFSampler.generate_ray_samples, eval branch.  weights [R,n], spacing_bins [R,n+1]
+    -> new spacing bins [R, num_samples+1]."""
+    w = weights + histogram_padding
+    wsum = torch.sum(w, dim=-1, keepdim=True)
+    padding = torch.relu(eps - wsum)
+    w = w + padding / w.shape[-1]
+    wsum = wsum + padding
+    pdf = w / wsum
+    cdf = torch.min(torch.ones_like(pdf), torch.cumsum(pdf, dim=-1))
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
+    nb = num_samples + 1
+    u = pdf_u(num_samples).expand(*cdf.shape[:-1], nb).contiguous()
+    existing = spacing_bins
+    inds = torch.searchsorted(cdf, u, side="right")
+    below = torch.clamp(inds - 1, 0, existing.shape[-1] - 1)
+    above = torch.clamp(inds, 0, existing.shape[-1] - 1)
+    cdf_g0 = torch.gather(cdf, -1, below)
+    bins_g0 = torch.gather(existing, -1, below)
+    cdf_g1 = torch.gather(cdf, -1, above)
+    bins_g1 = torch.gather(existing, -1, above)
+    t = torch.clip(torch.nan_to_num((u - cdf_g0) / (cdf_g1 - cdf_g0), 0), 0, 1)
+    return bins_g0 + t * (bins_g1 - bins_g0)
+
+
+@dataclass
+class GridMLP:
+    """hash grid + small MLP (weights in torch nn.Linear layout [out,in])."""
+    table: torch.Tensor
+    scalings: torch.Tensor
+    log2_T: int
+    weights: List[torch.Tensor]
+    biases: List[torch.Tensor]
+
+
+def sample_positions(origins, directions, euclid_bins):
+    """Frustums.get_positions(): o + d * (start+end)/2.  [R,3],[R,3],[R,n+1] -> [R,n,3]"""
+    starts, ends = euclid_bins[..., :-1], euclid_bins[..., 1:]
+    return origins[:, None, :] + directions[:, None, :] * (starts + ends)[..., None] / 2
+
+
+def density_field(positions: torch.Tensor, net: GridMLP, average_init_density: float) -> torch.Tensor:
+    """HashMLPDensityField.get_density on explicit positions [R,n,3] -> [R,n]."""
+    shp = positions.shape[:-1]
+    p, sel = normalized_positions(positions)
+    h = hash_encode(p.reshape(-1, 3), net.table, net.scalings, net.log2_T)
+    out = mlp_forward(h, net.weights, net.biases).view(*shp)
+    return average_init_density * torch.exp(out) * sel
+
+
+def proposal_sample(origins, directions, near, far, prop_nets: List[GridMLP], num_prop: Tuple[int, ...],
+                    num_nerf: int, average_init_density: float):
+    """ProposalNetworkSampler.generate_ray_samples at eval (anneal = 1, no jitter).
+    Returns (final spacing bins [R,num_nerf+1], weights_list, spacing_bins_list)."""
+    R = origins.shape[0]
+    weights_list, bins_list = [], []
+    bins = initial_spacing_bins(num_prop[0])[None].expand(R, -1).contiguous()
+    weights = None
+    n_iter = len(prop_nets)
+    for lvl in range(n_iter + 1):
+        if lvl > 0:
+            n_new = num_prop[lvl] if lvl < n_iter else num_nerf
+            bins = pdf_resample(weights, bins, n_new)
+        if lvl < n_iter:
+            eb = spacing_to_euclidean(bins, near, far)
+            pos = sample_positions(origins, directions, eb)
+            dens = density_field(pos, prop_nets[lvl], average_init_density)
+            weights = get_weights(dens, eb[..., 1:] - eb[..., :-1])
+            weights_list.append(weights)
+            bins_list.append(bins)
+    return bins, weights_list, bins_list
+
+
+# --------------------------------------------------------------------------
+# L0.8 renderers                                          [UPSTREAM nerfstudio]
+# --------------------------------------------------------------------------
+
+def render_rgb(rgb: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """RGBRenderer, eval, background_color='last_sample'.  rgb [R,S,3], weights [R,S]."""
+    rgb = torch.nan_to_num(rgb)
+    comp = torch.sum(weights[..., None] * rgb, dim=-2)
+    acc = torch.sum(weights, dim=-1, keepdim=True)
+    comp = comp + rgb[..., -1, :] * (1.0 - acc)
+    return torch.clamp(comp, 0.0, 1.0)
+
+
+def render_accumulation(weights: torch.Tensor) -> torch.Tensor:
+    return torch.sum(weights, dim=-1, keepdim=True)
+
+
+def render_depth_median(weights: torch.Tensor, steps: torch.Tensor) -> torch.Tensor:
+    cw = torch.cumsum(weights, dim=-1)
+    split = torch.ones((*weights.shape[:-1], 1)) * 0.5
+    idx = torch.searchsorted(cw, split, side="left")
+    idx = torch.clamp(idx, 0, steps.shape[-1] - 1)
+    return torch.gather(steps, dim=-1, index=idx)
+
+
+def render_depth_expected(weights: torch.Tensor, steps: torch.Tensor) -> torch.Tensor:
+    """clip bounds are the min/max of `steps` over the WHOLE chunk passed in (upstream quirk)."""
+    depth = torch.sum(weights * steps, dim=-1, keepdim=True) / (torch.sum(weights, -1, keepdim=True) + 1e-10)
+    return torch.clip(depth, steps.min(), steps.max())
+
+
+def render_uncertainty(betas: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    return torch.sum(weights * betas, dim=-1, keepdim=True)
+
+
+# --------------------------------------------------------------------------
+# counter-based RNG shared with the HIP kernels (this build's own definition)
+# --------------------------------------------------------------------------
+
+def _hash32(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x = x ^ (x >> np.uint32(16))
+        x = x * np.uint32(0x21F0AAAD)
+        x = x ^ (x >> np.uint32(15))
+        x = x * np.uint32(0x735A2D97)
+        x = x ^ (x >> np.uint32(15))
+    return x
+
+
+GOLDEN = np.uint32(0x9E3779B9)
+
+
+def mc_base(seed: int, pass_idx: int, sample_idx: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        key = _hash32(np.array([seed], dtype=np.uint32) + np.uint32(pass_idx) * GOLDEN)
+        return _hash32(_hash32(sample_idx.astype(np.uint32)) + key)
+
+
+def mc_keep_mask(seed: int, pass_idx: int, sample_idx: np.ndarray, stream: int, n_units: int,
+                 p_drop: float) -> np.ndarray:
+    """[N, n_units] bool keep-mask.  stream 0 = density trunk, 1 = colour head.
+    Unit pair j of stream s uses hash32(base + (s*32 + j + 1)*GOLDEN); low 16 bits -> unit 2j,
+    high 16 bits -> unit 2j+1; keep iff u16 < round((1-p)*65536)."""
+    assert n_units % 2 == 0 and n_units <= 64
+    thr = np.uint32(int(round((1.0 - p_drop) * 65536.0)))
+    base = mc_base(seed, pass_idx, sample_idx)[:, None]
+    j = np.arange(n_units // 2, dtype=np.uint32)[None, :]
+    with np.errstate(over="ignore"):
+        r = _hash32(base + (np.uint32(stream * 32) + j + np.uint32(1)) * GOLDEN)
+    lo = (r & np.uint32(0xFFFF)) < thr
+    hi = (r >> np.uint32(16)) < thr
+    return np.stack([lo, hi], axis=-1).reshape(base.shape[0], n_units)
+
+
+def normal_noise(seed: int, draw: int, sample_idx: np.ndarray) -> np.ndarray:
+    """Box-Muller standard normal per (draw, sample), fp32 -- twin of the kernel's generator
+    used when no explicit noise tensor is supplied (laplace depth draws)."""
+    base = mc_base(seed, draw, sample_idx)
+    with np.errstate(over="ignore"):
+        r1 = _hash32(base + GOLDEN)
+        r2 = _hash32(base + np.uint32(2) * GOLDEN)
+    u1 = ((r1 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    u2 = ((r2 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    rad = np.sqrt(np.float32(-2.0) * np.log(u1)).astype(np.float32)
+    return (rad * np.cos(np.float32(2.0 * math.pi) * u2)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# L1/L2 the reference's own fields and models
+# --------------------------------------------------------------------------
+
+@dataclass
+class FieldParams:
+    """Weights of one nerfacto-style field.  Layout mirrors the reference state-dict
+    (SURVEY.md 8b); all Linear weights in torch [out,in] layout."""
+    grid: GridMLP                      # table + trunk (2 Linear layers; laplace: see below)
+    head_w: List[torch.Tensor]         # colour head Linear weights (3 layers: 63->64->64->3)
+    head_b: List[torch.Tensor]
+    appearance: torch.Tensor           # [32] constant eval embedding (mean or zeros)
+    # laplace-only heads (laplace_field.py:139-160): base Linear(32,64) is grid.weights[0]
+    hidden_w: Optional[torch.Tensor] = None   # mlp_hidden 64->15
+    hidden_b: Optional[torch.Tensor] = None
+    density_w: Optional[torch.Tensor] = None  # mlp_density 64->1
+    density_b: Optional[torch.Tensor] = None
+    average_init_density: float = 1.0
+    beta_min: float = 0.01
+    geo_feat_dim: int = 15
+
+
+def _color_inputs(directions: torch.Tensor, S: int, geo: torch.Tensor, appearance: torch.Tensor):
+    """[UPSTREAM NerfactoField.get_outputs; re-implemented by the reference at
+    laplace_field.py:378-398, 451-459]  directions [R,3], geo [R,S,15] -> h [R*S,63]"""
+    R = directions.shape[0]
+    dn = (directions + 1.0) / 2.0
+    d = sh16(dn)[:, None, :].expand(R, S, 16)
+    app = appearance.view(1, 1, -1).expand(R, S, -1)
+    return torch.cat([d, geo, app], dim=-1).reshape(R * S, -1)
+
+
+def active_field(origins, directions, euclid_bins, fp: FieldParams):
+    """[REF activenerfacto_field.py:162-215]  -> density [R,S], rgb [R,S,3], beta [R,S]"""
+    R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
+    pos = sample_positions(origins, directions, euclid_bins)
+    p, sel = normalized_positions(pos)
+    feat = hash_encode(p.reshape(-1, 3), fp.grid.table, fp.grid.scalings, fp.grid.log2_T)
+    h = mlp_forward(feat, fp.grid.weights, fp.grid.biases).view(R, S, -1)
+    g = fp.geo_feat_dim
+    dens_pre, geo, unc_pre = h[..., 0], h[..., 1:1 + g], h[..., 1 + g]
+    density = fp.average_init_density * torch.exp(dens_pre) * sel
+    beta = F.softplus(unc_pre) + fp.beta_min
+    rgb = mlp_forward(_color_inputs(directions, S, geo, fp.appearance), fp.head_w, fp.head_b, "sigmoid")
+    return density, rgb.view(R, S, 3), beta
+
+
+def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trunk: Optional[torch.Tensor],
+                    keep_head: Optional[torch.Tensor], p_drop: float):
+    """[REF mcdropout_fields.py:110-174 + utils.py:6-43]
+    trunk = Linear(32,64),ReLU,Dropout,Linear(64,16); head = Linear(63,64),ReLU,Linear(64,64),ReLU,
+    Dropout,Linear(64,3),Sigmoid.  keep_* are bool masks [R*S,64] (None = dropout off)."""
+    R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
+    scale = 1.0 / (1.0 - p_drop)
+    pos = sample_positions(origins, directions, euclid_bins)
+    p, sel = normalized_positions(pos)
+    feat = hash_encode(p.reshape(-1, 3), fp.grid.table, fp.grid.scalings, fp.grid.log2_T)
+    h = F.relu(F.linear(feat, fp.grid.weights[0], fp.grid.biases[0]))
+    if keep_trunk is not None:
+        h = h * keep_trunk.to(h.dtype) * scale
+    out = F.linear(h, fp.grid.weights[1], fp.grid.biases[1]).view(R, S, -1)
+    g = fp.geo_feat_dim
+    density = fp.average_init_density * torch.exp(out[..., 0]) * sel
+    geo = out[..., 1:1 + g]
+    x = _color_inputs(directions, S, geo, fp.appearance)
+    x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
+    x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
+    if keep_head is not None:
+        x = x * keep_head.to(x.dtype) * scale
+    rgb = torch.sigmoid(F.linear(x, fp.head_w[2], fp.head_b[2]))
+    return density, rgb.view(R, S, 3)
+
+
+def sample_laplace(weight_samples: torch.Tensor, activation: str, x: torch.Tensor, out_dim: int):
+    """[REF laplace_field.py:528-568] with the randn draw lifted out: `weight_samples` [n,P] are
+    the already-formed mu + randn*std rows (weight [out,in] row-major, then bias).
+    Sequential accumulation order as the reference loop."""
+    n, P = weight_samples.shape
+    in_dim = x.shape[-1]
+    mu = 0.0
+    mu2 = 0.0
+    for s in range(n):
+        w = weight_samples[s, : out_dim * in_dim].view(out_dim, in_dim)
+        b = weight_samples[s, out_dim * in_dim:]
+        pred = F.linear(x, w, b)
+        pred = torch.exp(pred) if activation == "exp" else torch.sigmoid(pred)
+        mu = mu + pred
+        mu2 = mu2 + pred ** 2
+    mu = mu / n
+    mu2 = mu2 / n
+    return mu, mu2 - mu ** 2
+
+
+def laplace_weight_samples(mu_q: torch.Tensor, diag_ggn: torch.Tensor, prior_prec: float, eps: float,
+                           noise: torch.Tensor) -> torch.Tensor:
+    """[REF laplace_field.py:538-547] noise = the randn(n,P) draw."""
+    std = 1 / torch.sqrt(diag_ggn + prior_prec + eps)
+    return mu_q.view(1, -1) + noise * std.view(1, -1)
+
+
+def laplace_field(origins, directions, euclid_bins, fp: FieldParams, ws_density: torch.Tensor,
+                  ws_rgb: torch.Tensor):
+    """[REF laplace_field.py:279-362, 365-485, 487-525] is_inference=True,
+    use_deterministic_density=False.  Quirks kept: base_mlp is a bare Linear (no ReLU,
+    utils.py:22-23); returned mu_d is NOT selector-masked (laplace_field.py:356-362).
+    -> mu_d [R,S], var_d [R,S], mu_rgb [R,S,3], var_rgb [R,S] (relu, channel-mean)"""
+    R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
+    pos = sample_positions(origins, directions, euclid_bins)
+    p, _sel = normalized_positions(pos)
+    feat = hash_encode(p.reshape(-1, 3), fp.grid.table, fp.grid.scalings, fp.grid.log2_T)
+    hb = F.linear(feat, fp.grid.weights[0], fp.grid.biases[0])
+    geo = F.linear(hb, fp.hidden_w, fp.hidden_b).view(R, S, -1)
+    mu_d, var_d = sample_laplace(ws_density, "exp", hb, 1)
+    x = _color_inputs(directions, S, geo, fp.appearance)
+    x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
+    x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
+    mu_rgb, var_rgb = sample_laplace(ws_rgb, "sigmoid", x, 3)
+    var_rgb = F.relu(var_rgb).mean(dim=-1)
+    return mu_d.view(R, S), var_d.view(R, S), mu_rgb.view(R, S, 3), var_rgb.view(R, S)
+
+
+def laplace_field_deterministic(origins, directions, euclid_bins, fp: FieldParams):
+    """[REF laplace_field.py:317-345, 462-465] is_inference=False path (plain forward)."""
+    R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
+    pos = sample_positions(origins, directions, euclid_bins)
+    p, sel = normalized_positions(pos)
+    feat = hash_encode(p.reshape(-1, 3), fp.grid.table, fp.grid.scalings, fp.grid.log2_T)
+    hb = F.linear(feat, fp.grid.weights[0], fp.grid.biases[0])
+    geo = F.linear(hb, fp.hidden_w, fp.hidden_b).view(R, S, -1)
+    density = torch.exp(F.linear(hb, fp.density_w, fp.density_b)).view(R, S) * sel
+    x = _color_inputs(directions, S, geo, fp.appearance)
+    x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
+    x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
+    rgb = torch.sigmoid(F.linear(x, fp.head_w[2], fp.head_b[2]))
+    return density, rgb.view(R, S, 3)
+
+
+@dataclass
+class NerfScene:
+    """Everything a nerfacto-family model needs at eval."""
+    field: FieldParams
+    prop_nets: List[GridMLP]
+    near: float = 0.05
+    far: float = 1000.0
+    num_prop: Tuple[int, ...] = (256, 96)
+    num_nerf: int = 48
+    prop_average_init_density: float = 0.01
+
+
+def _sample(scene: NerfScene, origins, directions):
+    bins, wl, bl = proposal_sample(origins, directions, scene.near, scene.far, scene.prop_nets, scene.num_prop,
+                                   scene.num_nerf, scene.prop_average_init_density)
+    eb = spacing_to_euclidean(bins, scene.near, scene.far)
+    return eb, wl, bl
+
+
+def _prop_depths(scene, wl, bl):
+    out = {}
+    for i, (w, b) in enumerate(zip(wl, bl)):
+        eb = spacing_to_euclidean(b, scene.near, scene.far)
+        out[f"prop_depth_{i}"] = render_depth_median(w, (eb[..., :-1] + eb[..., 1:]) / 2)
+    return out
+
+
+def active_outputs(scene: NerfScene, origins, directions) -> Dict[str, torch.Tensor]:
+    """[REF activenerfacto_model.py:83-152] one chunk of rays [R,3]."""
+    eb, wl, bl = _sample(scene, origins, directions)
+    density, rgb, beta = active_field(origins, directions, eb, scene.field)
+    deltas = eb[..., 1:] - eb[..., :-1]
+    steps = (eb[..., :-1] + eb[..., 1:]) / 2
+    w = get_weights(density, deltas)
+    out = {
+        "rgb": render_rgb(rgb, w),
+        "accumulation": render_accumulation(w),
+        "depth": render_depth_median(w, steps),
+        "expected_depth": render_depth_expected(w, steps),
+        "density": density,
+    }
+    beta = torch.nan_to_num(beta, 0.0) if torch.isnan(beta).any() else beta
+    out["rgb_var"] = render_uncertainty(beta, w ** 2)
+    out["rgb_std"] = out["rgb_var"].sqrt()
+    out["depth_var"] = torch.sum(w * (steps - out["depth"]) ** 2, dim=-1, keepdim=True) + 1e-5
+    out["depth_std"] = out["depth_var"].sqrt()
+    out.update(_prop_depths(scene, wl, bl))
+    return out
+
+
+def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, density, rgb):
+    """[UPSTREAM NerfactoModel.get_outputs] rgb/accumulation/depth/expected_depth/prop_depth_i."""
+    deltas = eb[..., 1:] - eb[..., :-1]
+    steps = (eb[..., :-1] + eb[..., 1:]) / 2
+    w = get_weights(density, deltas)
+    out = {
+        "rgb": render_rgb(rgb, w),
+        "accumulation": render_accumulation(w),
+        "depth": render_depth_median(w, steps),
+        "expected_depth": render_depth_expected(w, steps),
+    }
+    out.update(_prop_depths(scene, wl, bl))
+    return out
+
+
+def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, p_drop: float,
+                      ray_offset: int = 0) -> Dict[str, torch.Tensor]:
+    """[REF mcdropout_models.py:94-131] K stochastic passes of one chunk + mean / unbiased std.
+    Masks come from the shared counter RNG keyed by the global sample index
+    (ray_offset+r)*S+s, so chunking does not change them."""
+    R = origins.shape[0]
+    S = scene.num_nerf
+    eb, wl, bl = _sample(scene, origins, directions)  # deterministic: identical in every pass
+    sidx = ((np.arange(R, dtype=np.int64)[:, None] + ray_offset) * S + np.arange(S)[None, :]).reshape(-1)
+    outs = []
+    for k in range(K):
+        kt = torch.from_numpy(mc_keep_mask(seed, k, sidx, 0, 64, p_drop))
+        kh = torch.from_numpy(mc_keep_mask(seed, k, sidx, 1, 64, p_drop))
+        density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop)
+        outs.append(nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb))
+    res = {}
+    for key in outs[0].keys():
+        el = torch.stack([o[key] for o in outs], dim=0)
+        res[key] = el.mean(dim=0)
+        if key in ("rgb", "depth", "expected_depth"):
+            res[key + "_std"] = el.std(dim=0).mean(dim=-1)[..., None]
+    return res
+
+
+def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
+                    depth_noise: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """[REF laplace_model.py:456-556] is_inference=True, use_deterministic_density=False.
+    depth_noise [D,R,S] = the standard-normal draw behind Normal(mu_d, sigma_d).sample((D,))."""
+    eb, wl, bl = _sample(scene, origins, directions)
+    mu_d, var_d, mu_rgb, var_rgb = laplace_field(origins, directions, eb, scene.field, ws_density, ws_rgb)
+    deltas = eb[..., 1:] - eb[..., :-1]
+    steps = (eb[..., :-1] + eb[..., 1:]) / 2
+    w = get_weights(mu_d, deltas)
+    rgb = render_rgb(mu_rgb, w)
+    rgb_var = render_uncertainty(var_rgb, w ** 2)
+    sd = torch.maximum(var_d.sqrt(), torch.tensor([1e-10]))
+    sd = torch.nan_to_num(sd, nan=1e-10) if torch.isnan(sd).any() else sd
+    sampled = F.relu(mu_d[None] + sd[None] * depth_noise)
+    sw = torch.stack([get_weights(sampled[i], deltas) for i in range(sampled.shape[0])], dim=0)
+    wm = sw.mean(dim=0)
+    depth = render_depth_median(wm, steps)
+    depth_var = torch.sum(wm * (steps - depth) ** 2, dim=-1, keepdim=True) + 1e-5
+    out = {
+        "rgb": rgb, "rgb_std": rgb_var.sqrt(), "accumulation": render_accumulation(wm), "depth": depth,
+        "depth_std": depth_var.sqrt(), "expected_depth": render_depth_expected(wm, steps),
+    }
+    out.update(_prop_depths(scene, wl, bl))
+    return out
+
+
+def render_camera(chunk_fn, origins_hw, directions_hw, chunk: int = 1 << 15) -> Dict[str, torch.Tensor]:
+    """[UPSTREAM Model.get_outputs_for_camera_ray_bundle; in-repo twin laplace_model.py:269-297]
+    row-major chunk loop; chunk_fn(origins[R,3], dirs[R,3], ray_offset) -> dict."""
+    H, W = origins_hw.shape[:2]
+    o = origins_hw.reshape(-1, 3)
+    d = directions_hw.reshape(-1, 3)
+    lists: Dict[str, List[torch.Tensor]] = {}
+    for i in range(0, H * W, chunk):
+        out = chunk_fn(o[i:i + chunk], d[i:i + chunk], i)
+        for k, v in out.items():
+            lists.setdefault(k, []).append(v)
+    return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}
+
+
+def ensemble_aggregate(outputs_list: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
+    """[REF ensemble_pipeline.py:159-189]"""
+    outputs = {}
+    keys0 = outputs_list[0].keys()
+    for k in keys0:
+        el = torch.stack([o[k] for o in outputs_list], dim=0)
+        outputs[k] = el.mean(dim=0)
+        if "rgb_std" in keys0 and "depth_std" in keys0:
+            if k in ("rgb", "depth"):
+                alea = torch.stack([o[k + "_var"] for o in outputs_list], dim=0)
+                outputs[k + "_var_alea"] = alea.mean(dim=0).mean(dim=-1).unsqueeze(-1)
+                outputs[k + "_var_epi"] = el.var(dim=0).mean(dim=-1).unsqueeze(-1)
+                outputs[k + "_var"] = outputs[k + "_var_epi"] + outputs[k + "_var_alea"]
+                outputs[k + "_std"] = outputs[k + "_var"].sqrt()
+        else:
+            if k in ("rgb", "depth", "expected_depth"):
+                outputs[k + "_std"] = el.std(dim=0).mean(dim=-1).unsqueeze(-1)
+    return outputs
+
+
+# --------------------------------------------------------------------------
+# scene construction from a plain tensor dict (format: uncertainty-nerf-gs_amd/synthetic.py)
+# --------------------------------------------------------------------------
+
+def scene_from_tensors(t: dict) -> NerfScene:
+    """Build the oracle-side scene from the same weight dict the device path is built from."""
+    def grid(d):
+        ws, bs = [d["w0"]], [d["b0"]]
+        if "w1" in d and d.get("w1") is not None and not d.get("_laplace", False):
+            ws.append(d["w1"])
+            bs.append(d["b1"])
+        return GridMLP(d["table"], d["scalings"], int(d["log2T"]), ws, bs)
+
+    f = t["field"]
+    lap = t["kind"] == "laplace"
+    fd = dict(f)
+    fd["_laplace"] = lap
+    fp = FieldParams(grid=grid(fd), head_w=list(f["head_w"]), head_b=list(f["head_b"]), appearance=f["appearance"],
+                     average_init_density=float(f.get("average_init_density", 1.0)),
+                     beta_min=float(f.get("beta_min", 0.01)))
+    if lap:
+        fp.hidden_w, fp.hidden_b = f["w1"], f["b1"]
+        fp.density_w, fp.density_b = f["density_w"], f["density_b"]
+    return NerfScene(field=fp, prop_nets=[grid(p) for p in t["props"]], near=float(t["near"]), far=float(t["far"]),
+                     num_prop=tuple(t["num_prop"]), num_nerf=int(t["num_nerf"]),
+                     prop_average_init_density=float(t["prop_average_init_density"]))

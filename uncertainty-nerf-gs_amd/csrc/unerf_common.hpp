@@ -1,0 +1,159 @@
+// Shared host/device helpers for libunerf (gfx950 only).
+// Built with -ffp-contract=off: every fused multiply-add in here is an explicit fmaf(),
+// so the index/blend arithmetic that must be bit-exact against the CPU oracle
+// (hash-grid corners + trilinear blend, splat projection, tile boxes, sort keys)
+// rounds exactly like numpy/torch fp32 ops do.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "unerf.h"
+
+// ---- host-side error plumbing -------------------------------------------------------
+void unerf_set_error(const char* fmt, ...);
+int unerf_check_launch(const char* what);
+
+#define UNERF_REQUIRE(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            unerf_set_error(__VA_ARGS__);   \
+            return UNERF_ERR_ARG;           \
+        }                                   \
+    } while (0)
+
+// ---- counter-based RNG (twin: oracle/nerf_oracle.py::_hash32 / mc_keep_mask) --------
+#define UNERF_GOLDEN 0x9E3779B9u
+
+__host__ __device__ __forceinline__ uint32_t unerf_hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x21F0AAADu;
+    x ^= x >> 15;
+    x *= 0x735A2D97u;
+    x ^= x >> 15;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t unerf_mc_key(uint32_t seed, uint32_t pass) {
+    return unerf_hash32(seed + pass * UNERF_GOLDEN);
+}
+__host__ __device__ __forceinline__ uint32_t unerf_mc_base(uint32_t key, uint32_t sample_idx) {
+    return unerf_hash32(unerf_hash32(sample_idx) + key);
+}
+
+// ---- spacing (UniformLinDispPiecewiseSampler) ---------------------------------------
+__host__ __device__ __forceinline__ float unerf_spacing_fn(float x) {
+    return x < 1.f ? x / 2.f : 1.f - 1.f / (2.f * x);
+}
+__host__ __device__ __forceinline__ float unerf_spacing_inv(float x) {
+    return x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x);
+}
+__device__ __forceinline__ float unerf_s2e(float b, float s_near, float s_far) {
+    return unerf_spacing_inv(b * s_far + (1.f - b) * s_near);
+}
+
+__device__ __forceinline__ float unerf_nan_to_num(float w) {
+    if (w != w) return 0.f;
+    if (w > FLT_MAX) return FLT_MAX;
+    if (w < -FLT_MAX) return -FLT_MAX;
+    return w;
+}
+
+// ---- SceneContraction(inf) -> (x+2)/4 -> selector mask ------------------------------
+__device__ __forceinline__ float unerf_normalize_position(float& x, float& y, float& z) {
+    float mag = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
+    if (!(mag < 1.f)) {
+        float s = 2.f - (1.f / mag);
+        x = s * (x / mag);
+        y = s * (y / mag);
+        z = s * (z / mag);
+    }
+    x = (x + 2.f) / 4.f;
+    y = (y + 2.f) / 4.f;
+    z = (z + 2.f) / 4.f;
+    float sel = (x > 0.f && x < 1.f && y > 0.f && y < 1.f && z > 0.f && z < 1.f) ? 1.f : 0.f;
+    x *= sel;
+    y *= sel;
+    z *= sel;
+    return sel;
+}
+
+// ---- one level of the nerfstudio torch HashEncoding ---------------------------------
+// corner order ccc,cfc,ffc,fcc,ccf,cff,fff,fcf; every level hashed; primes 1,2654435761,805459861.
+__device__ __forceinline__ void unerf_hash_corners(float px, float py, float pz, float scale, uint32_t mask,
+                                                   uint32_t (&idx)[8], float& ox, float& oy, float& oz) {
+    float sx = px * scale, sy = py * scale, sz = pz * scale;
+    int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
+    int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
+    ox = sx - (float)fx;
+    oy = sy - (float)fy;
+    oz = sz - (float)fz;
+    uint32_t hcx = (uint32_t)cx, hfx = (uint32_t)fx;
+    uint32_t hcy = (uint32_t)cy * 2654435761u, hfy = (uint32_t)fy * 2654435761u;
+    uint32_t hcz = (uint32_t)cz * 805459861u, hfz = (uint32_t)fz * 805459861u;
+    idx[0] = (hcx ^ hcy ^ hcz) & mask;
+    idx[1] = (hcx ^ hfy ^ hcz) & mask;
+    idx[2] = (hfx ^ hfy ^ hcz) & mask;
+    idx[3] = (hfx ^ hcy ^ hcz) & mask;
+    idx[4] = (hcx ^ hcy ^ hfz) & mask;
+    idx[5] = (hcx ^ hfy ^ hfz) & mask;
+    idx[6] = (hfx ^ hfy ^ hfz) & mask;
+    idx[7] = (hfx ^ hcy ^ hfz) & mask;
+}
+
+__device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lvl, float px, float py, float pz,
+                                                   float scale, uint32_t mask) {
+    uint32_t idx[8];
+    float ox, oy, oz;
+    unerf_hash_corners(px, py, pz, scale, mask, idx, ox, oy, oz);
+    float2 f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = lvl[idx[k]];
+    float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+    float2 r;
+    {
+        float f03 = f[0].x * ox + f[3].x * mx;
+        float f12 = f[1].x * ox + f[2].x * mx;
+        float f56 = f[5].x * ox + f[6].x * mx;
+        float f47 = f[4].x * ox + f[7].x * mx;
+        float f0312 = f03 * oy + f12 * my;
+        float f4756 = f47 * oy + f56 * my;
+        r.x = f0312 * oz + f4756 * mz;
+    }
+    {
+        float f03 = f[0].y * ox + f[3].y * mx;
+        float f12 = f[1].y * ox + f[2].y * mx;
+        float f56 = f[5].y * ox + f[6].y * mx;
+        float f47 = f[4].y * ox + f[7].y * mx;
+        float f0312 = f03 * oy + f12 * my;
+        float f4756 = f47 * oy + f56 * my;
+        r.y = f0312 * oz + f4756 * mz;
+    }
+    return r;
+}
+
+// ---- real SH, 4 levels (components_from_spherical_harmonics) -------------------------
+__device__ __forceinline__ void unerf_sh16(float x, float y, float z, float (&c)[16]) {
+    float xx = x * x, yy = y * y, zz = z * z;
+    c[0] = 0.28209479177387814f;
+    c[1] = 0.4886025119029199f * y;
+    c[2] = 0.4886025119029199f * z;
+    c[3] = 0.4886025119029199f * x;
+    c[4] = 1.0925484305920792f * x * y;
+    c[5] = 1.0925484305920792f * y * z;
+    c[6] = 0.9461746957575601f * zz - 0.31539156525251999f;
+    c[7] = 1.0925484305920792f * x * z;
+    c[8] = 0.5462742152960396f * (xx - yy);
+    c[9] = 0.5900435899266435f * y * (3.f * xx - yy);
+    c[10] = 2.890611442640554f * x * y * z;
+    c[11] = 0.4570457994644658f * y * (5.f * zz - 1.f);
+    c[12] = 0.3731763325901154f * z * (5.f * zz - 3.f);
+    c[13] = 0.4570457994644658f * x * (5.f * zz - 1.f);
+    c[14] = 1.445305721320277f * z * (xx - yy);
+    c[15] = 0.5900435899266435f * x * (xx - 3.f * yy);
+}
+
+__device__ __forceinline__ float unerf_softplus(float x) {
+    // torch.nn.Softplus(beta=1, threshold=20)
+    return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float unerf_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }

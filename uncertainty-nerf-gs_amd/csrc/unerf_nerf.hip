@@ -1,0 +1,947 @@
+// NeRF half of libunerf: ray generation, hash grid, proposal density, weights+PDF resampling,
+// fused main field (active / mc-dropout / laplace heads), composite with variance, moments.
+// gfx950 only; wave = 64.  See include/unerf.h for the contract of each entry point.
+#include "unerf_common.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+// ======================================================================================
+// host plumbing
+// ======================================================================================
+static thread_local char g_err[512] = "";
+
+void unerf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int unerf_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        unerf_set_error("%s: %s", what, hipGetErrorString(e));
+        return UNERF_ERR_HIP;
+    }
+    return UNERF_OK;
+}
+extern "C" const char* unerf_last_error(void) { return g_err; }
+extern "C" int unerf_version(void) { return 1000; }
+extern "C" int unerf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// ======================================================================================
+// wave / group helpers
+// ======================================================================================
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, WIDTH);
+    return v;
+}
+// inclusive scan over a WIDTH-lane group
+template <int WIDTH>
+__device__ __forceinline__ float group_incl_scan(float v, int lane_in_group) {
+#pragma unroll
+    for (int d = 1; d < WIDTH; d <<= 1) {
+        float t = __shfl_up(v, d, WIDTH);
+        if (lane_in_group >= d) v += t;
+    }
+    return v;
+}
+
+// ======================================================================================
+// 1. rays
+// ======================================================================================
+struct RayGenArgs {
+    float R[9];
+    float T[3];
+    float fx, fy, cx, cy;
+    int H, W;
+    int64_t start, count;
+    float* o;
+    float* d;
+    float* pa;
+};
+
+__device__ __forceinline__ void raygen_dir(const RayGenArgs& a, float u, float v, float& dx, float& dy, float& dz) {
+    // sum_c dir[c] * R[r][c], dir = (u, v, -1); torch.sum over 3 elements left to right
+    float x = (u * a.R[0] + v * a.R[1]) + (-1.f) * a.R[2];
+    float y = (u * a.R[3] + v * a.R[4]) + (-1.f) * a.R[5];
+    float z = (u * a.R[6] + v * a.R[7]) + (-1.f) * a.R[8];
+    float n = fmaxf(sqrtf((x * x + y * y) + z * z), 1e-7f);
+    dx = x / n;
+    dy = y / n;
+    dz = z / n;
+}
+
+__global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a) {
+    int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.count) return;
+    int64_t g = a.start + n;
+    int i = (int)(g / a.W), j = (int)(g % a.W);
+    float y = (float)i + 0.5f, x = (float)j + 0.5f;
+    float u0 = (x - a.cx) / a.fx, v0 = -(y - a.cy) / a.fy;
+    float u1 = (x - a.cx + 1.f) / a.fx;
+    float v2 = -(y - a.cy + 1.f) / a.fy;
+    float d0x, d0y, d0z, d1x, d1y, d1z, d2x, d2y, d2z;
+    raygen_dir(a, u0, v0, d0x, d0y, d0z);
+    a.o[n * 3 + 0] = a.T[0];
+    a.o[n * 3 + 1] = a.T[1];
+    a.o[n * 3 + 2] = a.T[2];
+    a.d[n * 3 + 0] = d0x;
+    a.d[n * 3 + 1] = d0y;
+    a.d[n * 3 + 2] = d0z;
+    if (a.pa) {
+        raygen_dir(a, u1, v0, d1x, d1y, d1z);
+        raygen_dir(a, u0, v2, d2x, d2y, d2z);
+        float ex = d0x - d1x, ey = d0y - d1y, ez = d0z - d1z;
+        float fx_ = d0x - d2x, fy_ = d0y - d2y, fz_ = d0z - d2z;
+        float dxn = sqrtf((ex * ex + ey * ey) + ez * ez);
+        float dyn = sqrtf((fx_ * fx_ + fy_ * fy_) + fz_ * fz_);
+        a.pa[n] = dxn * dyn;
+    }
+}
+
+extern "C" int unerf_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, int H, int W,
+                                   int64_t ray_start, int64_t count, float* origins, float* directions,
+                                   float* pixel_area, void* stream) {
+    UNERF_REQUIRE(c2w && origins && directions, "generate_rays: null pointer");
+    UNERF_REQUIRE(H > 0 && W > 0 && ray_start >= 0 && count >= 0 && ray_start + count <= (int64_t)H * W,
+                  "generate_rays: ray range [%lld,+%lld) outside %dx%d", (long long)ray_start, (long long)count, H, W);
+    if (count == 0) return UNERF_OK;
+    RayGenArgs a;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) a.R[r * 3 + c] = c2w[r * 4 + c];
+        a.T[r] = c2w[r * 4 + 3];
+    }
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.H = H; a.W = W;
+    a.start = ray_start; a.count = count; a.o = origins; a.d = directions; a.pa = pixel_area;
+    hipLaunchKernelGGL(raygen_kernel, dim3(blocks_for(count, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return unerf_check_launch("generate_rays");
+}
+
+// ======================================================================================
+// 2. stand-alone hash grid (parity surface for the index bookkeeping)
+// ======================================================================================
+__global__ __launch_bounds__(256) void hashgrid_kernel(const float* __restrict__ xyz, const float* __restrict__ table,
+                                                       const float* __restrict__ scalings, int64_t N, int L, int log2T,
+                                                       float* __restrict__ out, int32_t* __restrict__ out_idx) {
+    int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float px = xyz[n * 3 + 0], py = xyz[n * 3 + 1], pz = xyz[n * 3 + 2];
+    const uint32_t mask = (1u << log2T) - 1u;
+    for (int l = 0; l < L; ++l) {
+        const float2* lvl = reinterpret_cast<const float2*>(table) + ((size_t)l << log2T);
+        float2 f = unerf_hash_level(lvl, px, py, pz, scalings[l], mask);
+        out[n * (2 * L) + 2 * l + 0] = f.x;
+        out[n * (2 * L) + 2 * l + 1] = f.y;
+        if (out_idx) {
+            uint32_t idx[8];
+            float ox, oy, oz;
+            unerf_hash_corners(px, py, pz, scalings[l], mask, idx, ox, oy, oz);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out_idx[(n * L + l) * 8 + k] = (int32_t)(idx[k] + ((uint32_t)l << log2T));
+        }
+    }
+}
+
+extern "C" int unerf_hashgrid_fwd(const float* xyz, const float* table, const float* scalings, int64_t N, int L,
+                                  int log2T, float* out, int32_t* out_idx, void* stream) {
+    UNERF_REQUIRE(xyz && table && scalings && out, "hashgrid_fwd: null pointer");
+    UNERF_REQUIRE(L >= 1 && L <= 32 && log2T >= 1 && log2T <= 24 && N >= 0, "hashgrid_fwd: bad L=%d log2T=%d", L, log2T);
+    if (N == 0) return UNERF_OK;
+    hipLaunchKernelGGL(hashgrid_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, xyz, table,
+                       scalings, N, L, log2T, out, out_idx);
+    return unerf_check_launch("hashgrid_fwd");
+}
+
+// ======================================================================================
+// 3. proposal density: positions -> contraction -> hash grid (L levels) -> MLP(2L->HID->1)
+// ======================================================================================
+struct PropArgs {
+    const float* origins;
+    const float* dirs;
+    const float* sbins;
+    int64_t sstride;
+    int64_t R;
+    int n;
+    float s_near, s_far;
+    unerf_density_net net;
+    float avg;
+    float* out;
+};
+
+template <int L, int HID>
+__global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.R * a.n) return;
+    int64_t r = idx / a.n;
+    int i = (int)(idx - r * a.n);
+    const float* sb = a.sbins + r * a.sstride;
+    float e0 = unerf_s2e(sb[i], a.s_near, a.s_far);
+    float e1 = unerf_s2e(sb[i + 1], a.s_near, a.s_far);
+    float t = e0 + e1;
+    float px = a.origins[r * 3 + 0] + a.dirs[r * 3 + 0] * t / 2.f;
+    float py = a.origins[r * 3 + 1] + a.dirs[r * 3 + 1] * t / 2.f;
+    float pz = a.origins[r * 3 + 2] + a.dirs[r * 3 + 2] * t / 2.f;
+    float sel = unerf_normalize_position(px, py, pz);
+    const uint32_t mask = (1u << a.net.log2T) - 1u;
+    float feat[2 * L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float2* lvl = reinterpret_cast<const float2*>(a.net.table) + ((size_t)l << a.net.log2T);
+        float2 f = unerf_hash_level(lvl, px, py, pz, a.net.scalings[l], mask);
+        feat[2 * l] = f.x;
+        feat[2 * l + 1] = f.y;
+    }
+    const float* __restrict__ w0t = a.net.w0t;
+    const float* __restrict__ b0 = a.net.b0;
+    const float* __restrict__ w1t = a.net.w1t;
+    float h[HID];
+#pragma unroll
+    for (int j = 0; j < HID; ++j) h[j] = b0[j];
+#pragma unroll
+    for (int k = 0; k < 2 * L; ++k) {
+#pragma unroll
+        for (int j = 0; j < HID; ++j) h[j] = fmaf(feat[k], w0t[k * HID + j], h[j]);
+    }
+    float o = a.net.b1[0];
+#pragma unroll
+    for (int j = 0; j < HID; ++j) o = fmaf(fmaxf(h[j], 0.f), w1t[j], o);
+    a.out[idx] = a.avg * expf(o) * sel;
+}
+
+extern "C" int unerf_proposal_density(const float* origins, const float* directions, const float* sbins,
+                                      int64_t sbins_stride, int64_t R, int n, float near_plane, float far_plane,
+                                      const unerf_density_net* net, float average_init_density, float* density_out,
+                                      void* stream) {
+    UNERF_REQUIRE(origins && directions && sbins && net && density_out, "proposal_density: null pointer");
+    UNERF_REQUIRE(net->table && net->scalings && net->w0t && net->b0 && net->w1t && net->b1,
+                  "proposal_density: null pointer inside unerf_density_net");
+    UNERF_REQUIRE(R >= 0 && n >= 1, "proposal_density: bad R/n");
+    UNERF_REQUIRE(sbins_stride == 0 || sbins_stride >= n + 1, "proposal_density: sbins_stride %lld < n+1",
+                  (long long)sbins_stride);
+    UNERF_REQUIRE(net->log2T >= 1 && net->log2T <= 24, "proposal_density: bad log2T");
+    if (R == 0) return UNERF_OK;
+    PropArgs a;
+    a.origins = origins; a.dirs = directions; a.sbins = sbins; a.sstride = sbins_stride; a.R = R; a.n = n;
+    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    a.net = *net; a.avg = average_init_density; a.out = density_out;
+    dim3 grid(blocks_for(R * (int64_t)n, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (net->L == 5 && net->hidden == 16) hipLaunchKernelGGL((prop_density_kernel<5, 16>), grid, block, 0, st, a);
+    else if (net->L == 5 && net->hidden == 64) hipLaunchKernelGGL((prop_density_kernel<5, 64>), grid, block, 0, st, a);
+    else if (net->L == 8 && net->hidden == 64) hipLaunchKernelGGL((prop_density_kernel<8, 64>), grid, block, 0, st, a);
+    else if (net->L == 8 && net->hidden == 16) hipLaunchKernelGGL((prop_density_kernel<8, 16>), grid, block, 0, st, a);
+    else {
+        unerf_set_error("proposal_density: unsupported (L=%d, hidden=%d); built: (5,16) (5,64) (8,16) (8,64)", net->L,
+                        net->hidden);
+        return UNERF_ERR_ARG;
+    }
+    return unerf_check_launch("proposal_density");
+}
+
+// ======================================================================================
+// 4. weights + PDF resampling: one wave per ray, lane owns EPL consecutive samples
+// ======================================================================================
+struct PdfArgs {
+    const float* density;
+    const float* sbins;
+    int64_t sstride;
+    int64_t R;
+    int n;
+    float s_near, s_far;
+    const float* u;
+    int m;
+    float pad, eps;
+    float* sbins_out;
+    float* prop_depth;
+    float* weights_out;
+    float* clip;
+    int64_t ray_offset, chunk_rays;
+};
+
+#define PDF_MAXN 256
+
+template <int EPL>
+__global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
+    __shared__ float s_sb[4][PDF_MAXN + 4];
+    __shared__ float s_cdf[4][PDF_MAXN + 4];
+    __shared__ float s_nb[4][PDF_MAXN + 4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    const bool ray_ok = r < a.R;
+    if (!ray_ok) r = a.R - 1;  // keep all waves alive for the block barriers
+    const int n = a.n, nb = a.m + 1;
+    const float* sb = a.sbins + r * a.sstride;
+    for (int k = lane; k <= n; k += 64) s_sb[wv][k] = sb[k];
+    __syncthreads();
+
+    float eu[EPL + 1], w[EPL], dd[EPL];
+    const int k0 = lane * EPL;
+#pragma unroll
+    for (int e = 0; e <= EPL; ++e) eu[e] = unerf_s2e(s_sb[wv][min(k0 + e, n)], a.s_near, a.s_far);
+    float lsum = 0.f, lexcl[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int k = k0 + e;
+        float dens = (k < n) ? a.density[r * n + k] : 0.f;
+        dd[e] = (k < n) ? (eu[e + 1] - eu[e]) * dens : 0.f;
+        lexcl[e] = lsum;
+        lsum += dd[e];
+    }
+    float carry = group_incl_scan<64>(lsum, lane) - lsum;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        float alpha = 1.f - expf(-dd[e]);
+        float T = expf(-(carry + lexcl[e]));
+        w[e] = (k0 + e < n) ? unerf_nan_to_num(alpha * T) : 0.f;
+        if (a.weights_out && ray_ok && k0 + e < n) a.weights_out[r * n + k0 + e] = w[e];
+    }
+    // median depth of this level (prop_depth_i)
+    if (a.prop_depth) {
+        float ls = 0.f, lc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            ls += w[e];
+            lc[e] = ls;
+        }
+        float cbase = group_incl_scan<64>(ls, lane) - ls;
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) cnt += (k0 + e < n && (cbase + lc[e]) < 0.5f) ? 1 : 0;
+#pragma unroll
+        for (int msk = 32; msk >= 1; msk >>= 1) cnt += __shfl_xor(cnt, msk, 64);
+        int idx = min(cnt, n - 1);
+        int owner = idx / EPL, slot = idx - owner * EPL;
+        float val = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            float st = (eu[e] + eu[e + 1]) / 2.f;
+            float got = __shfl(st, owner, 64);
+            if (e == slot) val = got;
+        }
+        if (lane == 0 && ray_ok) a.prop_depth[r] = val;
+    }
+    // histogram -> pdf -> cdf
+    float wp[EPL], lw = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        wp[e] = (k0 + e < n) ? w[e] + a.pad : 0.f;
+        lw += wp[e];
+    }
+    float wsum = group_sum<64>(lw);
+    float padding = fmaxf(a.eps - wsum, 0.f);
+    float padn = padding / (float)n;
+    wsum += padding;
+    float lp = 0.f, lcdf[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        float pdf = (k0 + e < n) ? (wp[e] + padn) / wsum : 0.f;
+        lp += pdf;
+        lcdf[e] = lp;
+    }
+    float cb = group_incl_scan<64>(lp, lane) - lp;
+    if (lane == 0) s_cdf[wv][0] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+        if (k0 + e < n) s_cdf[wv][k0 + e + 1] = fminf(1.f, cb + lcdf[e]);
+    __syncthreads();
+
+    for (int j = lane; j < nb; j += 64) {
+        float u = a.u[j];
+        int lo = 0, hi = n + 1;  // searchsorted(cdf[0..n], u, side="right")
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (s_cdf[wv][mid] <= u) lo = mid + 1;
+            else hi = mid;
+        }
+        int below = min(max(lo - 1, 0), n), above = min(max(lo, 0), n);
+        float g0 = s_cdf[wv][below], g1 = s_cdf[wv][above];
+        float b0 = s_sb[wv][below], b1 = s_sb[wv][above];
+        float t = (u - g0) / (g1 - g0);
+        t = unerf_nan_to_num(t);
+        t = fminf(fmaxf(t, 0.f), 1.f);
+        float v = b0 + t * (b1 - b0);
+        s_nb[wv][j] = v;
+        if (ray_ok) a.sbins_out[r * nb + j] = v;
+    }
+    if (a.clip) {
+        __syncthreads();
+        if (lane == 0 && ray_ok) {
+            float f0 = unerf_s2e(s_nb[wv][0], a.s_near, a.s_far), f1 = unerf_s2e(s_nb[wv][1], a.s_near, a.s_far);
+            float l0 = unerf_s2e(s_nb[wv][nb - 2], a.s_near, a.s_far), l1 = unerf_s2e(s_nb[wv][nb - 1], a.s_near, a.s_far);
+            float first = (f0 + f1) / 2.f, last = (l0 + l1) / 2.f;
+            int64_t chunk = (a.ray_offset + r) / a.chunk_rays;
+            unsigned int* c = reinterpret_cast<unsigned int*>(a.clip) + chunk * 2;
+            atomicMin(c + 0, __float_as_uint(first));  // positive floats order like their bit patterns
+            atomicMax(c + 1, __float_as_uint(last));
+        }
+    }
+}
+
+extern "C" int unerf_weights_pdf_resample(const float* density, const float* sbins, int64_t sbins_stride, int64_t R,
+                                          int n, float near_plane, float far_plane, const float* u, int m,
+                                          float histogram_padding, float eps, float* sbins_out, float* prop_depth_out,
+                                          float* weights_out, float* clip_minmax, int64_t ray_offset,
+                                          int64_t chunk_rays, void* stream) {
+    UNERF_REQUIRE(density && sbins && u && sbins_out, "weights_pdf_resample: null pointer");
+    UNERF_REQUIRE(n >= 1 && n <= PDF_MAXN, "weights_pdf_resample: n=%d outside [1,%d]", n, PDF_MAXN);
+    UNERF_REQUIRE(m >= 1 && m + 1 <= PDF_MAXN, "weights_pdf_resample: m=%d outside [1,%d]", m, PDF_MAXN - 1);
+    UNERF_REQUIRE(sbins_stride == 0 || sbins_stride >= n + 1, "weights_pdf_resample: sbins_stride < n+1");
+    UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "weights_pdf_resample: chunk_rays must be > 0 with clip_minmax");
+    UNERF_REQUIRE(near_plane > 0.f, "weights_pdf_resample: near plane must be > 0");
+    if (R <= 0) return UNERF_OK;
+    PdfArgs a;
+    a.density = density; a.sbins = sbins; a.sstride = sbins_stride; a.R = R; a.n = n;
+    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    a.u = u; a.m = m; a.pad = histogram_padding; a.eps = eps; a.sbins_out = sbins_out; a.prop_depth = prop_depth_out;
+    a.weights_out = weights_out; a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays;
+    dim3 grid(blocks_for(R, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    int epl = (n + 63) / 64;
+    switch (epl) {
+        case 1: hipLaunchKernelGGL((pdf_kernel<1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((pdf_kernel<2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((pdf_kernel<3>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((pdf_kernel<4>), grid, block, 0, st, a); break;
+    }
+    return unerf_check_launch("weights_pdf_resample");
+}
+
+// ======================================================================================
+// 5. main field.  One wave per block; lane = one sample; activations live in LDS as
+//    [feature][lane] (bank-conflict free), weights stream through the scalar cache
+//    (uniform addresses -> s_load), accumulators are static registers.
+// ======================================================================================
+struct FieldArgs {
+    const float* origins;
+    const float* dirs;
+    const float* sbins;
+    int64_t R;
+    int S;
+    float s_near, s_far;
+    int64_t ray_offset;
+    unerf_field_params p;
+    float* density;
+    float* rgb;
+    float* aux;
+    float* aux2;
+    uint32_t keep_thr;
+    float drop_scale;
+};
+
+// acc[o] = b[o] + sum_i act[i] * Wt[i][o]   (sequential over i, fused multiply-add)
+template <int IN, int OUT>
+__device__ __forceinline__ void dense_lds(const float* __restrict__ Wt, const float* __restrict__ b,
+                                          const float* act, int lane, float (&acc)[OUT]) {
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) acc[o] = b[o];
+#pragma unroll 2
+    for (int i = 0; i < IN; ++i) {
+        float x = act[i * 64 + lane];
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) acc[o] = fmaf(x, Wt[i * OUT + o], acc[o]);
+    }
+}
+
+// same, with an inverted-dropout mask on the 64 inputs (pairs share one hash draw)
+template <int OUT>
+__device__ __forceinline__ void dense_lds_dropout(const float* __restrict__ Wt, const float* __restrict__ b,
+                                                  const float* act, int lane, uint32_t base, uint32_t stream_id,
+                                                  uint32_t thr, float scale, float (&acc)[OUT]) {
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) acc[o] = b[o];
+    for (int j = 0; j < 32; ++j) {
+        uint32_t rnd = unerf_hash32(base + (stream_id * 32u + (uint32_t)j + 1u) * UNERF_GOLDEN);
+        float x0 = act[(2 * j) * 64 + lane];
+        float x1 = act[(2 * j + 1) * 64 + lane];
+        x0 = ((rnd & 0xFFFFu) < thr) ? x0 * scale : 0.f;
+        x1 = ((rnd >> 16) < thr) ? x1 * scale : 0.f;
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) acc[o] = fmaf(x0, Wt[(2 * j) * OUT + o], acc[o]);
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) acc[o] = fmaf(x1, Wt[(2 * j + 1) * OUT + o], acc[o]);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void store_act(float* act, int lane, const float (&v)[N], int row0, bool relu) {
+#pragma unroll
+    for (int o = 0; o < N; ++o) act[(row0 + o) * 64 + lane] = relu ? fmaxf(v[o], 0.f) : v[o];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
+    extern __shared__ float lds[];
+    float* A = lds;                 // [64][64]
+    float* Bf = lds + 64 * 64;      // [64][64] (MCDROPOUT only)
+    const int lane = threadIdx.x;
+    const int64_t N = a.R * (int64_t)a.S;
+    int64_t n = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = n < N;
+    if (!valid) n = N - 1;
+    const int64_t r = n / a.S;
+    const int s = (int)(n - r * a.S);
+
+    const float* sb = a.sbins + r * (a.S + 1);
+    float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+    float t = e0 + e1;
+    float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
+    float px = a.origins[r * 3 + 0] + dxr * t / 2.f;
+    float py = a.origins[r * 3 + 1] + dyr * t / 2.f;
+    float pz = a.origins[r * 3 + 2] + dzr * t / 2.f;
+    const float sel = unerf_normalize_position(px, py, pz);
+
+    const uint32_t mask = (1u << a.p.log2T) - 1u;
+#pragma unroll 4
+    for (int l = 0; l < 16; ++l) {
+        const float2* lvl = reinterpret_cast<const float2*>(a.p.table) + ((size_t)l << a.p.log2T);
+        float2 f = unerf_hash_level(lvl, px, py, pz, a.p.scalings[l], mask);
+        A[(2 * l) * 64 + lane] = f.x;
+        A[(2 * l + 1) * 64 + lane] = f.y;
+    }
+
+    // direction encoding inputs: get_normalized_directions(d) = (d+1)/2 (torch SHEncoding uses it as is)
+    float sh[16];
+    {
+        float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
+        if (a.p.sh_remap) {
+            ux = ux * 2.f - 1.f;
+            uy = uy * 2.f - 1.f;
+            uz = uz * 2.f - 1.f;
+        }
+        unerf_sh16(ux, uy, uz, sh);
+    }
+
+    float acc[64];
+    dense_lds<32, 64>(a.p.w0t, a.p.b0, A, lane, acc);
+
+    if constexpr (MODE == UNERF_FIELD_ACTIVE) {
+        store_act<64>(A, lane, acc, 0, true);
+        float o1[17];
+        dense_lds<64, 17>(a.p.w1t, a.p.b1, A, lane, o1);
+        float density = a.p.average_init_density * expf(o1[0]) * sel;
+        float beta = unerf_softplus(o1[16]) + a.p.beta_min;
+        store_act<16>(A, lane, sh, 0, false);
+#pragma unroll
+        for (int g = 0; g < 15; ++g) A[(16 + g) * 64 + lane] = o1[1 + g];
+        dense_lds<31, 64>(a.p.h0t, a.p.hb0, A, lane, acc);
+        store_act<64>(A, lane, acc, 0, true);
+        dense_lds<64, 64>(a.p.h1t, a.p.hb1, A, lane, acc);
+        store_act<64>(A, lane, acc, 0, true);
+        float c[3];
+        dense_lds<64, 3>(a.p.h2t, a.p.hb2, A, lane, c);
+        if (valid) {
+            a.density[n] = density;
+            a.aux[n] = beta;
+            a.rgb[n * 3 + 0] = unerf_sigmoid(c[0]);
+            a.rgb[n * 3 + 1] = unerf_sigmoid(c[1]);
+            a.rgb[n * 3 + 2] = unerf_sigmoid(c[2]);
+        }
+    } else if constexpr (MODE == UNERF_FIELD_MCDROPOUT) {
+        store_act<64>(A, lane, acc, 0, true);  // hidden h stays in A for every pass
+        const int passes = a.p.K > 0 ? a.p.K : 1;
+        const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
+        for (int k = 0; k < passes; ++k) {
+            const uint32_t base = unerf_mc_base(unerf_mc_key(a.p.seed, (uint32_t)k), sidx);
+            float o1[16];
+            if (a.p.K > 0) dense_lds_dropout<16>(a.p.w1t, a.p.b1, A, lane, base, 0u, a.keep_thr, a.drop_scale, o1);
+            else dense_lds<64, 16>(a.p.w1t, a.p.b1, A, lane, o1);
+            float density = a.p.average_init_density * expf(o1[0]) * sel;
+            store_act<16>(Bf, lane, sh, 0, false);
+#pragma unroll
+            for (int g = 0; g < 15; ++g) Bf[(16 + g) * 64 + lane] = o1[1 + g];
+            dense_lds<31, 64>(a.p.h0t, a.p.hb0, Bf, lane, acc);
+            store_act<64>(Bf, lane, acc, 0, true);
+            dense_lds<64, 64>(a.p.h1t, a.p.hb1, Bf, lane, acc);
+            store_act<64>(Bf, lane, acc, 0, true);
+            float c[3];
+            if (a.p.K > 0) dense_lds_dropout<3>(a.p.h2t, a.p.hb2, Bf, lane, base, 1u, a.keep_thr, a.drop_scale, c);
+            else dense_lds<64, 3>(a.p.h2t, a.p.hb2, Bf, lane, c);
+            if (valid) {
+                int64_t q = (int64_t)k * N + n;
+                a.density[q] = density;
+                a.rgb[q * 3 + 0] = unerf_sigmoid(c[0]);
+                a.rgb[q * 3 + 1] = unerf_sigmoid(c[1]);
+                a.rgb[q * 3 + 2] = unerf_sigmoid(c[2]);
+            }
+        }
+    } else {  // LAPLACE: bare Linear base (no ReLU), sampled last layers
+        store_act<64>(A, lane, acc, 0, false);
+        float geo[15];
+        dense_lds<64, 15>(a.p.w1t, a.p.b1, A, lane, geo);
+        const int nl = a.p.n_lap;
+        float mu = 0.f, mu2 = 0.f;
+        for (int q = 0; q < nl; ++q) {
+            const float* __restrict__ w = a.p.ws_density + (size_t)q * 65;
+            float pre = 0.f;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) pre = fmaf(acc[i], w[i], pre);
+            pre += w[64];
+            float pred = expf(pre);
+            mu += pred;
+            mu2 += pred * pred;
+        }
+        mu /= (float)nl;
+        mu2 /= (float)nl;
+        float var_d = mu2 - mu * mu;
+        store_act<16>(A, lane, sh, 0, false);
+        store_act<15>(A, lane, geo, 16, false);
+        dense_lds<31, 64>(a.p.h0t, a.p.hb0, A, lane, acc);
+        store_act<64>(A, lane, acc, 0, true);
+        dense_lds<64, 64>(a.p.h1t, a.p.hb1, A, lane, acc);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) acc[i] = fmaxf(acc[i], 0.f);
+        float m1[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
+        for (int q = 0; q < nl; ++q) {
+            const float* __restrict__ w = a.p.ws_rgb + (size_t)q * 195;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float pre = 0.f;
+#pragma unroll
+                for (int i = 0; i < 64; ++i) pre = fmaf(acc[i], w[c * 64 + i], pre);
+                pre += w[192 + c];
+                float pred = unerf_sigmoid(pre);
+                m1[c] += pred;
+                m2[c] += pred * pred;
+            }
+        }
+        float vsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            m1[c] /= (float)nl;
+            m2[c] /= (float)nl;
+            vsum += fmaxf(m2[c] - m1[c] * m1[c], 0.f);
+        }
+        if (valid) {
+            a.density[n] = mu;  // NOT selector-masked (laplace_field.py:356-362)
+            a.aux[n] = var_d;
+            a.aux2[n] = vsum / 3.f;
+            a.rgb[n * 3 + 0] = m1[0];
+            a.rgb[n * 3 + 1] = m1[1];
+            a.rgb[n * 3 + 2] = m1[2];
+        }
+    }
+}
+
+extern "C" int unerf_field_fwd(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
+                               float near_plane, float far_plane, int64_t ray_offset, const unerf_field_params* p,
+                               float* density, float* rgb, float* aux, float* aux2, void* stream) {
+    UNERF_REQUIRE(origins && directions && sbins && p && density && rgb, "field_fwd: null pointer");
+    UNERF_REQUIRE(p->table && p->scalings && p->w0t && p->b0 && p->w1t && p->b1 && p->h0t && p->hb0 && p->h1t &&
+                      p->hb1 && p->h2t && p->hb2,
+                  "field_fwd: null weight pointer");
+    UNERF_REQUIRE(p->L == 16, "field_fwd: L=%d (only the nerfacto 16-level grid is built)", p->L);
+    UNERF_REQUIRE(p->log2T >= 1 && p->log2T <= 24, "field_fwd: bad log2T=%d", p->log2T);
+    UNERF_REQUIRE(R >= 0 && S >= 1, "field_fwd: bad R/S");
+    UNERF_REQUIRE((uint64_t)(ray_offset + R) * (uint64_t)S < (1ull << 32),
+                  "field_fwd: sample index exceeds 32 bits (RNG counter)");
+    if (R == 0) return UNERF_OK;
+    FieldArgs a;
+    a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
+    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = ray_offset;
+    a.p = *p; a.density = density; a.rgb = rgb; a.aux = aux; a.aux2 = aux2;
+    a.keep_thr = (uint32_t)lrint((1.0 - (double)p->p_drop) * 65536.0);
+    a.drop_scale = 1.f / (1.f - p->p_drop);
+    dim3 grid(blocks_for(R * (int64_t)S, 64)), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    switch (p->mode) {
+        case UNERF_FIELD_ACTIVE:
+            UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
+            hipLaunchKernelGGL((field_kernel<UNERF_FIELD_ACTIVE>), grid, block, 64 * 64 * 4, st, a);
+            break;
+        case UNERF_FIELD_MCDROPOUT:
+            UNERF_REQUIRE(p->out1 == 16, "field_fwd MCDROPOUT: out1 must be 16");
+            UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
+            hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
+            break;
+        case UNERF_FIELD_LAPLACE:
+            UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,
+                          "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
+            hipLaunchKernelGGL((field_kernel<UNERF_FIELD_LAPLACE>), grid, block, 64 * 64 * 4, st, a);
+            break;
+        default:
+            unerf_set_error("field_fwd: unknown mode %d", p->mode);
+            return UNERF_ERR_ARG;
+    }
+    return unerf_check_launch("field_fwd");
+}
+
+// ======================================================================================
+// 6. per-ray groups of 16 lanes x SPL samples: get_weights, composite, laplace depth draws
+// ======================================================================================
+template <int SPL>
+__device__ __forceinline__ void group_weights(const float (&dens)[SPL], const float (&delta)[SPL], int l16,
+                                              float (&w)[SPL]) {
+    float dd[SPL], lex[SPL], ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        dd[e] = delta[e] * dens[e];
+        lex[e] = ls;
+        ls += dd[e];
+    }
+    float carry = group_incl_scan<16>(ls, l16) - ls;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        float alpha = 1.f - expf(-dd[e]);
+        float T = expf(-(carry + lex[e]));
+        w[e] = unerf_nan_to_num(alpha * T);
+    }
+}
+
+struct CompArgs {
+    const float* density;
+    const float* rgb;
+    const float* beta;
+    const float* walt;
+    const float* sbins;
+    int B;
+    int64_t R;
+    int S;
+    float s_near, s_far;
+    const float* clip;
+    int64_t ray_offset, chunk_rays;
+    float* out;
+};
+
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
+    const int l16 = threadIdx.x & 15;
+    int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t G = (int64_t)a.B * a.R;
+    const bool ok = g < G;
+    if (!ok) g = G - 1;
+    const int64_t r = g % a.R;
+    const int S = a.S, k0 = l16 * SPL;
+    const float* sb = a.sbins + r * (S + 1);
+    float eu[SPL + 1], delta[SPL], steps[SPL], dens[SPL], w[SPL];
+#pragma unroll
+    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[k0 + e], a.s_near, a.s_far);
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        delta[e] = eu[e + 1] - eu[e];
+        steps[e] = (eu[e] + eu[e + 1]) / 2.f;
+        dens[e] = a.density[g * S + k0 + e];
+    }
+    group_weights<SPL>(dens, delta, l16, w);
+
+    float cr = 0.f, cg = 0.f, cb = 0.f, accw = 0.f, uvar = 0.f, lr = 0.f, lg = 0.f, lb = 0.f;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        const float* c = a.rgb + (g * S + k0 + e) * 3;
+        float r0 = unerf_nan_to_num(c[0]), g0 = unerf_nan_to_num(c[1]), b0 = unerf_nan_to_num(c[2]);
+        cr += w[e] * r0;
+        cg += w[e] * g0;
+        cb += w[e] * b0;
+        accw += w[e];
+        if (a.beta) uvar += (w[e] * w[e]) * a.beta[r * S + k0 + e];
+        lr = r0; lg = g0; lb = b0;  // after the loop: this lane's last sample
+    }
+    cr = group_sum<16>(cr);
+    cg = group_sum<16>(cg);
+    cb = group_sum<16>(cb);
+    accw = group_sum<16>(accw);
+    uvar = group_sum<16>(uvar);
+    // background_color = "last_sample"
+    float bgr = __shfl(lr, 15, 16), bgg = __shfl(lg, 15, 16), bgb = __shfl(lb, 15, 16);
+    cr = fminf(fmaxf(cr + bgr * (1.f - accw), 0.f), 1.f);
+    cg = fminf(fmaxf(cg + bgg * (1.f - accw), 0.f), 1.f);
+    cb = fminf(fmaxf(cb + bgb * (1.f - accw), 0.f), 1.f);
+
+    // depth-side weights: the laplace mean sampled weights when given
+    float wd[SPL];
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) wd[e] = a.walt ? a.walt[r * S + k0 + e] : w[e];
+    float ls = 0.f, lc[SPL], wt = 0.f;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        ls += wd[e];
+        lc[e] = ls;
+        wt += wd[e] * steps[e];
+    }
+    float tot = group_incl_scan<16>(ls, l16);
+    float cbase = tot - ls;
+    float acc = __shfl(tot, 15, 16);
+    wt = group_sum<16>(wt);
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) cnt += ((cbase + lc[e]) < 0.5f) ? 1 : 0;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 16);
+    int idx = min(cnt, S - 1);
+    int owner = idx / SPL, slot = idx - owner * SPL;
+    float depth = 0.f;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        float got = __shfl(steps[e], owner, 16);
+        if (e == slot) depth = got;
+    }
+    float dv = 0.f;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        float df = steps[e] - depth;
+        dv += wd[e] * (df * df);
+    }
+    dv = group_sum<16>(dv) + 1e-5f;
+    float ed = wt / (acc + 1e-10f);
+    if (a.clip) {
+        int64_t chunk = (a.ray_offset + r) / a.chunk_rays;
+        ed = fminf(fmaxf(ed, a.clip[chunk * 2 + 0]), a.clip[chunk * 2 + 1]);
+    }
+    if (ok && l16 == 0) {
+        float4* o = reinterpret_cast<float4*>(a.out + g * 8);
+        o[0] = make_float4(cr, cg, cb, acc);
+        o[1] = make_float4(depth, ed, uvar, dv);
+    }
+}
+
+#define UNERF_DISPATCH_SPL(S, KERNEL, ...)                                                                          \
+    switch ((S) / 16) {                                                                                             \
+        case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break;                                                \
+        case 2: hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__); break;                                                \
+        case 3: hipLaunchKernelGGL((KERNEL<3>), __VA_ARGS__); break;                                                \
+        case 4: hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__); break;                                                \
+        case 6: hipLaunchKernelGGL((KERNEL<6>), __VA_ARGS__); break;                                                \
+        case 8: hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__); break;                                                \
+        case 16: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;                                              \
+        default:                                                                                                    \
+            unerf_set_error("samples per ray S=%d unsupported (need S = 16*k, k in {1,2,3,4,6,8,16})", (S));        \
+            return UNERF_ERR_ARG;                                                                                   \
+    }
+
+extern "C" int unerf_composite_var(const float* density, const float* rgb, const float* beta, const float* weights_alt,
+                                   const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane,
+                                   const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, float* out,
+                                   void* stream) {
+    UNERF_REQUIRE(density && rgb && sbins && out, "composite_var: null pointer");
+    UNERF_REQUIRE(B >= 1 && R >= 0, "composite_var: bad B/R");
+    UNERF_REQUIRE(S % 16 == 0, "composite_var: S=%d must be a multiple of 16", S);
+    UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "composite_var: chunk_rays must be > 0 with clip_minmax");
+    if (R == 0) return UNERF_OK;
+    CompArgs a;
+    a.density = density; a.rgb = rgb; a.beta = beta; a.walt = weights_alt; a.sbins = sbins; a.B = B; a.R = R; a.S = S;
+    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays; a.out = out;
+    dim3 grid(blocks_for((int64_t)B * R, 16)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    UNERF_DISPATCH_SPL(S, composite_kernel, grid, block, 0, st, a);
+    return unerf_check_launch("composite_var");
+}
+
+// ---- laplace depth draws --------------------------------------------------------------
+struct LapDepthArgs {
+    const float* mu;
+    const float* var;
+    const float* sbins;
+    int64_t R;
+    int S;
+    float s_near, s_far;
+    const float* noise;
+    int D;
+    uint32_t seed;
+    int64_t ray_offset;
+    float* out;
+};
+
+__device__ __forceinline__ float unerf_normal_from_hash(uint32_t base) {
+    uint32_t r1 = unerf_hash32(base + UNERF_GOLDEN), r2 = unerf_hash32(base + 2u * UNERF_GOLDEN);
+    float u1 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(r2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+template <int SPL>
+__global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
+    const int l16 = threadIdx.x & 15;
+    int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = r < a.R;
+    if (!ok) r = a.R - 1;
+    const int S = a.S, k0 = l16 * SPL;
+    const float* sb = a.sbins + r * (S + 1);
+    float eu[SPL + 1], delta[SPL], mu[SPL], sd[SPL], wsum[SPL], dens[SPL], w[SPL];
+#pragma unroll
+    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[k0 + e], a.s_near, a.s_far);
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        delta[e] = eu[e + 1] - eu[e];
+        mu[e] = a.mu[r * S + k0 + e];
+        float s = sqrtf(a.var[r * S + k0 + e]);
+        sd[e] = (s != s) ? 1e-10f : fmaxf(s, 1e-10f);
+        wsum[e] = 0.f;
+    }
+    for (int d = 0; d < a.D; ++d) {
+        const uint32_t key = unerf_mc_key(a.seed, (uint32_t)d);
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) {
+            float z;
+            if (a.noise) z = a.noise[((int64_t)d * a.R + r) * S + k0 + e];
+            else z = unerf_normal_from_hash(unerf_mc_base(key, (uint32_t)((a.ray_offset + r) * S + k0 + e)));
+            dens[e] = fmaxf(mu[e] + sd[e] * z, 0.f);
+        }
+        group_weights<SPL>(dens, delta, l16, w);
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) wsum[e] += w[e];
+    }
+    if (ok) {
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) a.out[r * S + k0 + e] = wsum[e] / (float)a.D;
+    }
+}
+
+extern "C" int unerf_laplace_depth_weights(const float* density_mu, const float* density_var, const float* sbins,
+                                           int64_t R, int S, float near_plane, float far_plane, const float* noise,
+                                           int D, uint32_t seed, int64_t ray_offset, float* weights_out, void* stream) {
+    UNERF_REQUIRE(density_mu && density_var && sbins && weights_out, "laplace_depth_weights: null pointer");
+    UNERF_REQUIRE(D >= 1 && R >= 0 && S % 16 == 0, "laplace_depth_weights: bad D/R/S");
+    if (R == 0) return UNERF_OK;
+    LapDepthArgs a;
+    a.mu = density_mu; a.var = density_var; a.sbins = sbins; a.R = R; a.S = S;
+    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    a.noise = noise; a.D = D; a.seed = seed; a.ray_offset = ray_offset; a.out = weights_out;
+    dim3 grid(blocks_for(R, 16)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    UNERF_DISPATCH_SPL(S, lap_depth_kernel, grid, block, 0, st, a);
+    return unerf_check_launch("laplace_depth_weights");
+}
+
+// ======================================================================================
+// 7. moments over the leading (pass / member) dimension
+// ======================================================================================
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, int K, int64_t NC,
+                                                      float* __restrict__ mean, float* __restrict__ var) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += x[(int64_t)k * NC + i];
+    float m = s / (float)K;
+    mean[i] = m;
+    if (var) {
+        float q = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float d = x[(int64_t)k * NC + i] - m;
+            q += d * d;
+        }
+        var[i] = q / (float)(K - 1);  // K==1 -> NaN, as torch.var(unbiased) does
+    }
+}
+
+extern "C" int unerf_moments(const float* x, int K, int64_t N, int C, float* mean, float* var, void* stream) {
+    UNERF_REQUIRE(x && mean, "moments: null pointer");
+    UNERF_REQUIRE(K >= 1 && N >= 0 && C >= 1, "moments: bad K/N/C");
+    if (N == 0) return UNERF_OK;
+    hipLaunchKernelGGL(moments_kernel, dim3(blocks_for(N * C, 256)), dim3(256), 0, (hipStream_t)stream, x, K, N * C,
+                       mean, var);
+    return unerf_check_launch("moments");
+}

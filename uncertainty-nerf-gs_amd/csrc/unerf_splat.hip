@@ -1,0 +1,503 @@
+// Gaussian-splat half of libunerf (gsplat 0.1.11 semantics, see include/unerf.h):
+// EWA projection, SH colours + per-splat beta, one bin-and-sort per frame, tile rasteriser with
+// C interleaved channels, alpha normalisation and the per-splat depth-difference gather.
+// Built with -ffp-contract=off: projection / tile boxes / sort keys are bit-exact against the
+// numpy oracle (oracle/splat_oracle.py) which performs the same fp32 operations in the same order.
+#include "unerf_common.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// ======================================================================================
+// projection
+// ======================================================================================
+struct ProjArgs {
+    const float* means;
+    const float* scales;
+    float glob_scale;
+    const float* quats;
+    float V[12];
+    float fx, fy, cx, cy;
+    int H, W, bw;
+    float clip;
+    int64_t N;
+    float* xys;
+    float* depths;
+    int32_t* radii;
+    float* conics;
+    float* comp;
+    int32_t* tiles;
+    float* cov3d;
+};
+
+__device__ __forceinline__ void tile_bbox(float cx, float cy, float radius, int bw, int tbx, int tby, int& x0, int& y0,
+                                          int& x1, int& y1) {
+    float tcx = cx / (float)bw, tcy = cy / (float)bw, tr = radius / (float)bw;
+    x0 = min(max(0, (int)(tcx - tr)), tbx);
+    x1 = min(max(0, (int)(tcx + tr + 1.f)), tbx);
+    y0 = min(max(0, (int)(tcy - tr)), tby);
+    y1 = min(max(0, (int)(tcy + tr + 1.f)), tby);
+}
+
+__global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    // gsplat allocates every output zero-filled; culled splats keep zeros
+    a.radii[i] = 0;
+    a.tiles[i] = 0;
+    a.xys[i * 2] = 0.f;
+    a.xys[i * 2 + 1] = 0.f;
+    a.depths[i] = 0.f;
+    a.comp[i] = 0.f;
+    a.conics[i * 3] = 0.f;
+    a.conics[i * 3 + 1] = 0.f;
+    a.conics[i * 3 + 2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.cov3d[i * 6 + k] = 0.f;
+
+    const float p0 = a.means[i * 3], p1 = a.means[i * 3 + 1], p2 = a.means[i * 3 + 2];
+    const float* V = a.V;
+    float tx = ((V[0] * p0 + V[1] * p1) + V[2] * p2) + V[3];
+    float ty = ((V[4] * p0 + V[5] * p1) + V[6] * p2) + V[7];
+    float tz = ((V[8] * p0 + V[9] * p1) + V[10] * p2) + V[11];
+    if (tz <= a.clip) return;
+
+    // scale_rot_to_cov3d
+    float qw = a.quats[i * 4], qx = a.quats[i * 4 + 1], qy = a.quats[i * 4 + 2], qz = a.quats[i * 4 + 3];
+    float qs = 1.f / sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
+    float w = qw * qs, x = qx * qs, y = qy * qs, z = qz * qs;
+    float Rm[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - w * z),       2.f * (x * z + w * y),
+                   2.f * (x * y + w * z),       1.f - 2.f * (x * x + z * z), 2.f * (y * z - w * x),
+                   2.f * (x * z - w * y),       2.f * (y * z + w * x),       1.f - 2.f * (x * x + y * y)};
+    float s0 = a.glob_scale * a.scales[i * 3], s1 = a.glob_scale * a.scales[i * 3 + 1],
+          s2 = a.glob_scale * a.scales[i * 3 + 2];
+    float M[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        M[r * 3 + 0] = Rm[r * 3 + 0] * s0;
+        M[r * 3 + 1] = Rm[r * 3 + 1] * s1;
+        M[r * 3 + 2] = Rm[r * 3 + 2] * s2;
+    }
+    float Sg[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            Sg[r * 3 + c] = (M[r * 3] * M[c * 3] + M[r * 3 + 1] * M[c * 3 + 1]) + M[r * 3 + 2] * M[c * 3 + 2];
+    a.cov3d[i * 6 + 0] = Sg[0];
+    a.cov3d[i * 6 + 1] = Sg[1];
+    a.cov3d[i * 6 + 2] = Sg[2];
+    a.cov3d[i * 6 + 3] = Sg[4];
+    a.cov3d[i * 6 + 4] = Sg[5];
+    a.cov3d[i * 6 + 5] = Sg[8];
+    // symmetric V from the 6 stored entries (as gsplat rebuilds it)
+    float C3[9] = {Sg[0], Sg[1], Sg[2], Sg[1], Sg[4], Sg[5], Sg[2], Sg[5], Sg[8]};
+
+    // project_cov3d_ewa
+    float tan_fovx = 0.5f * (float)a.W / a.fx, tan_fovy = 0.5f * (float)a.H / a.fy;
+    float lim_x = 1.3f * tan_fovx, lim_y = 1.3f * tan_fovy;
+    float ex = tz * fminf(lim_x, fmaxf(-lim_x, tx / tz));
+    float ey = tz * fminf(lim_y, fmaxf(-lim_y, ty / tz));
+    float rz = 1.f / tz, rz2 = rz * rz;
+    float J00 = a.fx * rz, J02 = (-a.fx * ex) * rz2, J11 = a.fy * rz, J12 = (-a.fy * ey) * rz2;
+    float T0[3], T1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        T0[c] = J00 * V[0 * 4 + c] + J02 * V[2 * 4 + c];
+        T1[c] = J11 * V[1 * 4 + c] + J12 * V[2 * 4 + c];
+    }
+    float TV0[3], TV1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        TV0[c] = (T0[0] * C3[0 * 3 + c] + T0[1] * C3[1 * 3 + c]) + T0[2] * C3[2 * 3 + c];
+        TV1[c] = (T1[0] * C3[0 * 3 + c] + T1[1] * C3[1 * 3 + c]) + T1[2] * C3[2 * 3 + c];
+    }
+    float c00 = (TV0[0] * T0[0] + TV0[1] * T0[1]) + TV0[2] * T0[2];
+    float c01 = (TV0[0] * T1[0] + TV0[1] * T1[1]) + TV0[2] * T1[2];
+    float c11 = (TV1[0] * T1[0] + TV1[1] * T1[1]) + TV1[2] * T1[2];
+    float det_orig = c00 * c11 - c01 * c01;
+    float ca = c00 + 0.3f, cb = c01, cc = c11 + 0.3f;
+    float det = ca * cc - cb * cb;
+    float comp = sqrtf(fmaxf(0.f, det_orig / det));
+    // compute_cov2d_bounds
+    if (det == 0.f) return;
+    float inv_det = 1.f / det;
+    a.conics[i * 3 + 0] = cc * inv_det;
+    a.conics[i * 3 + 1] = -cb * inv_det;
+    a.conics[i * 3 + 2] = ca * inv_det;
+    float bh = 0.5f * (ca + cc);
+    float sq = sqrtf(fmaxf(0.1f, bh * bh - det));
+    float v1 = bh + sq, v2 = bh - sq;
+    float radius = ceilf(3.f * sqrtf(fmaxf(v1, v2)));
+    // project_pix
+    float rw = 1.f / (tz + 1e-6f);
+    float u = (tx * rw) * a.fx + a.cx, v = (ty * rw) * a.fy + a.cy;
+    int tbx = (a.W + a.bw - 1) / a.bw, tby = (a.H + a.bw - 1) / a.bw;
+    int x0, y0, x1, y1;
+    tile_bbox(u, v, radius, a.bw, tbx, tby, x0, y0, x1, y1);
+    int area = (x1 - x0) * (y1 - y0);
+    if (area <= 0) return;
+    a.tiles[i] = area;
+    a.depths[i] = tz;
+    a.radii[i] = (int)radius;
+    a.xys[i * 2] = u;
+    a.xys[i * 2 + 1] = v;
+    a.comp[i] = comp;
+}
+
+extern "C" int unerf_splat_project(const float* means3d, const float* scales, float glob_scale, const float* quats,
+                                   const float* viewmat, float fx, float fy, float cx, float cy, int H, int W,
+                                   int block_width, float clip_thresh, int64_t N, float* xys, float* depths,
+                                   int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit,
+                                   float* cov3d, void* stream) {
+    UNERF_REQUIRE(means3d && scales && quats && viewmat && xys && depths && radii && conics && compensation &&
+                      num_tiles_hit && cov3d,
+                  "splat_project: null pointer");
+    UNERF_REQUIRE(H > 0 && W > 0 && block_width > 0 && block_width <= 16 && N >= 0, "splat_project: bad H/W/block/N");
+    if (N == 0) return UNERF_OK;
+    ProjArgs a;
+    a.means = means3d; a.scales = scales; a.glob_scale = glob_scale; a.quats = quats;
+    for (int k = 0; k < 12; ++k) a.V[k] = viewmat[k];
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.H = H; a.W = W; a.bw = block_width; a.clip = clip_thresh; a.N = N;
+    a.xys = xys; a.depths = depths; a.radii = radii; a.conics = conics; a.comp = compensation;
+    a.tiles = num_tiles_hit; a.cov3d = cov3d;
+    hipLaunchKernelGGL(project_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return unerf_check_launch("splat_project");
+}
+
+// ======================================================================================
+// SH colours (+0.5, clamp>=0) and beta = softplus(log_unc) + beta_min
+// ======================================================================================
+__global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float* __restrict__ means, float cxp,
+                                                        float cyp, float czp, const float* __restrict__ coeffs,
+                                                        const float* __restrict__ log_unc, float beta_min, int64_t N,
+                                                        float* __restrict__ colors, float* __restrict__ beta) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                         0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    const float* k = coeffs + i * 48;
+    float col[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) col[c] = C0 * k[c];
+    if (degree >= 1) {
+        float vx = means[i * 3] - cxp, vy = means[i * 3 + 1] - cyp, vz = means[i * 3 + 2] - czp;
+        float nrm = sqrtf((vx * vx + vy * vy) + vz * vz);
+        float x = vx / nrm, y = vy / nrm, z = vz / nrm;
+        float xx = x * x, xy = x * y, xz = x * z, yy = y * y, yz = y * z, zz = z * z;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            col[c] += C1 * (-y * k[1 * 3 + c] + z * k[2 * 3 + c] - x * k[3 * 3 + c]);
+            if (degree >= 2) {
+                col[c] += (C2[0] * xy * k[4 * 3 + c] + C2[1] * yz * k[5 * 3 + c] +
+                           C2[2] * (2.f * zz - xx - yy) * k[6 * 3 + c] + C2[3] * xz * k[7 * 3 + c] +
+                           C2[4] * (xx - yy) * k[8 * 3 + c]);
+            }
+            if (degree >= 3) {
+                col[c] += (C3[0] * y * (3.f * xx - yy) * k[9 * 3 + c] + C3[1] * xy * z * k[10 * 3 + c] +
+                           C3[2] * y * (4.f * zz - xx - yy) * k[11 * 3 + c] +
+                           C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * k[12 * 3 + c] +
+                           C3[4] * x * (4.f * zz - xx - yy) * k[13 * 3 + c] + C3[5] * z * (xx - yy) * k[14 * 3 + c] +
+                           C3[6] * x * (xx - 3.f * yy) * k[15 * 3 + c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) colors[i * 3 + c] = fmaxf(col[c] + 0.5f, 0.f);
+    if (beta) beta[i] = unerf_softplus(log_unc[i]) + beta_min;
+}
+
+extern "C" int unerf_splat_sh_colors(int degree, const float* means3d, const float* cam_pos, const float* sh_coeffs,
+                                     const float* log_unc, float beta_min, int64_t N, float* colors_out,
+                                     float* beta_out, void* stream) {
+    UNERF_REQUIRE(means3d && cam_pos && sh_coeffs && colors_out, "splat_sh_colors: null pointer");
+    UNERF_REQUIRE(degree >= 0 && degree <= 3, "splat_sh_colors: degree %d outside [0,3]", degree);
+    UNERF_REQUIRE(!beta_out || log_unc, "splat_sh_colors: beta_out without log_unc");
+    if (N <= 0) return UNERF_OK;
+    hipLaunchKernelGGL(sh_colors_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree, means3d,
+                       cam_pos[0], cam_pos[1], cam_pos[2], sh_coeffs, log_unc, beta_min, N, colors_out, beta_out);
+    return unerf_check_launch("splat_sh_colors");
+}
+
+// ======================================================================================
+// bin and sort (once per frame)
+// ======================================================================================
+static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static int sort_bits(int H, int W, int bw) {
+    int64_t tiles = (int64_t)((W + bw - 1) / bw) * ((H + bw - 1) / bw);
+    int b = 1;
+    while (((int64_t)1 << b) < tiles) ++b;
+    return 32 + b;
+}
+
+extern "C" int64_t unerf_splat_sort_workspace_bytes(int64_t N, int64_t I) {
+    size_t scan_tmp = 0, sort_tmp = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, (const int32_t*)nullptr, (int32_t*)nullptr, (int)N);
+    if (I > 0)
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const int64_t*)nullptr, (int64_t*)nullptr,
+                                                 (const int32_t*)nullptr, (int32_t*)nullptr, (int)I, 0, 64);
+    (void)hipGetLastError();
+    int64_t tmp = (int64_t)(scan_tmp > sort_tmp ? scan_tmp : sort_tmp);
+    return align256(tmp) + align256(I * 8) + align256(I * 4) + 1024;
+}
+
+extern "C" int unerf_splat_count_intersects(const int32_t* num_tiles_hit, int64_t N, int32_t* cum_tiles_hit,
+                                            void* workspace, int64_t workspace_bytes, void* stream) {
+    UNERF_REQUIRE(num_tiles_hit && cum_tiles_hit && workspace, "splat_count_intersects: null pointer");
+    UNERF_REQUIRE(N >= 1 && N < (1ll << 31), "splat_count_intersects: bad N");
+    size_t tmp = (size_t)workspace_bytes;
+    hipError_t e = hipcub::DeviceScan::InclusiveSum(workspace, tmp, num_tiles_hit, cum_tiles_hit, (int)N,
+                                                    (hipStream_t)stream);
+    if (e != hipSuccess) {
+        unerf_set_error("splat_count_intersects: %s", hipGetErrorString(e));
+        return UNERF_ERR_HIP;
+    }
+    return unerf_check_launch("splat_count_intersects");
+}
+
+__global__ __launch_bounds__(256) void map_intersects_kernel(const float* __restrict__ xys,
+                                                             const float* __restrict__ depths,
+                                                             const int32_t* __restrict__ radii,
+                                                             const int32_t* __restrict__ cum, int64_t N, int bw, int tbx,
+                                                             int tby, int64_t* __restrict__ keys,
+                                                             int32_t* __restrict__ vals) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    if (radii[i] <= 0) return;
+    int x0, y0, x1, y1;
+    tile_bbox(xys[i * 2], xys[i * 2 + 1], (float)radii[i], bw, tbx, tby, x0, y0, x1, y1);
+    int64_t cur = (i == 0) ? 0 : cum[i - 1];
+    int64_t depth_id = (int64_t)(uint32_t)__float_as_int(depths[i]);
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) {
+            int64_t tile_id = (int64_t)ty * tbx + tx;
+            keys[cur] = (tile_id << 32) | depth_id;
+            vals[cur] = (int32_t)i;
+            ++cur;
+        }
+}
+
+__global__ __launch_bounds__(256) void tile_edges_kernel(const int64_t* __restrict__ keys, int64_t I,
+                                                         int32_t* __restrict__ bins) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    int32_t cur = (int32_t)(keys[i] >> 32);
+    if (i == 0) bins[cur * 2] = 0;
+    if (i == I - 1) bins[cur * 2 + 1] = (int32_t)I;
+    if (i > 0) {
+        int32_t prev = (int32_t)(keys[i - 1] >> 32);
+        if (prev != cur) {
+            bins[prev * 2 + 1] = (int32_t)i;
+            bins[cur * 2] = (int32_t)i;
+        }
+    }
+}
+
+extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const int32_t* radii,
+                                    const int32_t* cum_tiles_hit, int64_t N, int64_t I, int H, int W, int block_width,
+                                    int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted, int32_t* tile_bins,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+    UNERF_REQUIRE(xys && depths && radii && cum_tiles_hit && tile_bins && workspace, "splat_bin_sort: null pointer");
+    UNERF_REQUIRE(N >= 1 && I >= 0 && I < (1ll << 31), "splat_bin_sort: bad N/I");
+    hipStream_t st = (hipStream_t)stream;
+    int tbx = (W + block_width - 1) / block_width, tby = (H + block_width - 1) / block_width;
+    if (hipMemsetAsync(tile_bins, 0, (size_t)tbx * tby * 2 * sizeof(int32_t), st) != hipSuccess)
+        return unerf_check_launch("splat_bin_sort memset");
+    if (I == 0) return UNERF_OK;
+    UNERF_REQUIRE(isect_ids_sorted && gaussian_ids_sorted, "splat_bin_sort: null output");
+    char* ws = (char*)workspace;
+    int64_t off_keys = 0, off_vals = align256(I * 8), off_tmp = off_vals + align256(I * 4);
+    UNERF_REQUIRE(workspace_bytes > off_tmp, "splat_bin_sort: workspace too small");
+    int64_t* keys = (int64_t*)(ws + off_keys);
+    int32_t* vals = (int32_t*)(ws + off_vals);
+    hipLaunchKernelGGL(map_intersects_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, xys, depths, radii,
+                       cum_tiles_hit, N, block_width, tbx, tby, keys, vals);
+    int rc = unerf_check_launch("splat_bin_sort map");
+    if (rc) return rc;
+    size_t tmp = (size_t)(workspace_bytes - off_tmp);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(ws + off_tmp, tmp, keys, isect_ids_sorted, vals,
+                                                      gaussian_ids_sorted, (int)I, 0, sort_bits(H, W, block_width), st);
+    if (e != hipSuccess) {
+        unerf_set_error("splat_bin_sort: radix sort: %s", hipGetErrorString(e));
+        return UNERF_ERR_HIP;
+    }
+    hipLaunchKernelGGL(tile_edges_kernel, dim3(blocks_for(I, 256)), dim3(256), 0, st, isect_ids_sorted, I, tile_bins);
+    return unerf_check_launch("splat_bin_sort edges");
+}
+
+// ======================================================================================
+// rasteriser: one 16x16 tile per workgroup, 256-splat LDS batches, C channels at once
+// ======================================================================================
+struct RasterArgs {
+    const int32_t* ids;
+    const int32_t* bins;
+    const float* xys;
+    const float* conics;
+    const float* colors;
+    const float* opac;
+    const float* bg;
+    int H, W, bw;
+    float* out;
+    float* finalT;
+    int32_t* final_idx;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
+    __shared__ float s_xyo[256 * 3];
+    __shared__ float s_con[256 * 3];
+    __shared__ float s_col[256 * C];
+    const int bw = a.bw;
+    const int tbx = (a.W + bw - 1) / bw;
+    const int tile = blockIdx.y * tbx + blockIdx.x;
+    const int tr = threadIdx.x;
+    const int ly = tr / bw, lx = tr - ly * bw;
+    const int i = blockIdx.y * bw + ly, j = blockIdx.x * bw + lx;
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const bool inside = (ly < bw) && (i < a.H) && (j < a.W);
+    bool done = !inside;
+    const int r0 = a.bins[tile * 2], r1 = a.bins[tile * 2 + 1];
+    const int nbatch = (r1 - r0 + 255) / 256;
+    float T = 1.f;
+    int cur_idx = 0;
+    float pix[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) pix[c] = 0.f;
+    for (int b = 0; b < nbatch; ++b) {
+        if (__syncthreads_count(done ? 1 : 0) >= 256) break;
+        const int start = r0 + 256 * b;
+        const int idx = start + tr;
+        if (idx < r1) {
+            int g = a.ids[idx];
+            s_xyo[tr * 3 + 0] = a.xys[g * 2];
+            s_xyo[tr * 3 + 1] = a.xys[g * 2 + 1];
+            s_xyo[tr * 3 + 2] = a.opac[g];
+            s_con[tr * 3 + 0] = a.conics[g * 3];
+            s_con[tr * 3 + 1] = a.conics[g * 3 + 1];
+            s_con[tr * 3 + 2] = a.conics[g * 3 + 2];
+#pragma unroll
+            for (int c = 0; c < C; ++c) s_col[tr * C + c] = a.colors[(int64_t)g * C + c];
+        }
+        __syncthreads();
+        const int bsz = min(256, r1 - start);
+        for (int t = 0; t < bsz && !done; ++t) {
+            float dx = s_xyo[t * 3] - px, dy = s_xyo[t * 3 + 1] - py, op = s_xyo[t * 3 + 2];
+            float ca = s_con[t * 3], cb = s_con[t * 3 + 1], cc = s_con[t * 3 + 2];
+            float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+            float alpha = fminf(0.999f, op * __expf(-sigma));
+            if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+            float nT = T * (1.f - alpha);
+            if (nT <= 1e-4f) {
+                done = true;
+                break;
+            }
+            float vis = alpha * T;
+#pragma unroll
+            for (int c = 0; c < C; ++c) pix[c] += s_col[t * C + c] * vis;
+            T = nT;
+            cur_idx = start + t;
+        }
+    }
+    if (inside) {
+        int64_t p = (int64_t)i * a.W + j;
+        a.finalT[p] = T;
+        if (a.final_idx) a.final_idx[p] = cur_idx;
+#pragma unroll
+        for (int c = 0; c < C; ++c) a.out[p * C + c] = pix[c] + T * (a.bg ? a.bg[c] : 0.f);
+    }
+}
+
+extern "C" int unerf_splat_rasterize(const int32_t* gaussian_ids_sorted, const int32_t* tile_bins, const float* xys,
+                                     const float* conics, const float* colors, const float* opacities,
+                                     const float* background, int C, int H, int W, int block_width, float* out_img,
+                                     float* final_T, int32_t* final_idx, void* stream) {
+    UNERF_REQUIRE(tile_bins && xys && conics && colors && opacities && out_img && final_T,
+                  "splat_rasterize: null pointer");
+    UNERF_REQUIRE(C >= 1 && C <= 8, "splat_rasterize: C=%d outside [1,8]", C);
+    UNERF_REQUIRE(block_width >= 1 && block_width <= 16 && H > 0 && W > 0, "splat_rasterize: bad block_width/H/W");
+    RasterArgs a;
+    a.ids = gaussian_ids_sorted; a.bins = tile_bins; a.xys = xys; a.conics = conics; a.colors = colors;
+    a.opac = opacities; a.bg = background; a.H = H; a.W = W; a.bw = block_width; a.out = out_img; a.finalT = final_T;
+    a.final_idx = final_idx;
+    dim3 grid((W + block_width - 1) / block_width, (H + block_width - 1) / block_width), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 1: hipLaunchKernelGGL((raster_kernel<1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((raster_kernel<2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((raster_kernel<3>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((raster_kernel<4>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((raster_kernel<5>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((raster_kernel<6>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((raster_kernel<7>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((raster_kernel<8>), grid, block, 0, st, a); break;
+    }
+    return unerf_check_launch("splat_rasterize");
+}
+
+// ======================================================================================
+// alpha normalisation and per-splat depth difference
+// ======================================================================================
+__global__ __launch_bounds__(256) void chan_max_kernel(const float* __restrict__ img, int stride, int ch, int64_t HW,
+                                                       unsigned int* __restrict__ mx) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float v = (i < HW) ? img[i * stride + ch] : 0.f;
+    v = fmaxf(v, 0.f);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(mx, __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void alpha_norm_kernel(float* __restrict__ img, int stride, int ch,
+                                                         const float* __restrict__ finalT, int64_t HW,
+                                                         const float* __restrict__ mx) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    float alpha = 1.f - finalT[i];
+    float v = img[i * stride + ch];
+    img[i * stride + ch] = (alpha > 0.f) ? v / alpha : mx[0];
+}
+
+extern "C" int unerf_splat_alpha_normalize(float* img, int stride, int ch, const float* final_T, int64_t HW,
+                                           float* scratch_max, void* stream) {
+    UNERF_REQUIRE(img && final_T && scratch_max, "splat_alpha_normalize: null pointer");
+    UNERF_REQUIRE(stride >= 1 && ch >= 0 && ch < stride && HW >= 0, "splat_alpha_normalize: bad stride/ch");
+    if (HW == 0) return UNERF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch_max, 0, sizeof(float), st) != hipSuccess)
+        return unerf_check_launch("splat_alpha_normalize memset");
+    hipLaunchKernelGGL(chan_max_kernel, dim3(blocks_for(HW, 256)), dim3(256), 0, st, img, stride, ch, HW,
+                       reinterpret_cast<unsigned int*>(scratch_max));
+    hipLaunchKernelGGL(alpha_norm_kernel, dim3(blocks_for(HW, 256)), dim3(256), 0, st, img, stride, ch, final_T, HW,
+                       scratch_max);
+    return unerf_check_launch("splat_alpha_normalize");
+}
+
+__global__ __launch_bounds__(256) void depth_sqdiff_kernel(const float* __restrict__ xys,
+                                                           const float* __restrict__ depths,
+                                                           const float* __restrict__ dimg, int stride, int ch, int H,
+                                                           int W, int64_t N, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float fxp = floorf(xys[i * 2]), fyp = floorf(xys[i * 2 + 1]);
+    float z = depths[i];
+    // reference uses strict ">0" on both axes (activesplatfacto_model.py:327-332)
+    bool valid = fxp > 0.f && fxp < (float)W && fyp > 0.f && fyp < (float)H;
+    float d = z;
+    if (valid) d = z - dimg[((int64_t)fyp * W + (int64_t)fxp) * stride + ch];
+    out[i] = d * d;
+}
+
+extern "C" int unerf_splat_depth_sqdiff(const float* xys, const float* depths, const float* depth_img, int stride,
+                                        int ch, int H, int W, int64_t N, float* sq_diff_out, void* stream) {
+    UNERF_REQUIRE(xys && depths && depth_img && sq_diff_out, "splat_depth_sqdiff: null pointer");
+    UNERF_REQUIRE(stride >= 1 && ch >= 0 && ch < stride, "splat_depth_sqdiff: bad stride/ch");
+    if (N <= 0) return UNERF_OK;
+    hipLaunchKernelGGL(depth_sqdiff_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, xys, depths,
+                       depth_img, stride, ch, H, W, N, sq_diff_out);
+    return unerf_check_launch("splat_depth_sqdiff");
+}

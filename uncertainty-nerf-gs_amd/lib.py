@@ -1,0 +1,121 @@
+"""ctypes binding of libunerf (include/unerf.h).
+
+The library is built in-tree by ``build_library()`` (called from ``__graft_entry__.build()``)
+with ``hipcc --offload-arch=gfx950``.  There is no Python/CPU fallback: if the shared
+object is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB_PATH = os.path.join(CSRC, "libunerf.so")
+SOURCES = ["unerf_nerf.hip", "unerf_splat.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
+
+
+class UnerfError(RuntimeError):
+    pass
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into csrc/libunerf.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "unerf_common.hpp"), os.path.join(INCLUDE, "unerf.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise UnerfError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+class DensityNet(C.Structure):
+    _fields_ = [
+        ("table", C.c_void_p), ("scalings", C.c_void_p), ("L", C.c_int), ("log2T", C.c_int),
+        ("w0t", C.c_void_p), ("b0", C.c_void_p), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("hidden", C.c_int),
+    ]
+
+
+class FieldParams(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int),
+        ("table", C.c_void_p), ("scalings", C.c_void_p), ("L", C.c_int), ("log2T", C.c_int),
+        ("w0t", C.c_void_p), ("b0", C.c_void_p), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("out1", C.c_int),
+        ("h0t", C.c_void_p), ("hb0", C.c_void_p), ("h1t", C.c_void_p), ("hb1", C.c_void_p),
+        ("h2t", C.c_void_p), ("hb2", C.c_void_p),
+        ("average_init_density", C.c_float), ("beta_min", C.c_float), ("sh_remap", C.c_int),
+        ("K", C.c_int), ("seed", C.c_uint32), ("p_drop", C.c_float),
+        ("ws_density", C.c_void_p), ("ws_rgb", C.c_void_p), ("n_lap", C.c_int),
+    ]
+
+
+FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
+
+_vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every symbol include/unerf.h declares
+SIGNATURES = {
+    "unerf_last_error": (C.c_char_p, []),
+    "unerf_version": (_i, []),
+    "unerf_device_count": (_i, []),
+    "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "unerf_hashgrid_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "unerf_proposal_density": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, C.POINTER(DensityNet), _f, _vp, _vp]),
+    "unerf_weights_pdf_resample": (_i, [_vp, _vp, _i64, _i64, _i, _f, _f, _vp, _i, _f, _f, _vp, _vp, _vp, _vp,
+                                        _i64, _i64, _vp]),
+    "unerf_field_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i64, C.POINTER(FieldParams), _vp, _vp, _vp, _vp, _vp]),
+    "unerf_laplace_depth_weights": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp, _i, _u32, _i64, _vp, _vp]),
+    "unerf_composite_var": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp]),
+    "unerf_moments": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
+    "unerf_splat_project": (_i, [_vp, _vp, _f, _vp, _fp, _f, _f, _f, _f, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp, _vp]),
+    "unerf_splat_sh_colors": (_i, [_i, _vp, _fp, _vp, _vp, _f, _i64, _vp, _vp, _vp]),
+    "unerf_splat_sort_workspace_bytes": (_i64, [_i64, _i64]),
+    "unerf_splat_count_intersects": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
+    "unerf_splat_bin_sort": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "unerf_splat_rasterize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "unerf_splat_alpha_normalize": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp]),
+    "unerf_splat_depth_sqdiff": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen csrc/libunerf.so and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UnerfError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().unerf_last_error().decode(errors="replace")
+        raise UnerfError(f"{what or 'libunerf'} failed (rc={rc}): {msg}")
+
+
+def require_gpu() -> None:
+    if load().unerf_device_count() <= 0:
+        raise UnerfError("no HIP device visible: libunerf has no CPU path")

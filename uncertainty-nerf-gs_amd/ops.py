@@ -1,0 +1,334 @@
+"""torch-tensor wrappers around the libunerf C ABI -- one function per entry point.
+
+torch is plumbing here: it owns device memory and the current HIP stream; every number is
+produced by the HIP kernels in csrc/.  All tensors must be fp32 (or int32/int64 where
+stated), contiguous and on a HIP device; nothing is silently copied to or from the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as _l
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ctx(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _l.UnerfError(f"expected a HIP device, got {device} (libunerf has no CPU path)")
+    return torch.cuda.device(device)
+
+
+def _p(t: Optional[torch.Tensor], dtype=torch.float32, name: str = "tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _l.UnerfError(f"{name}: expected a HIP device tensor (libunerf has no CPU path)")
+    if t.dtype != dtype:
+        raise _l.UnerfError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise _l.UnerfError(f"{name}: must be contiguous")
+    return t.data_ptr()
+
+
+def _host12(m: torch.Tensor):
+    flat = [float(v) for v in m.detach().cpu().to(torch.float32).reshape(-1)[:12]]
+    return (C.c_float * 12)(*flat)
+
+
+# ------------------------------------------------------------------ rays ---------------
+
+def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int, device,
+                  ray_start: int = 0, count: Optional[int] = None, pixel_area: bool = False):
+    """-> origins [count,3], directions [count,3], (pixel_area [count,1] | None)"""
+    lib = _l.load()
+    count = H * W - ray_start if count is None else count
+    o = torch.empty(count, 3, device=device, dtype=torch.float32)
+    d = torch.empty(count, 3, device=device, dtype=torch.float32)
+    pa = torch.empty(count, 1, device=device, dtype=torch.float32) if pixel_area else None
+    with _ctx(o.device):
+        _l.check(lib.unerf_generate_rays(_host12(c2w), fx, fy, cx, cy, H, W, ray_start, count, _p(o), _p(d),
+                                         _p(pa), _stream()), "generate_rays")
+    return o, d, pa
+
+
+# ------------------------------------------------------------- hash grid ---------------
+
+def hashgrid_fwd(xyz: torch.Tensor, table: torch.Tensor, scalings: torch.Tensor, log2T: int,
+                 return_indices: bool = False):
+    lib = _l.load()
+    N, L = xyz.shape[0], scalings.numel()
+    out = torch.empty(N, 2 * L, device=xyz.device, dtype=torch.float32)
+    idx = torch.empty(N, L, 8, device=xyz.device, dtype=torch.int32) if return_indices else None
+    with _ctx(xyz.device):
+        _l.check(lib.unerf_hashgrid_fwd(_p(xyz, name="xyz"), _p(table, name="table"), _p(scalings), N, L, log2T,
+                                        _p(out), _p(idx, torch.int32), _stream()), "hashgrid_fwd")
+    return (out, idx) if return_indices else out
+
+
+# --------------------------------------------------------- parameter packs --------------
+
+@dataclass
+class DensityNetDev:
+    """Device-resident proposal network (hash grid + Linear-ReLU-Linear), weights transposed."""
+    table: torch.Tensor
+    scalings: torch.Tensor
+    log2T: int
+    w0t: torch.Tensor
+    b0: torch.Tensor
+    w1t: torch.Tensor
+    b1: torch.Tensor
+
+    @classmethod
+    def from_torch(cls, table, scalings, log2T, w0, b0, w1, b1, device):
+        f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        return cls(f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1))
+
+    def cstruct(self) -> _l.DensityNet:
+        return _l.DensityNet(_p(self.table), _p(self.scalings), self.scalings.numel(), self.log2T, _p(self.w0t),
+                             _p(self.b0), _p(self.w1t), _p(self.b1), self.b0.numel())
+
+
+@dataclass
+class FieldDev:
+    """Device-resident main field.  `head0` is the first colour Linear (64x63) split as
+    [SH16 | geo15 | appearance32]: the appearance block is folded into the bias with the
+    constant eval embedding (NerfactoField.get_outputs eval branch; laplace_field.py:386-398)."""
+    mode: int
+    table: torch.Tensor
+    scalings: torch.Tensor
+    log2T: int
+    w0t: torch.Tensor
+    b0: torch.Tensor
+    w1t: torch.Tensor
+    b1: torch.Tensor
+    h0t: torch.Tensor
+    hb0: torch.Tensor
+    h1t: torch.Tensor
+    hb1: torch.Tensor
+    h2t: torch.Tensor
+    hb2: torch.Tensor
+    average_init_density: float = 1.0
+    beta_min: float = 0.01
+    sh_remap: int = 0
+    K: int = 0
+    seed: int = 0
+    p_drop: float = 0.2
+    ws_density: Optional[torch.Tensor] = None
+    ws_rgb: Optional[torch.Tensor] = None
+
+    @classmethod
+    def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device, **kw):
+        f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        h0 = head_w[0].detach().to(torch.float32)
+        hb0 = head_b[0].detach().to(torch.float32) + h0[:, 31:] @ appearance.detach().to(torch.float32)
+        return cls(mode, f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
+                   f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]), **kw)
+
+    def cstruct(self) -> _l.FieldParams:
+        return _l.FieldParams(
+            self.mode, _p(self.table), _p(self.scalings), self.scalings.numel(), self.log2T,
+            _p(self.w0t), _p(self.b0), _p(self.w1t), _p(self.b1), self.b1.numel(),
+            _p(self.h0t), _p(self.hb0), _p(self.h1t), _p(self.hb1), _p(self.h2t), _p(self.hb2),
+            self.average_init_density, self.beta_min, self.sh_remap, self.K, self.seed & 0xFFFFFFFF, self.p_drop,
+            _p(self.ws_density), _p(self.ws_rgb), 0 if self.ws_density is None else self.ws_density.shape[0])
+
+
+# ------------------------------------------------------- proposal sampling -------------
+
+def proposal_density(origins, directions, sbins, net: DensityNetDev, near: float, far: float,
+                     average_init_density: float, n: Optional[int] = None) -> torch.Tensor:
+    """sbins: [n+1] shared row or [R,n+1] per ray -> density [R,n]"""
+    lib = _l.load()
+    R = origins.shape[0]
+    stride = 0 if sbins.dim() == 1 else sbins.shape[1]
+    n = sbins.shape[-1] - 1 if n is None else n
+    out = torch.empty(R, n, device=origins.device, dtype=torch.float32)
+    cs = net.cstruct()
+    with _ctx(origins.device):
+        _l.check(lib.unerf_proposal_density(_p(origins), _p(directions), _p(sbins), stride, R, n, near, far,
+                                            C.byref(cs), average_init_density, _p(out), _stream()), "proposal_density")
+    return out
+
+
+def weights_pdf_resample(density, sbins, u, near: float, far: float, histogram_padding: float = 0.01,
+                         eps: float = 1e-5, want_prop_depth: bool = True, want_weights: bool = False,
+                         clip_minmax: Optional[torch.Tensor] = None, ray_offset: int = 0, chunk_rays: int = 1 << 15):
+    """-> (new sbins [R,m+1], prop_depth [R,1] | None, weights [R,n] | None)"""
+    lib = _l.load()
+    R, n = density.shape
+    m = u.numel() - 1
+    stride = 0 if sbins.dim() == 1 else sbins.shape[1]
+    out = torch.empty(R, m + 1, device=density.device, dtype=torch.float32)
+    pd = torch.empty(R, 1, device=density.device, dtype=torch.float32) if want_prop_depth else None
+    w = torch.empty(R, n, device=density.device, dtype=torch.float32) if want_weights else None
+    with _ctx(density.device):
+        _l.check(lib.unerf_weights_pdf_resample(_p(density), _p(sbins), stride, R, n, near, far, _p(u), m,
+                                                histogram_padding, eps, _p(out), _p(pd), _p(w), _p(clip_minmax),
+                                                ray_offset, chunk_rays, _stream()), "weights_pdf_resample")
+    return out, pd, w
+
+
+def new_clip_buffer(num_rays: int, chunk_rays: int, device) -> torch.Tensor:
+    nchunks = (num_rays + chunk_rays - 1) // chunk_rays
+    buf = torch.empty(nchunks, 2, device=device, dtype=torch.float32)
+    buf[:, 0] = float("inf")
+    buf[:, 1] = 0.0
+    return buf
+
+
+# ------------------------------------------------------------ main field ---------------
+
+def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0):
+    """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h)"""
+    lib = _l.load()
+    R, S = sbins.shape[0], sbins.shape[1] - 1
+    B = max(field.K, 1) if field.mode == _l.FIELD_MCDROPOUT else 1
+    dev = origins.device
+    density = torch.empty(B, R, S, device=dev, dtype=torch.float32)
+    rgb = torch.empty(B, R, S, 3, device=dev, dtype=torch.float32)
+    aux = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
+    aux2 = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode == _l.FIELD_LAPLACE else None
+    cs = field.cstruct()
+    with _ctx(dev):
+        _l.check(lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, ray_offset,
+                                     C.byref(cs), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()), "field_fwd")
+    return density, rgb, aux, aux2
+
+
+def laplace_depth_weights(density_mu, density_var, sbins, near: float, far: float, noise: Optional[torch.Tensor],
+                          D: int = 100, seed: int = 0, ray_offset: int = 0) -> torch.Tensor:
+    lib = _l.load()
+    R, S = density_mu.shape
+    out = torch.empty(R, S, device=density_mu.device, dtype=torch.float32)
+    with _ctx(out.device):
+        _l.check(lib.unerf_laplace_depth_weights(_p(density_mu), _p(density_var), _p(sbins), R, S, near, far,
+                                                 _p(noise), D, seed & 0xFFFFFFFF, ray_offset, _p(out), _stream()),
+                 "laplace_depth_weights")
+    return out
+
+
+def composite_var(density, rgb, sbins, near: float, far: float, beta=None, weights_alt=None, clip_minmax=None,
+                  ray_offset: int = 0, chunk_rays: int = 1 << 15) -> torch.Tensor:
+    """density [B,R,S] -> out [B,R,8] = rgb3, accumulation, depth, expected_depth, rgb_var, depth_var"""
+    lib = _l.load()
+    B, R, S = density.shape
+    out = torch.empty(B, R, 8, device=density.device, dtype=torch.float32)
+    with _ctx(out.device):
+        _l.check(lib.unerf_composite_var(_p(density), _p(rgb), _p(beta), _p(weights_alt), _p(sbins), B, R, S, near,
+                                         far, _p(clip_minmax), ray_offset, chunk_rays, _p(out), _stream()),
+                 "composite_var")
+    return out
+
+
+def moments(x: torch.Tensor, want_var: bool = True):
+    """x [K,N,C] -> mean [N,C], var [N,C] (unbiased) | None"""
+    lib = _l.load()
+    K, N, Cc = x.shape
+    mean = torch.empty(N, Cc, device=x.device, dtype=torch.float32)
+    var = torch.empty(N, Cc, device=x.device, dtype=torch.float32) if want_var else None
+    with _ctx(x.device):
+        _l.check(lib.unerf_moments(_p(x), K, N, Cc, _p(mean), _p(var), _stream()), "moments")
+    return mean, var
+
+
+# ---------------------------------------------------------------- splats ---------------
+
+def splat_project(means3d, scales, glob_scale: float, quats, viewmat: torch.Tensor, fx, fy, cx, cy, H: int, W: int,
+                  block_width: int = 16, clip_thresh: float = 0.01):
+    """gsplat.project_gaussians signature -> (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)"""
+    lib = _l.load()
+    N, dev = means3d.shape[0], means3d.device
+    xys = torch.empty(N, 2, device=dev)
+    depths = torch.empty(N, device=dev)
+    radii = torch.empty(N, device=dev, dtype=torch.int32)
+    conics = torch.empty(N, 3, device=dev)
+    comp = torch.empty(N, device=dev)
+    tiles = torch.empty(N, device=dev, dtype=torch.int32)
+    cov3d = torch.empty(N, 6, device=dev)
+    with _ctx(dev):
+        _l.check(lib.unerf_splat_project(_p(means3d), _p(scales), glob_scale, _p(quats), _host12(viewmat), fx, fy, cx,
+                                         cy, H, W, block_width, clip_thresh, N, _p(xys), _p(depths),
+                                         _p(radii, torch.int32), _p(conics), _p(comp), _p(tiles, torch.int32),
+                                         _p(cov3d), _stream()), "splat_project")
+    return xys, depths, radii, conics, comp, tiles, cov3d
+
+
+def splat_sh_colors(degree: int, means3d, cam_pos: torch.Tensor, sh_coeffs, log_unc=None, beta_min: float = 0.01):
+    lib = _l.load()
+    N, dev = means3d.shape[0], means3d.device
+    colors = torch.empty(N, 3, device=dev)
+    beta = torch.empty(N, device=dev) if log_unc is not None else None
+    cp = (C.c_float * 3)(*[float(v) for v in cam_pos.detach().cpu().reshape(-1)[:3]])
+    with _ctx(dev):
+        _l.check(lib.unerf_splat_sh_colors(degree, _p(means3d), cp, _p(sh_coeffs), _p(log_unc), beta_min, N,
+                                           _p(colors), _p(beta), _stream()), "splat_sh_colors")
+    return colors, beta
+
+
+def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_width: int = 16):
+    """-> (num_intersects, cum_tiles_hit, isect_ids_sorted, gaussian_ids_sorted, tile_bins [tiles,2])
+    One host read-back (num_intersects) sizes the buffers, as gsplat's compute_cumulative_intersects does."""
+    lib = _l.load()
+    N, dev = xys.shape[0], xys.device
+    tbx, tby = (W + block_width - 1) // block_width, (H + block_width - 1) // block_width
+    cum = torch.empty(N, device=dev, dtype=torch.int32)
+    with _ctx(dev):
+        ws0 = torch.empty(int(lib.unerf_splat_sort_workspace_bytes(N, 0)), device=dev, dtype=torch.uint8)
+        _l.check(lib.unerf_splat_count_intersects(_p(num_tiles_hit, torch.int32), N, _p(cum, torch.int32),
+                                                  _p(ws0, torch.uint8), ws0.numel(), _stream()), "splat_count")
+        I = int(cum[-1].item())
+        ws = torch.empty(int(lib.unerf_splat_sort_workspace_bytes(N, I)), device=dev, dtype=torch.uint8)
+        ids = torch.empty(max(I, 1), device=dev, dtype=torch.int64)
+        gids = torch.empty(max(I, 1), device=dev, dtype=torch.int32)
+        bins = torch.empty(tbx * tby, 2, device=dev, dtype=torch.int32)
+        _l.check(lib.unerf_splat_bin_sort(_p(xys), _p(depths), _p(radii, torch.int32), _p(cum, torch.int32), N, I, H,
+                                          W, block_width, _p(ids, torch.int64), _p(gids, torch.int32),
+                                          _p(bins, torch.int32), _p(ws, torch.uint8), ws.numel(), _stream()),
+                 "splat_bin_sort")
+    return I, cum, ids[:I], gids[:I], bins
+
+
+def splat_rasterize(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, H: int, W: int,
+                    background: Optional[torch.Tensor] = None, block_width: int = 16, want_final_idx: bool = False):
+    """colors [N,C] -> (out_img [H,W,C], final_T [H,W], final_idx | None)"""
+    lib = _l.load()
+    dev, Cn = xys.device, colors.shape[1]
+    out = torch.empty(H, W, Cn, device=dev)
+    fT = torch.empty(H, W, device=dev)
+    fidx = torch.empty(H, W, device=dev, dtype=torch.int32) if want_final_idx else None
+    if gaussian_ids_sorted.numel() == 0:
+        gaussian_ids_sorted = torch.zeros(1, device=dev, dtype=torch.int32)
+    with _ctx(dev):
+        _l.check(lib.unerf_splat_rasterize(_p(gaussian_ids_sorted, torch.int32), _p(tile_bins, torch.int32), _p(xys),
+                                           _p(conics), _p(colors), _p(opacities), _p(background), Cn, H, W,
+                                           block_width, _p(out), _p(fT), _p(fidx, torch.int32), _stream()),
+                 "splat_rasterize")
+    return out, fT, fidx
+
+
+def splat_alpha_normalize(img: torch.Tensor, ch: int, final_T: torch.Tensor) -> None:
+    """in place on channel `ch` of img [H,W,C]"""
+    lib = _l.load()
+    H, W, Cn = img.shape
+    scratch = torch.empty(1, device=img.device)
+    with _ctx(img.device):
+        _l.check(lib.unerf_splat_alpha_normalize(_p(img), Cn, ch, _p(final_T), H * W, _p(scratch), _stream()),
+                 "splat_alpha_normalize")
+
+
+def splat_depth_sqdiff(xys, depths, depth_img: torch.Tensor, ch: int) -> torch.Tensor:
+    lib = _l.load()
+    H, W, Cn = depth_img.shape
+    out = torch.empty(xys.shape[0], device=xys.device)
+    with _ctx(xys.device):
+        _l.check(lib.unerf_splat_depth_sqdiff(_p(xys), _p(depths), _p(depth_img), Cn, ch, H, W, xys.shape[0], _p(out),
+                                              _stream()), "splat_depth_sqdiff")
+    return out

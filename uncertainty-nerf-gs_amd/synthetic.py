@@ -1,0 +1,143 @@
+"""Seeded synthetic workloads: no dataset, no checkpoint, no network.
+
+Everything here is plain torch-CPU tensor generation; the result is a dict of tensors in the
+torch nn.Linear layout ([out,in]) that both the device path (`scene_to_device`) and the CPU
+oracle (`oracle.nerf_oracle.scene_from_tensors`) are built from, so they see identical weights.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from . import lib as _l
+from . import ops
+from .render import NerfSceneDev
+
+
+def hash_scalings(num_levels: int, min_res: int, max_res: int) -> torch.Tensor:
+    """nerfstudio HashEncoding.__init__: floor(min_res * growth**levels) with the growth factor a
+    numpy float64 raised to an int64 torch tensor (-> float32 pow; a 16..2048 grid ends at 2047)."""
+    levels = torch.arange(num_levels)
+    growth = np.exp((np.log(max_res) - np.log(min_res)) / (num_levels - 1)) if num_levels > 1 else 1
+    return torch.floor(min_res * growth ** levels).to(torch.float32)
+
+
+def _linear(gen, out_dim, in_dim):
+    bound = 1.0 / math.sqrt(in_dim)
+    w = (torch.rand(out_dim, in_dim, generator=gen) * 2 - 1) * bound
+    b = (torch.rand(out_dim, generator=gen) * 2 - 1) * bound
+    return w, b
+
+
+def _grid(gen, num_levels, min_res, max_res, log2T, table_scale):
+    T = 1 << log2T
+    table = (torch.rand(num_levels * T, 2, generator=gen) * 2 - 1) * table_scale
+    return {"table": table, "scalings": hash_scalings(num_levels, min_res, max_res), "log2T": log2T}
+
+
+def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, prop_log2T: int = 17,
+                       max_res: int = 2048, table_scale: float = 0.5, density_gain: float = 16.0,
+                       density_bias: float = -2.0, color_gain: float = 4.0) -> Dict:
+    """Random-init nerfacto-shaped scene.  Tables U(-1,1)*table_scale; Linear layers
+    Kaiming-uniform like nn.Linear; the density row is gained up so accumulation, depth and the
+    variances vary over the image instead of saturating."""
+    assert kind in ("active", "mcdropout", "laplace")
+    gen = torch.Generator().manual_seed(seed)
+    f = _grid(gen, 16, 16, max_res, log2T, table_scale)
+    f["w0"], f["b0"] = _linear(gen, 64, 32)
+    out1 = {"active": 17, "mcdropout": 16, "laplace": 15}[kind]
+    f["w1"], f["b1"] = _linear(gen, out1, 64)
+    head_w, head_b = [], []
+    for i, o in ((63, 64), (64, 64), (64, 3)):
+        w, b = _linear(gen, o, i)
+        head_w.append(w * (color_gain if o == 3 else 1.0))
+        head_b.append(b)
+    f["head_w"], f["head_b"] = head_w, head_b
+    f["appearance"] = torch.randn(32, generator=gen) * 0.1
+    f["average_init_density"] = 1.0
+    f["beta_min"] = 0.01
+    if kind == "laplace":
+        f["w1"] = f["w1"] * color_gain
+        dw, db = _linear(gen, 1, 64)
+        f["density_w"] = dw * (density_gain / 4)
+        f["density_b"] = db * 0 + density_bias
+    else:
+        f["w1"][0] *= density_gain
+        f["w1"][1:16] *= color_gain
+        f["b1"][0] = density_bias
+    props = []
+    for mr in (128, 256):
+        p = _grid(gen, 5, 16, mr, prop_log2T, table_scale)
+        p["w0"], p["b0"] = _linear(gen, 16, 10)
+        p["w1"], p["b1"] = _linear(gen, 1, 16)
+        p["w1"][0] *= density_gain
+        p["b1"][0] = density_bias + math.log(100.0)  # proposal nets carry average_init_density = 0.01
+        props.append(p)
+    return {"kind": kind, "field": f, "props": props, "near": 0.05, "far": 1000.0, "num_prop": (256, 96),
+            "num_nerf": 48, "prop_average_init_density": 0.01}
+
+
+_MODE = {"active": _l.FIELD_ACTIVE, "mcdropout": _l.FIELD_MCDROPOUT, "laplace": _l.FIELD_LAPLACE}
+
+
+def scene_to_device(t: Dict, device, **field_kw) -> NerfSceneDev:
+    f = t["field"]
+    fd = ops.FieldDev.from_torch(_MODE[t["kind"]], f["table"], f["scalings"], f["log2T"], f["w0"], f["b0"], f["w1"],
+                                 f["b1"], f["head_w"], f["head_b"], f["appearance"], device,
+                                 average_init_density=float(f["average_init_density"]),
+                                 beta_min=float(f["beta_min"]), **field_kw)
+    props = [ops.DensityNetDev.from_torch(p["table"], p["scalings"], p["log2T"], p["w0"], p["b0"], p["w1"], p["b1"],
+                                          device) for p in t["props"]]
+    return NerfSceneDev(field=fd, props=props, near=float(t["near"]), far=float(t["far"]),
+                        num_prop=tuple(t["num_prop"]), num_nerf=int(t["num_nerf"]),
+                        prop_average_init_density=float(t["prop_average_init_density"]))
+
+
+def laplace_weight_samples(t: Dict, seed: int = 42, n_samples: int = 100, prior_prec: float = 1.0,
+                           eps: float = 1e-9, ggn_scale: float = 1e3):
+    """Synthetic diagonal GGN ~ U(0, ggn_scale) and the n_samples last-layer parameter draws
+    mu + randn * 1/sqrt(ggn + prior + eps) for both heads (laplace_field.py:538-547).
+    -> (ws_density [n,65], ws_rgb [n,195])  (CPU tensors)"""
+    g = torch.Generator().manual_seed(seed)
+    f = t["field"]
+    out = []
+    for w, b in ((f["density_w"], f["density_b"]), (f["head_w"][2], f["head_b"][2])):
+        mu = torch.cat([w.reshape(-1), b.reshape(-1)])
+        ggn = torch.rand(mu.numel(), generator=g) * ggn_scale
+        std = 1 / torch.sqrt(ggn + prior_prec + eps)
+        out.append(mu.view(1, -1) + torch.randn(n_samples, mu.numel(), generator=g) * std.view(1, -1))
+    return out[0], out[1]
+
+
+def orbit_c2w(theta: float, radius: float = 0.6, height: float = 0.15) -> torch.Tensor:
+    """3x4 camera-to-world on a circle, looking at the origin, up = +z (nerfstudio: camera looks down -z)."""
+    eye = np.array([radius * math.cos(theta), radius * math.sin(theta), height], dtype=np.float64)
+    fwd = -eye / np.linalg.norm(eye)
+    up = np.array([0.0, 0.0, 1.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    up2 = np.cross(right, fwd)
+    return torch.from_numpy(np.stack([right, up2, -fwd, eye], axis=1).astype(np.float32))
+
+
+# cameras of SURVEY.md 8(d)
+CAMERA_1080P = dict(fx=1111.0, fy=1111.0, cx=960.0, cy=540.0, H=1080, W=1920)
+CAMERA_LEGO200 = dict(fx=277.78, fy=277.78, cx=100.0, cy=100.0, H=200, W=200)
+
+
+def make_splat_tensors(seed: int = 7, N: int = 1_000_000) -> Dict[str, torch.Tensor]:
+    """Synthetic splat set of SURVEY.md 8(d) (gauss_params names of activesplatfacto_model.py:72)."""
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(N, 4, generator=g)
+    return {
+        "means": torch.rand(N, 3, generator=g) * 2 - 1,
+        "scales": torch.randn(N, 3, generator=g) * 0.5 - 4.0,
+        "quats": q / q.norm(dim=-1, keepdim=True),
+        "opacities": torch.randn(N, 1, generator=g) * 2.0,
+        "features_dc": torch.randn(N, 3, generator=g) * 0.5,
+        "features_rest": torch.randn(N, 15, 3, generator=g) * 0.05,
+        "log_uncertainties": torch.rand(N, 1, generator=g),
+    }
