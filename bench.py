@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the uncertainty-rendering hot path on MI355X.
+
+A "step" is one full 1920x1080 frame (2,073,600 rays, Mip-NeRF360-garden-shaped synthetic
+camera orbit) through the whole path: ray generation -> proposal sampling (256 -> 96 -> 48
+samples, two hash-MLP density nets + PDF resampling) -> main field (16-level hash grid + fused
+MLPs with the method's uncertainty head) -> front-to-back composite with variance
+[-> per-pixel mean/std over the K MC passes].  Inputs (weights, tables, camera) are resident in
+HBM before the timed region; synthetic seeded data, random-init weights of the nerfacto shape.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--method active|mcdropout|laplace] [--mc-samples 8]
+
+N>1 is launched by torch.distributed.run (one rank per GPU).  Rays are independent, so ranks
+render different cameras of the orbit with replicated weights and no data-path collective
+("weak" scaling); the barrier + max-over-ranks timing uses RCCL.
+Prints ONE JSON line on rank 0 (contract in the task statement), carrying `roofline` for the
+dominant kernel and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same rays).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector = fp32-input MFMA peak (the field MLP computes in fp32)
+
+# algorithmic work per ray (SURVEY.md 8d / DESIGN.md "Kernels"): bytes the algorithm must touch
+def _alg(kind, K):
+    S0, S1, S = 256, 96, 48
+    corner = 8 * 8  # 8 corners x (2 x fp32)
+    passes = max(K, 1)
+    mlp_shared = 2 * 32 * 64
+    mlp_tail = {"active": 2 * 64 * 17, "mcdropout": 2 * 64 * 16, "laplace": 2 * 64 * 15}[kind] + 2 * 63 * 64 + 2 * 64 * 64
+    last = 2 * 64 * 3 if kind != "laplace" else 100 * (2 * 64 * 1 + 2 * 64 * 3)
+    return {
+        "proposal_density_256": {"bytes": S0 * 5 * corner + 24 + S0 * 4, "flops": S0 * (2 * 10 * 16 + 2 * 16)},
+        "proposal_density_96": {"bytes": S1 * 5 * corner + 24 + (S1 + 1) * 4 + S1 * 4, "flops": S1 * (2 * 10 * 16 + 2 * 16)},
+        "weights_pdf_resample_256": {"bytes": S0 * 4 + (S1 + 1) * 4 + 4, "flops": 0},
+        "weights_pdf_resample_96": {"bytes": S1 * 4 + (S1 + 1) * 4 + (S + 1) * 4 + 4, "flops": 0},
+        "field_fwd": {"bytes": S * 16 * corner + 24 + (S + 1) * 4 + passes * S * 16 + S * 8,
+                      "flops": S * (mlp_shared + passes * (mlp_tail + last))},
+        "composite_var": {"bytes": passes * (S * 16 + 32) + (S + 1) * 4 + S * 4, "flops": 0},
+        "moments": {"bytes": passes * 24 + 48, "flops": 0},
+        "laplace_depth_weights": {"bytes": S * 12 + (S + 1) * 4, "flops": 0},
+        "generate_rays": {"bytes": 24, "flops": 0},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--method", default="active", choices=["active", "mcdropout", "laplace"])
+    ap.add_argument("--mc-samples", type=int, default=8)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--rays-per-launch", type=int, default=1 << 18)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+
+    from uncertainty_nerf_gs_amd import lib, ops, render, synthetic
+    lib.build_library()
+    lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    K = args.mc_samples if args.method == "mcdropout" else 0
+    t = synthetic.make_scene_tensors(seed=0, kind=args.method)   # full nerfacto shape: 16x2^19x2 + 2 x 5x2^17x2
+    kw = {}
+    if args.method == "mcdropout":
+        kw = dict(K=K, seed=1234, p_drop=0.2)
+    if args.method == "laplace":
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+        kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+    scene = synthetic.scene_to_device(t, dev, **kw)
+    H, W = args.height, args.width
+    cam = dict(synthetic.CAMERA_1080P)
+    cam.update(H=H, W=W, cx=W / 2, cy=H / 2)
+    n_views = 24
+    poses = [synthetic.orbit_c2w(2 * math.pi * i / n_views) for i in range(n_views)]
+
+    def frame(i):
+        c2w = poses[(rank + i * world) % n_views]   # view-batch partition across ranks
+        return render.render_camera(scene, c2w, rays_per_launch=args.rays_per_launch, depth_seed=7, **cam)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = frame(i)
+    sync_all()
+    ops.TIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = frame(args.warmup + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    timer = ops.TIMER
+    ops.TIMER = None
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out["rgb"]).all()
+
+    rays = H * W * args.steps * world
+    mrays = rays / elapsed / 1e6
+
+    if rank == 0:
+        ksum = timer.summary()
+        alg = _alg(args.method, K)
+        dom = max(ksum, key=lambda k: ksum[k]["total_ms"])
+        rays_per_launch = H * W * args.steps / ksum[dom]["launches"]
+        avg_s = ksum[dom]["avg_ms"] * 1e-3
+        a = alg.get(dom, {"bytes": 0, "flops": 0})
+        if dom == "field_fwd":
+            roof = {"kernel": dom, "bound": "mfma", "achieved": a["flops"] * rays_per_launch / avg_s / 1e12,
+                    "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                    "note": "fp32 arithmetic (fp32-input MFMA peak = fp32 vector peak)"}
+        else:
+            roof = {"kernel": dom, "bound": "hbm", "achieved": a["bytes"] * rays_per_launch / avg_s / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["avg_launch_ms"] = ksum[dom]["avg_ms"]
+        roof["launches"] = ksum[dom]["launches"]
+        roof["per_kernel_ms_per_frame"] = {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(ksum.items())}
+        # whole-path algorithmic bytes per ray against the HBM roof
+        path_bytes = sum(alg[k]["bytes"] for k in ksum if k in alg)
+        roof["path_bytes_per_ray"] = path_bytes
+        roof["path_frac_of_hbm_peak"] = path_bytes * (H * W * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(t, args, poses[0], cam, K)
+
+        line = {
+            "metric": "Mrays/s (+var), Mip-NeRF360-garden-shaped 1080p", "value": mrays, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.method}-nerfacto {W}x{H} render with variance"
+                                   + (f", K={K} MC-dropout passes" if K else "")
+                                   + (", 100 last-layer Laplace samples" if args.method == "laplace" else ""),
+                       "rays_per_step": H * W, "samples_per_ray": [256, 96, 48], "hash_grid": "16x2^19x2 fp32",
+                       "parallelism": f"views x{world}" if world > 1 else "single"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(t, args, c2w, cam, K):
+    """The CPU oracle (a port: the reference's own stack is not installable here) on a bounded,
+    strided sample of the same frame's rays, all host cores."""
+    from oracle import nerf_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sc = O.scene_from_tensors(t)
+    o, d, _ = O.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["H"], cam["W"])
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    chunk = 1024
+    stride = max(1, o.shape[0] // 64 // chunk) * chunk
+    done, t0, i = 0, time.perf_counter(), 0
+    wsd = wsr = None
+    if args.method == "laplace":
+        from uncertainty_nerf_gs_amd import synthetic
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+    while time.perf_counter() - t0 < args.cpu_seconds and i * stride + chunk <= o.shape[0]:
+        oo, dd = o[i * stride:i * stride + chunk], d[i * stride:i * stride + chunk]
+        if args.method == "active":
+            O.active_outputs(sc, oo, dd)
+        elif args.method == "mcdropout":
+            O.mcdropout_outputs(sc, oo, dd, K, 1234, 0.2, ray_offset=i * stride)
+        else:
+            O.laplace_outputs(sc, oo, dd, wsd, wsr, torch.randn(100, chunk, 48))
+        done += chunk
+        i += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{done} rays ({done // chunk} strided 1024-ray chunks of the same 1080p camera), {dt:.1f} s, "
+                      f"torch-CPU fp32 oracle, {cores} threads"}
+
+
+if __name__ == "__main__":
+    main()

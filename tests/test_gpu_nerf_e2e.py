@@ -1,0 +1,168 @@
+"""End-to-end parity of the three NeRF methods: full camera render through the C ABI against the
+CPU oracle; gates = the north-star tolerances (|dPSNR| <= 1e-4 dB, |dAUSE| <= 1e-3) plus
+per-key image tolerances.  Sizes are small enough for the oracle to finish in seconds."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cam(H, W):
+    return dict(fx=0.9 * W, fy=0.9 * W, cx=W / 2, cy=H / 2, H=H, W=W)
+
+
+def _oracle_rays(c2w, cam):
+    o, d, _ = O.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["H"], cam["W"])
+    return o, d
+
+
+def _gt_image(ref_rgb):
+    """Synthetic ground truth: the oracle image plus seeded structured noise (sigma 0.05),
+    so PSNR is ~26 dB and the error has spatial structure for AUSE."""
+    g = torch.Generator().manual_seed(123)
+    noise = torch.randn(ref_rgb.shape, generator=g) * 0.05 * (0.3 + torch.rand(ref_rgb.shape[:2] + (1,), generator=g))
+    return torch.clamp(ref_rgb + noise, 0, 1)
+
+
+def _report(name, rec):
+    """Append the achieved deltas to gpurun_out/parity_report.jsonl (scratch dir on the GPU box)."""
+    import json, os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **rec}) + "\n")
+
+
+def _gates(name, out_rgb, out_std, ref_rgb, ref_std):
+    """The north-star parity gates: |dPSNR| <= 1e-4 dB and |dAUSE| <= 1e-3 against the same GT."""
+    from uncertainty_nerf_gs_amd import metrics
+    gt = _gt_image(ref_rgb)
+    rec = {"psnr_ref": metrics.psnr(ref_rgb, gt), "d_psnr": abs(metrics.psnr(out_rgb, gt) - metrics.psnr(ref_rgb, gt)),
+           "max_abs_rgb": (out_rgb - ref_rgb).abs().max().item(),
+           "max_abs_rgb_std": (out_std - ref_std).abs().max().item()}
+    for et in ("mse", "mae", "rmse"):
+        def a(rgb, std):
+            err = torch.sum((rgb - gt) ** 2, -1).flatten() if et != "mae" else torch.sum((rgb - gt).abs(), -1).flatten()
+            return metrics.ause((std ** 2).flatten(), err, et)[3]
+        rec[f"ause_{et}_ref"] = a(ref_rgb, ref_std)
+        rec[f"d_ause_{et}"] = abs(a(out_rgb, out_std) - rec[f"ause_{et}_ref"])
+    _report(name, rec)
+    assert rec["d_psnr"] <= 1e-4, f"|dPSNR| = {rec['d_psnr']:.2e} dB"
+    for et in ("mse", "mae", "rmse"):
+        assert rec[f"d_ause_{et}"] <= 1e-3, f"|dAUSE_{et}| = {rec[f'd_ause_{et}']:.2e}"
+
+
+def _img_close(got, ref, atol, rtol, what, max_bad_frac=0.0):
+    got, ref = got.cpu().double(), ref.double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    bad = (got - ref).abs() > atol + rtol * ref.abs()
+    frac = bad.double().mean().item()
+    assert frac <= max_bad_frac, f"{what}: {frac:.3e} of pixels off, worst {(got - ref).abs().max().item():.3e}"
+
+
+def test_active_nerfacto_camera_parity(dev):
+    from uncertainty_nerf_gs_amd import render, synthetic
+    t = synthetic.make_scene_tensors(seed=0, kind="active", log2T=15, prop_log2T=13)
+    sc = O.scene_from_tensors(t)
+    sd = synthetic.scene_to_device(t, dev)
+    sd.chunk_rays = 1024  # several reference chunks + a ragged tail: 56*72 = 4032 = 3*1024 + 960
+    H, W = 56, 72
+    cam, c2w = _cam(H, W), synthetic.orbit_c2w(0.7)
+    out = render.render_camera(sd, c2w, rays_per_launch=2048, keep_density=True, **cam)
+    o, d = _oracle_rays(c2w, cam)
+    ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=1024)
+    assert set(ref) <= set(out), set(ref) - set(out)
+    _gates("active", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    # Image-level tolerances.  The whole chain runs in fp32 on both sides, but the sample positions
+    # pass through cumsum -> searchsorted -> the spacing->euclidean map (d euclid / d s = 2 euclid^2),
+    # so a 1e-6 difference in a CDF (sequential vs parallel scan order) moves far samples by ~1e-3.
+    _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb")
+    _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=2e-3)
+    _img_close(out["rgb_var"], ref["rgb_var"], 1e-6, 2e-3, "rgb_var")
+    _img_close(out["rgb_std"], ref["rgb_std"], 1e-5, 1e-3, "rgb_std")
+    _img_close(out["depth"], ref["depth"], 0, 1e-3, "median depth", max_bad_frac=1e-2)
+    _img_close(out["depth_var"], ref["depth_var"], 0, 5e-3, "depth_var", max_bad_frac=1e-2)
+    _img_close(out["prop_depth_0"], ref["prop_depth_0"], 0, 1e-4, "prop_depth_0", max_bad_frac=5e-3)
+    _img_close(out["prop_depth_1"], ref["prop_depth_1"], 0, 1e-3, "prop_depth_1", max_bad_frac=1e-2)
+    _img_close(out["density"], ref["density"], 1e-6, 1e-2, "density", max_bad_frac=1e-3)
+
+
+def test_mcdropout_camera_parity(dev):
+    from uncertainty_nerf_gs_amd import render, synthetic
+    K, seed, p = 4, 1234, 0.2
+    t = synthetic.make_scene_tensors(seed=1, kind="mcdropout", log2T=14, prop_log2T=12)
+    sc = O.scene_from_tensors(t)
+    sd = synthetic.scene_to_device(t, dev, K=K, seed=seed, p_drop=p)
+    sd.chunk_rays = 512
+    H, W = 32, 40
+    cam, c2w = _cam(H, W), synthetic.orbit_c2w(2.1)
+    out = render.render_camera(sd, c2w, rays_per_launch=1024, **cam)
+    o, d = _oracle_rays(c2w, cam)
+    ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, K, seed, p, ray_offset=off), o, d, chunk=512)
+    assert set(ref) == set(out), set(ref) ^ set(out)
+    _gates("mcdropout", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb (mean over K)")
+    _img_close(out["rgb_std"], ref["rgb_std"], 1e-5, 5e-3, "rgb_std")
+    _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=2e-3)
+    _img_close(out["expected_depth_std"], ref["expected_depth_std"], 1e-3, 2e-2, "expected_depth_std", max_bad_frac=1e-2)
+    _img_close(out["depth"], ref["depth"], 0, 1e-3, "depth", max_bad_frac=2e-2)
+
+
+def test_laplace_camera_parity(dev):
+    from uncertainty_nerf_gs_amd import render, synthetic
+    t = synthetic.make_scene_tensors(seed=2, kind="laplace", log2T=14, prop_log2T=12)
+    wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+    sc = O.scene_from_tensors(t)
+    sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+    H, W = 24, 32
+    cam, c2w = _cam(H, W), synthetic.orbit_c2w(4.0)
+    g = torch.Generator().manual_seed(8)
+    noise = torch.randn(100, H * W, 48, generator=g)
+    from uncertainty_nerf_gs_amd import ops
+    o, d, _ = ops.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, dev)
+    out = render.render_rays(sd, o, d, depth_noise=noise.to(dev))
+    oo, dd = _oracle_rays(c2w, cam)
+    ref = O.laplace_outputs(sc, oo.reshape(-1, 3), dd.reshape(-1, 3), wsd, wsr, noise)
+    assert set(ref) == set(out), set(ref) ^ set(out)
+    _gates("laplace", out["rgb"].cpu().view(H, W, 3), out["rgb_std"].cpu().view(H, W, 1), ref["rgb"].view(H, W, 3),
+           ref["rgb_std"].view(H, W, 1))
+    _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb")
+    _img_close(out["rgb_std"], ref["rgb_std"], 2e-5, 5e-3, "rgb_std")
+    _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=2e-3)
+    _img_close(out["depth"], ref["depth"], 0, 1e-3, "depth", max_bad_frac=2e-2)
+    _img_close(out["depth_std"], ref["depth_std"], 0, 5e-3, "depth_std", max_bad_frac=2e-2)
+
+
+def test_full_1080p_frame_properties(dev):
+    """BASELINE size (full nerfacto tables, 1920x1080): size-independent properties instead of an
+    oracle comparison -- finite outputs, accumulation in [0,1], sorted sample bins, chunk-independent
+    results (a 2^15-ray slice rendered alone equals the same rows of the full frame, bit for bit)."""
+    from uncertainty_nerf_gs_amd import ops, render, synthetic
+    t = synthetic.make_scene_tensors(seed=0, kind="active")
+    sd = synthetic.scene_to_device(t, dev)
+    cam, c2w = dict(synthetic.CAMERA_1080P), synthetic.orbit_c2w(0.0)
+    out = render.render_camera(sd, c2w, **cam)
+    H, W = cam["H"], cam["W"]
+    for k in ("rgb", "accumulation", "depth", "expected_depth", "rgb_var", "depth_var"):
+        assert out[k].shape[:2] == (H, W) and torch.isfinite(out[k]).all(), k
+    assert out["rgb"].min() >= 0 and out["rgb"].max() <= 1
+    assert out["accumulation"].min() >= -1e-6 and out["accumulation"].max() <= 1 + 1e-5
+    assert (out["rgb_var"] >= 0).all() and (out["depth_var"] >= 1e-5 * 0.999).all()
+    assert out["accumulation"].std() > 1e-3, "synthetic scene must not be degenerate"
+    # slice [a, a+2^15) on its own (chunk-aligned so the clip bounds are the same chunk's)
+    a = 7 * (1 << 15)
+    o, d, _ = ops.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, dev, a, 1 << 15)
+    part = render.render_rays(sd, o, d, ray_offset=a, total_rays=H * W)
+    for k in ("rgb", "accumulation", "depth", "expected_depth", "rgb_var", "depth_var"):
+        full = out[k].view(H * W, -1)[a:a + (1 << 15)]
+        assert torch.equal(part[k], full), f"{k}: launch grouping changed the result"
+    sb, _ = render.sample_rays(sd, o, d, None, a)
+    assert torch.all(sb[:, 1:] >= sb[:, :-1]) and sb.min() >= 0 and sb.max() <= 1

@@ -1,0 +1,293 @@
+"""Per-kernel parity: each HIP entry point (called through the C ABI) against the CPU oracle on
+the same seeded inputs.  Tolerances are stated per test; integer/index results are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+NEAR, FAR = 0.05, 1000.0
+
+
+def _scene(kind, dev, log2T=14, prop_log2T=12, **kw):
+    from uncertainty_nerf_gs_amd import synthetic
+    t = synthetic.make_scene_tensors(seed=0, kind=kind, log2T=log2T, prop_log2T=prop_log2T)
+    return t, O.scene_from_tensors(t), synthetic.scene_to_device(t, dev, **kw)
+
+
+def _rays(H=24, W=32, theta=0.3):
+    from uncertainty_nerf_gs_amd import synthetic
+    c2w = synthetic.orbit_c2w(theta)
+    o, d, _ = O.generate_rays(c2w, 30.0, 30.0, W / 2, H / 2, H, W)
+    return o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()
+
+
+def _close(got, ref, rtol, atol, what, max_bad_frac=0.0):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    bad = (got - ref).abs() > (atol + rtol * ref.abs())
+    frac = bad.double().mean().item()
+    worst = (got - ref).abs().max().item()
+    assert frac <= max_bad_frac, f"{what}: {frac:.3e} of elements off (worst |diff|={worst:.3e})"
+
+
+def test_generate_rays_matches_oracle_and_row_major_indexing(dev):
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    c2w = synthetic.orbit_c2w(1.1)
+    H, W = 37, 53
+    o_ref, d_ref, pa_ref = O.generate_rays(c2w, 41.0, 43.0, 26.0, 18.0, H, W)
+    o, d, pa = ops.generate_rays(c2w, 41.0, 43.0, 26.0, 18.0, H, W, dev, pixel_area=True)
+    _close(o, o_ref.reshape(-1, 3), 0, 0, "origins")
+    _close(d, d_ref.reshape(-1, 3), 0, 3e-7, "directions")
+    _close(pa, pa_ref.reshape(-1, 1), 1e-3, 1e-9, "pixel_area")
+    # ray/chunk bookkeeping is exact: a slice [a,b) equals rows a..b of the full bundle, bit for bit
+    a, b = 123, 123 + 777
+    o2, d2, _ = ops.generate_rays(c2w, 41.0, 43.0, 26.0, 18.0, H, W, dev, ray_start=a, count=b - a)
+    assert torch.equal(d2, d[a:b]) and torch.equal(o2, o[a:b])
+
+
+@pytest.mark.parametrize("L,min_res,max_res,log2T", [(16, 16, 2048, 14), (5, 16, 128, 12), (5, 16, 256, 17), (16, 16, 2048, 19)])
+def test_hashgrid_indices_and_features_bit_exact(dev, L, min_res, max_res, log2T):
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    g = torch.Generator().manual_seed(L * 100 + log2T)
+    scal = synthetic.hash_scalings(L, min_res, max_res)
+    table = (torch.rand(L << log2T, 2, generator=g) * 2 - 1)
+    xyz = torch.rand(4096, 3, generator=g)
+    # edge cases: origin (masked positions), exact grid nodes, upper border, tiny values
+    xyz[0] = 0.0
+    xyz[1] = torch.tensor([0.5, 0.25, 0.125])
+    xyz[2] = 1.0 - 2 ** -24
+    xyz[3] = torch.tensor([1.0 / 16, 2.0 / 16, 3.0 / 16])
+    xyz[4] = 1e-30
+    out, idx = ops.hashgrid_fwd(xyz.to(dev), table.to(dev), scal.to(dev), log2T, return_indices=True)
+    idx_ref, _ = O.hash_indices(xyz, scal, log2T)
+    assert torch.equal(idx.cpu().long(), idx_ref), "hash table row indices must be bit-exact"
+    ref = O.hash_encode(xyz, table, scal, log2T)
+    assert torch.equal(out.cpu(), ref), f"features differ: max {(out.cpu() - ref).abs().max().item():.3e}"
+
+
+def test_hashgrid_empty_input(dev):
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    scal = synthetic.hash_scalings(16, 16, 2048).to(dev)
+    out = ops.hashgrid_fwd(torch.empty(0, 3, device=dev), torch.rand(16 << 4, 2, device=dev), scal, 4)
+    assert out.shape == (0, 32)
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_proposal_density_matches_oracle(dev, level):
+    from uncertainty_nerf_gs_amd import ops
+    t, sc, sd = _scene("active", dev)
+    o, d = _rays()
+    n = 256 if level == 0 else 96
+    if level == 0:
+        sb = O.initial_spacing_bins(n)
+        sb_ref = sb[None].expand(o.shape[0], -1)
+    else:
+        g = torch.Generator().manual_seed(1)
+        sb = torch.sort(torch.rand(o.shape[0], n + 1, generator=g), dim=-1).values
+        sb_ref = sb
+    eb = O.spacing_to_euclidean(sb_ref, NEAR, FAR)
+    ref = O.density_field(O.sample_positions(o, d, eb), sc.prop_nets[level], 0.01)
+    got = ops.proposal_density(o.to(dev), d.to(dev), sb.contiguous().to(dev), sd.props[level], NEAR, FAR, 0.01)
+    _close(got, ref, 3e-5, 1e-9, f"proposal density level {level}")
+
+
+@pytest.mark.parametrize("n,m", [(256, 96), (96, 48), (64, 32), (100, 48)])
+def test_weights_pdf_resample_matches_oracle(dev, n, m):
+    from uncertainty_nerf_gs_amd import ops, render
+    g = torch.Generator().manual_seed(n + m)
+    R = 203
+    dens = torch.exp(torch.randn(R, n, generator=g) * 2.5)
+    dens[0] = 0.0               # empty ray -> uniform resampling through the padding branch
+    dens[1, : n // 2] = 0.0
+    dens[2] = 1e4               # saturates immediately
+    dens[3, 5] = float("inf")   # nan_to_num path
+    sb = torch.sort(torch.rand(R, n + 1, generator=g), dim=-1).values
+    sb[4] = O.initial_spacing_bins(n)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    w_ref = O.get_weights(dens, eb[:, 1:] - eb[:, :-1])
+    new_ref = O.pdf_resample(w_ref, sb, m)
+    pd_ref = O.render_depth_median(w_ref, (eb[:, :-1] + eb[:, 1:]) / 2)
+    clip = ops.new_clip_buffer(R, 64, dev)
+    new, pd, w = ops.weights_pdf_resample(dens.to(dev), sb.to(dev), render._pdf_u(m).to(dev), NEAR, FAR,
+                                          want_weights=True, clip_minmax=clip, ray_offset=0, chunk_rays=64)
+    _close(w, w_ref, 2e-5, 1e-7, "weights")
+    _close(new, new_ref, 0, 3e-6, "resampled spacing bins", max_bad_frac=2e-4)
+    assert torch.all(new[:, 1:] >= new[:, :-1]), "bins must stay sorted"
+    # median depth picks a sample mid-point: identical except where cumsum(w) grazes 0.5
+    _close(pd, pd_ref, 1e-5, 0, "prop depth", max_bad_frac=0.02)
+    # per-chunk clip bounds == min / max of the new samples' mid-points over each 64-ray chunk
+    eb_new = O.spacing_to_euclidean(new.cpu(), NEAR, FAR)
+    steps = (eb_new[:, :-1] + eb_new[:, 1:]) / 2
+    for c in range(clip.shape[0]):
+        rows = steps[c * 64:(c + 1) * 64]
+        assert abs(clip[c, 0].item() - rows.min().item()) <= 1e-6 * rows.min().item()
+        assert abs(clip[c, 1].item() - rows.max().item()) <= 1e-6 * rows.max().item()
+
+
+def test_weights_pdf_resample_shared_initial_bins(dev):
+    from uncertainty_nerf_gs_amd import ops, render
+    g = torch.Generator().manual_seed(5)
+    dens = torch.exp(torch.randn(64, 256, generator=g) * 2)
+    sb = O.initial_spacing_bins(256)
+    eb = O.spacing_to_euclidean(sb[None].expand(64, -1), NEAR, FAR)
+    ref = O.pdf_resample(O.get_weights(dens, eb[:, 1:] - eb[:, :-1]), sb[None].expand(64, -1), 96)
+    new, _, _ = ops.weights_pdf_resample(dens.to(dev), sb.to(dev), render._pdf_u(96).to(dev), NEAR, FAR)
+    _close(new, ref, 0, 3e-6, "bins from shared row", max_bad_frac=2e-4)
+
+
+def _final_bins(sc, o, d):
+    bins, wl, bl = O.proposal_sample(o, d, NEAR, FAR, sc.prop_nets, sc.num_prop, sc.num_nerf, 0.01)
+    return bins.contiguous()
+
+
+def test_field_active_matches_oracle(dev):
+    from uncertainty_nerf_gs_amd import ops
+    t, sc, sd = _scene("active", dev)
+    o, d = _rays()
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    dens_ref, rgb_ref, beta_ref = O.active_field(o, d, eb, sc.field)
+    dens, rgb, beta, _ = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
+    _close(dens[0], dens_ref, 2e-4, 1e-7, "density")
+    _close(rgb[0], rgb_ref, 0, 2e-5, "rgb")
+    _close(beta, beta_ref, 1e-4, 1e-6, "beta")
+
+
+@pytest.mark.parametrize("K", [0, 3])
+def test_field_mcdropout_matches_oracle(dev, K):
+    from uncertainty_nerf_gs_amd import ops
+    seed, p = 1234, 0.2
+    t, sc, sd = _scene("mcdropout", dev, K=K, seed=seed, p_drop=p)
+    o, d = _rays(16, 24)
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    ray_offset = 1000
+    dens, rgb, _, _ = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR, ray_offset=ray_offset)
+    R, S = sb.shape[0], sb.shape[1] - 1
+    assert dens.shape == (max(K, 1), R, S)
+    sidx = ((np.arange(R)[:, None] + ray_offset) * S + np.arange(S)[None]).reshape(-1)
+    for k in range(max(K, 1)):
+        kt = kh = None
+        if K > 0:
+            kt = torch.from_numpy(O.mc_keep_mask(seed, k, sidx, 0, 64, p))
+            kh = torch.from_numpy(O.mc_keep_mask(seed, k, sidx, 1, 64, p))
+            assert 0.75 < kt.float().mean() < 0.85
+        dr, cr = O.mcdropout_field(o, d, eb, sc.field, kt, kh, p)
+        _close(dens[k], dr, 2e-4, 1e-7, f"density pass {k}")
+        _close(rgb[k], cr, 0, 2e-5, f"rgb pass {k}")
+    if K > 1:
+        assert not torch.equal(dens[0], dens[1]), "passes must use different masks"
+
+
+def test_field_laplace_matches_oracle(dev):
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    t, sc, _ = _scene("laplace", dev)
+    wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+    sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+    o, d = _rays(12, 16)
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    mu_d, var_d, mu_rgb, var_rgb = O.laplace_field(o, d, eb, sc.field, wsd, wsr)
+    dens, rgb, dvar, rvar = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
+    _close(dens[0], mu_d, 2e-4, 1e-7, "mu_d")
+    _close(rgb[0], mu_rgb, 0, 2e-5, "mu_rgb")
+    # variances are E[x^2]-E[x]^2 in fp32: compare against the scale of E[x^2]
+    _close(dvar, var_d, 0, 2e-5 * float((mu_d ** 2).max()), "var_d")
+    _close(rvar, var_rgb, 0, 2e-6, "var_rgb")
+
+
+@pytest.mark.parametrize("B,S", [(1, 48), (3, 48), (1, 96), (2, 16), (1, 256)])
+def test_composite_var_matches_oracle(dev, B, S):
+    from uncertainty_nerf_gs_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    R = 131
+    dens = torch.exp(torch.randn(B, R, S, generator=g) * 2.0)
+    dens[:, 0] = 0.0
+    dens[:, 1, S // 3:] = 1e5
+    rgb = torch.rand(B, R, S, 3, generator=g)
+    rgb[0, 2, 3, 1] = float("nan")
+    beta = torch.rand(R, S, generator=g) + 0.01
+    sb = torch.sort(torch.rand(R, S + 1, generator=g), dim=-1).values
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    deltas, steps = eb[:, 1:] - eb[:, :-1], (eb[:, :-1] + eb[:, 1:]) / 2
+    chunk = 50
+    clip = torch.empty((R + chunk - 1) // chunk, 2)
+    for c in range(clip.shape[0]):
+        clip[c, 0], clip[c, 1] = steps[c * chunk:(c + 1) * chunk].min(), steps[c * chunk:(c + 1) * chunk].max()
+    out = ops.composite_var(dens.to(dev), rgb.to(dev), sb.to(dev), NEAR, FAR, beta=beta.to(dev),
+                            clip_minmax=clip.to(dev), ray_offset=0, chunk_rays=chunk).cpu()
+    for b in range(B):
+        w = O.get_weights(dens[b], deltas)
+        _close(out[b, :, 0:3], O.render_rgb(rgb[b], w), 0, 3e-6, "rgb")
+        _close(out[b, :, 3:4], O.render_accumulation(w), 2e-6, 1e-7, "accumulation")
+        depth_ref = O.render_depth_median(w, steps)
+        _close(out[b, :, 4:5], depth_ref, 1e-6, 0, "median depth", max_bad_frac=0.02)
+        ed = torch.cat([O.render_depth_expected(w[c * chunk:(c + 1) * chunk], steps[c * chunk:(c + 1) * chunk])
+                        for c in range(clip.shape[0])])
+        _close(out[b, :, 5:6], ed, 2e-5, 1e-6, "expected depth")
+        _close(out[b, :, 6:7], O.render_uncertainty(beta, w ** 2), 2e-5, 1e-8, "rgb_var")
+        same = (out[b, :, 4:5] - depth_ref).abs() <= 1e-6 * depth_ref.abs()
+        dv_ref = torch.sum(w * (steps - depth_ref) ** 2, dim=-1, keepdim=True) + 1e-5
+        _close(out[b, :, 7:8][same], dv_ref[same], 5e-5, 1e-7, "depth_var")
+
+
+def test_composite_var_weights_alt(dev):
+    """laplace: rgb / rgb_var from get_weights(mu_d), depth-side outputs from the mean sampled weights"""
+    from uncertainty_nerf_gs_amd import ops
+    g = torch.Generator().manual_seed(77)
+    R, S = 64, 48
+    dens = torch.exp(torch.randn(1, R, S, generator=g))
+    rgb = torch.rand(1, R, S, 3, generator=g)
+    var = torch.rand(R, S, generator=g) * 0.01
+    walt = torch.rand(R, S, generator=g) / S
+    sb = torch.sort(torch.rand(R, S + 1, generator=g), dim=-1).values
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    deltas, steps = eb[:, 1:] - eb[:, :-1], (eb[:, :-1] + eb[:, 1:]) / 2
+    out = ops.composite_var(dens.to(dev), rgb.to(dev), sb.to(dev), NEAR, FAR, beta=var.to(dev),
+                            weights_alt=walt.to(dev)).cpu()[0]
+    w = O.get_weights(dens[0], deltas)
+    _close(out[:, 0:3], O.render_rgb(rgb[0], w), 0, 3e-6, "rgb")
+    _close(out[:, 6:7], O.render_uncertainty(var, w ** 2), 2e-5, 1e-9, "rgb_var")
+    _close(out[:, 3:4], O.render_accumulation(walt), 2e-6, 1e-7, "accumulation(alt)")
+    _close(out[:, 4:5], O.render_depth_median(walt, steps), 1e-6, 0, "depth(alt)", max_bad_frac=0.02)
+
+
+@pytest.mark.parametrize("explicit_noise", [True, False])
+def test_laplace_depth_weights_matches_oracle(dev, explicit_noise):
+    from uncertainty_nerf_gs_amd import ops
+    g = torch.Generator().manual_seed(3)
+    R, S, D = 40, 48, 100
+    mu = torch.exp(torch.randn(R, S, generator=g))
+    var = torch.rand(R, S, generator=g) * mu ** 2
+    var[0, 0] = -1e-3   # sqrt -> NaN -> 1e-10 (laplace_model.py:489-494)
+    var[0, 1] = 0.0
+    sb = torch.sort(torch.rand(R, S + 1, generator=g), dim=-1).values
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    deltas = eb[:, 1:] - eb[:, :-1]
+    seed, off = 99, 17
+    if explicit_noise:
+        noise = torch.randn(D, R, S, generator=g)
+    else:
+        sidx = ((np.arange(R)[:, None] + off) * S + np.arange(S)[None]).reshape(-1)
+        noise = torch.from_numpy(np.stack([O.normal_noise(seed, dd, sidx).reshape(R, S) for dd in range(D)]))
+        assert abs(noise.mean().item()) < 0.02 and abs(noise.std().item() - 1) < 0.02
+    sd = var.sqrt()
+    sd = torch.where(torch.isnan(sd), torch.tensor(1e-10), torch.clamp_min(sd, 1e-10))
+    samp = torch.relu(mu[None] + sd[None] * noise)
+    ref = torch.stack([O.get_weights(samp[i], deltas) for i in range(D)]).mean(0)
+    got = ops.laplace_depth_weights(mu.to(dev), var.to(dev), sb.to(dev), NEAR, FAR,
+                                    noise.to(dev) if explicit_noise else None, D, seed, off)
+    _close(got, ref, 3e-4 if not explicit_noise else 3e-5, 2e-7, "mean sampled weights")
+
+
+@pytest.mark.parametrize("K", [2, 8])
+def test_moments_matches_torch(dev, K):
+    from uncertainty_nerf_gs_amd import ops
+    g = torch.Generator().manual_seed(K)
+    x = torch.rand(K, 1000, 6, generator=g)
+    mean, var = ops.moments(x.to(dev))
+    _close(mean, x.mean(0), 1e-6, 1e-7, "mean")
+    _close(var, x.var(0), 2e-5, 1e-8, "var")

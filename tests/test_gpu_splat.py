@@ -1,0 +1,143 @@
+"""Gaussian-splat path through the C ABI against the numpy oracle.  Projection, tile boxes, sort
+keys, sorted ids and bin edges are BIT-EXACT (same fp32 op order, -ffp-contract=off); the blended
+images agree within the stated tolerances (exp implementation differs by ulps)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import splat_oracle as SO
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(N, seed=7, scale_shift=1.5):
+    from uncertainty_nerf_gs_amd import synthetic
+    gp = synthetic.make_splat_tensors(seed, N)
+    gp["scales"] = gp["scales"] + scale_shift
+    return gp
+
+
+def _camera(theta=0.5, radius=2.5):
+    from uncertainty_nerf_gs_amd import synthetic
+    return synthetic.orbit_c2w(theta, radius=radius, height=0.5)
+
+
+def _project_both(gp, c2w, fx, fy, cx, cy, H, W, dev):
+    from uncertainty_nerf_gs_amd import ops, splat
+    V = splat.viewmat_from_c2w(c2w)
+    scales = torch.exp(gp["scales"])
+    quats = gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True)
+    ref = SO.project_gaussians(gp["means"].numpy(), scales.numpy(), 1.0, quats.numpy(), V[:3].numpy(), fx, fy, cx, cy, H, W)
+    got = ops.splat_project(gp["means"].to(dev), scales.to(dev), 1.0, quats.to(dev), V[:3], fx, fy, cx, cy, H, W)
+    return ref, got, V
+
+
+@pytest.mark.parametrize("N,H,W", [(20000, 48, 64), (5000, 200, 200), (1, 16, 16)])
+def test_project_bit_exact(dev, N, H, W):
+    gp = _scene(N)
+    ref, got, _ = _project_both(gp, _camera(), 0.9 * W, 0.9 * W, W / 2, H / 2, H, W, dev)
+    names = ("xys", "depths", "radii", "conics", "compensation", "num_tiles_hit", "cov3d")
+    for name, g in zip(names, got):
+        r = ref[name]
+        g = g.cpu().numpy()
+        same = (g == r) | (np.isnan(g) & np.isnan(r))
+        assert same.all(), f"{name}: {np.count_nonzero(~same)} of {same.size} entries differ (bit-exact required)"
+    assert (ref["radii"] > 0).sum() > 0 or N == 1
+
+
+def test_project_culls_behind_camera_and_keeps_zeros(dev):
+    from uncertainty_nerf_gs_amd import ops
+    gp = _scene(4096)
+    gp["means"][:100] *= 50.0       # far outside / behind
+    gp["scales"][100:110] = -30.0   # degenerate tiny splats
+    ref, got, _ = _project_both(gp, _camera(), 60.0, 60.0, 32.0, 24.0, 48, 64, dev)
+    radii = got[2].cpu().numpy()
+    assert np.array_equal(radii, ref["radii"])
+    dead = radii == 0
+    assert dead.any()
+    assert np.all(got[0].cpu().numpy()[dead] == 0) and np.all(got[5].cpu().numpy()[dead] == 0)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+def test_sh_colors_and_beta(dev, degree):
+    from uncertainty_nerf_gs_amd import ops
+    gp = _scene(3000)
+    c2w = _camera()
+    coeffs = torch.cat((gp["features_dc"][:, None, :], gp["features_rest"]), dim=1).contiguous()
+    col, beta = ops.splat_sh_colors(degree, gp["means"].to(dev), c2w[:3, 3], coeffs.to(dev),
+                                    gp["log_uncertainties"].reshape(-1).to(dev), 0.01)
+    ref = np.maximum(SO.spherical_harmonics(degree, (gp["means"] - c2w[:3, 3]).numpy(), coeffs.numpy()) + np.float32(0.5), 0)
+    np.testing.assert_allclose(col.cpu().numpy(), ref, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(beta.cpu().numpy(), SO.softplus(gp["log_uncertainties"].numpy()).reshape(-1) + np.float32(0.01),
+                               rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("N,H,W", [(6000, 48, 64), (2000, 100, 37)])
+def test_bin_sort_bit_exact(dev, N, H, W):
+    from uncertainty_nerf_gs_amd import ops
+    gp = _scene(N)
+    ref, got, _ = _project_both(gp, _camera(1.3), 0.9 * W, 0.9 * W, W / 2, H / 2, H, W, dev)
+    xys, depths, radii, conics, comp, tiles, _ = got
+    I, cum, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W)
+    Ir, cumr, keysr, gidsr, binsr = SO.bin_and_sort(ref["xys"], ref["depths"], ref["radii"], ref["num_tiles_hit"], H, W)
+    assert I == Ir and I > 0
+    assert np.array_equal(cum.cpu().numpy(), cumr)
+    assert np.array_equal(keys.cpu().numpy(), keysr), "sorted (tile<<32|depth) keys must be bit-exact"
+    assert np.array_equal(gids.cpu().numpy(), gidsr), "sorted gaussian ids must match (stable radix order)"
+    assert np.array_equal(bins.cpu().numpy(), binsr), "tile bin edges must be bit-exact"
+    k = keys.cpu().numpy()
+    assert np.all(k[1:] >= k[:-1])
+
+
+def test_bin_sort_no_intersections(dev):
+    from uncertainty_nerf_gs_amd import ops
+    N, H, W = 128, 32, 32
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+    I, cum, keys, gids, bins = ops.splat_bin_sort(z(N, 2), z(N), z(N, dt=torch.int32), z(N, dt=torch.int32), H, W)
+    assert I == 0 and keys.numel() == 0 and int(bins.abs().sum()) == 0
+    img, fT, _ = ops.splat_rasterize(gids, bins, z(N, 2), z(N, 3), z(N, 3), z(N), H, W,
+                                     torch.tensor([0.25, 0.5, 0.75], device=dev))
+    assert torch.all(fT == 1) and torch.allclose(img[3, 5], torch.tensor([0.25, 0.5, 0.75], device=dev))
+
+
+@pytest.mark.parametrize("C", [1, 3, 5])
+def test_rasterize_matches_oracle(dev, C):
+    from uncertainty_nerf_gs_amd import ops
+    N, H, W = 4000, 50, 70   # ragged: not a multiple of the 16-pixel tile
+    gp = _scene(N)
+    ref, got, _ = _project_both(gp, _camera(2.2), 60.0, 60.0, W / 2, H / 2, H, W, dev)
+    xys, depths, radii, conics, comp, tiles, _ = got
+    I, cum, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W)
+    g = torch.Generator().manual_seed(C)
+    colors = torch.rand(N, C, generator=g)
+    opac = torch.sigmoid(gp["opacities"]).reshape(-1)
+    bg = torch.rand(C, generator=g)
+    img, fT, fidx = ops.splat_rasterize(gids, bins, xys, conics, colors.to(dev), opac.to(dev), H, W, bg.to(dev),
+                                        want_final_idx=True)
+    img_r, fT_r, fidx_r = SO.rasterize(gids.cpu().numpy(), bins.cpu().numpy(), ref["xys"], ref["conics"], colors.numpy(),
+                                       opac.numpy(), H, W, bg.numpy())
+    d = np.abs(img.cpu().numpy() - img_r)
+    # a splat whose alpha grazes 1/255 (or T grazes 1e-4) may flip with a 1-ulp exp difference
+    assert (d > 2e-5).mean() <= 2e-3, f"{(d > 2e-5).mean():.2e} of values off, worst {d.max():.2e}"
+    assert np.abs(fT.cpu().numpy() - fT_r).max() <= 5e-3 and (np.abs(fT.cpu().numpy() - fT_r) > 2e-6).mean() <= 2e-3
+    assert (fidx.cpu().numpy() != fidx_r).mean() <= 2e-3
+
+
+def test_active_splatfacto_full_pipeline(dev):
+    """ActiveSplatfactoModel.get_outputs: one sort + 5-channel pass + depth-variance pass vs the
+    oracle's restatement of the reference's four-pass formulation."""
+    from uncertainty_nerf_gs_amd import splat
+    N, H, W = 6000, 60, 80
+    gp = _scene(N)
+    c2w = _camera(0.9)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    out = splat.active_splatfacto_outputs({k: v.to(dev) for k, v in gp.items()}, c2w, 70.0, 70.0, W / 2, H / 2, H, W,
+                                          bg.to(dev))
+    ref = SO.active_splatfacto_outputs({k: v.numpy() for k, v in gp.items()}, c2w.numpy(), 70.0, 70.0, W / 2, H / 2, H, W,
+                                       bg.numpy())
+    for k, atol, rtol in (("rgb", 3e-5, 0), ("accumulation", 3e-5, 0), ("uncertainty", 3e-5, 1e-5),
+                          ("rgb_var", 3e-5, 1e-4), ("depth", 0, 2e-4), ("depth_var", 1e-6, 2e-3), ("depth_std", 1e-5, 2e-3)):
+        g, r = out[k].cpu().numpy().astype(np.float64), ref[k].astype(np.float64)
+        bad = np.abs(g - r) > atol + rtol * np.abs(r)
+        assert bad.mean() <= 5e-3, f"{k}: {bad.mean():.2e} of pixels off, worst {np.abs(g - r).max():.2e}"
+    assert out["rgb"].max() <= 1.0

@@ -60,6 +60,15 @@ __device__ __forceinline__ float group_incl_scan(float v, int lane_in_group) {
     return v;
 }
 
+// exclusive scan: the inclusive result shifted by one lane.  (NOT "inclusive - own": that loses
+// the low bits of small prefixes behind a large element and turns inf - inf into NaN.)
+template <int WIDTH>
+__device__ __forceinline__ float group_excl_scan(float v, int lane_in_group) {
+    float incl = group_incl_scan<WIDTH>(v, lane_in_group);
+    float up = __shfl_up(incl, 1, WIDTH);
+    return lane_in_group == 0 ? 0.f : up;
+}
+
 // ======================================================================================
 // 1. rays
 // ======================================================================================
@@ -158,9 +167,9 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(const float* __restrict__
 
 extern "C" int unerf_hashgrid_fwd(const float* xyz, const float* table, const float* scalings, int64_t N, int L,
                                   int log2T, float* out, int32_t* out_idx, void* stream) {
-    UNERF_REQUIRE(xyz && table && scalings && out, "hashgrid_fwd: null pointer");
     UNERF_REQUIRE(L >= 1 && L <= 32 && log2T >= 1 && log2T <= 24 && N >= 0, "hashgrid_fwd: bad L=%d log2T=%d", L, log2T);
-    if (N == 0) return UNERF_OK;
+    if (N == 0) return UNERF_OK;  // empty input: nothing to read or write (pointers may be null)
+    UNERF_REQUIRE(xyz && table && scalings && out, "hashgrid_fwd: null pointer");
     hipLaunchKernelGGL(hashgrid_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, xyz, table,
                        scalings, N, L, log2T, out, out_idx);
     return unerf_check_launch("hashgrid_fwd");
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
         lexcl[e] = lsum;
         lsum += dd[e];
     }
-    float carry = group_incl_scan<64>(lsum, lane) - lsum;
+    float carry = group_excl_scan<64>(lsum, lane);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         float alpha = 1.f - expf(-dd[e]);
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
             ls += w[e];
             lc[e] = ls;
         }
-        float cbase = group_incl_scan<64>(ls, lane) - ls;
+        float cbase = group_excl_scan<64>(ls, lane);
         int cnt = 0;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) cnt += (k0 + e < n && (cbase + lc[e]) < 0.5f) ? 1 : 0;
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
         lp += pdf;
         lcdf[e] = lp;
     }
-    float cb = group_incl_scan<64>(lp, lane) - lp;
+    float cb = group_excl_scan<64>(lp, lane);
     if (lane == 0) s_cdf[wv][0] = 0.f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e)
@@ -692,7 +701,7 @@ __device__ __forceinline__ void group_weights(const float (&dens)[SPL], const fl
         lex[e] = ls;
         ls += dd[e];
     }
-    float carry = group_incl_scan<16>(ls, l16) - ls;
+    float carry = group_excl_scan<16>(ls, l16);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
         float alpha = 1.f - expf(-dd[e]);
@@ -772,7 +781,8 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
         wt += wd[e] * steps[e];
     }
     float tot = group_incl_scan<16>(ls, l16);
-    float cbase = tot - ls;
+    float cbase = __shfl_up(tot, 1, 16);
+    if (l16 == 0) cbase = 0.f;
     float acc = __shfl(tot, 15, 16);
     wt = group_sum<16>(wt);
     int cnt = 0;

@@ -97,6 +97,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the one that
+    # initialises the device, so import torch before dlopen-ing libunerf (same SONAME -> shared).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise UnerfError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -26,6 +26,38 @@ def _ctx(device):
     return torch.cuda.device(device)
 
 
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events recorded on the launch stream (torch's current
+    stream is the stream handed to libunerf).  bench.py uses it for the roofline figure."""
+
+    def __init__(self):
+        self.events = {}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, pairs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = {"launches": len(ms), "total_ms": float(sum(ms)), "avg_ms": float(sum(ms) / max(len(ms), 1))}
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _run(name: str, rc_fn):
+    """rc_fn() launches one libunerf entry point and returns its status code."""
+    if TIMER is None:
+        _l.check(rc_fn(), name)
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = rc_fn()
+    b.record()
+    _l.check(rc, name)
+    TIMER.events.setdefault(name, []).append((a, b))
+
+
 def _p(t: Optional[torch.Tensor], dtype=torch.float32, name: str = "tensor") -> Optional[int]:
     if t is None:
         return None
@@ -54,8 +86,8 @@ def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
     d = torch.empty(count, 3, device=device, dtype=torch.float32)
     pa = torch.empty(count, 1, device=device, dtype=torch.float32) if pixel_area else None
     with _ctx(o.device):
-        _l.check(lib.unerf_generate_rays(_host12(c2w), fx, fy, cx, cy, H, W, ray_start, count, _p(o), _p(d),
-                                         _p(pa), _stream()), "generate_rays")
+        _run("generate_rays", lambda: lib.unerf_generate_rays(_host12(c2w), fx, fy, cx, cy, H, W, ray_start, count, _p(o), _p(d),
+                                         _p(pa), _stream()))
     return o, d, pa
 
 
@@ -68,8 +100,8 @@ def hashgrid_fwd(xyz: torch.Tensor, table: torch.Tensor, scalings: torch.Tensor,
     out = torch.empty(N, 2 * L, device=xyz.device, dtype=torch.float32)
     idx = torch.empty(N, L, 8, device=xyz.device, dtype=torch.int32) if return_indices else None
     with _ctx(xyz.device):
-        _l.check(lib.unerf_hashgrid_fwd(_p(xyz, name="xyz"), _p(table, name="table"), _p(scalings), N, L, log2T,
-                                        _p(out), _p(idx, torch.int32), _stream()), "hashgrid_fwd")
+        _run("hashgrid_fwd", lambda: lib.unerf_hashgrid_fwd(_p(xyz, name="xyz"), _p(table, name="table"), _p(scalings), N, L, log2T,
+                                        _p(out), _p(idx, torch.int32), _stream()))
     return (out, idx) if return_indices else out
 
 
@@ -153,8 +185,8 @@ def proposal_density(origins, directions, sbins, net: DensityNetDev, near: float
     out = torch.empty(R, n, device=origins.device, dtype=torch.float32)
     cs = net.cstruct()
     with _ctx(origins.device):
-        _l.check(lib.unerf_proposal_density(_p(origins), _p(directions), _p(sbins), stride, R, n, near, far,
-                                            C.byref(cs), average_init_density, _p(out), _stream()), "proposal_density")
+        _run(f"proposal_density_{n}", lambda: lib.unerf_proposal_density(_p(origins), _p(directions), _p(sbins), stride, R, n, near, far,
+                                            C.byref(cs), average_init_density, _p(out), _stream()))
     return out
 
 
@@ -170,9 +202,9 @@ def weights_pdf_resample(density, sbins, u, near: float, far: float, histogram_p
     pd = torch.empty(R, 1, device=density.device, dtype=torch.float32) if want_prop_depth else None
     w = torch.empty(R, n, device=density.device, dtype=torch.float32) if want_weights else None
     with _ctx(density.device):
-        _l.check(lib.unerf_weights_pdf_resample(_p(density), _p(sbins), stride, R, n, near, far, _p(u), m,
+        _run(f"weights_pdf_resample_{n}", lambda: lib.unerf_weights_pdf_resample(_p(density), _p(sbins), stride, R, n, near, far, _p(u), m,
                                                 histogram_padding, eps, _p(out), _p(pd), _p(w), _p(clip_minmax),
-                                                ray_offset, chunk_rays, _stream()), "weights_pdf_resample")
+                                                ray_offset, chunk_rays, _stream()))
     return out, pd, w
 
 
@@ -198,8 +230,8 @@ def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: flo
     aux2 = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode == _l.FIELD_LAPLACE else None
     cs = field.cstruct()
     with _ctx(dev):
-        _l.check(lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, ray_offset,
-                                     C.byref(cs), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()), "field_fwd")
+        _run("field_fwd", lambda: lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, ray_offset,
+                                     C.byref(cs), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()))
     return density, rgb, aux, aux2
 
 
@@ -209,9 +241,8 @@ def laplace_depth_weights(density_mu, density_var, sbins, near: float, far: floa
     R, S = density_mu.shape
     out = torch.empty(R, S, device=density_mu.device, dtype=torch.float32)
     with _ctx(out.device):
-        _l.check(lib.unerf_laplace_depth_weights(_p(density_mu), _p(density_var), _p(sbins), R, S, near, far,
-                                                 _p(noise), D, seed & 0xFFFFFFFF, ray_offset, _p(out), _stream()),
-                 "laplace_depth_weights")
+        _run("laplace_depth_weights", lambda: lib.unerf_laplace_depth_weights(_p(density_mu), _p(density_var), _p(sbins), R, S, near, far,
+                                                 _p(noise), D, seed & 0xFFFFFFFF, ray_offset, _p(out), _stream()))
     return out
 
 
@@ -222,9 +253,8 @@ def composite_var(density, rgb, sbins, near: float, far: float, beta=None, weigh
     B, R, S = density.shape
     out = torch.empty(B, R, 8, device=density.device, dtype=torch.float32)
     with _ctx(out.device):
-        _l.check(lib.unerf_composite_var(_p(density), _p(rgb), _p(beta), _p(weights_alt), _p(sbins), B, R, S, near,
-                                         far, _p(clip_minmax), ray_offset, chunk_rays, _p(out), _stream()),
-                 "composite_var")
+        _run("composite_var", lambda: lib.unerf_composite_var(_p(density), _p(rgb), _p(beta), _p(weights_alt), _p(sbins), B, R, S, near,
+                                         far, _p(clip_minmax), ray_offset, chunk_rays, _p(out), _stream()))
     return out
 
 
@@ -235,7 +265,7 @@ def moments(x: torch.Tensor, want_var: bool = True):
     mean = torch.empty(N, Cc, device=x.device, dtype=torch.float32)
     var = torch.empty(N, Cc, device=x.device, dtype=torch.float32) if want_var else None
     with _ctx(x.device):
-        _l.check(lib.unerf_moments(_p(x), K, N, Cc, _p(mean), _p(var), _stream()), "moments")
+        _run("moments", lambda: lib.unerf_moments(_p(x), K, N, Cc, _p(mean), _p(var), _stream()))
     return mean, var
 
 
@@ -254,10 +284,10 @@ def splat_project(means3d, scales, glob_scale: float, quats, viewmat: torch.Tens
     tiles = torch.empty(N, device=dev, dtype=torch.int32)
     cov3d = torch.empty(N, 6, device=dev)
     with _ctx(dev):
-        _l.check(lib.unerf_splat_project(_p(means3d), _p(scales), glob_scale, _p(quats), _host12(viewmat), fx, fy, cx,
+        _run("splat_project", lambda: lib.unerf_splat_project(_p(means3d), _p(scales), glob_scale, _p(quats), _host12(viewmat), fx, fy, cx,
                                          cy, H, W, block_width, clip_thresh, N, _p(xys), _p(depths),
                                          _p(radii, torch.int32), _p(conics), _p(comp), _p(tiles, torch.int32),
-                                         _p(cov3d), _stream()), "splat_project")
+                                         _p(cov3d), _stream()))
     return xys, depths, radii, conics, comp, tiles, cov3d
 
 
@@ -268,8 +298,8 @@ def splat_sh_colors(degree: int, means3d, cam_pos: torch.Tensor, sh_coeffs, log_
     beta = torch.empty(N, device=dev) if log_unc is not None else None
     cp = (C.c_float * 3)(*[float(v) for v in cam_pos.detach().cpu().reshape(-1)[:3]])
     with _ctx(dev):
-        _l.check(lib.unerf_splat_sh_colors(degree, _p(means3d), cp, _p(sh_coeffs), _p(log_unc), beta_min, N,
-                                           _p(colors), _p(beta), _stream()), "splat_sh_colors")
+        _run("splat_sh_colors", lambda: lib.unerf_splat_sh_colors(degree, _p(means3d), cp, _p(sh_coeffs), _p(log_unc), beta_min, N,
+                                           _p(colors), _p(beta), _stream()))
     return colors, beta
 
 
@@ -282,17 +312,16 @@ def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_widt
     cum = torch.empty(N, device=dev, dtype=torch.int32)
     with _ctx(dev):
         ws0 = torch.empty(int(lib.unerf_splat_sort_workspace_bytes(N, 0)), device=dev, dtype=torch.uint8)
-        _l.check(lib.unerf_splat_count_intersects(_p(num_tiles_hit, torch.int32), N, _p(cum, torch.int32),
-                                                  _p(ws0, torch.uint8), ws0.numel(), _stream()), "splat_count")
+        _run("splat_count", lambda: lib.unerf_splat_count_intersects(_p(num_tiles_hit, torch.int32), N, _p(cum, torch.int32),
+                                                  _p(ws0, torch.uint8), ws0.numel(), _stream()))
         I = int(cum[-1].item())
         ws = torch.empty(int(lib.unerf_splat_sort_workspace_bytes(N, I)), device=dev, dtype=torch.uint8)
         ids = torch.empty(max(I, 1), device=dev, dtype=torch.int64)
         gids = torch.empty(max(I, 1), device=dev, dtype=torch.int32)
         bins = torch.empty(tbx * tby, 2, device=dev, dtype=torch.int32)
-        _l.check(lib.unerf_splat_bin_sort(_p(xys), _p(depths), _p(radii, torch.int32), _p(cum, torch.int32), N, I, H,
+        _run("splat_bin_sort", lambda: lib.unerf_splat_bin_sort(_p(xys), _p(depths), _p(radii, torch.int32), _p(cum, torch.int32), N, I, H,
                                           W, block_width, _p(ids, torch.int64), _p(gids, torch.int32),
-                                          _p(bins, torch.int32), _p(ws, torch.uint8), ws.numel(), _stream()),
-                 "splat_bin_sort")
+                                          _p(bins, torch.int32), _p(ws, torch.uint8), ws.numel(), _stream()))
     return I, cum, ids[:I], gids[:I], bins
 
 
@@ -307,10 +336,9 @@ def splat_rasterize(gaussian_ids_sorted, tile_bins, xys, conics, colors, opaciti
     if gaussian_ids_sorted.numel() == 0:
         gaussian_ids_sorted = torch.zeros(1, device=dev, dtype=torch.int32)
     with _ctx(dev):
-        _l.check(lib.unerf_splat_rasterize(_p(gaussian_ids_sorted, torch.int32), _p(tile_bins, torch.int32), _p(xys),
+        _run("splat_rasterize", lambda: lib.unerf_splat_rasterize(_p(gaussian_ids_sorted, torch.int32), _p(tile_bins, torch.int32), _p(xys),
                                            _p(conics), _p(colors), _p(opacities), _p(background), Cn, H, W,
-                                           block_width, _p(out), _p(fT), _p(fidx, torch.int32), _stream()),
-                 "splat_rasterize")
+                                           block_width, _p(out), _p(fT), _p(fidx, torch.int32), _stream()))
     return out, fT, fidx
 
 
@@ -320,8 +348,7 @@ def splat_alpha_normalize(img: torch.Tensor, ch: int, final_T: torch.Tensor) -> 
     H, W, Cn = img.shape
     scratch = torch.empty(1, device=img.device)
     with _ctx(img.device):
-        _l.check(lib.unerf_splat_alpha_normalize(_p(img), Cn, ch, _p(final_T), H * W, _p(scratch), _stream()),
-                 "splat_alpha_normalize")
+        _run("splat_alpha_normalize", lambda: lib.unerf_splat_alpha_normalize(_p(img), Cn, ch, _p(final_T), H * W, _p(scratch), _stream()))
 
 
 def splat_depth_sqdiff(xys, depths, depth_img: torch.Tensor, ch: int) -> torch.Tensor:
@@ -329,6 +356,6 @@ def splat_depth_sqdiff(xys, depths, depth_img: torch.Tensor, ch: int) -> torch.T
     H, W, Cn = depth_img.shape
     out = torch.empty(xys.shape[0], device=xys.device)
     with _ctx(xys.device):
-        _l.check(lib.unerf_splat_depth_sqdiff(_p(xys), _p(depths), _p(depth_img), Cn, ch, H, W, xys.shape[0], _p(out),
-                                              _stream()), "splat_depth_sqdiff")
+        _run("splat_depth_sqdiff", lambda: lib.unerf_splat_depth_sqdiff(_p(xys), _p(depths), _p(depth_img), Cn, ch, H, W, xys.shape[0], _p(out),
+                                              _stream()))
     return out
