@@ -178,7 +178,9 @@ def cpu_baseline(t, args, c2w, cam, K):
     """The CPU oracle (a port: the reference's own stack is not installable here) on a bounded,
     strided sample of the same frame's rays, all host cores."""
     from oracle import nerf_oracle as O
-    cores = os.cpu_count() or 1
+    # torch-CPU oversubscribes badly on many-core hosts for these small tensors (256 threads were
+    # 40x slower than 16 on the MI355X host): cap the pool and report the threads actually used.
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     sc = O.scene_from_tensors(t)
     o, d, _ = O.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["H"], cam["W"])

@@ -84,8 +84,8 @@ def test_active_nerfacto_camera_parity(dev):
     _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb")
     _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
     _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=2e-3)
-    _img_close(out["rgb_var"], ref["rgb_var"], 1e-6, 2e-3, "rgb_var")
-    _img_close(out["rgb_std"], ref["rgb_std"], 1e-5, 1e-3, "rgb_std")
+    _img_close(out["rgb_var"], ref["rgb_var"], 1e-6, 2e-3, "rgb_var", max_bad_frac=2e-3)
+    _img_close(out["rgb_std"], ref["rgb_std"], 1e-5, 1e-3, "rgb_std", max_bad_frac=2e-3)
     _img_close(out["depth"], ref["depth"], 0, 1e-3, "median depth", max_bad_frac=1e-2)
     _img_close(out["depth_var"], ref["depth_var"], 0, 5e-3, "depth_var", max_bad_frac=1e-2)
     _img_close(out["prop_depth_0"], ref["prop_depth_0"], 0, 1e-4, "prop_depth_0", max_bad_frac=5e-3)

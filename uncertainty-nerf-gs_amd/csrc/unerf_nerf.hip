@@ -394,8 +394,12 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
             float first = (f0 + f1) / 2.f, last = (l0 + l1) / 2.f;
             int64_t chunk = (a.ray_offset + r) / a.chunk_rays;
             unsigned int* c = reinterpret_cast<unsigned int*>(a.clip) + chunk * 2;
-            atomicMin(c + 0, __float_as_uint(first));  // positive floats order like their bit patterns
-            atomicMax(c + 1, __float_as_uint(last));
+            // positive floats order like their bit patterns.  Thousands of rays share one chunk word:
+            // peek first (L2-coherent relaxed load) and only send the atomic when it can still win --
+            // a stale peek merely costs a redundant atomic, never a wrong result.
+            unsigned int fb = __float_as_uint(first), lb = __float_as_uint(last);
+            if (fb < __hip_atomic_load(c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(c + 0, fb);
+            if (lb > __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(c + 1, lb);
         }
     }
 }

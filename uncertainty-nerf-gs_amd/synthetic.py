@@ -40,7 +40,7 @@ def _grid(gen, num_levels, min_res, max_res, log2T, table_scale):
 
 def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, prop_log2T: int = 17,
                        max_res: int = 2048, table_scale: float = 0.5, density_gain: float = 16.0,
-                       density_bias: float = -2.0, color_gain: float = 4.0) -> Dict:
+                       density_bias: float = -2.0, color_gain: float = 4.0, beta_gain: float = 12.0) -> Dict:
     """Random-init nerfacto-shaped scene.  Tables U(-1,1)*table_scale; Linear layers
     Kaiming-uniform like nn.Linear; the density row is gained up so accumulation, depth and the
     variances vary over the image instead of saturating."""
@@ -68,6 +68,9 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
         f["w1"][0] *= density_gain
         f["w1"][1:16] *= color_gain
         f["b1"][0] = density_bias
+        if kind == "active":
+            f["w1"][16] *= beta_gain  # learned-variance logit: give the variance image dynamic range
+            f["b1"][16] = -2.0
     props = []
     for mr in (128, 256):
         p = _grid(gen, 5, 16, mr, prop_log2T, table_scale)
