@@ -130,7 +130,13 @@ typedef struct {
     const float* ws_density;  /* [n_lap][65]  */
     const float* ws_rgb;      /* [n_lap][195] */
     int n_lap;
+    /* Optional (ACTIVE / MCDROPOUT): the same MLP weights pre-arranged as fp32-MFMA A-operand
+       fragments (layout: uncertainty-nerf-gs_amd/ops.py::pack_field_mfma, UNERF_MFMA_BLOB_FLOATS
+       floats).  When non-NULL the fused kernel runs its dense layers on v_mfma_f32_32x32x2_f32
+       (exact fp32) with the weights resident in LDS; NULL selects the VALU kernel. */
+    const float* mfma_blob;
 } unerf_field_params;
+#define UNERF_MFMA_BLOB_FLOATS 10660
 
 /* outputs: B = max(K,1) passes
  *   density [B,R,S]; rgb [B,R,S,3];

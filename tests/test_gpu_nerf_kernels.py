@@ -143,9 +143,11 @@ def _final_bins(sc, o, d):
     return bins.contiguous()
 
 
-def test_field_active_matches_oracle(dev):
+@pytest.mark.parametrize("use_mfma", [True, False], ids=["mfma", "valu"])
+def test_field_active_matches_oracle(dev, use_mfma):
     from uncertainty_nerf_gs_amd import ops
     t, sc, sd = _scene("active", dev)
+    sd.field.use_mfma = use_mfma
     o, d = _rays()
     sb = _final_bins(sc, o, d)
     eb = O.spacing_to_euclidean(sb, NEAR, FAR)
@@ -156,11 +158,13 @@ def test_field_active_matches_oracle(dev):
     _close(beta, beta_ref, 1e-4, 1e-6, "beta")
 
 
+@pytest.mark.parametrize("use_mfma", [True, False], ids=["mfma", "valu"])
 @pytest.mark.parametrize("K", [0, 3])
-def test_field_mcdropout_matches_oracle(dev, K):
+def test_field_mcdropout_matches_oracle(dev, K, use_mfma):
     from uncertainty_nerf_gs_amd import ops
     seed, p = 1234, 0.2
     t, sc, sd = _scene("mcdropout", dev, K=K, seed=seed, p_drop=p)
+    sd.field.use_mfma = use_mfma
     o, d = _rays(16, 24)
     sb = _final_bins(sc, o, d)
     eb = O.spacing_to_euclidean(sb, NEAR, FAR)

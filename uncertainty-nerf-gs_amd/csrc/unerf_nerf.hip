@@ -649,6 +649,203 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------------------
+// 5b. MFMA variant (ACTIVE, MCDROPOUT).  v_mfma_f32_32x32x2_f32 = exact fp32 FMA chains at the
+// fp32 vector rate; what it buys is operand delivery: one 256-B A fragment (weights, LDS
+// resident for the lifetime of a persistent workgroup) feeds 2048 MACs, where the VALU kernel
+// needs the scalar cache to deliver a weight pair for every 128 MACs (56 KB of weights do not
+// fit the scalar cache, so that kernel runs at the L2 scalar-fetch rate, rocprof r1_01).
+//
+// Mapping: a wave owns a tile of 32 samples.  Samples sit on the MFMA columns (lane & 31), layer
+// units on the rows, so D of one layer is directly the B operand of the next (no LDS, no
+// shuffles).  The two lane halves hold the two k-slices of every step; for the hash grid that
+// means half h looks up levels 8h..8h+7 of the same 32 samples.  Fragment/bias layout:
+// ops.py::pack_field_mfma (emulated bit for bit in tests/test_mfma_pack_cpu.py).
+// --------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MF_BIAS_OFF (160 * 64)
+#define MF_H2_OFF (MF_BIAS_OFF + 7 * 32)
+
+__device__ __forceinline__ f32x16 mf_bias(const float* lds, int k, int h) {
+    const float4* b = reinterpret_cast<const float4*>(lds + MF_BIAS_OFF + (k * 2 + h) * 16);
+    float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    f32x16 v = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    return v;
+}
+__device__ __forceinline__ f32x16 mf_relu(f32x16 v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+    return v;
+}
+// acc += W_frag(frag0 + r) x src[r], r = 0..15 (one 16-step K slab)
+__device__ __forceinline__ f32x16 mf_slab(const float* lds, int frag0, int lane, const f32x16& src, f32x16 acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(frag0 + r) * 64 + lane], src[r], acc, 0, 0, 0);
+    return acc;
+}
+// inverted dropout on one accumulator block (units 32*blk + row(r,h)); register pairs (r, r+1)
+// are units (u, u+1) = one hash draw, exactly like dense_lds_dropout / oracle mc_keep_mask
+__device__ __forceinline__ f32x16 mf_dropout(f32x16 v, int blk, int h, uint32_t base, uint32_t stream_id,
+                                             uint32_t thr, float scale) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        uint32_t u = 32u * blk + (r & 3) + 8 * (r >> 2) + 4 * h;
+        uint32_t rnd = unerf_hash32(base + (stream_id * 32u + (u >> 1) + 1u) * UNERF_GOLDEN);
+        v[r] = ((rnd & 0xFFFFu) < thr) ? v[r] * scale : 0.f;
+        v[r + 1] = ((rnd >> 16) < thr) ? v[r + 1] * scale : 0.f;
+    }
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t num_tiles) {
+    extern __shared__ float lds[];
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.p.mfma_blob);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane_c = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane_c & 31, h = lane_c >> 5;
+    const int64_t N = a.R * (int64_t)a.S;
+    const uint32_t mask = (1u << a.p.log2T) - 1u;
+    // XCD-aware persistent walk: blocks b and b+8 share an XCD (L2); give each XCD one contiguous
+    // eighth of the tiles so neighbouring rays (same coarse hash cells) meet in the same L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int64_t tpx = (num_tiles + 7) / 8;
+    const int64_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
+    for (int64_t tile = xcd * tpx + (int64_t)slot * 4 + wv; tile < tile_end; tile += (int64_t)bpx * 4) {
+        // The LDS fragment reads are invariant across tiles; left alone, LICM hoists all 160 of
+        // them into registers (490 VGPR+AGPR, scratch spills).  An opaque copy of the lane index
+        // keeps them inside the iteration, where each read is consumed by the next MFMA.
+        int lane = lane_c;
+        asm volatile("" : "+v"(lane));
+        int64_t n = tile * 32 + j;
+        const bool valid = n < N;
+        if (!valid) n = N - 1;
+        const int64_t r = n / a.S;
+        const int s = (int)(n - r * a.S);
+        const float* sb = a.sbins + r * (a.S + 1);
+        float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+        float t01 = e0 + e1;
+        float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
+        float px = a.origins[r * 3 + 0] + dxr * t01 / 2.f;
+        float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
+        float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
+        const float sel = unerf_normalize_position(px, py, pz);
+
+        // hash grid: this half's 8 levels -> 16 features = the 16 k-steps of layer 0
+        f32x16 feat;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const int lev = 8 * h + l;
+            const float2* lvl = reinterpret_cast<const float2*>(a.p.table) + ((size_t)lev << a.p.log2T);
+            float2 f = unerf_hash_level(lvl, px, py, pz, a.p.scalings[lev], mask);
+            feat[2 * l] = f.x;
+            feat[2 * l + 1] = f.y;
+        }
+        // SH of the ray direction; this half feeds components 8h..8h+7
+        f32x16 shv;
+        {
+            float sh[16];
+            float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
+            if (a.p.sh_remap) {
+                ux = ux * 2.f - 1.f;
+                uy = uy * 2.f - 1.f;
+                uz = uz * 2.f - 1.f;
+            }
+            unerf_sh16(ux, uy, uz, sh);
+            // bitwise per-half select: a plain `h ? sh[8+k] : sh[k]` is rewritten by the compiler
+            // into a lane-indexed load from a scratch copy of sh[]
+            const uint32_t hm = 0u - (uint32_t)h;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                shv[k] = __uint_as_float((__float_as_uint(sh[8 + k]) & hm) | (__float_as_uint(sh[k]) & ~hm));
+#pragma unroll
+            for (int k = 8; k < 16; ++k) shv[k] = 0.f;
+        }
+
+        // layer 0: 32 -> 64, ReLU
+        f32x16 hid0 = mf_relu(mf_slab(lds, 0, lane, feat, mf_bias(lds, 0, h)));
+        f32x16 hid1 = mf_relu(mf_slab(lds, 16, lane, feat, mf_bias(lds, 1, h)));
+
+        const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
+        const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.p.K > 0;
+        const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
+        for (int k = 0; k < passes; ++k) {
+            asm volatile("" : "+v"(lane));  // same reason: keep the fragment reads inside the pass
+            const uint32_t base = unerf_mc_base(unerf_mc_key(a.p.seed, (uint32_t)k), sidx);
+            f32x16 m0 = hid0, m1 = hid1;
+            if (drop) {
+                m0 = mf_dropout(hid0, 0, h, base, 0u, a.keep_thr, a.drop_scale);
+                m1 = mf_dropout(hid1, 1, h, base, 0u, a.keep_thr, a.drop_scale);
+            }
+            // trunk out: 64 -> out1 (rows >= out1 are zero-padded): row 0 density, 1..15 geo, 16 beta
+            f32x16 t = mf_bias(lds, 2, h);
+            t = mf_slab(lds, 32, lane, m0, t);
+            t = mf_slab(lds, 48, lane, m1, t);
+            // colour 0: [geo rows of t (regs 0..7) | SH] -> 64, ReLU
+            f32x16 c0 = mf_bias(lds, 3, h), c1 = mf_bias(lds, 4, h);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(64 + q) * 64 + lane], t[q], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(80 + q) * 64 + lane], t[q], c1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 8; q < 16; ++q) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(64 + q) * 64 + lane], shv[q - 8], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(80 + q) * 64 + lane], shv[q - 8], c1, 0, 0, 0);
+            }
+            c0 = mf_relu(c0);
+            c1 = mf_relu(c1);
+            // colour 1: 64 -> 64, ReLU
+            f32x16 d0 = mf_bias(lds, 5, h), d1 = mf_bias(lds, 6, h);
+            d0 = mf_slab(lds, 96, lane, c0, d0);
+            d0 = mf_slab(lds, 112, lane, c1, d0);
+            d1 = mf_slab(lds, 128, lane, c0, d1);
+            d1 = mf_slab(lds, 144, lane, c1, d1);
+            d0 = mf_relu(d0);
+            d1 = mf_relu(d1);
+            if (drop) {
+                d0 = mf_dropout(d0, 0, h, base, 1u, a.keep_thr, a.drop_scale);
+                d1 = mf_dropout(d1, 1, h, base, 1u, a.keep_thr, a.drop_scale);
+            }
+            // colour 2: 64 -> 3 on the VALU: each half sums its 32 units, halves meet by one shuffle
+            float rgbv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* w0p = lds + MF_H2_OFF + ((0 * 2 + h) * 3 + c) * 16;
+                const float* w1p = lds + MF_H2_OFF + ((1 * 2 + h) * 3 + c) * 16;
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = fmaf(d0[q], w0p[q], acc);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = fmaf(d1[q], w1p[q], acc);
+                acc += __shfl_xor(acc, 32, 64);
+                rgbv[c] = unerf_sigmoid(acc + lds[MF_H2_OFF + 192 + c]);
+            }
+            if (valid && h == 0) {
+                int64_t q = (int64_t)k * N + n;
+                a.density[q] = a.p.average_init_density * expf(t[0]) * sel;
+                a.rgb[q * 3 + 0] = rgbv[0];
+                a.rgb[q * 3 + 1] = rgbv[1];
+                a.rgb[q * 3 + 2] = rgbv[2];
+                if (MODE == UNERF_FIELD_ACTIVE) a.aux[n] = unerf_softplus(t[8]) + a.p.beta_min;
+            }
+        }
+    }
+}
+
+static int mfma_grid(int64_t num_tiles) {
+    int64_t blocks = (num_tiles + 3) / 4;
+    const int64_t cap = 256 * 3;  // 3 workgroups of 4 waves per CU: 42.6 KB LDS each, <=168 VGPRs
+    if (blocks > cap) blocks = cap;
+    return (int)((blocks + 7) / 8 * 8);
+}
+
 extern "C" int unerf_field_fwd(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
                                float near_plane, float far_plane, int64_t ray_offset, const unerf_field_params* p,
                                float* density, float* rgb, float* aux, float* aux2, void* stream) {
@@ -673,12 +870,24 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     switch (p->mode) {
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
-            hipLaunchKernelGGL((field_kernel<UNERF_FIELD_ACTIVE>), grid, block, 64 * 64 * 4, st, a);
+            if (p->mfma_blob) {
+                int64_t tiles = (R * (int64_t)S + 31) / 32;
+                hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE>), dim3(mfma_grid(tiles)), dim3(256),
+                                   UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+            } else {
+                hipLaunchKernelGGL((field_kernel<UNERF_FIELD_ACTIVE>), grid, block, 64 * 64 * 4, st, a);
+            }
             break;
         case UNERF_FIELD_MCDROPOUT:
             UNERF_REQUIRE(p->out1 == 16, "field_fwd MCDROPOUT: out1 must be 16");
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
-            hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
+            if (p->mfma_blob) {
+                int64_t tiles = (R * (int64_t)S + 31) / 32;
+                hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT>), dim3(mfma_grid(tiles)), dim3(256),
+                                   UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+            } else {
+                hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
+            }
             break;
         case UNERF_FIELD_LAPLACE:
             UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,

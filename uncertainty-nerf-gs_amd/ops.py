@@ -155,14 +155,20 @@ class FieldDev:
     p_drop: float = 0.2
     ws_density: Optional[torch.Tensor] = None
     ws_rgb: Optional[torch.Tensor] = None
+    mfma_blob: Optional[torch.Tensor] = None
+    use_mfma: bool = True
 
     @classmethod
     def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device, **kw):
         f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         h0 = head_w[0].detach().to(torch.float32)
         hb0 = head_b[0].detach().to(torch.float32) + h0[:, 31:] @ appearance.detach().to(torch.float32)
+        blob = None
+        if mode != _l.FIELD_LAPLACE:
+            blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2]))
         return cls(mode, f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
-                   f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]), **kw)
+                   f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
+                   mfma_blob=blob, **kw)
 
     def cstruct(self) -> _l.FieldParams:
         return _l.FieldParams(
@@ -170,7 +176,75 @@ class FieldDev:
             _p(self.w0t), _p(self.b0), _p(self.w1t), _p(self.b1), self.b1.numel(),
             _p(self.h0t), _p(self.hb0), _p(self.h1t), _p(self.hb1), _p(self.h2t), _p(self.hb2),
             self.average_init_density, self.beta_min, self.sh_remap, self.K, self.seed & 0xFFFFFFFF, self.p_drop,
-            _p(self.ws_density), _p(self.ws_rgb), 0 if self.ws_density is None else self.ws_density.shape[0])
+            _p(self.ws_density), _p(self.ws_rgb), 0 if self.ws_density is None else self.ws_density.shape[0],
+            _p(self.mfma_blob) if self.use_mfma else None)
+
+
+# ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------
+# v_mfma_f32_32x32x2_f32 computes D[32x32] += A[32x2] B[2x32]; lane l holds A[i=l&31][k=l>>5],
+# B[k=l>>5][j=l&31] and D rows (r&3)+8(r>>2)+4(l>>5) of column l&31 in its 16 accumulator
+# registers r.  The kernel keeps samples on the columns (lanes) and layer units on the rows, so a
+# layer's accumulators ARE the next layer's B operands with no data movement; the weights are
+# pre-arranged here, once, into one 64-float "A fragment" per MFMA in exactly the (step, lane)
+# order the kernel consumes them from LDS.
+
+MFMA_FRAGS = 160            # L0: 32, trunk-out: 32, colour-0: 32, colour-1: 64
+MFMA_BIAS_OFF = MFMA_FRAGS * 64
+MFMA_H2_OFF = MFMA_BIAS_OFF + 7 * 32
+MFMA_BLOB_FLOATS = MFMA_H2_OFF + 2 * 2 * 3 * 16 + 4
+
+
+def _mfma_unit(r, h):
+    """accumulator register r of a lane in half h holds output row (unit) ..."""
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2) -> torch.Tensor:
+    """torch-layout ([out,in]) CPU tensors -> flat fp32 blob [MFMA_BLOB_FLOATS].
+    w0 [64,32]; w1 [out1<=32,64]; h0 [64,31] (cols: SH16 | geo15, appearance already folded into hb0);
+    h1 [64,64]; h2 [3,64]."""
+    f = lambda t: t.detach().to("cpu", torch.float32)
+    w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2 = map(f, (w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2))
+    out1 = w1.shape[0]
+    assert w0.shape == (64, 32) and w1.shape[1] == 64 and out1 <= 32 and h0.shape == (64, 31)
+    assert h1.shape == (64, 64) and h2.shape == (3, 64)
+    lane = torch.arange(64)
+    i, h = lane & 31, lane >> 5
+    blob = torch.zeros(MFMA_BLOB_FLOATS)
+    fr = blob[:MFMA_BIAS_OFF].view(MFMA_FRAGS, 64)
+    w1p = torch.zeros(32, 64)
+    w1p[:out1] = w1
+    b1p = torch.zeros(32)
+    b1p[:out1] = b1
+    for blk in range(2):
+        for s in range(16):
+            fr[blk * 16 + s] = w0[32 * blk + i, 16 * h + s]                      # L0: input 16h+s
+    for bi in range(2):
+        for r in range(16):
+            fr[32 + bi * 16 + r] = w1p[i, 32 * bi + _mfma_unit(r, h)]              # trunk-out
+    for blk in range(2):
+        for s in range(8):                                                         # geo rows of trunk-out
+            u = _mfma_unit(s, h)
+            col = (16 + u - 1).clamp(min=0)
+            fr[64 + blk * 16 + s] = torch.where(u >= 1, h0[32 * blk + i, col], torch.zeros(64))
+        for s in range(8, 16):                                                     # SH components 8h+s-8
+            fr[64 + blk * 16 + s] = h0[32 * blk + i, 8 * h + (s - 8)]
+    for blk in range(2):
+        for bi in range(2):
+            for r in range(16):
+                fr[96 + blk * 32 + bi * 16 + r] = h1[32 * blk + i, 32 * bi + _mfma_unit(r, h)]
+    bias = blob[MFMA_BIAS_OFF:MFMA_H2_OFF].view(7, 2, 16)
+    r16 = torch.arange(16)
+    for k, vec in enumerate((b0[:32], b0[32:], b1p, hb0[:32], hb0[32:], hb1[:32], hb1[32:])):
+        for hh in range(2):
+            bias[k, hh] = vec[_mfma_unit(r16, hh)]
+    hh2 = blob[MFMA_H2_OFF:MFMA_H2_OFF + 192].view(2, 2, 3, 16)
+    for blk in range(2):
+        for hh in range(2):
+            for c in range(3):
+                hh2[blk, hh, c] = h2[c, 32 * blk + _mfma_unit(r16, hh)]
+    blob[MFMA_H2_OFF + 192:MFMA_H2_OFF + 195] = hb2
+    return blob
 
 
 # ------------------------------------------------------- proposal sampling -------------
