@@ -1,0 +1,160 @@
+"""Drop-in surface on the GPU: the Model mirrors (reference class names / methods / output keys)
+drive the HIP kernels; ensemble aggregation runs on the HIP moments kernel."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_cfg(cfg):
+    cfg.log2_hashmap_size = 14
+    cfg.proposal_net_args_list = [dict(a, log2_hashmap_size=12) for a in cfg.proposal_net_args_list]
+    return cfg
+
+
+def _state_dict_from_tensors(t, kind):
+    """synthetic weight dict -> reference-named checkpoint (`_model.` prefixed like nerfstudio's)"""
+    f = t["field"]
+    sd = {}
+    if kind == "active":
+        sd["field.mlp_base_grid.hash_table"] = f["table"]
+        sd["field.mlp_base_mlp.layers.0.weight"], sd["field.mlp_base_mlp.layers.0.bias"] = f["w0"], f["b0"]
+        sd["field.mlp_base_mlp.layers.1.weight"], sd["field.mlp_base_mlp.layers.1.bias"] = f["w1"], f["b1"]
+        for i in range(3):
+            sd[f"field.mlp_head.layers.{i}.weight"], sd[f"field.mlp_head.layers.{i}.bias"] = f["head_w"][i], f["head_b"][i]
+    elif kind == "mcdropout":
+        sd["field.mlp_base_grid.hash_table"] = f["table"]
+        sd["field.mlp_base.0.weight"], sd["field.mlp_base.0.bias"] = f["w0"], f["b0"]
+        sd["field.mlp_base.3.weight"], sd["field.mlp_base.3.bias"] = f["w1"], f["b1"]
+        for i, j in enumerate((0, 2, 5)):
+            sd[f"field.mlp_head.{j}.weight"], sd[f"field.mlp_head.{j}.bias"] = f["head_w"][i], f["head_b"][i]
+    else:
+        sd["field.base_grid.hash_table"] = f["table"]
+        sd["field.base_mlp.0.weight"], sd["field.base_mlp.0.bias"] = f["w0"], f["b0"]
+        sd["field.mlp_hidden.weight"], sd["field.mlp_hidden.bias"] = f["w1"], f["b1"]
+        sd["field.mlp_density.weight"], sd["field.mlp_density.bias"] = f["density_w"], f["density_b"]
+        sd["field.mlp_head.0.weight"], sd["field.mlp_head.0.bias"] = f["head_w"][0], f["head_b"][0]
+        sd["field.mlp_head.2.weight"], sd["field.mlp_head.2.bias"] = f["head_w"][1], f["head_b"][1]
+        sd["field.mlp_rgb_ll.weight"], sd["field.mlp_rgb_ll.bias"] = f["head_w"][2], f["head_b"][2]
+    sd["field.embedding_appearance.embedding.weight"] = f["appearance"][None].repeat(4, 1)  # mean == appearance
+    for i, p in enumerate(t["props"]):
+        sd[f"proposal_networks.{i}.encoding.hash_table"] = p["table"]
+        sd[f"proposal_networks.{i}.mlp_base.1.layers.0.weight"] = p["w0"]
+        sd[f"proposal_networks.{i}.mlp_base.1.layers.0.bias"] = p["b0"]
+        sd[f"proposal_networks.{i}.mlp_base.1.layers.1.weight"] = p["w1"]
+        sd[f"proposal_networks.{i}.mlp_base.1.layers.1.bias"] = p["b1"]
+    return {"_model." + k: v for k, v in sd.items()}
+
+
+def _camera(H, W, theta=0.7):
+    from uncertainty_nerf_gs_amd import models, synthetic
+    return models.Camera(camera_to_worlds=synthetic.orbit_c2w(theta)[None], fx=torch.tensor([0.9 * W]),
+                         fy=torch.tensor([0.9 * W]), cx=W / 2, cy=H / 2, height=H, width=W)
+
+
+@pytest.mark.parametrize("kind,method", [("active", "active-nerfacto"), ("mcdropout", "nerfacto-mcdropout")])
+def test_model_from_checkpoint_equals_direct_pipeline(dev, kind, method):
+    from uncertainty_nerf_gs_amd import plugin, render, synthetic
+    t = synthetic.make_scene_tensors(seed=3, kind=kind, log2T=14, prop_log2T=12)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS[method]())
+    model = cfg._target(cfg, num_train_data=4)
+    model.load_state_dict(_state_dict_from_tensors(t, kind))
+    kw = {}
+    if kind == "mcdropout":
+        cfg.mc_samples = 4
+        model.seed = 77
+        model.invalidate()
+        kw = dict(K=4, seed=77, p_drop=0.2)
+    H, W = 40, 56
+    cam = _camera(H, W)
+    with torch.cuda.device(dev):
+        out = model.get_outputs_for_camera(cam)
+    sd = synthetic.scene_to_device(t, dev, **kw)
+    ref = render.render_camera(sd, cam.camera_to_worlds[0], fx=0.9 * W, fy=0.9 * W, cx=W / 2, cy=H / 2, H=H, W=W,
+                               keep_density=(kind == "active"))
+    assert set(out) == set(ref)
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    expect = {"active": {"rgb", "accumulation", "depth", "expected_depth", "density", "rgb_var", "rgb_std", "depth_var",
+                         "depth_std", "prop_depth_0", "prop_depth_1"},
+              "mcdropout": {"rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1", "rgb_std",
+                            "depth_std", "expected_depth_std"}}[kind]
+    assert set(out) == expect
+    assert out["rgb"].shape == (H, W, 3) and out["rgb_std"].shape == (H, W, 1)
+
+
+def test_laplace_model_unc_render_matches_oracle(dev):
+    from uncertainty_nerf_gs_amd import plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=4, kind="laplace", log2T=14, prop_log2T=12)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["nerfacto-laplace"]())
+    model = cfg._target(cfg, num_train_data=4)
+    model.load_state_dict(_state_dict_from_tensors(t, "laplace"))
+    g = torch.Generator().manual_seed(5)
+    model.field.mlp_density_ggn = torch.rand(65, generator=g) * 1e3
+    model.field.mlp_rgb_ggn = torch.rand(195, generator=g) * 1e3
+    H, W = 16, 24
+    cam = _camera(H, W, 2.0)
+    with torch.cuda.device(dev):
+        out = model.get_outputs_for_camera_unc(cam, is_inference=True, prior_prec=1.0, n_samples=100,
+                                               generator=torch.Generator().manual_seed(9))
+    assert set(out) == {"rgb", "rgb_std", "accumulation", "depth", "depth_std", "expected_depth", "prop_depth_0",
+                        "prop_depth_1"}
+    # oracle with the same last-layer draws (the generator is consumed in the same order: density, rgb)
+    g2 = torch.Generator().manual_seed(9)
+    f = t["field"]
+    mu_d = torch.cat([f["density_w"].reshape(-1), f["density_b"].reshape(-1)])
+    mu_r = torch.cat([f["head_w"][2].reshape(-1), f["head_b"][2].reshape(-1)])
+    wsd = O.laplace_weight_samples(mu_d, model.field.mlp_density_ggn, 1.0, 1e-9, torch.randn(100, 65, generator=g2))
+    wsr = O.laplace_weight_samples(mu_r, model.field.mlp_rgb_ggn, 1.0, 1e-9, torch.randn(100, 195, generator=g2))
+    sc = O.scene_from_tensors(t)
+    o, d, _ = O.generate_rays(cam.camera_to_worlds[0], 0.9 * W, 0.9 * W, W / 2, H / 2, H, W)
+    sidx = (np.arange(H * W)[:, None] * 48 + np.arange(48)[None]).reshape(-1)
+    noise = torch.from_numpy(np.stack([O.normal_noise(0, dd, sidx).reshape(H * W, 48) for dd in range(100)]))
+    ref = O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise)
+    for k, atol, rtol in (("rgb", 5e-5, 0), ("rgb_std", 2e-5, 5e-3), ("accumulation", 3e-4, 0), ("expected_depth", 0, 2e-3)):
+        got, want = out[k].cpu().reshape(H * W, -1).double(), ref[k].double()
+        bad = (got - want).abs() > atol + rtol * want.abs()
+        assert bad.double().mean() <= 5e-3, (k, (got - want).abs().max().item())
+
+
+def test_ensemble_aggregate_on_hip_moments(dev):
+    from uncertainty_nerf_gs_amd import ensemble
+    g = torch.Generator().manual_seed(12)
+    members = []
+    for _ in range(8):
+        o = {"rgb": torch.rand(30, 41, 3, generator=g), "depth": torch.rand(30, 41, 1, generator=g) * 5,
+             "expected_depth": torch.rand(30, 41, 1, generator=g) * 5, "accumulation": torch.rand(30, 41, 1, generator=g),
+             "rgb_var": torch.rand(30, 41, 1, generator=g) * 0.1, "depth_var": torch.rand(30, 41, 1, generator=g)}
+        o["rgb_std"], o["depth_std"] = o["rgb_var"].sqrt(), o["depth_var"].sqrt()
+        members.append(o)
+    ref = O.ensemble_aggregate(members)
+    out = ensemble.aggregate([{k: v.to(dev) for k, v in m.items()} for m in members])
+    assert set(out) == set(ref)
+    for k, v in ref.items():
+        torch.testing.assert_close(out[k].cpu(), v, rtol=2e-5, atol=1e-6, msg=k)
+    plain = [{k: m[k] for k in ("rgb", "depth", "expected_depth", "accumulation")} for m in members]
+    ref2 = O.ensemble_aggregate(plain)
+    out2 = ensemble.aggregate([{k: v.to(dev) for k, v in m.items()} for m in plain])
+    for k, v in ref2.items():
+        torch.testing.assert_close(out2[k].cpu(), v, rtol=2e-5, atol=1e-6, msg=k)
+
+
+def test_splat_model_get_outputs(dev):
+    from uncertainty_nerf_gs_amd import models, splat, synthetic
+    gp = synthetic.make_splat_tensors(7, 5000)
+    gp["scales"] = gp["scales"] + 1.5
+    m = models.ActiveSplatfactoModel(models.ActiveSplatfactoModelConfig(), num_points=10)
+    m.load_state_dict({f"gauss_params.{k}": v for k, v in gp.items()})
+    m.to(dev)
+    H, W = 48, 64
+    cam = models.Camera(synthetic.orbit_c2w(0.9, radius=2.5, height=0.5), 60.0, 60.0, W / 2, H / 2, H, W)
+    out = m.get_outputs(cam)
+    ref = splat.active_splatfacto_outputs({k: v.to(dev) for k, v in gp.items()}, cam.camera_to_worlds, 60.0, 60.0, W / 2,
+                                          H / 2, H, W, torch.zeros(3, device=dev))
+    assert set(out) == {"rgb", "depth", "accumulation", "background", "uncertainty", "rgb_var", "rgb_std", "depth_var",
+                        "depth_std"}
+    for k in ("rgb", "depth", "accumulation", "uncertainty", "depth_var"):
+        assert torch.equal(out[k], ref[k]), k

@@ -1,0 +1,115 @@
+"""Ensemble aggregation (models/ensemble/ensemble_pipeline.py:144-191), single- and multi-GPU.
+
+The reference renders its M members sequentially on one device and then does
+`torch.stack(...).mean(0) / .var(0) / .std(0)` per output key.  Here:
+
+  * `aggregate(outputs_list)`        -- members already on one device: the stack/mean/var is the
+                                        `unerf_moments` kernel (two-pass fp32, like torch).
+  * `aggregate_distributed(outputs)` -- ONE MEMBER PER RANK (one process per GPU, RCCL over xGMI):
+    every rank renders the same camera with its own member, then the per-pixel moments are formed
+    with the exact two-pass formula on a pixel slice per rank:
+        all_gather(member images)  ->  rank g reduces pixel rows [g*P/W, (g+1)*P/W)  ->  all_gather(slices)
+    This is SURVEY.md 8(e) option A (exact parity with torch.stack(...).var(0); no E[x^2]-E[x]^2
+    cancellation).  Payload per GPU at 1080p, M=8: 8 x 2.07 M px x <=8 floats = <=530 MB received,
+    spread over 7 point-to-point xGMI links -- a few ms, negligible next to a render.
+
+The moment math is injected (`moments_fn`) so that the collective plumbing can be tested with
+world_size=2 on the gloo backend without a GPU; the default is the HIP kernel.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+MomentsFn = Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]  # [K,N,C] -> mean [N,C], var [N,C]
+
+
+def _hip_moments(x: torch.Tensor):
+    from . import ops
+    return ops.moments(x.contiguous())
+
+
+def _finish(keys: Sequence[str], mean: Dict[str, torch.Tensor], var: Dict[str, torch.Tensor],
+            alea: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The key loop of ensemble_pipeline.py:159-189, in the members' key order.  Order matters and is
+    kept: the reference writes outputs[k] = mean for EVERY member key in sequence, so when members
+    themselves emit rgb_var / rgb_std / depth_var / depth_std after rgb / depth (the active-nerfacto
+    order, activenerfacto_model.py:117-127) the combined epistemic+aleatoric values written while
+    visiting "rgb"/"depth" are subsequently overwritten by the member means of those keys; only the
+    *_var_alea / *_var_epi keys survive.  Reproduced as is (parity), flagged in DESIGN.md."""
+    out: Dict[str, torch.Tensor] = {}
+    has_std = "rgb_std" in keys and "depth_std" in keys
+    for k in keys:
+        out[k] = mean[k]
+        if has_std:
+            if k in ("rgb", "depth"):
+                out[k + "_var_alea"] = alea[k].mean(dim=-1).unsqueeze(-1)
+                out[k + "_var_epi"] = var[k].mean(dim=-1).unsqueeze(-1)
+                out[k + "_var"] = out[k + "_var_epi"] + out[k + "_var_alea"]
+                out[k + "_std"] = out[k + "_var"].sqrt()
+        elif k in ("rgb", "depth", "expected_depth"):
+            out[k + "_std"] = var[k].sqrt().mean(dim=-1).unsqueeze(-1)
+    return out
+
+
+def aggregate(outputs_list: List[Dict[str, torch.Tensor]], moments_fn: Optional[MomentsFn] = None):
+    """All members on one device.  Every tensor is [H,W,C]."""
+    moments_fn = moments_fn or _hip_moments
+    keys = [k for k, v in outputs_list[0].items() if torch.is_tensor(v)]
+    mean, var = {}, {}
+    for k in keys:
+        x = torch.stack([o[k] for o in outputs_list], dim=0)
+        shp = x.shape[1:]
+        m, v = moments_fn(x.reshape(x.shape[0], -1, shp[-1]))
+        mean[k], var[k] = m.view(shp), v.view(shp)
+    alea = {k: mean[k + "_var"] for k in ("rgb", "depth") if k + "_var" in mean}
+    return _finish(keys, mean, var, alea)
+
+
+def pixel_slice(num_pixels: int, rank: int, world: int) -> Tuple[int, int]:
+    """contiguous, balanced split of the flattened pixel axis (bit-exact bookkeeping: the slices
+    tile [0,num_pixels) without gaps or overlap for every world size)."""
+    base, rem = divmod(num_pixels, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def aggregate_distributed(outputs: Dict[str, torch.Tensor], group=None, moments_fn: Optional[MomentsFn] = None):
+    """This rank's member outputs ([H,W,C] per key) -> the ensemble outputs, identical on every rank."""
+    import torch.distributed as dist
+    moments_fn = moments_fn or _hip_moments
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    keys = [k for k, v in outputs.items() if torch.is_tensor(v)]  # member key order (it matters, see _finish)
+    widths = [outputs[k].shape[-1] for k in keys]
+    H, W = outputs[keys[0]].shape[:2]
+    P = H * W
+    # one packed [P, sum(C)] image per member -> a single collective instead of one per key
+    packed = torch.cat([outputs[k].reshape(P, -1) for k in keys], dim=-1).contiguous()
+    Ctot = packed.shape[1]
+    gathered = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(gathered, packed, group=group)
+    a, b = pixel_slice(P, rank, world)
+    stack = torch.stack([g[a:b] for g in gathered], dim=0)          # [M, b-a, Ctot]
+    m, v = moments_fn(stack.contiguous())
+    part = torch.cat([m, v], dim=-1).contiguous()                   # [b-a, 2*Ctot]
+    # slices differ by at most one row: pad to the largest so all_gather sees equal shapes
+    rows = max(pixel_slice(P, r, world)[1] - pixel_slice(P, r, world)[0] for r in range(world))
+    padded = torch.zeros(rows, 2 * Ctot, dtype=part.dtype, device=part.device)
+    padded[: b - a] = part
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    full = torch.cat([parts[r][: pixel_slice(P, r, world)[1] - pixel_slice(P, r, world)[0]] for r in range(world)], dim=0)
+    mean, var, off = {}, {}, 0
+    for k, c in zip(keys, widths):
+        mean[k] = full[:, off:off + c].reshape(H, W, c)
+        var[k] = full[:, Ctot + off:Ctot + off + c].reshape(H, W, c)
+        off += c
+    alea = {k: mean[k + "_var"] for k in ("rgb", "depth") if k + "_var" in mean}
+    return _finish(keys, mean, var, alea)
+
+
+def views_for_rank(num_views: int, rank: int, world: int) -> List[int]:
+    """View-batch data parallelism for splats / single models: replicas of the scene,
+    disjoint cameras per rank, no data-path collective."""
+    return list(range(rank, num_views, world))

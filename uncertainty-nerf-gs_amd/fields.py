@@ -1,0 +1,210 @@
+"""Host-side Field mirrors: same class names, constructor arguments and state-dict key names as the
+reference's fields, holding the weights as ordinary torch parameters (so reference checkpoints
+load with `load_state_dict`) and lowering themselves to the device parameter packs the HIP
+kernels consume (`to_device`).
+
+These classes do not compute anything in Python: `get_density` / `get_outputs` of the reference
+are replaced by the fused `unerf_field_fwd` kernel, reached through `models.py` / `render.py`.
+nerfstudio is not required; when it is installed, `plugin.py` registers thin subclasses with its
+plugin registry.
+
+Reference:
+  ActiveNerfactoField      models/activenerfacto/activenerfacto_field.py:33-215
+  NerfactoMCDropoutField   models/mcdropout/mcdropout_fields.py:22-174
+  NerfactoLaplaceField     models/laplace/laplace_field.py:36-608
+  HashMLPDensityField      nerfstudio 1.1.0 fields/density_fields.py (proposal networks)
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import lib as _l
+from . import ops
+from .synthetic import hash_scalings
+from .utils import create_mlp
+
+
+class HashEncoding(nn.Module):
+    """nerfstudio HashEncoding (torch implementation): parameter `hash_table` [L*T, F]."""
+
+    def __init__(self, num_levels=16, min_res=16, max_res=1024, log2_hashmap_size=19, features_per_level=2,
+                 hash_init_scale=0.001):
+        super().__init__()
+        assert features_per_level == 2, "the HIP kernels are built for F=2"
+        self.num_levels, self.log2_hashmap_size = num_levels, log2_hashmap_size
+        self.register_buffer("scalings", hash_scalings(num_levels, min_res, max_res), persistent=False)
+        table = (torch.rand((1 << log2_hashmap_size) * num_levels, features_per_level) * 2 - 1) * hash_init_scale
+        self.hash_table = nn.Parameter(table)
+
+    def get_out_dim(self) -> int:
+        return self.num_levels * 2
+
+
+class MLP(nn.Module):
+    """nerfstudio MLP (torch implementation): `layers` ModuleList of Linear, ReLU between."""
+
+    def __init__(self, in_dim, num_layers, layer_width, out_dim):
+        super().__init__()
+        self.in_dim, self.num_layers, self.layer_width, self.out_dim = in_dim, num_layers, layer_width, out_dim
+        dims = [in_dim] + [layer_width] * (num_layers - 1) + [out_dim]
+        self.layers = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(num_layers)])
+
+
+class Embedding(nn.Module):
+    """nerfstudio Embedding: `embedding` nn.Embedding; mean(dim) = mean of the weight."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.embedding = nn.Embedding(in_dim, out_dim)
+
+    def mean(self, dim=0):
+        return self.embedding.weight.mean(dim)
+
+
+class HashMLPDensityField(nn.Module):
+    """Proposal network.  Keys: encoding.hash_table (= mlp_base.0.hash_table), mlp_base.1.layers.{0,1}.*"""
+
+    def __init__(self, num_layers=2, hidden_dim=16, num_levels=5, max_res=128, base_res=16, log2_hashmap_size=17,
+                 average_init_density=1.0):
+        super().__init__()
+        assert num_layers == 2, "proposal kernels are built for Linear-ReLU-Linear"
+        self.average_init_density = average_init_density
+        self.encoding = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size)
+        self.mlp_base = nn.Sequential(self.encoding, MLP(self.encoding.get_out_dim(), num_layers, hidden_dim, 1))
+
+    def to_device(self, device) -> ops.DensityNetDev:
+        m = self.mlp_base[1].layers
+        return ops.DensityNetDev.from_torch(self.encoding.hash_table, self.encoding.scalings,
+                                            self.encoding.log2_hashmap_size, m[0].weight, m[0].bias, m[1].weight,
+                                            m[1].bias, device)
+
+
+class _NerfactoFieldBase(nn.Module):
+    """Pieces shared with nerfstudio NerfactoField: colour head input = SH16 + geo15 + appearance32."""
+
+    def __init__(self, num_images, geo_feat_dim=15, appearance_embedding_dim=32,
+                 use_average_appearance_embedding=False):
+        super().__init__()
+        assert geo_feat_dim == 15 and appearance_embedding_dim == 32, "kernels are built for the nerfacto widths"
+        self.geo_feat_dim = geo_feat_dim
+        self.appearance_embedding_dim = appearance_embedding_dim
+        self.use_average_appearance_embedding = use_average_appearance_embedding
+        self.embedding_appearance = Embedding(num_images, appearance_embedding_dim)
+        self.average_init_density = 1.0
+
+    def eval_appearance(self) -> torch.Tensor:
+        """constant eval embedding: mean of the table or zeros (laplace_field.py:386-398)"""
+        if self.use_average_appearance_embedding:
+            return self.embedding_appearance.mean(dim=0).detach()
+        return torch.zeros(self.appearance_embedding_dim)
+
+
+class ActiveNerfactoField(_NerfactoFieldBase):
+    """17-wide trunk output: density, 15 geo features, learned variance logit (beta)."""
+
+    def __init__(self, aabb=None, num_images=1, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_levels=16,
+                 base_res=16, max_res=2048, log2_hashmap_size=19, num_layers_color=3, features_per_level=2,
+                 hidden_dim_color=64, appearance_embedding_dim=32, use_average_appearance_embedding=False,
+                 spatial_distortion=None, implementation="torch", beta_min=0.01, **_unused):
+        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding)
+        assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        self.beta_min = beta_min
+        self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level)
+        self.mlp_base_mlp = MLP(self.mlp_base_grid.get_out_dim(), num_layers, hidden_dim, 1 + geo_feat_dim + 1)
+        self.mlp_base = nn.Sequential(self.mlp_base_grid, self.mlp_base_mlp)  # alias keys mlp_base.{0,1}.*
+        self.mlp_head = MLP(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color, hidden_dim_color, 3)
+        self.average_init_density = 1.0  # activenerfacto_field.py:159
+
+    def to_device(self, device, **kw) -> ops.FieldDev:
+        t, h = self.mlp_base_mlp.layers, self.mlp_head.layers
+        return ops.FieldDev.from_torch(
+            _l.FIELD_ACTIVE, self.mlp_base_grid.hash_table, self.mlp_base_grid.scalings,
+            self.mlp_base_grid.log2_hashmap_size, t[0].weight, t[0].bias, t[1].weight, t[1].bias,
+            [l.weight for l in h], [l.bias for l in h], self.eval_appearance(), device,
+            average_init_density=self.average_init_density, beta_min=self.beta_min, **kw)
+
+
+class NerfactoMCDropoutField(_NerfactoFieldBase):
+    """create_mlp trunk (Linear,ReLU,Dropout,Linear -> keys 0,3) and head (keys 0,2,5)."""
+
+    def __init__(self, aabb=None, num_images=1, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_levels=16,
+                 base_res=16, max_res=2048, log2_hashmap_size=19, num_layers_color=3, features_per_level=2,
+                 hidden_dim_color=64, appearance_embedding_dim=32, use_average_appearance_embedding=False,
+                 spatial_distortion=None, implementation="torch", dropout_rate=0.2,
+                 rgb_dropout_layers: Optional[List[int]] = None, density_dropout_layers=True, **_unused):
+        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding)
+        assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        rgb_dropout_layers = [-1] if rgb_dropout_layers is None else rgb_dropout_layers
+        assert density_dropout_layers and list(rgb_dropout_layers) == [-1], \
+            "kernels implement the reference default: dropout before the last Linear of trunk and head"
+        self.dropout_rate = dropout_rate
+        self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level)
+        self.mlp_base = create_mlp(self.mlp_base_grid.get_out_dim(), num_layers, hidden_dim, 1 + geo_feat_dim,
+                                   activation=nn.ReLU, dropout_layers=[-1], dropout_rate=dropout_rate)
+        self.mlp_head = create_mlp(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color, hidden_dim_color, 3,
+                                   activation=nn.ReLU, out_activation=nn.Sigmoid, dropout_layers=rgb_dropout_layers,
+                                   dropout_rate=dropout_rate)
+
+    def to_device(self, device, mc_samples=10, seed=0, **kw) -> ops.FieldDev:
+        b, h = self.mlp_base, self.mlp_head
+        return ops.FieldDev.from_torch(
+            _l.FIELD_MCDROPOUT, self.mlp_base_grid.hash_table, self.mlp_base_grid.scalings,
+            self.mlp_base_grid.log2_hashmap_size, b[0].weight, b[0].bias, b[3].weight, b[3].bias,
+            [h[0].weight, h[2].weight, h[5].weight], [h[0].bias, h[2].bias, h[5].bias], self.eval_appearance(), device,
+            average_init_density=self.average_init_density, K=mc_samples, seed=seed, p_drop=self.dropout_rate, **kw)
+
+
+class NerfactoLaplaceField(_NerfactoFieldBase):
+    """Explicit last layers for the last-layer Laplace approximation.  Keys: base_grid.hash_table,
+    base_mlp.0.*, mlp_density.*, mlp_hidden.*, mlp_head.{0,2}.*, mlp_rgb_ll.*; buffers aabb, max_res,
+    num_levels, log2_hashmap_size; plain attributes mlp_density_ggn / mlp_rgb_ggn (laplace_field.py:231-238)."""
+
+    def __init__(self, aabb=None, num_images=1, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_levels=16,
+                 base_res=16, max_res=2048, log2_hashmap_size=19, num_layers_color=3, features_per_level=2,
+                 hidden_dim_color=64, appearance_embedding_dim=32, use_average_appearance_embedding=False,
+                 spatial_distortion=None, implementation="torch", density_activation="trunc_exp", **_unused):
+        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding)
+        assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        assert density_activation == "trunc_exp", "softplus density activation is not built"
+        self.register_buffer("aabb", torch.zeros(2, 3) if aabb is None else aabb)
+        self.register_buffer("max_res", torch.tensor(max_res))
+        self.register_buffer("num_levels", torch.tensor(num_levels))
+        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
+        self.base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level)
+        # num_layers-1 == 1 -> a bare Linear: activation AND out_activation are dropped (utils.py:22-23)
+        self.base_mlp = create_mlp(self.base_grid.get_out_dim(), num_layers - 1, hidden_dim, hidden_dim,
+                                   activation=nn.ReLU, out_activation=nn.ReLU)
+        self.mlp_density = nn.Linear(hidden_dim, 1)
+        self.mlp_hidden = nn.Linear(hidden_dim, geo_feat_dim)
+        self.mlp_head = create_mlp(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color - 1, hidden_dim_color,
+                                   hidden_dim_color, activation=nn.ReLU, out_activation=nn.ReLU)
+        self.mlp_rgb_ll = nn.Linear(hidden_dim_color, 3)
+        self.mlp_density_ggn = torch.zeros(hidden_dim + 1)
+        self.mlp_rgb_ggn = torch.zeros(hidden_dim_color * 3 + 3)
+
+    def sample_last_layers(self, n_samples=100, prior_prec=1.0, eps=1e-9, generator=None, rgb_prior_prec=1.0,
+                           rgb_n_samples=100, rgb_eps=1e-9):
+        """The draw of `sample_laplace` (laplace_field.py:538-547) for both heads: mu + randn * 1/sqrt(ggn+prior+eps).
+        Quirk kept: forward_unc does not forward prior_prec / n_samples / eps to the colour head
+        (laplace_field.py:516-520), which therefore always runs with the defaults 1.0 / 100 / 1e-9."""
+        from torch.nn.utils import parameters_to_vector
+        out = []
+        for mod, ggn, pp, n, e in ((self.mlp_density, self.mlp_density_ggn, prior_prec, n_samples, eps),
+                                   (self.mlp_rgb_ll, self.mlp_rgb_ggn, rgb_prior_prec, rgb_n_samples, rgb_eps)):
+            mu = parameters_to_vector(mod.parameters()).detach()
+            std = 1 / torch.sqrt(ggn.to(mu) + pp + e)
+            noise = torch.randn(n, mu.numel(), generator=generator, device=mu.device)
+            out.append(mu.view(1, -1) + noise * std.view(1, -1))
+        return out[0], out[1]
+
+    def to_device(self, device, ws_density=None, ws_rgb=None, **kw) -> ops.FieldDev:
+        h = self.mlp_head
+        f = lambda t: None if t is None else t.detach().to(device=device, dtype=torch.float32).contiguous()
+        return ops.FieldDev.from_torch(
+            _l.FIELD_LAPLACE, self.base_grid.hash_table, self.base_grid.scalings, self.base_grid.log2_hashmap_size,
+            self.base_mlp[0].weight, self.base_mlp[0].bias, self.mlp_hidden.weight, self.mlp_hidden.bias,
+            [h[0].weight, h[2].weight, self.mlp_rgb_ll.weight], [h[0].bias, h[2].bias, self.mlp_rgb_ll.bias],
+            self.eval_appearance(), device, ws_density=f(ws_density), ws_rgb=f(ws_rgb), **kw)

@@ -1,0 +1,314 @@
+"""Host-side Model mirrors: same class names, config fields, public methods and output-dict keys
+as the reference's models; every pixel is produced by the HIP kernels through `render.py` /
+`splat.py`.  Eval / inference only (the reference's loss and densification code is training-side
+and out of scope).
+
+  ActiveNerfactoModel      models/activenerfacto/activenerfacto_model.py:50-152
+  NerfactoMCDropoutModel   models/mcdropout/mcdropout_models.py:51-131
+  NerfactoLaplaceModel     models/laplace/laplace_model.py:156-556 (get_outputs_for_camera_unc :403-415)
+  ActiveSplatfactoModel    models/activesplatfacto/activesplatfacto_model.py:49-367
+
+nerfstudio is optional: a `Camera` here is any object with `camera_to_worlds` ([3,4] or [1,3,4]),
+`fx, fy, cx, cy, height, width` (python numbers or 1-element tensors) -- a nerfstudio `Cameras` of
+length 1 satisfies this.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple, Type
+
+import torch
+from torch import nn
+
+from . import fields as F
+from . import render, splat
+from .render import NerfSceneDev
+
+
+@dataclass
+class Camera:
+    camera_to_worlds: torch.Tensor
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    height: int
+    width: int
+
+
+def _scalar(v) -> float:
+    return float(v.reshape(-1)[0].item()) if torch.is_tensor(v) else float(v)
+
+
+def _camera_args(camera) -> Tuple[torch.Tensor, Dict[str, Any]]:
+    c2w = camera.camera_to_worlds
+    c2w = c2w[0] if c2w.dim() == 3 else c2w
+    return c2w[:3, :4], dict(fx=_scalar(camera.fx), fy=_scalar(camera.fy), cx=_scalar(camera.cx), cy=_scalar(camera.cy),
+                             H=int(_scalar(camera.height)), W=int(_scalar(camera.width)))
+
+
+# ------------------------------------------------------------------ configs ----------------
+
+@dataclass
+class NerfactoModelConfig:
+    """The nerfstudio 1.1.0 NerfactoModelConfig fields that shape eval rendering."""
+    near_plane: float = 0.05
+    far_plane: float = 1000.0
+    background_color: str = "last_sample"
+    hidden_dim: int = 64
+    hidden_dim_color: int = 64
+    num_levels: int = 16
+    base_res: int = 16
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    features_per_level: int = 2
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_nerf_samples_per_ray: int = 48
+    num_proposal_iterations: int = 2
+    proposal_net_args_list: List[Dict] = field(default_factory=lambda: [
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 128, "use_linear": False},
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 256, "use_linear": False}])
+    use_average_appearance_embedding: bool = True
+    appearance_embed_dim: int = 32
+    average_init_density: float = 1.0
+    eval_num_rays_per_chunk: int = 1 << 15
+    implementation: str = "torch"
+    disable_scene_contraction: bool = False
+    predict_normals: bool = False
+
+
+@dataclass
+class ActiveNerfactoModelConfig(NerfactoModelConfig):
+    _target: Type = field(default_factory=lambda: ActiveNerfactoModel)
+    beta_min: float = 0.01
+    density_loss_mult: float = 0.01
+    rendered_uncertainty_eps: float = 1e-6
+
+
+@dataclass
+class NerfactoMCDropoutModelConfig(NerfactoModelConfig):
+    _target: Type = field(default_factory=lambda: NerfactoMCDropoutModel)
+    dropout_rate: float = 0.2
+    rgb_dropout_layers: List[int] = field(default_factory=lambda: [-1])
+    density_dropout_layers: bool = True
+    mc_samples: int = 10
+
+
+@dataclass
+class NerfactoLaplaceModelConfig(NerfactoModelConfig):
+    _target: Type = field(default_factory=lambda: NerfactoLaplaceModel)
+    density_activation: str = "trunc_exp"
+
+
+@dataclass
+class ActiveSplatfactoModelConfig:
+    _target: Type = field(default_factory=lambda: ActiveSplatfactoModel)
+    sh_degree: int = 3
+    sh_degree_interval: int = 1000
+    rasterize_mode: str = "classic"
+    background_color: str = "random"
+    beta_min: float = 0.01
+    opacity_loss_mult: float = 0.01
+    rendered_uncertainty_eps: float = 1e-6
+
+
+# ------------------------------------------------------------------ NeRF models --------------
+
+class _NerfactoBase(nn.Module):
+    config: NerfactoModelConfig
+
+    def __init__(self, config, scene_box=None, num_train_data: int = 1, **_kw):
+        super().__init__()
+        self.config = config
+        self.scene_box = scene_box
+        self.num_train_data = num_train_data
+        self._dev_scene: Optional[NerfSceneDev] = None
+        self.rays_per_launch = 1 << 18
+        self.populate_modules()
+
+    # -- construction -------------------------------------------------------------------------
+    def _field_kwargs(self):
+        c = self.config
+        if c.disable_scene_contraction:
+            raise NotImplementedError("only SceneContraction(order=inf) is built (the reference default)")
+        return dict(num_images=self.num_train_data, hidden_dim=c.hidden_dim, num_levels=c.num_levels, max_res=c.max_res,
+                    base_res=c.base_res, features_per_level=c.features_per_level,
+                    log2_hashmap_size=c.log2_hashmap_size, hidden_dim_color=c.hidden_dim_color,
+                    use_average_appearance_embedding=c.use_average_appearance_embedding,
+                    appearance_embedding_dim=c.appearance_embed_dim, implementation=c.implementation)
+
+    def populate_modules(self):
+        c = self.config
+        assert c.num_proposal_iterations == 2 and len(c.proposal_net_args_list) == 2
+        self.proposal_networks = nn.ModuleList([
+            F.HashMLPDensityField(hidden_dim=a["hidden_dim"], num_levels=a["num_levels"], max_res=a["max_res"],
+                                  log2_hashmap_size=a["log2_hashmap_size"],
+                                  average_init_density=c.average_init_density) for a in c.proposal_net_args_list])
+        self.field = self._make_field()
+
+    def _make_field(self):
+        raise NotImplementedError
+
+    # -- checkpoints --------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict: bool = False, **kw):  # type: ignore[override]
+        """Accepts nerfstudio checkpoints: `pipeline` keys carry a `_model.` (and, under DDP,
+        `module.`) prefix (ensemble_pipeline.py:77-91).  Non-field keys (camera optimizer, ...) are ignored."""
+        sd = {}
+        for k, v in state_dict.items():
+            k = k[len("_model."):] if k.startswith("_model.") else k
+            k = k[len("module."):] if k.startswith("module.") else k
+            sd[k] = v
+        own = self.state_dict()
+        sd = {k: v for k, v in sd.items() if k in own}
+        self._dev_scene = None
+        return super().load_state_dict(sd, strict=False, **kw)
+
+    # -- lowering to the device ---------------------------------------------------------------
+    def _field_to_device(self, device):
+        return self.field.to_device(device)
+
+    def device_scene(self, device=None) -> NerfSceneDev:
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self._dev_scene is None or self._dev_scene.device != device:
+            c = self.config
+            self._dev_scene = NerfSceneDev(
+                field=self._field_to_device(device), props=[p.to_device(device) for p in self.proposal_networks],
+                near=c.near_plane, far=c.far_plane, num_prop=tuple(c.num_proposal_samples_per_ray),
+                num_nerf=c.num_nerf_samples_per_ray, prop_average_init_density=c.average_init_density,
+                chunk_rays=c.eval_num_rays_per_chunk)
+        return self._dev_scene
+
+    def invalidate(self):
+        """call after changing weights or eval-time knobs (mc_samples, GGN, ...)"""
+        self._dev_scene = None
+
+    # -- rendering ----------------------------------------------------------------------------
+    def _render_kwargs(self) -> Dict[str, Any]:
+        return {}
+
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, torch.Tensor]:
+        if obb_box is not None:
+            raise NotImplementedError("obb_box cropping is not built")
+        c2w, cam = _camera_args(camera)
+        return render.render_camera(self.device_scene(), c2w, rays_per_launch=self.rays_per_launch,
+                                    **cam, **self._render_kwargs())
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, origins: torch.Tensor, directions: torch.Tensor):
+        """origins / directions [H,W,3] on the device (a nerfstudio RayBundle's fields)."""
+        H, W = origins.shape[:2]
+        scene = self.device_scene(origins.device)
+        o, d = origins.reshape(-1, 3).contiguous(), directions.reshape(-1, 3).contiguous()
+        rpl = max(scene.chunk_rays, (self.rays_per_launch // scene.chunk_rays) * scene.chunk_rays)
+        from .ops import new_clip_buffer
+        clip = new_clip_buffer(H * W, scene.chunk_rays, o.device)
+        lists: Dict[str, List[torch.Tensor]] = {}
+        for s in range(0, H * W, rpl):
+            out = render.render_rays(scene, o[s:s + rpl], d[s:s + rpl], ray_offset=s, total_rays=H * W, clip=clip,
+                                     **self._render_kwargs())
+            for k, v in out.items():
+                lists.setdefault(k, []).append(v)
+        return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}
+
+
+class ActiveNerfactoModel(_NerfactoBase):
+    config: ActiveNerfactoModelConfig
+
+    def _make_field(self):
+        return F.ActiveNerfactoField(beta_min=self.config.beta_min, **self._field_kwargs())
+
+    def _render_kwargs(self):
+        return {"keep_density": True}  # the reference returns the raw [H,W,48] density too (:115,:122)
+
+
+class NerfactoMCDropoutModel(_NerfactoBase):
+    config: NerfactoMCDropoutModelConfig
+    seed: int = 0
+
+    def _make_field(self):
+        c = self.config
+        return F.NerfactoMCDropoutField(dropout_rate=c.dropout_rate, rgb_dropout_layers=c.rgb_dropout_layers,
+                                        density_dropout_layers=c.density_dropout_layers, **self._field_kwargs())
+
+    def _field_to_device(self, device):
+        return self.field.to_device(device, mc_samples=self.config.mc_samples, seed=self.seed)
+
+
+class NerfactoLaplaceModel(_NerfactoBase):
+    config: NerfactoLaplaceModelConfig
+    depth_seed: int = 0
+
+    def _make_field(self):
+        return F.NerfactoLaplaceField(density_activation=self.config.density_activation, **self._field_kwargs())
+
+    def _field_to_device(self, device):
+        ws_d, ws_r = self._ws
+        return self.field.to_device(device, ws_density=ws_d, ws_rgb=ws_r)
+
+    @torch.no_grad()
+    def get_outputs_for_camera_unc(self, camera, obb_box=None, is_inference: bool = True,
+                                   use_deterministic_density: bool = False, prior_prec: float = 1.0,
+                                   n_samples: int = 100, eps: float = 1e-9, generator=None):
+        """laplace_model.py:403-415.  Draws the last-layer parameter samples on the host the way
+        `sample_laplace` does (one torch.randn per head), then renders with the fused kernels."""
+        if not is_inference or use_deterministic_density:
+            raise NotImplementedError("only is_inference=True, use_deterministic_density=False "
+                                      "(eval_configs.py:60 default) is built")
+        self._ws = self.field.sample_last_layers(n_samples=n_samples, prior_prec=prior_prec, eps=eps,
+                                                 generator=generator)
+        self.invalidate()
+        return self.get_outputs_for_camera(camera, obb_box)
+
+    def _render_kwargs(self):
+        return {"depth_draws": 100, "depth_seed": self.depth_seed}  # num_samples = 100 (laplace_model.py:487)
+
+
+# ------------------------------------------------------------------ splats --------------------
+
+class ActiveSplatfactoModel(nn.Module):
+    config: ActiveSplatfactoModelConfig
+    GAUSS = ("means", "scales", "quats", "features_dc", "features_rest", "opacities", "log_uncertainties")
+
+    def __init__(self, config: ActiveSplatfactoModelConfig, num_points: int = 1000, **_kw):
+        super().__init__()
+        self.config = config
+        self.step = 0
+        self.populate_modules(num_points)
+
+    def populate_modules(self, num_points: int):
+        q = torch.randn(num_points, 4)
+        self.gauss_params = nn.ParameterDict({
+            "means": nn.Parameter((torch.rand(num_points, 3) - 0.5) * 10), "scales": nn.Parameter(torch.zeros(num_points, 3) - 4),
+            "quats": nn.Parameter(q / q.norm(dim=-1, keepdim=True)), "features_dc": nn.Parameter(torch.rand(num_points, 3)),
+            "features_rest": nn.Parameter(torch.zeros(num_points, 15, 3)),
+            "opacities": nn.Parameter(torch.logit(0.1 * torch.ones(num_points, 1))),
+            # optimised in log space, initialised U(0,1) (activesplatfacto_model.py:58-61)
+            "log_uncertainties": nn.Parameter(torch.rand(num_points, 1)),
+        })
+        self.register_buffer("background_color", torch.zeros(3), persistent=False)
+
+    def load_state_dict(self, dict, **kwargs):  # type: ignore[override]
+        """activesplatfacto_model.py:87-100: resize every gaussian parameter to the checkpoint's point
+        count, accept the legacy un-prefixed names, and pin step = 30000 (-> SH degree 3)."""
+        self.step = 30000
+        dict = {(k[len("_model."):] if k.startswith("_model.") else k): v for k, v in dict.items()}
+        if "means" in dict:
+            for p in self.GAUSS:
+                dict[f"gauss_params.{p}"] = dict[p]
+        newp = dict["gauss_params.means"].shape[0]
+        for name, param in self.gauss_params.items():
+            self.gauss_params[name] = nn.Parameter(torch.zeros((newp,) + param.shape[1:], device=param.device))
+        own = self.state_dict()
+        return super().load_state_dict({k: v for k, v in dict.items() if k in own}, strict=False)
+
+    @torch.no_grad()
+    def get_outputs(self, camera) -> Dict[str, Optional[torch.Tensor]]:
+        c2w, cam = _camera_args(camera)
+        n = min(self.step // self.config.sh_degree_interval, self.config.sh_degree) if self.config.sh_degree > 0 else 0
+        gp = {k: v.detach() for k, v in self.gauss_params.items()}
+        return splat.active_splatfacto_outputs(gp, c2w, background=self.background_color.to(gp["means"].device),
+                                               beta_min=self.config.beta_min, sh_degree=n,
+                                               rasterize_mode=self.config.rasterize_mode, **cam)
+
+    get_outputs_for_camera = get_outputs
