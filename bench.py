@@ -50,6 +50,7 @@ def _alg(kind, K):
         "moments": {"bytes": passes * 24 + 48, "flops": 0},
         "laplace_depth_weights": {"bytes": S * 12 + (S + 1) * 4, "flops": 0},
         "generate_rays": {"bytes": 24, "flops": 0},
+        "field_gather": {"bytes": S * 16 * corner + 24 + (S + 1) * 4 + S * 128, "flops": 0},
     }
 
 
@@ -63,6 +64,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--rays-per-launch", type=int, default=1 << 18)
+    ap.add_argument("--overlap", action="store_true", help="sampling / shading stages on two HIP streams (experiment)")
+    ap.add_argument("--split-gather", action="store_true", help="level-major gather kernel + feature planes (experiment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -95,6 +98,7 @@ def main():
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
         kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
     scene = synthetic.scene_to_device(t, dev, **kw)
+    scene.split_gather = args.split_gather
     H, W = args.height, args.width
     cam = dict(synthetic.CAMERA_1080P)
     cam.update(H=H, W=W, cx=W / 2, cy=H / 2)
@@ -103,7 +107,8 @@ def main():
 
     def frame(i):
         c2w = poses[(rank + i * world) % n_views]   # view-batch partition across ranks
-        return render.render_camera(scene, c2w, rays_per_launch=args.rays_per_launch, depth_seed=7, **cam)
+        return render.render_camera(scene, c2w, rays_per_launch=args.rays_per_launch, overlap=args.overlap,
+                                    depth_seed=7, **cam)
 
     def sync_all():
         torch.cuda.synchronize()

@@ -145,8 +145,17 @@ typedef struct {
  * sbins [R,S+1] spacing-domain bins of the final samples; ray_offset keys the dropout RNG. */
 int unerf_field_fwd(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
                     float near_plane, float far_plane, int64_t ray_offset,
-                    const unerf_field_params* p /* host struct */, float* density, float* rgb, float* aux,
-                    float* aux2, void* stream);
+                    const unerf_field_params* p /* host struct */,
+                    const float* features /* NULL, or the planes written by unerf_field_gather */,
+                    float* density, float* rgb, float* aux, float* aux2, void* stream);
+
+/* Level-major form of the same HashEncoding lookup for the main field: writes the features of the
+ * R*S final samples as planes [L][R*S][2] (level, sample, feature).  Each level table is 4 MiB --
+ * one XCD's L2 -- so sweeping level by level runs the gathers out of L2 instead of the Infinity
+ * Cache; unerf_field_fwd(features=...) then skips its own lookup.  Same values bit for bit. */
+int unerf_field_gather(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
+                       float near_plane, float far_plane, const float* table, const float* scalings, int L,
+                       int log2T, float* feature_planes, void* stream);
 
 /* Laplace depth path: models/laplace/laplace_model.py:486-507.  mean over D draws of
  * get_weights(relu(mu + max(sqrt(var),1e-10) * eps)).  noise [D,R,S] or NULL (then the

@@ -158,6 +158,26 @@ def test_field_active_matches_oracle(dev, use_mfma):
     _close(beta, beta_ref, 1e-4, 1e-6, "beta")
 
 
+@pytest.mark.parametrize("kind,kw", [("active", {}), ("mcdropout", dict(K=2, seed=5, p_drop=0.2))])
+def test_field_level_major_gather_equals_fused_lookup(dev, kind, kw):
+    """unerf_field_gather + unerf_field_fwd(features=...) == the fused kernel, bit for bit, and the
+    feature planes equal the stand-alone hash grid of the oracle positions."""
+    from uncertainty_nerf_gs_amd import ops
+    t, sc, sd = _scene(kind, dev, **kw)
+    o, d = _rays(20, 28)
+    sb = _final_bins(sc, o, d)
+    od, dd, sbd = o.to(dev), d.to(dev), sb.to(dev)
+    feats = ops.field_gather(od, dd, sbd, sd.field, NEAR, FAR)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    p, _ = O.normalized_positions(O.sample_positions(o, d, eb))
+    ref = O.hash_encode(p.reshape(-1, 3), sc.field.grid.table, sc.field.grid.scalings, sc.field.grid.log2_T)
+    assert torch.equal(feats.permute(1, 0, 2).reshape(-1, 32).cpu(), ref)
+    a = ops.field_fwd(od, dd, sbd, sd.field, NEAR, FAR, ray_offset=3)
+    b = ops.field_fwd(od, dd, sbd, sd.field, NEAR, FAR, ray_offset=3, features=feats)
+    for x, y in zip(a, b):
+        assert (x is None and y is None) or torch.equal(x, y)
+
+
 @pytest.mark.parametrize("use_mfma", [True, False], ids=["mfma", "valu"])
 @pytest.mark.parametrize("K", [0, 3])
 def test_field_mcdropout_matches_oracle(dev, K, use_mfma):

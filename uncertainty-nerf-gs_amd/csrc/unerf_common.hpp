@@ -100,14 +100,7 @@ __device__ __forceinline__ void unerf_hash_corners(float px, float py, float pz,
     idx[7] = (hfx ^ hcy ^ hfz) & mask;
 }
 
-__device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lvl, float px, float py, float pz,
-                                                   float scale, uint32_t mask) {
-    uint32_t idx[8];
-    float ox, oy, oz;
-    unerf_hash_corners(px, py, pz, scale, mask, idx, ox, oy, oz);
-    float2 f[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = lvl[idx[k]];
+__device__ __forceinline__ float2 unerf_blend8(const float2 (&f)[8], float ox, float oy, float oz) {
     float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
     float2 r;
     {
@@ -129,6 +122,26 @@ __device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lv
         r.y = f0312 * oz + f4756 * mz;
     }
     return r;
+}
+
+// All 8 corner rows are requested back to back (one s_waitcnt for the batch).  Tried and rejected
+// (r1, MI355X): fetching x-neighbour rows (idx, idx^1 for even floor(x)) as one 16-B load plus a
+// predicated 8-B load for the odd case -- the divergent second load serialises into four dependent
+// round trips per level and ran 1.6-2.1x slower; the neighbour row is an L1 hit anyway.
+__device__ __forceinline__ void unerf_fetch_corners(const float2* __restrict__ lvl, const uint32_t (&idx)[8],
+                                                    float2 (&f)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = lvl[idx[k]];
+}
+
+__device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lvl, float px, float py, float pz,
+                                                   float scale, uint32_t mask) {
+    uint32_t idx[8];
+    float ox, oy, oz;
+    unerf_hash_corners(px, py, pz, scale, mask, idx, ox, oy, oz);
+    float2 f[8];
+    unerf_fetch_corners(lvl, idx, f);
+    return unerf_blend8(f, ox, oy, oz);
 }
 
 // ---- real SH, 4 levels (components_from_spherical_harmonics) -------------------------

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 // ======================================================================================
 // host plumbing
@@ -453,6 +454,7 @@ struct FieldArgs {
     float* aux2;
     uint32_t keep_thr;
     float drop_scale;
+    const float* features;  // optional [16][N][2] level-major planes from unerf_field_gather (MFMA kernel)
 };
 
 // acc[o] = b[o] + sum_i act[i] * Wt[i][o]   (sequential over i, fused multiply-add)
@@ -699,7 +701,7 @@ __device__ __forceinline__ f32x16 mf_dropout(f32x16 v, int blk, int h, uint32_t 
     return v;
 }
 
-template <int MODE>
+template <int MODE, bool FEAT_IN>
 __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t num_tiles) {
     extern __shared__ float lds[];
     {
@@ -739,16 +741,52 @@ __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t nu
 
         // hash grid: this half's 8 levels -> 16 features = the 16 k-steps of layer 0
         f32x16 feat;
+        if (FEAT_IN) {  // features were gathered level-major by field_gather_kernel: coalesced 8-B reads
+            const float2* fp = reinterpret_cast<const float2*>(a.features);
 #pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            const int lev = 8 * h + l;
-            const float2* lvl = reinterpret_cast<const float2*>(a.p.table) + ((size_t)lev << a.p.log2T);
-            float2 f = unerf_hash_level(lvl, px, py, pz, a.p.scalings[lev], mask);
-            feat[2 * l] = f.x;
-            feat[2 * l + 1] = f.y;
+            for (int l = 0; l < 8; ++l) {
+                float2 f = fp[(int64_t)(8 * h + l) * N + n];
+                feat[2 * l] = f.x;
+                feat[2 * l + 1] = f.y;
+            }
+        } else {
+            // Two batches of 4 levels: all 32 corner rows of a batch are requested back to back
+            // (uniform table base + 32-bit byte offset per lane), THEN blended.  Left to itself the
+            // compiler interleaves address math, 4-load groups and waits (about 20 dependent round
+            // trips per tile, r1 ISA), which made this phase latency-bound: 38.8 ms/frame for a
+            // kernel whose gathers alone take 8.4 ms and whose matrix work alone takes 18.6 ms.
+            const char* tbase = reinterpret_cast<const char*>(a.p.table);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                float2 cd[32];
+                float of[12];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int lev = 8 * h + 4 * hb + q;
+                    uint32_t idx[8];
+                    unerf_hash_corners(px, py, pz, a.p.scalings[lev], mask, idx, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t off = ((((uint32_t)lev) << a.p.log2T) + idx[k]) * 8u;
+                        cd[8 * q + k] = *reinterpret_cast<const float2*>(tbase + off);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float2 c8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
+                    float2 f = unerf_blend8(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+                    feat[2 * (4 * hb + q)] = f.x;
+                    feat[2 * (4 * hb + q) + 1] = f.y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        // SH of the ray direction; this half feeds components 8h..8h+7
-        f32x16 shv;
+        // Colour layer 0 sees [geo(15) | SH(16)]; the SH half does not depend on the MC pass, so its
+        // 16 MFMAs (+ bias) are done once per tile and every pass starts from that partial sum.
+        f32x16 csh0 = mf_bias(lds, 3, h), csh1 = mf_bias(lds, 4, h);
         {
             float sh[16];
             float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
@@ -758,14 +796,15 @@ __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t nu
                 uz = uz * 2.f - 1.f;
             }
             unerf_sh16(ux, uy, uz, sh);
-            // bitwise per-half select: a plain `h ? sh[8+k] : sh[k]` is rewritten by the compiler
-            // into a lane-indexed load from a scratch copy of sh[]
+            // this half feeds components 8h..8h+7.  Bitwise per-half select: a plain
+            // `h ? sh[8+k] : sh[k]` is rewritten into a lane-indexed load from a scratch copy of sh[]
             const uint32_t hm = 0u - (uint32_t)h;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                shv[k] = __uint_as_float((__float_as_uint(sh[8 + k]) & hm) | (__float_as_uint(sh[k]) & ~hm));
-#pragma unroll
-            for (int k = 8; k < 16; ++k) shv[k] = 0.f;
+            for (int q = 0; q < 8; ++q) {
+                float v = __uint_as_float((__float_as_uint(sh[8 + q]) & hm) | (__float_as_uint(sh[q]) & ~hm));
+                csh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(64 + 8 + q) * 64 + lane], v, csh0, 0, 0, 0);
+                csh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(80 + 8 + q) * 64 + lane], v, csh1, 0, 0, 0);
+            }
         }
 
         // layer 0: 32 -> 64, ReLU
@@ -787,17 +826,12 @@ __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t nu
             f32x16 t = mf_bias(lds, 2, h);
             t = mf_slab(lds, 32, lane, m0, t);
             t = mf_slab(lds, 48, lane, m1, t);
-            // colour 0: [geo rows of t (regs 0..7) | SH] -> 64, ReLU
-            f32x16 c0 = mf_bias(lds, 3, h), c1 = mf_bias(lds, 4, h);
+            // colour 0: the geo rows of t (regs 0..7) on top of the per-tile SH partial sum, ReLU
+            f32x16 c0 = csh0, c1 = csh1;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(64 + q) * 64 + lane], t[q], c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(80 + q) * 64 + lane], t[q], c1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 8; q < 16; ++q) {
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(64 + q) * 64 + lane], shv[q - 8], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(80 + q) * 64 + lane], shv[q - 8], c1, 0, 0, 0);
             }
             c0 = mf_relu(c0);
             c1 = mf_relu(c1);
@@ -839,6 +873,65 @@ __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t nu
     }
 }
 
+// --------------------------------------------------------------------------------------
+// 5c. level-major hash-grid gather.  One level of the main grid is 2^19 x 8 B = 4 MiB -- exactly
+// one XCD's L2.  Sample-major lookup (all 16 levels per sample) keeps 64 MiB live and runs at the
+// Infinity-Cache random-64-B-request rate (40 ms/frame inside the fused kernel, 5.05 ms per 2^18
+// rays stand-alone); walking the levels in the SLOW grid dimension makes every XCD sweep one
+// 4-MiB table at a time out of its own L2: 2.3 ms per 2^18 rays (benchmarks/exp_level_major.py).
+// Features go to level-major planes [16][N] float2 (coalesced 8-B stores here, coalesced 8-B
+// loads in field_kernel_mfma<.., FEAT_IN>), and the gather runs on its own stream underneath the
+// previous launch group's matrix work (render.py).
+// --------------------------------------------------------------------------------------
+struct GatherArgs {
+    const float* origins;
+    const float* dirs;
+    const float* sbins;
+    int64_t R;
+    int S;
+    float s_near, s_far;
+    const float* table;
+    const float* scalings;
+    int L, log2T;
+    float* planes;
+};
+
+__global__ __launch_bounds__(256) void field_gather_kernel(GatherArgs a) {
+    const int64_t N = a.R * (int64_t)a.S;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int lev = blockIdx.y;
+    const int64_t r = n / a.S;
+    const int s = (int)(n - r * a.S);
+    const float* sb = a.sbins + r * (a.S + 1);
+    float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+    float t01 = e0 + e1;
+    float px = a.origins[r * 3 + 0] + a.dirs[r * 3 + 0] * t01 / 2.f;
+    float py = a.origins[r * 3 + 1] + a.dirs[r * 3 + 1] * t01 / 2.f;
+    float pz = a.origins[r * 3 + 2] + a.dirs[r * 3 + 2] * t01 / 2.f;
+    (void)unerf_normalize_position(px, py, pz);
+    const float2* lvl = reinterpret_cast<const float2*>(a.table) + ((size_t)lev << a.log2T);
+    float2 f = unerf_hash_level(lvl, px, py, pz, a.scalings[lev], (1u << a.log2T) - 1u);
+    reinterpret_cast<float2*>(a.planes)[(int64_t)lev * N + n] = f;
+}
+
+extern "C" int unerf_field_gather(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
+                                  float near_plane, float far_plane, const float* table, const float* scalings, int L,
+                                  int log2T, float* feature_planes, void* stream) {
+    UNERF_REQUIRE(origins && directions && sbins && table && scalings && feature_planes, "field_gather: null pointer");
+    UNERF_REQUIRE(L >= 1 && L <= 32 && log2T >= 1 && log2T <= 24 && R >= 0 && S >= 1, "field_gather: bad L/log2T/R/S");
+    if (R == 0) return UNERF_OK;
+    GatherArgs a;
+    a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
+    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    a.table = table; a.scalings = scalings; a.L = L; a.log2T = log2T; a.planes = feature_planes;
+    // blockIdx.x runs fastest in dispatch order, so all workgroups of level l are issued before
+    // level l+1: the chip works on (at most) two adjacent level tables at any time
+    dim3 grid(blocks_for(R * (int64_t)S, 256), L), block(256);
+    hipLaunchKernelGGL(field_gather_kernel, grid, block, 0, (hipStream_t)stream, a);
+    return unerf_check_launch("field_gather");
+}
+
 static int mfma_grid(int64_t num_tiles) {
     int64_t blocks = (num_tiles + 3) / 4;
     const int64_t cap = 256 * 3;  // 3 workgroups of 4 waves per CU: 42.6 KB LDS each, <=168 VGPRs
@@ -848,12 +941,15 @@ static int mfma_grid(int64_t num_tiles) {
 
 extern "C" int unerf_field_fwd(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
                                float near_plane, float far_plane, int64_t ray_offset, const unerf_field_params* p,
-                               float* density, float* rgb, float* aux, float* aux2, void* stream) {
+                               const float* features, float* density, float* rgb, float* aux, float* aux2,
+                               void* stream) {
     UNERF_REQUIRE(origins && directions && sbins && p && density && rgb, "field_fwd: null pointer");
     UNERF_REQUIRE(p->table && p->scalings && p->w0t && p->b0 && p->w1t && p->b1 && p->h0t && p->hb0 && p->h1t &&
                       p->hb1 && p->h2t && p->hb2,
                   "field_fwd: null weight pointer");
     UNERF_REQUIRE(p->L == 16, "field_fwd: L=%d (only the nerfacto 16-level grid is built)", p->L);
+    UNERF_REQUIRE(!features || (p->mfma_blob && p->mode != UNERF_FIELD_LAPLACE),
+                  "field_fwd: pre-gathered features are consumed by the MFMA kernel only (ACTIVE/MCDROPOUT with mfma_blob)");
     UNERF_REQUIRE(p->log2T >= 1 && p->log2T <= 24, "field_fwd: bad log2T=%d", p->log2T);
     UNERF_REQUIRE(R >= 0 && S >= 1, "field_fwd: bad R/S");
     UNERF_REQUIRE((uint64_t)(ray_offset + R) * (uint64_t)S < (1ull << 32),
@@ -863,6 +959,7 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = ray_offset;
     a.p = *p; a.density = density; a.rgb = rgb; a.aux = aux; a.aux2 = aux2;
+    a.features = features;
     a.keep_thr = (uint32_t)lrint((1.0 - (double)p->p_drop) * 65536.0);
     a.drop_scale = 1.f / (1.f - p->p_drop);
     dim3 grid(blocks_for(R * (int64_t)S, 64)), block(64);
@@ -872,8 +969,12 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
             if (p->mfma_blob) {
                 int64_t tiles = (R * (int64_t)S + 31) / 32;
-                hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE>), dim3(mfma_grid(tiles)), dim3(256),
-                                   UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+                if (features)
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid(tiles)), dim3(256),
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+                else
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid(tiles)), dim3(256),
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_ACTIVE>), grid, block, 64 * 64 * 4, st, a);
             }
@@ -883,8 +984,12 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
             if (p->mfma_blob) {
                 int64_t tiles = (R * (int64_t)S + 31) / 32;
-                hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT>), dim3(mfma_grid(tiles)), dim3(256),
-                                   UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+                if (features)
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid(tiles)), dim3(256),
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+                else
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid(tiles)), dim3(256),
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
             }

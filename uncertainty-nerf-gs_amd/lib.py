@@ -75,7 +75,9 @@ SIGNATURES = {
     "unerf_proposal_density": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, C.POINTER(DensityNet), _f, _vp, _vp]),
     "unerf_weights_pdf_resample": (_i, [_vp, _vp, _i64, _i64, _i, _f, _f, _vp, _i, _f, _f, _vp, _vp, _vp, _vp,
                                         _i64, _i64, _vp]),
-    "unerf_field_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i64, C.POINTER(FieldParams), _vp, _vp, _vp, _vp, _vp]),
+    "unerf_field_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i64, C.POINTER(FieldParams), _vp, _vp, _vp, _vp, _vp,
+                             _vp]),
+    "unerf_field_gather": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
     "unerf_laplace_depth_weights": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp, _i, _u32, _i64, _vp, _vp]),
     "unerf_composite_var": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp]),
     "unerf_moments": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),

@@ -292,7 +292,23 @@ def new_clip_buffer(num_rays: int, chunk_rays: int, device) -> torch.Tensor:
 
 # ------------------------------------------------------------ main field ---------------
 
-def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0):
+def field_gather(origins, directions, sbins, field: FieldDev, near: float, far: float,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """level-major hash-grid lookup of the final samples -> feature planes [L, R*S, 2]"""
+    lib = _l.load()
+    R, S = sbins.shape[0], sbins.shape[1] - 1
+    L = field.scalings.numel()
+    if out is None:
+        out = torch.empty(L, R * S, 2, device=origins.device, dtype=torch.float32)
+    with _ctx(origins.device):
+        _run("field_gather", lambda: lib.unerf_field_gather(_p(origins), _p(directions), _p(sbins), R, S, near, far,
+                                                            _p(field.table), _p(field.scalings), L, field.log2T,
+                                                            _p(out), _stream()))
+    return out
+
+
+def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0,
+              features: Optional[torch.Tensor] = None):
     """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h)"""
     lib = _l.load()
     R, S = sbins.shape[0], sbins.shape[1] - 1
@@ -305,7 +321,7 @@ def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: flo
     cs = field.cstruct()
     with _ctx(dev):
         _run("field_fwd", lambda: lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, ray_offset,
-                                     C.byref(cs), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()))
+                                     C.byref(cs), _p(features), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()))
     return density, rgb, aux, aux2
 
 

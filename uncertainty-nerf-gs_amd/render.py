@@ -7,10 +7,17 @@ kernels at once -- 288 GB of HBM make the reference's 32768-ray chunking unneces
 place the reference chunk size is observable (DepthRenderer("expected") clips to the chunk's
 min/max sample position) is reproduced exactly through `chunk_rays`.
 
-Kernel sequence per launch group (all on the caller's current stream):
-  proposal_density(256) -> weights_pdf_resample(->96) -> proposal_density(96)
-  -> weights_pdf_resample(->48) -> field_fwd -> [laplace_depth_weights] -> composite_var
-  -> [moments over K]
+Kernel sequence per launch group:
+  sampling stage : proposal_density(256) -> weights_pdf_resample(->96) -> proposal_density(96)
+                   -> weights_pdf_resample(->48) -> field_gather (level-major hash-grid lookup)
+  shading stage  : field_fwd (fp32-MFMA MLPs) -> [laplace_depth_weights] -> composite_var -> [moments over K]
+
+By default the hash-grid lookup is fused into `field_fwd` and everything runs on the caller's
+stream.  Two measured alternatives are kept as options (numbers: DESIGN.md section 4.3):
+`scene.split_gather` (level-major gather kernel, one 4-MiB level table = one XCD L2 at a time) and
+`render_camera(overlap=True)` (sampling stage of launch group g+1 on a second HIP stream underneath
+the shading stage of group g).  On MI355X neither beats the fused single-stream form for these
+shapes: the stages contend for the same CUs' issue slots and register file.
 """
 from __future__ import annotations
 
@@ -45,6 +52,7 @@ class NerfSceneDev:
     num_nerf: int = 48
     prop_average_init_density: float = 0.01
     chunk_rays: int = 1 << 15
+    split_gather: bool = False  # True: level-major gather kernel + feature planes instead of the fused lookup
     _const: Dict[str, torch.Tensor] = field(default_factory=dict)
 
     @property
@@ -85,23 +93,23 @@ def _unpack(out: torch.Tensor) -> Dict[str, torch.Tensor]:
     }
 
 
-def render_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Tensor, ray_offset: int = 0,
-                total_rays: Optional[int] = None, clip: Optional[torch.Tensor] = None,
-                depth_noise: Optional[torch.Tensor] = None, depth_draws: int = 100, depth_seed: int = 0,
-                keep_density: bool = False) -> Dict[str, torch.Tensor]:
-    """Render rays [R,3] with the scene's method (field.mode).  Output keys follow the reference:
-      ACTIVE     activenerfacto_model.py:117-127   rgb accumulation depth expected_depth rgb_var rgb_std
-                                                   depth_var depth_std prop_depth_i (+density)
-      MCDROPOUT  mcdropout_models.py:121-126       means of every key + rgb_std depth_std expected_depth_std
-      LAPLACE    laplace_model.py:523-530          rgb rgb_std accumulation depth depth_std expected_depth
-    """
-    _l.require_gpu()
-    R = origins.shape[0]
-    if clip is None:
-        clip = ops.new_clip_buffer((total_rays or (ray_offset + R)), scene.chunk_rays, origins.device)
-    sb, prop_depths = sample_rays(scene, origins, directions, clip, ray_offset)
+def _uses_split(scene: NerfSceneDev) -> bool:
     f = scene.field
-    density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset)
+    return bool(scene.split_gather and f.mode != _l.FIELD_LAPLACE and f.use_mfma and f.mfma_blob is not None)
+
+
+def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: int):
+    """-> (final spacing bins, prop depths, feature planes | None)"""
+    sb, prop_depths = sample_rays(scene, origins, directions, clip, ray_offset)
+    feats = ops.field_gather(origins, directions, sb, scene.field, scene.near, scene.far) if _uses_split(scene) else None
+    return sb, prop_depths, feats
+
+
+def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, feats, clip, ray_offset: int = 0,
+                  depth_noise: Optional[torch.Tensor] = None, depth_draws: int = 100, depth_seed: int = 0,
+                  keep_density: bool = False) -> Dict[str, torch.Tensor]:
+    f = scene.field
+    density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset, features=feats)
     kw = dict(clip_minmax=clip, ray_offset=ray_offset, chunk_rays=scene.chunk_rays)
     res: Dict[str, torch.Tensor] = {}
     if f.mode == _l.FIELD_ACTIVE:
@@ -137,20 +145,73 @@ def render_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Te
     return res
 
 
+def render_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Tensor, ray_offset: int = 0,
+                total_rays: Optional[int] = None, clip: Optional[torch.Tensor] = None, **shade_kw) -> Dict[str, torch.Tensor]:
+    """Render rays [R,3] with the scene's method (field.mode).  Output keys follow the reference:
+      ACTIVE     activenerfacto_model.py:117-127   rgb accumulation depth expected_depth rgb_var rgb_std
+                                                   depth_var depth_std prop_depth_i (+density)
+      MCDROPOUT  mcdropout_models.py:121-126       means of every key + rgb_std depth_std expected_depth_std
+      LAPLACE    laplace_model.py:523-530          rgb rgb_std accumulation depth depth_std expected_depth
+    """
+    _l.require_gpu()
+    R = origins.shape[0]
+    if clip is None:
+        clip = ops.new_clip_buffer((total_rays or (ray_offset + R)), scene.chunk_rays, origins.device)
+    sb, prop_depths, feats = sampling_stage(scene, origins, directions, clip, ray_offset)
+    return shading_stage(scene, origins, directions, sb, prop_depths, feats, clip, ray_offset, **shade_kw)
+
+
 def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int,
-                  rays_per_launch: int = 1 << 18, **kw) -> Dict[str, torch.Tensor]:
+                  rays_per_launch: int = 1 << 18, overlap: bool = False, **shade_kw) -> Dict[str, torch.Tensor]:
     """get_outputs_for_camera: generate the H*W rays on device, render them in row-major launch
-    groups, return images [H,W,C]."""
+    groups, return images [H,W,C].  With `overlap`, sampling (group g+1) and shading (group g) run on
+    two streams."""
+    _l.require_gpu()
     total = H * W
     dev = scene.device
     clip = ops.new_clip_buffer(total, scene.chunk_rays, dev)
     # launch groups must not split a reference chunk (the clip bounds are per chunk)
     rpl = max(scene.chunk_rays, (rays_per_launch // scene.chunk_rays) * scene.chunk_rays)
+    starts = list(range(0, total, rpl))
     lists: Dict[str, List[torch.Tensor]] = {}
-    for start in range(0, total, rpl):
-        cnt = min(rpl, total - start)
-        o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, cnt)
-        out = render_rays(scene, o, d, ray_offset=start, total_rays=total, clip=clip, **kw)
-        for k, v in out.items():
-            lists.setdefault(k, []).append(v)
-    return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}
+    with torch.cuda.device(dev):
+        cur = torch.cuda.current_stream()
+        if not overlap or len(starts) == 1:
+            for start in starts:
+                o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start))
+                out = render_rays(scene, o, d, ray_offset=start, total_rays=total, clip=clip, **shade_kw)
+                for k, v in out.items():
+                    lists.setdefault(k, []).append(v)
+        else:
+            s_samp, s_shade = _streams(dev)
+            s_samp.wait_stream(cur)
+            s_shade.wait_stream(cur)
+            for start in starts:
+                with torch.cuda.stream(s_samp):
+                    o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start))
+                    sb, pds, feats = sampling_stage(scene, o, d, clip, start)
+                    ev = torch.cuda.Event()
+                    ev.record(s_samp)
+                    for t in (o, d, sb, feats, *pds):   # handed to the other stream: keep the allocator honest
+                        if t is not None:
+                            t.record_stream(s_shade)
+                with torch.cuda.stream(s_shade):
+                    s_shade.wait_event(ev)
+                    out = shading_stage(scene, o, d, sb, pds, feats, clip, start, **shade_kw)
+                    for v in out.values():
+                        v.record_stream(cur)
+                for k, v in out.items():
+                    lists.setdefault(k, []).append(v)
+            cur.wait_stream(s_shade)
+            cur.wait_stream(s_samp)
+        return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}
+
+
+_STREAMS: Dict[int, Tuple["torch.cuda.Stream", "torch.cuda.Stream"]] = {}
+
+
+def _streams(dev):
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _STREAMS:
+        _STREAMS[idx] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _STREAMS[idx]
