@@ -59,7 +59,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--method", default="active", choices=["active", "mcdropout", "laplace"])
+    ap.add_argument("--method", default="active", choices=["active", "mcdropout", "laplace", "splat"])
+    ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--mc-samples", type=int, default=8)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
@@ -89,6 +90,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.method == "splat":
+        return bench_splat(args, rank, world, dev, dist)
     K = args.mc_samples if args.method == "mcdropout" else 0
     t = synthetic.make_scene_tensors(seed=0, kind=args.method)   # full nerfacto shape: 16x2^19x2 + 2 x 5x2^17x2
     kw = {}
@@ -187,6 +190,62 @@ def main():
                        "rays_per_step": H * W, "samples_per_ray": [256, 96, 48], "hash_grid": "16x2^19x2 fp32",
                        "parallelism": f"views x{world}" if world > 1 else "single"},
             "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_splat(args, rank, world, dev, dist):
+    """config 5: active-splatfacto, N splats (SURVEY.md 8d synthetic set), 1080p, per-splat variance.
+    A step = one frame: project + SH/beta + ONE bin-and-sort + 5-channel raster + depth-variance raster.
+    Ranks render different views of the orbit with replicated splats (view-batch DP, no collective)."""
+    from uncertainty_nerf_gs_amd import ops, splat, synthetic
+    gp = {k: v.to(dev) for k, v in synthetic.make_splat_tensors(seed=7, N=args.splats).items()}
+    H, W = args.height, args.width
+    cam = dict(fx=1111.0 * W / 1920, fy=1111.0 * W / 1920, cx=W / 2, cy=H / 2, H=H, W=W)
+    n_views = 24
+    poses = [synthetic.orbit_c2w(2 * math.pi * i / n_views, radius=2.5, height=0.5) for i in range(n_views)]
+    bg = torch.zeros(3, device=dev)
+
+    def frame(i):
+        return splat.active_splatfacto_outputs(gp, poses[(rank + i * world) % n_views], background=bg, **cam)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = frame(i)
+    sync_all()
+    ops.TIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = frame(args.warmup + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out["rgb"]).all()
+    if rank == 0:
+        ksum = timer.summary()
+        dom = max(ksum, key=lambda k: ksum[k]["total_ms"])
+        line = {
+            "metric": "Mrays/s (+var) [pixels of an active-splatfacto frame], 1080p", "value": H * W * args.steps * world / elapsed / 1e6,
+            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"active-splatfacto {W}x{H}, N={args.splats} splats, rgb+beta+depth+depth_var",
+                       "parallelism": f"views x{world}" if world > 1 else "single"},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                         "traffic": None, "avg_launch_ms": ksum[dom]["avg_ms"],
+                         "per_kernel_ms_per_frame": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(ksum.items())}},
+            "cpu_baseline": None,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -135,8 +135,12 @@ typedef struct {
        floats).  When non-NULL the fused kernel runs its dense layers on v_mfma_f32_32x32x2_f32
        (exact fp32) with the weights resident in LDS; NULL selects the VALU kernel. */
     const float* mfma_blob;
+    /* Optional (LAPLACE, with mfma_blob): the n_lap <= 128 sampled last-layer rows of both heads as MFMA A
+       fragments (ops.py::pack_laplace_heads, UNERF_LAP_BLOB_FLOATS floats; streamed from L2, not LDS). */
+    const float* lap_blob;
 } unerf_field_params;
 #define UNERF_MFMA_BLOB_FLOATS 10660
+#define UNERF_LAP_BLOB_FLOATS 33280
 
 /* outputs: B = max(K,1) passes
  *   density [B,R,S]; rgb [B,R,S,3];

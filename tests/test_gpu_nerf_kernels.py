@@ -206,11 +206,15 @@ def test_field_mcdropout_matches_oracle(dev, K, use_mfma):
         assert not torch.equal(dens[0], dens[1]), "passes must use different masks"
 
 
-def test_field_laplace_matches_oracle(dev):
+@pytest.mark.parametrize("use_mfma,n_samples", [(True, 100), (False, 100), (True, 37), (True, 128)],
+                         ids=["mfma-100", "valu-100", "mfma-37", "mfma-128"])
+def test_field_laplace_matches_oracle(dev, use_mfma, n_samples):
     from uncertainty_nerf_gs_amd import ops, synthetic
     t, sc, _ = _scene("laplace", dev)
-    wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+    wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=n_samples)
     sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+    sd.field.use_mfma = use_mfma
+    assert sd.field.lap_blob is not None
     o, d = _rays(12, 16)
     sb = _final_bins(sc, o, d)
     eb = O.spacing_to_euclidean(sb, NEAR, FAR)

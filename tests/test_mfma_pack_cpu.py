@@ -103,3 +103,87 @@ def test_packed_operands_16_wide_trunk():
     fr = blob[:ops.MFMA_BIAS_OFF].view(ops.MFMA_FRAGS, 64)
     # rows 16..31 of the padded trunk-out block must be zero on every fragment
     assert torch.all(fr[32:64][:, (torch.arange(64) & 31) >= 16] == 0)
+
+
+def emulate_laplace_tile(blob, lap, feats, sh, n_lap):
+    """Laplace dataflow of field_kernel_mfma_laplace: bare Linear base, geo = mlp_hidden, sampled heads."""
+    blob = blob.numpy().astype(np.float64)
+    lap = lap.numpy().astype(np.float64)
+    fr = blob[:ops.MFMA_BIAS_OFF].reshape(ops.MFMA_FRAGS, 64)
+    bias = blob[ops.MFMA_BIAS_OFF:ops.MFMA_H2_OFF].reshape(7, 2, 16)
+    lfr = lap[:ops.LAP_BIAS_OFF].reshape(4, ops.LAP_BLOCKS, 2, 16, 64)
+    lbias = lap[ops.LAP_BIAS_OFF:].reshape(4, ops.LAP_BLOCKS, 2, 16)
+    j = I_
+    feat = np.stack([feats[j, 16 * H_ + s] for s in range(16)])
+    binit = lambda k: np.stack([bias[k, H_, r] for r in range(16)])
+    hb = [binit(0), binit(1)]
+    for blk in range(2):
+        for s in range(16):
+            hb[blk] = mfma(fr[blk * 16 + s], feat[s], hb[blk])          # NO ReLU (utils.py:22-23 quirk)
+    t = binit(2)
+    for bi in range(2):
+        for r in range(16):
+            t = mfma(fr[32 + bi * 16 + r], hb[bi][r], t)               # geo = mlp_hidden(hb)
+
+    def head(q, src, act):
+        s1 = np.zeros(64)
+        s2 = np.zeros(64)
+        for b in range(ops.LAP_BLOCKS):
+            acc = np.stack([lbias[q, b, H_, r] for r in range(16)])
+            for bi in range(2):
+                for r in range(16):
+                    acc = mfma(lfr[q, b, bi, r], src[bi][r], acc)
+            p = act(acc)
+            s1 += p.sum(0)
+            s2 += (p * p).sum(0)
+        s1 = s1 + s1[LANE ^ 32]
+        s2 = s2 + s2[LANE ^ 32]
+        mu, mu2 = s1 / n_lap, s2 / n_lap
+        return mu[:32], (mu2 - mu * mu)[:32]
+
+    with np.errstate(over="ignore"):
+        mu_d, var_d = head(0, hb, np.exp)
+    shv = np.stack([sh[j, 8 * H_ + k] for k in range(8)])
+    c = [binit(3), binit(4)]
+    for blk in range(2):
+        for s in range(8):
+            c[blk] = mfma(fr[64 + blk * 16 + s], t[s], c[blk])
+        for s in range(8, 16):
+            c[blk] = mfma(fr[64 + blk * 16 + s], shv[s - 8], c[blk])
+    c = [np.maximum(a, 0) for a in c]
+    d = [binit(5), binit(6)]
+    for blk in range(2):
+        for bi in range(2):
+            for r in range(16):
+                d[blk] = mfma(fr[96 + blk * 32 + bi * 16 + r], c[bi][r], d[blk])
+    d = [np.maximum(a, 0) for a in d]
+    sig = lambda x: 1 / (1 + np.exp(-np.maximum(x, -700)))
+    mus, vars_ = zip(*[head(1 + ch, d, sig) for ch in range(3)])
+    return mu_d, var_d, np.stack(mus, -1), np.stack(vars_, -1)
+
+
+def test_laplace_packed_heads_reproduce_sample_laplace():
+    g = torch.Generator().manual_seed(2)
+    rnd = lambda *s: torch.randn(*s, generator=g) * 0.3
+    w0, b0, wh, bh = rnd(64, 32), rnd(64), rnd(15, 64), rnd(15)
+    h0, hb0, h1, hb1, h2, hb2 = rnd(64, 31), rnd(64), rnd(64, 64), rnd(64), rnd(3, 64), rnd(3)
+    n = 100
+    ws_d, ws_r = rnd(n, 65), rnd(n, 195)
+    blob = ops.pack_field_mfma(w0, b0, wh, bh, h0, hb0, h1, hb1, h2, hb2, geo_first_unit=0)
+    lap = ops.pack_laplace_heads(ws_d, ws_r)
+    assert lap.numel() == ops.LAP_BLOB_FLOATS
+    feats, sh = rnd(32, 32), rnd(32, 16)
+    mu_d, var_d, mu_c, var_c = emulate_laplace_tile(blob, lap, feats.numpy().astype(np.float64),
+                                                    sh.numpy().astype(np.float64), n)
+    hb = F.linear(feats.double(), w0.double(), b0.double())
+    geo = F.linear(hb, wh.double(), bh.double())
+    pd = torch.exp(F.linear(hb, ws_d[:, :64].double(), ws_d[:, 64].double()))          # [32, n]
+    x = torch.cat([sh.double(), geo], dim=-1)
+    x = F.relu(F.linear(x, h0.double(), hb0.double()))
+    x = F.relu(F.linear(x, h1.double(), hb1.double()))
+    np.testing.assert_allclose(mu_d, pd.mean(1).numpy(), rtol=1e-9)
+    np.testing.assert_allclose(var_d, ((pd ** 2).mean(1) - pd.mean(1) ** 2).numpy(), rtol=1e-6, atol=1e-12)
+    for ch in range(3):
+        pc = torch.sigmoid(F.linear(x, ws_r[:, ch * 64:(ch + 1) * 64].double(), ws_r[:, 192 + ch].double()))
+        np.testing.assert_allclose(mu_c[:, ch], pc.mean(1).numpy(), rtol=1e-9)
+        np.testing.assert_allclose(var_c[:, ch], ((pc ** 2).mean(1) - pc.mean(1) ** 2).numpy(), rtol=1e-6, atol=1e-12)

@@ -701,6 +701,43 @@ __device__ __forceinline__ f32x16 mf_dropout(f32x16 v, int blk, int h, uint32_t 
     return v;
 }
 
+// This half's 8 levels of the main grid for one sample -> the 16 k-steps of layer 0.
+// Two batches of 4 levels: all 32 corner rows of a batch are requested back to back (uniform table
+// base + 32-bit byte offset per lane), THEN blended.  Left to itself the compiler interleaves
+// address math, 4-load groups and waits (about 20 dependent round trips per tile in the r1 ISA).
+__device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, float py, float pz, int h, uint32_t mask) {
+    f32x16 feat;
+    const char* tbase = reinterpret_cast<const char*>(a.p.table);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        float2 cd[32];
+        float of[12];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int lev = 8 * h + 4 * hb + q;
+            uint32_t idx[8];
+            unerf_hash_corners(px, py, pz, a.p.scalings[lev], mask, idx, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t off = ((((uint32_t)lev) << a.p.log2T) + idx[k]) * 8u;
+                cd[8 * q + k] = *reinterpret_cast<const float2*>(tbase + off);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float2 c8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
+            float2 f = unerf_blend8(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+            feat[2 * (4 * hb + q)] = f.x;
+            feat[2 * (4 * hb + q) + 1] = f.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return feat;
+}
+
 template <int MODE, bool FEAT_IN>
 __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t num_tiles) {
     extern __shared__ float lds[];
@@ -750,39 +787,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t nu
                 feat[2 * l + 1] = f.y;
             }
         } else {
-            // Two batches of 4 levels: all 32 corner rows of a batch are requested back to back
-            // (uniform table base + 32-bit byte offset per lane), THEN blended.  Left to itself the
-            // compiler interleaves address math, 4-load groups and waits (about 20 dependent round
-            // trips per tile, r1 ISA), which made this phase latency-bound: 38.8 ms/frame for a
-            // kernel whose gathers alone take 8.4 ms and whose matrix work alone takes 18.6 ms.
-            const char* tbase = reinterpret_cast<const char*>(a.p.table);
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                float2 cd[32];
-                float of[12];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int lev = 8 * h + 4 * hb + q;
-                    uint32_t idx[8];
-                    unerf_hash_corners(px, py, pz, a.p.scalings[lev], mask, idx, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t off = ((((uint32_t)lev) << a.p.log2T) + idx[k]) * 8u;
-                        cd[8 * q + k] = *reinterpret_cast<const float2*>(tbase + off);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float2 c8[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
-                    float2 f = unerf_blend8(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
-                    feat[2 * (4 * hb + q)] = f.x;
-                    feat[2 * (4 * hb + q) + 1] = f.y;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            feat = mf_gather_feats(a, px, py, pz, h, mask);
         }
         // Colour layer 0 sees [geo(15) | SH(16)]; the SH half does not depend on the MC pass, so its
         // 16 MFMAs (+ bias) are done once per tile and every pass starts from that partial sum.
@@ -869,6 +874,163 @@ __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t nu
                 a.rgb[q * 3 + 2] = rgbv[2];
                 if (MODE == UNERF_FIELD_ACTIVE) a.aux[n] = unerf_softplus(t[8]) + a.p.beta_min;
             }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// 5b'. LAPLACE on the matrix cores.  The reference evaluates the two sampled last layers in a
+// 100-iteration Python loop of GEMVs (laplace_field.py:553-560); as a matrix product the weight
+// SAMPLES are the output rows: density head 128(100) x 64, colour head 3 x 128(100) x 64 per
+// 32-sample tile, followed by exp / sigmoid and the running sums of p and p^2 on the accumulator
+// registers (rows = registers + lane half).  Padded rows carry bias -1e30 -> contribute exactly 0.
+// The 512 sampled-head fragments (128 KB) do not fit LDS next to the base network; they stream
+// from L2 with coalesced 256-B loads (one per MFMA), the base network stays LDS-resident.
+// --------------------------------------------------------------------------------------
+#define LAP_BLOCKS 4
+#define LAP_BIAS_OFF (4 * LAP_BLOCKS * 32 * 64)
+
+// One sampled head (q) over its LAP_BLOCKS row blocks.  The A fragments come from L2 (one coalesced
+// 256-B load per MFMA); the 32 fragments of block b+1 are requested BEFORE the 32 MFMAs of block b
+// issue, so ~2000 cycles of matrix work cover their latency (without this every MFMA waited on its
+// own load: 254 ms/frame instead of the ~70 ms the MFMA count predicts).
+template <bool SIGMOID>
+__device__ __forceinline__ void mf_lap_head(const float* __restrict__ lap, int q, int lane, int h, const f32x16& s0,
+                                            const f32x16& s1, float& sum1, float& sum2) {
+    sum1 = 0.f;
+    sum2 = 0.f;
+    float cur[32], nxt[32];
+    {
+        const float* f = lap + (size_t)((q * LAP_BLOCKS + 0) * 32) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) cur[r] = f[r * 64];
+    }
+#pragma unroll
+    for (int b = 0; b < LAP_BLOCKS; ++b) {
+        if (b + 1 < LAP_BLOCKS) {
+            const float* f = lap + (size_t)((q * LAP_BLOCKS + b + 1) * 32) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) nxt[r] = f[r * 64];
+        }
+        const float4* bp = reinterpret_cast<const float4*>(lap + LAP_BIAS_OFF + ((q * LAP_BLOCKS + b) * 2 + h) * 16);
+        float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[r], s0[r], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[16 + r], s1[r], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = SIGMOID ? unerf_sigmoid(acc[r]) : expf(acc[r]);
+            sum1 += p;
+            sum2 += p * p;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 1 < LAP_BLOCKS) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) cur[r] = nxt[r];
+        }
+    }
+    sum1 += __shfl_xor(sum1, 32, 64);
+    sum2 += __shfl_xor(sum2, 32, 64);
+}
+
+__global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, int64_t num_tiles) {
+    extern __shared__ float lds[];
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.p.mfma_blob);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane_c = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane_c & 31, h = lane_c >> 5;
+    const int64_t N = a.R * (int64_t)a.S;
+    const uint32_t mask = (1u << a.p.log2T) - 1u;
+    const float inv_n = 1.f / (float)a.p.n_lap;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int64_t tpx = (num_tiles + 7) / 8;
+    const int64_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
+    for (int64_t tile = xcd * tpx + (int64_t)slot * 4 + wv; tile < tile_end; tile += (int64_t)bpx * 4) {
+        int lane = lane_c;  // opaque per iteration: keeps the (tile-invariant) fragment reads in the loop
+        asm volatile("" : "+v"(lane));
+        int64_t n = tile * 32 + j;
+        const bool valid = n < N;
+        if (!valid) n = N - 1;
+        const int64_t r = n / a.S;
+        const int s = (int)(n - r * a.S);
+        const float* sb = a.sbins + r * (a.S + 1);
+        float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+        float t01 = e0 + e1;
+        float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
+        float px = a.origins[r * 3 + 0] + dxr * t01 / 2.f;
+        float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
+        float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
+        (void)unerf_normalize_position(px, py, pz);  // the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
+        f32x16 feat = mf_gather_feats(a, px, py, pz, h, mask);
+
+        // base_mlp is a bare Linear: no ReLU (utils.py:22-23)
+        f32x16 hb0 = mf_slab(lds, 0, lane, feat, mf_bias(lds, 0, h));
+        f32x16 hb1 = mf_slab(lds, 16, lane, feat, mf_bias(lds, 1, h));
+        // geo = mlp_hidden(hb): rows 0..14
+        f32x16 t = mf_bias(lds, 2, h);
+        t = mf_slab(lds, 32, lane, hb0, t);
+        t = mf_slab(lds, 48, lane, hb1, t);
+        // density head: mean / variance of exp(w_s . hb + b_s) over the n_lap sampled rows
+        float d1, d2;
+        mf_lap_head<false>(a.p.lap_blob, 0, lane, h, hb0, hb1, d1, d2);
+        const float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
+
+        // colour trunk
+        f32x16 c0 = mf_bias(lds, 3, h), c1 = mf_bias(lds, 4, h);
+        {
+            float sh[16];
+            float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
+            if (a.p.sh_remap) {
+                ux = ux * 2.f - 1.f;
+                uy = uy * 2.f - 1.f;
+                uz = uz * 2.f - 1.f;
+            }
+            unerf_sh16(ux, uy, uz, sh);
+            const uint32_t hm = 0u - (uint32_t)h;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(64 + q) * 64 + lane], t[q], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(80 + q) * 64 + lane], t[q], c1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float v = __uint_as_float((__float_as_uint(sh[8 + q]) & hm) | (__float_as_uint(sh[q]) & ~hm));
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(64 + 8 + q) * 64 + lane], v, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(80 + 8 + q) * 64 + lane], v, c1, 0, 0, 0);
+            }
+        }
+        c0 = mf_relu(c0);
+        c1 = mf_relu(c1);
+        f32x16 x0 = mf_bias(lds, 5, h), x1 = mf_bias(lds, 6, h);
+        x0 = mf_slab(lds, 96, lane, c0, x0);
+        x0 = mf_slab(lds, 112, lane, c1, x0);
+        x1 = mf_slab(lds, 128, lane, c0, x1);
+        x1 = mf_slab(lds, 144, lane, c1, x1);
+        x0 = mf_relu(x0);
+        x1 = mf_relu(x1);
+        // colour head: per channel mean / variance of sigmoid(w_s . x + b_s)
+        float mu_c[3], vsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float c1s, c2s;
+            mf_lap_head<true>(a.p.lap_blob, 1 + c, lane, h, x0, x1, c1s, c2s);
+            mu_c[c] = c1s * inv_n;
+            vsum += fmaxf(c2s * inv_n - mu_c[c] * mu_c[c], 0.f);
+        }
+        if (valid && h == 0) {
+            a.density[n] = mu_d;
+            a.aux[n] = mu2_d - mu_d * mu_d;
+            a.aux2[n] = vsum / 3.f;
+            a.rgb[n * 3 + 0] = mu_c[0];
+            a.rgb[n * 3 + 1] = mu_c[1];
+            a.rgb[n * 3 + 2] = mu_c[2];
         }
     }
 }
@@ -997,7 +1159,13 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_LAPLACE:
             UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
-            hipLaunchKernelGGL((field_kernel<UNERF_FIELD_LAPLACE>), grid, block, 64 * 64 * 4, st, a);
+            if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
+                int64_t tiles = (R * (int64_t)S + 31) / 32;
+                hipLaunchKernelGGL(field_kernel_mfma_laplace, dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
+                                   st, a, tiles);
+            } else {
+                hipLaunchKernelGGL((field_kernel<UNERF_FIELD_LAPLACE>), grid, block, 64 * 64 * 4, st, a);
+            }
             break;
         default:
             unerf_set_error("field_fwd: unknown mode %d", p->mode);

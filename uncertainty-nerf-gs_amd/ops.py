@@ -156,6 +156,7 @@ class FieldDev:
     ws_density: Optional[torch.Tensor] = None
     ws_rgb: Optional[torch.Tensor] = None
     mfma_blob: Optional[torch.Tensor] = None
+    lap_blob: Optional[torch.Tensor] = None
     use_mfma: bool = True
 
     @classmethod
@@ -163,12 +164,15 @@ class FieldDev:
         f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         h0 = head_w[0].detach().to(torch.float32)
         hb0 = head_b[0].detach().to(torch.float32) + h0[:, 31:] @ appearance.detach().to(torch.float32)
-        blob = None
-        if mode != _l.FIELD_LAPLACE:
-            blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2]))
+        lap = mode == _l.FIELD_LAPLACE
+        blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
+                                 geo_first_unit=0 if lap else 1))
+        lap_blob = None
+        if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
+            lap_blob = f(pack_laplace_heads(kw["ws_density"], kw["ws_rgb"]))
         return cls(mode, f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
                    f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
-                   mfma_blob=blob, **kw)
+                   mfma_blob=blob, lap_blob=lap_blob, **kw)
 
     def cstruct(self) -> _l.FieldParams:
         return _l.FieldParams(
@@ -177,7 +181,7 @@ class FieldDev:
             _p(self.h0t), _p(self.hb0), _p(self.h1t), _p(self.hb1), _p(self.h2t), _p(self.hb2),
             self.average_init_density, self.beta_min, self.sh_remap, self.K, self.seed & 0xFFFFFFFF, self.p_drop,
             _p(self.ws_density), _p(self.ws_rgb), 0 if self.ws_density is None else self.ws_density.shape[0],
-            _p(self.mfma_blob) if self.use_mfma else None)
+            _p(self.mfma_blob) if self.use_mfma else None, _p(self.lap_blob) if self.use_mfma else None)
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------
@@ -199,10 +203,11 @@ def _mfma_unit(r, h):
     return (r & 3) + 8 * (r >> 2) + 4 * h
 
 
-def pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2) -> torch.Tensor:
+def pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit: int = 1) -> torch.Tensor:
     """torch-layout ([out,in]) CPU tensors -> flat fp32 blob [MFMA_BLOB_FLOATS].
     w0 [64,32]; w1 [out1<=32,64]; h0 [64,31] (cols: SH16 | geo15, appearance already folded into hb0);
-    h1 [64,64]; h2 [3,64]."""
+    h1 [64,64]; h2 [3,64].  geo_first_unit: trunk-out row of geo feature 0 (1 when row 0 is the density
+    logit -- active / mc-dropout; 0 for the laplace `mlp_hidden`, whose 15 rows are all geo)."""
     f = lambda t: t.detach().to("cpu", torch.float32)
     w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2 = map(f, (w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2))
     out1 = w1.shape[0]
@@ -224,9 +229,9 @@ def pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2) -> torch.Tensor:
             fr[32 + bi * 16 + r] = w1p[i, 32 * bi + _mfma_unit(r, h)]              # trunk-out
     for blk in range(2):
         for s in range(8):                                                         # geo rows of trunk-out
-            u = _mfma_unit(s, h)
-            col = (16 + u - 1).clamp(min=0)
-            fr[64 + blk * 16 + s] = torch.where(u >= 1, h0[32 * blk + i, col], torch.zeros(64))
+            g = _mfma_unit(s, h) - geo_first_unit                                      # geo feature index of this row
+            ok = (g >= 0) & (g < 15)
+            fr[64 + blk * 16 + s] = torch.where(ok, h0[32 * blk + i, (16 + g).clamp(16, 30)], torch.zeros(64))
         for s in range(8, 16):                                                     # SH components 8h+s-8
             fr[64 + blk * 16 + s] = h0[32 * blk + i, 8 * h + (s - 8)]
     for blk in range(2):
@@ -244,6 +249,44 @@ def pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2) -> torch.Tensor:
             for c in range(3):
                 hh2[blk, hh, c] = h2[c, 32 * blk + _mfma_unit(r16, hh)]
     blob[MFMA_H2_OFF + 192:MFMA_H2_OFF + 195] = hb2
+    return blob
+
+
+# sampled last layers of the Laplace field as MFMA A fragments: rows = weight samples (padded to 128
+# per output channel), K = the 64 hidden units in accumulator-register order.
+LAP_BLOCKS = 4                                   # 128 rows per output channel
+LAP_FRAGS = (1 + 3) * LAP_BLOCKS * 32            # density + 3 colour channels
+LAP_BIAS_OFF = LAP_FRAGS * 64
+LAP_BLOB_FLOATS = LAP_BIAS_OFF + (1 + 3) * LAP_BLOCKS * 32
+LAP_PAD_BIAS = -1e30                             # exp / sigmoid of a padded row contributes exactly 0
+
+
+def pack_laplace_heads(ws_density: torch.Tensor, ws_rgb: torch.Tensor) -> torch.Tensor:
+    """ws_density [n,65], ws_rgb [n,195] (rows = mu + randn*std, torch [out,in] row-major then bias;
+    laplace_field.py:538-547) -> flat fp32 blob [LAP_BLOB_FLOATS].  Head q: 0 = density, 1..3 = r,g,b."""
+    wd = ws_density.detach().to("cpu", torch.float32)
+    wr = ws_rgb.detach().to("cpu", torch.float32)
+    n = wd.shape[0]
+    assert wd.shape == (n, 65) and wr.shape == (n, 195) and 1 <= n <= 32 * LAP_BLOCKS
+    heads_w = [wd[:, :64]] + [wr[:, c * 64:(c + 1) * 64] for c in range(3)]
+    heads_b = [wd[:, 64]] + [wr[:, 192 + c] for c in range(3)]
+    lane = torch.arange(64)
+    i, h = lane & 31, lane >> 5
+    r16 = torch.arange(16)
+    blob = torch.zeros(LAP_BLOB_FLOATS)
+    fr = blob[:LAP_BIAS_OFF].view(4, LAP_BLOCKS, 2, 16, 64)
+    bias = blob[LAP_BIAS_OFF:].view(4, LAP_BLOCKS, 2, 16)
+    for q in range(4):
+        W = torch.zeros(32 * LAP_BLOCKS, 64)
+        W[:n] = heads_w[q]
+        bv = torch.full((32 * LAP_BLOCKS,), LAP_PAD_BIAS)
+        bv[:n] = heads_b[q]
+        for b in range(LAP_BLOCKS):
+            for bi in range(2):
+                for r in range(16):
+                    fr[q, b, bi, r] = W[32 * b + i, 32 * bi + _mfma_unit(r, h)]
+            for hh in range(2):
+                bias[q, b, hh] = bv[32 * b + _mfma_unit(r16, hh)]
     return blob
 
 
