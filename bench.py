@@ -59,7 +59,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--method", default="active", choices=["active", "mcdropout", "laplace", "splat"])
+    ap.add_argument("--method", default="active", choices=["active", "mcdropout", "laplace", "splat", "ensemble"])
+    ap.add_argument("--members", type=int, default=8, help="ensemble size M (members are sharded over the ranks)")
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--mc-samples", type=int, default=8)
     ap.add_argument("--height", type=int, default=1080)
@@ -92,6 +93,8 @@ def main():
 
     if args.method == "splat":
         return bench_splat(args, rank, world, dev, dist)
+    if args.method == "ensemble":
+        return bench_ensemble(args, rank, world, dev, dist)
     K = args.mc_samples if args.method == "mcdropout" else 0
     t = synthetic.make_scene_tensors(seed=0, kind=args.method)   # full nerfacto shape: 16x2^19x2 + 2 x 5x2^17x2
     kw = {}
@@ -190,6 +193,64 @@ def main():
                        "rays_per_step": H * W, "samples_per_ray": [256, 96, 48], "hash_grid": "16x2^19x2 fp32",
                        "parallelism": f"views x{world}" if world > 1 else "single"},
             "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_ensemble(args, rank, world, dev, dist):
+    """config 4: M-member nerfacto ensemble (ensemble_pipeline.py:144-191), members sharded over the ranks
+    (M/N per GPU; 1 per GPU at N = M = 8).  Every rank renders the SAME camera with its own members, then the
+    per-pixel moments are formed exactly (two-pass) on pixel slices after an RCCL all_gather.  Strong scaling:
+    the frame's total work (M renders) is fixed, so value = frame rays / time grows with N."""
+    from uncertainty_nerf_gs_amd import ensemble, ops, render, synthetic
+    M = args.members
+    assert M % world == 0, "members must divide evenly over the ranks"
+    mine = [rank * (M // world) + i for i in range(M // world)]
+    scenes = [synthetic.scene_to_device(synthetic.make_scene_tensors(seed=100 + m, kind="mcdropout"), dev, K=0)
+              for m in mine]   # plain nerfacto members (dropout off): seeds 100..100+M-1
+    H, W = args.height, args.width
+    cam = dict(synthetic.CAMERA_1080P)
+    cam.update(H=H, W=W, cx=W / 2, cy=H / 2)
+    poses = [synthetic.orbit_c2w(2 * math.pi * i / 24) for i in range(24)]
+
+    def frame(i):
+        outs = [render.render_camera(sc, poses[i % 24], rays_per_launch=args.rays_per_launch, **cam) for sc in scenes]
+        outs = [{k: o[k] for k in ("rgb", "accumulation", "depth", "expected_depth")} for o in outs]
+        if dist is None:
+            return ensemble.aggregate(outs)
+        return ensemble.aggregate_distributed(outs)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = frame(i)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = frame(args.warmup + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out["rgb"]).all() and "rgb_std" in out
+    if rank == 0:
+        line = {
+            "metric": "Mrays/s (+var), Mip-NeRF360-shaped 1080p, M-member ensemble", "value": H * W * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{M}-member nerfacto ensemble {W}x{H}, per-pixel mean/std over members",
+                       "members": M, "members_per_gpu": M // world, "member_render_rays_per_s": M * H * W * args.steps / elapsed,
+                       "parallelism": f"ensemble members x{world} (all_gather + exact two-pass moments)"},
+            "roofline": None, "cpu_baseline": None,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -25,14 +25,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tag, ret):
+def _member(g, tag, i):
+    return {k[len(f"{tag}_in{i}_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_in{i}_")}
+
+
+def _worker(rank, world, port, tag, ret, per_rank=1):
     import torch.distributed as dist
     from uncertainty_nerf_gs_amd import ensemble
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = golden("ensemble.npz")
-    member = {k[len(f"{tag}_in{rank}_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_in{rank}_")}
+    if per_rank == 1:
+        member = _member(g, tag, rank)
+    else:  # rank-major member order: rank r holds members r*per_rank .. r*per_rank+per_rank-1
+        member = [_member(g, tag, rank * per_rank + i) for i in range(per_rank)]
     out = ensemble.aggregate_distributed(member, moments_fn=_torch_moments)
     ret[rank] = {k: v.numpy() for k, v in out.items()}
     dist.destroy_process_group()
@@ -52,6 +59,19 @@ def test_one_member_per_rank_matches_single_process(tag):
         assert set(ret.keys()) == {0, 1}
         for r in range(world):
             assert set(ret[r]) == set(single)
+            for k, v in single.items():
+                assert np.array_equal(ret[r][k], v.numpy()), (r, k)
+
+
+def test_two_members_per_rank_matches_single_process():
+    """M = 4 members over 2 ranks (the M > N case of bench.py --method ensemble)."""
+    from uncertainty_nerf_gs_amd import ensemble
+    g = golden("ensemble.npz")
+    single = ensemble.aggregate([_member(g, "alea", i) for i in range(4)], moments_fn=_torch_moments)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), "alea", ret, 2), nprocs=2, join=True)
+        for r in range(2):
             for k, v in single.items():
                 assert np.array_equal(ret[r][k], v.numpy()), (r, k)
 

@@ -75,22 +75,25 @@ def pixel_slice(num_pixels: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def aggregate_distributed(outputs: Dict[str, torch.Tensor], group=None, moments_fn: Optional[MomentsFn] = None):
-    """This rank's member outputs ([H,W,C] per key) -> the ensemble outputs, identical on every rank."""
+def aggregate_distributed(outputs, group=None, moments_fn: Optional[MomentsFn] = None):
+    """This rank's member outputs -> the ensemble outputs, identical on every rank.
+    `outputs` is one member's dict ([H,W,C] per key) or a list of such dicts when a rank holds several
+    members (M members over N < M GPUs; every rank must hold the same number)."""
     import torch.distributed as dist
     moments_fn = moments_fn or _hip_moments
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    keys = [k for k, v in outputs.items() if torch.is_tensor(v)]  # member key order (it matters, see _finish)
-    widths = [outputs[k].shape[-1] for k in keys]
-    H, W = outputs[keys[0]].shape[:2]
+    members = outputs if isinstance(outputs, (list, tuple)) else [outputs]
+    keys = [k for k, v in members[0].items() if torch.is_tensor(v)]  # member key order (it matters, see _finish)
+    widths = [members[0][k].shape[-1] for k in keys]
+    H, W = members[0][keys[0]].shape[:2]
     P = H * W
-    # one packed [P, sum(C)] image per member -> a single collective instead of one per key
-    packed = torch.cat([outputs[k].reshape(P, -1) for k in keys], dim=-1).contiguous()
-    Ctot = packed.shape[1]
+    # one packed [m_local, P, sum(C)] block per rank -> a single collective instead of one per key
+    packed = torch.stack([torch.cat([m[k].reshape(P, -1) for k in keys], dim=-1) for m in members], dim=0).contiguous()
+    Ctot = packed.shape[-1]
     gathered = [torch.empty_like(packed) for _ in range(world)]
     dist.all_gather(gathered, packed, group=group)
     a, b = pixel_slice(P, rank, world)
-    stack = torch.stack([g[a:b] for g in gathered], dim=0)          # [M, b-a, Ctot]
+    stack = torch.cat([g[:, a:b] for g in gathered], dim=0)         # [M, b-a, Ctot], member order = rank-major
     m, v = moments_fn(stack.contiguous())
     part = torch.cat([m, v], dim=-1).contiguous()                   # [b-a, 2*Ctot]
     # slices differ by at most one row: pad to the largest so all_gather sees equal shapes
