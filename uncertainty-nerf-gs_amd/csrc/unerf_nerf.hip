@@ -762,11 +762,16 @@ __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t nu
         // keeps them inside the iteration, where each read is consumed by the next MFMA.
         int lane = lane_c;
         asm volatile("" : "+v"(lane));
-        int64_t n = tile * 32 + j;
-        const bool valid = n < N;
-        if (!valid) n = N - 1;
-        const int64_t r = n / a.S;
-        const int s = (int)(n - r * a.S);
+        // tile -> (block of 32 neighbouring rays, sample index s): the 32 columns of a tile are the SAME
+        // sample slot of 32 adjacent pixels, which sit in the same or neighbouring grid cells, so a gather
+        // instruction presents few distinct lines to the texture-address unit (it retires ~1 divergent
+        // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_03)
+        const int64_t rb = tile / a.S;
+        const int s = (int)(tile - rb * a.S);
+        int64_t r = rb * 32 + j;
+        const bool valid = r < a.R;
+        if (!valid) r = a.R - 1;
+        const int64_t n = r * a.S + s;
         const float* sb = a.sbins + r * (a.S + 1);
         float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
         float t01 = e0 + e1;
@@ -955,11 +960,16 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, in
     for (int64_t tile = xcd * tpx + (int64_t)slot * 4 + wv; tile < tile_end; tile += (int64_t)bpx * 4) {
         int lane = lane_c;  // opaque per iteration: keeps the (tile-invariant) fragment reads in the loop
         asm volatile("" : "+v"(lane));
-        int64_t n = tile * 32 + j;
-        const bool valid = n < N;
-        if (!valid) n = N - 1;
-        const int64_t r = n / a.S;
-        const int s = (int)(n - r * a.S);
+        // tile -> (block of 32 neighbouring rays, sample index s): the 32 columns of a tile are the SAME
+        // sample slot of 32 adjacent pixels, which sit in the same or neighbouring grid cells, so a gather
+        // instruction presents few distinct lines to the texture-address unit (it retires ~1 divergent
+        // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_03)
+        const int64_t rb = tile / a.S;
+        const int s = (int)(tile - rb * a.S);
+        int64_t r = rb * 32 + j;
+        const bool valid = r < a.R;
+        if (!valid) r = a.R - 1;
+        const int64_t n = r * a.S + s;
         const float* sb = a.sbins + r * (a.S + 1);
         float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
         float t01 = e0 + e1;
@@ -1130,7 +1140,7 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
             if (p->mfma_blob) {
-                int64_t tiles = (R * (int64_t)S + 31) / 32;
+                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid(tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
@@ -1145,7 +1155,7 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->out1 == 16, "field_fwd MCDROPOUT: out1 must be 16");
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
             if (p->mfma_blob) {
-                int64_t tiles = (R * (int64_t)S + 31) / 32;
+                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid(tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
@@ -1160,7 +1170,7 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
             if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
-                int64_t tiles = (R * (int64_t)S + 31) / 32;
+                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 hipLaunchKernelGGL(field_kernel_mfma_laplace, dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
                                    st, a, tiles);
             } else {
