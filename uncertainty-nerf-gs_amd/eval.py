@@ -1,0 +1,93 @@
+"""Eval harness: the counterpart of scripts/eval_uncertainty.py for this build.
+
+`get_average_uncertainty_metrics` walks (camera, ground-truth image) pairs, renders each camera with
+the method's callable (`model.get_outputs_for_camera`, `get_outputs_for_camera_unc`, an ensemble
+closure ...), computes the reference's per-image RGB metrics under the reference's key names
+(eval_uncertainty.py:756-771: psnr, rgb_ause_{mse,mae,rmse}, rgb_mse, rgb_rmse, rgb_nll, rgb_avg_var,
+rgb_auc_{abs_error,length,neg_error}) plus `num_rays_per_sec` / `fps` (:948-952), averages them over
+the images (:1069-1077) and writes the same `metrics.json` envelope (:1156-1169).
+
+Differences, on purpose: SSIM / LPIPS (torchmetrics / torchvision networks, absent here) are not
+computed; no plots; and `num_rays_per_sec` is reported twice -- `num_rays_per_sec` covers render +
+metrics like the reference's counter (so numbers stay comparable with its metrics.json), while
+`render_rays_per_sec` times the render alone (HIP-synchronised).  Depth metrics need the dataset's
+`depth_gt_XX.npy` / `scale_parameters.txt` files (eval_uncertainty.py:415-644) and are a "next" row.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Callable, Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import metrics as M
+
+
+def image_metrics_unc(outputs: Dict[str, torch.Tensor], gt_image: torch.Tensor, eval_rgb_unc: bool = True,
+                      min_rgb_std_for_nll: float = 3e-2, composite_gt: Optional[Callable] = None):
+    """get_image_metrics_and_images_unc (eval_uncertainty.py:647-813), RGB part.
+    -> (metrics_dict, curves) where curves carries the per-image sparsification / calibration curves
+    that the reference accumulates for its test-set plots."""
+    rgb = torch.clip(outputs["rgb"], max=1.0)
+    image = gt_image.to(rgb.device)
+    if "background" in outputs and composite_gt is not None:  # splatfacto: blend GT alpha with the background
+        image = composite_gt(image, outputs["background"])
+    md: Dict[str, float] = {"psnr": M.psnr(rgb, image)}
+    curves: Dict[str, np.ndarray] = {}
+    if eval_rgb_unc:
+        rgb_std = outputs["rgb_std"]
+        sq = torch.sum((rgb - image) ** 2, dim=-1).flatten()
+        ab = torch.sum(torch.abs(rgb - image), dim=-1).flatten()
+        var = (rgb_std ** 2).flatten()
+        for et, err in (("mae", ab), ("mse", sq), ("rmse", sq)):
+            _, e, ev, a = M.ause(var, err, et)
+            md[f"rgb_ause_{et}"] = float(a)
+            curves[f"rgb_all_ause_{et}"], curves[f"rgb_all_var_ause_{et}"] = e, ev
+        md["rgb_mse"] = float(sq.mean().item())
+        md["rgb_rmse"] = float(np.sqrt(sq.mean().item()))
+        md["rgb_nll"] = float(M.negative_gaussian_loglikelihood(rgb.reshape(-1, 3), image.reshape(-1, 3), rgb_std,
+                                                               eps=min_rgb_std_for_nll).mean().item())
+        md["rgb_avg_var"] = float(var.mean().item())
+        std3 = var.sqrt().unsqueeze(-1).repeat(1, 3)
+        a = M.auce(rgb.reshape(-1, 3).cpu().numpy(), std3.cpu().numpy(), image.reshape(-1, 3).cpu().numpy())
+        md["rgb_auc_abs_error"], md["rgb_auc_length"] = a["auc_abs_error_values"], a["auc_length_values"]
+        md["rgb_auc_neg_error"] = a["auc_neg_error_values"]
+        for k in ("coverage_values", "avg_length_values", "coverage_error_values", "abs_coverage_error_values",
+                  "neg_coverage_error_values"):
+            curves[f"rgb_all_auce_{k}"] = a[k]
+    return md, curves
+
+
+def get_average_uncertainty_metrics(get_outputs_for_camera: Callable, eval_set: Iterable[Tuple[object, torch.Tensor]],
+                                    eval_rgb_unc: bool = True, min_rgb_std_for_nll: float = 3e-2,
+                                    composite_gt: Optional[Callable] = None):
+    """eval_uncertainty.py:816-1079.  -> (averaged metrics dict, averaged curves dict)"""
+    rows: List[Dict[str, float]] = []
+    sums: Dict[str, np.ndarray] = {}
+    for camera, gt in eval_set:
+        inner_start = time.time()
+        outputs = get_outputs_for_camera(camera)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        render_s = time.time() - inner_start
+        H, W = outputs["rgb"].shape[:2]
+        md, curves = image_metrics_unc(outputs, gt, eval_rgb_unc, min_rgb_std_for_nll, composite_gt)
+        md["num_rays_per_sec"] = H * W / (time.time() - inner_start)
+        md["fps"] = md["num_rays_per_sec"] / (H * W)
+        md["render_rays_per_sec"] = H * W / render_s
+        rows.append(md)
+        for k, v in curves.items():
+            sums[k] = sums.get(k, 0) + np.asarray(v, dtype=np.float64)
+    avg = {k: float(torch.mean(torch.tensor([r[k] for r in rows], dtype=torch.float64))) for k in rows[0]}
+    return avg, {k: v / len(rows) for k, v in sums.items()}
+
+
+def write_metrics_json(path: str, experiment_name: str, method_name: str, checkpoint: str, results: Dict[str, float]):
+    """the envelope of eval_uncertainty.py:1156-1169"""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w", encoding="utf8") as f:
+        json.dump({"experiment_name": experiment_name, "method_name": method_name, "checkpoint": checkpoint,
+                   "results": results}, f, indent=2)
