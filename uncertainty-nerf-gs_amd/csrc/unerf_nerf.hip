@@ -675,9 +675,13 @@ __device__ __forceinline__ f32x16 mf_bias(const float* lds, int k, int h) {
     f32x16 v = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
     return v;
 }
+// ReLU as a signed-integer max on the bit pattern: one v_max_i32 per element.  fmaxf() costs two
+// VALU ops here (a canonicalising v_max before the real one, IEEE maxnum), and with ~10 VALU per
+// MFMA the K-pass kernel is issue-bound (rocprof r1_03: MFMA busy 61 % + VALU busy 38 %).
+// Negative floats (incl. -0.0) have negative bit patterns -> 0; non-negative ones pass unchanged.
 __device__ __forceinline__ f32x16 mf_relu(f32x16 v) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+    for (int r = 0; r < 16; ++r) v[r] = __int_as_float(max(__float_as_int(v[r]), 0));
     return v;
 }
 // acc += W_frag(frag0 + r) x src[r], r = 0..15 (one 16-step K slab)
