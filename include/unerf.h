@@ -182,6 +182,13 @@ int unerf_composite_var(const float* density, const float* rgb, const float* bet
                         const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, float* out,
                         void* stream);
 
+/* Fused K-pass form of the two calls above/below for MC-dropout: composites the B <= 16 passes of every
+ * ray and reduces them in registers.  mean_out / var_out [R,8] over the passes of
+ * rgb(3), accumulation, depth, expected_depth, rgb_var, depth_var (var unbiased, B-1). */
+int unerf_composite_moments(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
+                            float near_plane, float far_plane, const float* clip_minmax, int64_t ray_offset,
+                            int64_t chunk_rays, float* mean_out, float* var_out, void* stream);
+
 /* ------------------------------------------------------ moments over K --
  * Replaces torch.stack(...).mean(0) / .std(0) / .var(0) over MC passes
  * (models/mcdropout/mcdropout_models.py:121-126) and over ensemble members

@@ -311,6 +311,24 @@ def test_laplace_depth_weights_matches_oracle(dev, explicit_noise):
     _close(got, ref, 3e-4 if not explicit_noise else 3e-5, 2e-7, "mean sampled weights")
 
 
+@pytest.mark.parametrize("B,S", [(8, 48), (2, 48), (16, 16), (1, 48)])
+def test_composite_moments_equals_composite_then_moments(dev, B, S):
+    """fused K-pass composite + mean/var == per-pass composite followed by torch mean / var"""
+    from uncertainty_nerf_gs_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + S)
+    R = 77
+    dens = torch.exp(torch.randn(B, R, S, generator=g) * 2.0).to(dev)
+    rgb = torch.rand(B, R, S, 3, generator=g).to(dev)
+    sb = torch.sort(torch.rand(R, S + 1, generator=g), dim=-1).values.to(dev)
+    per = ops.composite_var(dens, rgb, sb, NEAR, FAR)          # [B,R,8]
+    mean, var = ops.composite_moments(dens, rgb, sb, NEAR, FAR)
+    _close(mean, per.mean(0), 2e-6, 1e-7, "mean over passes")
+    if B > 1:
+        _close(var[:, :6], per.var(0)[:, :6], 2e-4, 1e-9, "unbiased variance over passes")
+    else:
+        assert torch.isnan(var).all()   # torch.var of a single sample
+
+
 @pytest.mark.parametrize("K", [2, 8])
 def test_moments_matches_torch(dev, K):
     from uncertainty_nerf_gs_amd import ops

@@ -1225,14 +1225,9 @@ struct CompArgs {
     float* out;
 };
 
+// one (pass b, ray r) composite, executed by a 16-lane group; g = b*R + r.  Results are replicated on all 16 lanes.
 template <int SPL>
-__global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
-    const int l16 = threadIdx.x & 15;
-    int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int64_t G = (int64_t)a.B * a.R;
-    const bool ok = g < G;
-    if (!ok) g = G - 1;
-    const int64_t r = g % a.R;
+__device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int64_t r, int l16, float (&o8)[8]) {
     const int S = a.S, k0 = l16 * SPL;
     const float* sb = a.sbins + r * (S + 1);
     float eu[SPL + 1], delta[SPL], steps[SPL], dens[SPL], w[SPL];
@@ -1310,12 +1305,66 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
         int64_t chunk = (a.ray_offset + r) / a.chunk_rays;
         ed = fminf(fmaxf(ed, a.clip[chunk * 2 + 0]), a.clip[chunk * 2 + 1]);
     }
+    o8[0] = cr; o8[1] = cg; o8[2] = cb; o8[3] = acc;
+    o8[4] = depth; o8[5] = ed; o8[6] = uvar; o8[7] = dv;
+}
+
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
+    const int l16 = threadIdx.x & 15;
+    int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t G = (int64_t)a.B * a.R;
+    const bool ok = g < G;
+    if (!ok) g = G - 1;
+    float o8[8];
+    composite_one<SPL>(a, g, g % a.R, l16, o8);
     if (ok && l16 == 0) {
         float4* o = reinterpret_cast<float4*>(a.out + g * 8);
-        o[0] = make_float4(cr, cg, cb, acc);
-        o[1] = make_float4(depth, ed, uvar, dv);
+        o[0] = make_float4(o8[0], o8[1], o8[2], o8[3]);
+        o[1] = make_float4(o8[4], o8[5], o8[6], o8[7]);
     }
 }
+
+// K-pass form: one 16-lane group walks the B <= 16 passes of a ray, lane b keeps pass b's eight
+// outputs, and the per-pixel mean and unbiased variance over the passes (two-pass, like
+// torch.stack(...).mean(0) / .var(0), mcdropout_models.py:121-126) come out of two group reductions:
+// the [B,R,8] per-pass images never touch HBM.
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_moments_kernel(CompArgs a, float* __restrict__ mean_out,
+                                                                float* __restrict__ var_out) {
+    const int l16 = threadIdx.x & 15;
+    int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = r < a.R;
+    if (!ok) r = a.R - 1;
+    float mine[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) mine[c] = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        float o8[8];
+        composite_one<SPL>(a, (int64_t)b * a.R + r, r, l16, o8);
+        if (l16 == b) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) mine[c] = o8[c];
+        }
+    }
+    const float invB = 1.f / (float)a.B, invB1 = 1.f / (float)(a.B - 1);
+    float m8[8], v8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        m8[c] = group_sum<16>(mine[c]) * invB;
+        float d = (l16 < a.B) ? mine[c] - m8[c] : 0.f;
+        v8[c] = group_sum<16>(d * d) * invB1;
+    }
+    if (ok && l16 == 0) {
+        float4* mo = reinterpret_cast<float4*>(mean_out + r * 8);
+        float4* vo = reinterpret_cast<float4*>(var_out + r * 8);
+        mo[0] = make_float4(m8[0], m8[1], m8[2], m8[3]);
+        mo[1] = make_float4(m8[4], m8[5], m8[6], m8[7]);
+        vo[0] = make_float4(v8[0], v8[1], v8[2], v8[3]);
+        vo[1] = make_float4(v8[4], v8[5], v8[6], v8[7]);
+    }
+}
+
 
 #define UNERF_DISPATCH_SPL(S, KERNEL, ...)                                                                          \
     switch ((S) / 16) {                                                                                             \
@@ -1348,6 +1397,24 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
     hipStream_t st = (hipStream_t)stream;
     UNERF_DISPATCH_SPL(S, composite_kernel, grid, block, 0, st, a);
     return unerf_check_launch("composite_var");
+}
+
+extern "C" int unerf_composite_moments(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
+                                       float near_plane, float far_plane, const float* clip_minmax, int64_t ray_offset,
+                                       int64_t chunk_rays, float* mean_out, float* var_out, void* stream) {
+    UNERF_REQUIRE(density && rgb && sbins && mean_out && var_out, "composite_moments: null pointer");
+    UNERF_REQUIRE(B >= 1 && B <= 16 && R >= 0, "composite_moments: B=%d outside [1,16] (use composite_var + moments)", B);
+    UNERF_REQUIRE(S % 16 == 0, "composite_moments: S=%d must be a multiple of 16", S);
+    UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "composite_moments: chunk_rays must be > 0 with clip_minmax");
+    if (R == 0) return UNERF_OK;
+    CompArgs a;
+    a.density = density; a.rgb = rgb; a.beta = nullptr; a.walt = nullptr; a.sbins = sbins; a.B = B; a.R = R; a.S = S;
+    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays; a.out = nullptr;
+    dim3 grid(blocks_for(R, 16)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    UNERF_DISPATCH_SPL(S, composite_moments_kernel, grid, block, 0, st, a, mean_out, var_out);
+    return unerf_check_launch("composite_moments");
 }
 
 // ---- laplace depth draws --------------------------------------------------------------

@@ -84,6 +84,7 @@ SIGNATURES = {
     "unerf_field_gather": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
     "unerf_laplace_depth_weights": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp, _i, _u32, _i64, _vp, _vp]),
     "unerf_composite_var": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp]),
+    "unerf_composite_moments": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp, _vp]),
     "unerf_moments": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "unerf_splat_project": (_i, [_vp, _vp, _f, _vp, _fp, _f, _f, _f, _f, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp]),

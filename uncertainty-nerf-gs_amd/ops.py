@@ -391,6 +391,20 @@ def composite_var(density, rgb, sbins, near: float, far: float, beta=None, weigh
     return out
 
 
+def composite_moments(density, rgb, sbins, near: float, far: float, clip_minmax=None, ray_offset: int = 0,
+                      chunk_rays: int = 1 << 15):
+    """density [B<=16,R,S], rgb [B,R,S,3] -> (mean [R,8], var [R,8]) over the B passes (fused composite + moments)"""
+    lib = _l.load()
+    B, R, S = density.shape
+    mean = torch.empty(R, 8, device=density.device, dtype=torch.float32)
+    var = torch.empty(R, 8, device=density.device, dtype=torch.float32)
+    with _ctx(mean.device):
+        _run("composite_moments", lambda: lib.unerf_composite_moments(_p(density), _p(rgb), _p(sbins), B, R, S, near, far,
+                                                                      _p(clip_minmax), ray_offset, chunk_rays, _p(mean),
+                                                                      _p(var), _stream()))
+    return mean, var
+
+
 def moments(x: torch.Tensor, want_var: bool = True):
     """x [K,N,C] -> mean [N,C], var [N,C] (unbiased) | None"""
     lib = _l.load()

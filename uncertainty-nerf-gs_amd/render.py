@@ -120,9 +120,12 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
         if keep_density:
             res["density"] = density[0]
     elif f.mode == _l.FIELD_MCDROPOUT:
-        out = ops.composite_var(density, rgb, sb, scene.near, scene.far, **kw)  # [B,R,8]
-        if f.K > 0:
+        if 0 < f.K <= 16:
+            mean, var = ops.composite_moments(density, rgb, sb, scene.near, scene.far, **kw)
+        elif f.K > 16:
+            out = ops.composite_var(density, rgb, sb, scene.near, scene.far, **kw)  # [B,R,8]
             mean, var = ops.moments(out[:, :, :6].contiguous())
+        if f.K > 0:
             res = {"rgb": mean[:, 0:3], "accumulation": mean[:, 3:4], "depth": mean[:, 4:5],
                    "expected_depth": mean[:, 5:6]}
             std = var.sqrt()
@@ -130,7 +133,7 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
             res["depth_std"] = std[:, 4:5].mean(dim=-1)[..., None]
             res["expected_depth_std"] = std[:, 5:6].mean(dim=-1)[..., None]
         else:
-            u = _unpack(out[0])
+            u = _unpack(ops.composite_var(density, rgb, sb, scene.near, scene.far, **kw)[0])
             res = {k: u[k] for k in ("rgb", "accumulation", "depth", "expected_depth")}
     else:
         walt = ops.laplace_depth_weights(density[0], aux, sb, scene.near, scene.far, depth_noise, depth_draws,
