@@ -68,6 +68,15 @@ typedef struct {
     const float* w1t;        /* [hidden][1] */
     const float* b1;         /* [1] */
     int hidden;              /* 16 (nerfacto proposal nets) or 64 */
+    /* Optional dense re-indexing of the first n_dense (coarse) levels, n_dense <= 8 (0 = none).  Level l
+       then has (dense_dim[l])^3 cells, dense_dim = scalings[l]+1, stored x-fastest from cell offset
+       dense_off[l] in `dense` as float4 = { table[hash(x,y,z)], table[hash(x+1,y,z)] }: the same values the
+       hashed lookup returns, but both x-neighbours of a cell edge arrive in ONE 16-byte load (4 instead of 8
+       gather instructions per level; the texture-address unit bounds these kernels). */
+    const float* dense;
+    int n_dense;
+    int dense_off[8];
+    int dense_dim[8];
 } unerf_density_net;
 
 /* -------------------------------------------------- proposal density --

@@ -92,6 +92,11 @@ def test_proposal_density_matches_oracle(dev, level):
     ref = O.density_field(O.sample_positions(o, d, eb), sc.prop_nets[level], 0.01)
     got = ops.proposal_density(o.to(dev), d.to(dev), sb.contiguous().to(dev), sd.props[level], NEAR, FAR, 0.01)
     _close(got, ref, 3e-5, 1e-9, f"proposal density level {level}")
+    # the dense x-paired copy of the coarse levels is pure data movement: identical bits to the hashed lookup
+    assert len(sd.props[level].dense_off) >= 3
+    sd.props[level].use_dense = False
+    hashed = ops.proposal_density(o.to(dev), d.to(dev), sb.contiguous().to(dev), sd.props[level], NEAR, FAR, 0.01)
+    assert torch.equal(got, hashed)
 
 
 @pytest.mark.parametrize("n,m", [(256, 96), (96, 48), (64, 32), (100, 48)])

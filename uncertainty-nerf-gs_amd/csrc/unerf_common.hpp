@@ -144,6 +144,32 @@ __device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lv
     return unerf_blend8(f, ox, oy, oz);
 }
 
+// Dense re-indexed level (see unerf_density_net in include/unerf.h): cell (x,y,z) holds
+// { table[hash(x,y,z)], table[hash(x+1,y,z)] }, so the floor-x and ceil-x corners of one (y,z) edge
+// arrive in a single 16-byte load.  Same values, same blend order as unerf_hash_level.
+__device__ __forceinline__ float2 unerf_dense_level(const float4* __restrict__ cells, int dim, float px, float py,
+                                                    float pz, float scale) {
+    float sx = px * scale, sy = py * scale, sz = pz * scale;
+    int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
+    int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
+    float ox = sx - (float)fx, oy = sy - (float)fy, oz = sz - (float)fz;
+    const float4 pcc = cells[(cz * dim + cy) * dim + fx];
+    const float4 pfc = cells[(cz * dim + fy) * dim + fx];
+    const float4 pcf = cells[(fz * dim + cy) * dim + fx];
+    const float4 pff = cells[(fz * dim + fy) * dim + fx];
+    const bool step = cx != fx;  // false only when the scaled x is an exact integer (ceil == floor)
+    float2 f[8];
+    f[3] = make_float2(pcc.x, pcc.y);
+    f[0] = step ? make_float2(pcc.z, pcc.w) : f[3];
+    f[2] = make_float2(pfc.x, pfc.y);
+    f[1] = step ? make_float2(pfc.z, pfc.w) : f[2];
+    f[7] = make_float2(pcf.x, pcf.y);
+    f[4] = step ? make_float2(pcf.z, pcf.w) : f[7];
+    f[6] = make_float2(pff.x, pff.y);
+    f[5] = step ? make_float2(pff.z, pff.w) : f[6];
+    return unerf_blend8(f, ox, oy, oz);
+}
+
 // ---- real SH, 4 levels (components_from_spherical_harmonics) -------------------------
 __device__ __forceinline__ void unerf_sh16(float x, float y, float z, float (&c)[16]) {
     float xx = x * x, yy = y * y, zz = z * z;

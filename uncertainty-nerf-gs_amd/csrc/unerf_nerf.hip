@@ -210,8 +210,14 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
     float feat[2 * L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        const float2* lvl = reinterpret_cast<const float2*>(a.net.table) + ((size_t)l << a.net.log2T);
-        float2 f = unerf_hash_level(lvl, px, py, pz, a.net.scalings[l], mask);
+        float2 f;
+        if (l < a.net.n_dense) {  // wave-uniform: coarse level with a dense, x-paired copy
+            f = unerf_dense_level(reinterpret_cast<const float4*>(a.net.dense) + a.net.dense_off[l], a.net.dense_dim[l],
+                                  px, py, pz, a.net.scalings[l]);
+        } else {
+            const float2* lvl = reinterpret_cast<const float2*>(a.net.table) + ((size_t)l << a.net.log2T);
+            f = unerf_hash_level(lvl, px, py, pz, a.net.scalings[l], mask);
+        }
         feat[2 * l] = f.x;
         feat[2 * l + 1] = f.y;
     }
@@ -243,6 +249,8 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
     UNERF_REQUIRE(sbins_stride == 0 || sbins_stride >= n + 1, "proposal_density: sbins_stride %lld < n+1",
                   (long long)sbins_stride);
     UNERF_REQUIRE(net->log2T >= 1 && net->log2T <= 24, "proposal_density: bad log2T");
+    UNERF_REQUIRE(net->n_dense >= 0 && net->n_dense <= 8 && net->n_dense <= net->L && (net->n_dense == 0 || net->dense),
+                  "proposal_density: bad dense level description");
     if (R == 0) return UNERF_OK;
     PropArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.sstride = sbins_stride; a.R = R; a.n = n;

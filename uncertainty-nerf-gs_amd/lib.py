@@ -47,6 +47,7 @@ class DensityNet(C.Structure):
     _fields_ = [
         ("table", C.c_void_p), ("scalings", C.c_void_p), ("L", C.c_int), ("log2T", C.c_int),
         ("w0t", C.c_void_p), ("b0", C.c_void_p), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("hidden", C.c_int),
+        ("dense", C.c_void_p), ("n_dense", C.c_int), ("dense_off", C.c_int * 8), ("dense_dim", C.c_int * 8),
     ]
 
 

@@ -107,6 +107,35 @@ def hashgrid_fwd(xyz: torch.Tensor, table: torch.Tensor, scalings: torch.Tensor,
 
 # --------------------------------------------------------- parameter packs --------------
 
+_HASH_P1, _HASH_P2 = 2654435761, 805459861
+
+
+def build_dense_pairs(table: torch.Tensor, scalings: torch.Tensor, log2T: int, max_level_bytes: int = 6 << 20,
+                      max_levels: int = 8):
+    """Dense re-indexing of the coarse (prefix) levels of a hash grid (include/unerf.h, unerf_density_net):
+    cell (x,y,z), x fastest, holds float4 = (table[hash(x,y,z)], table[hash(x+1,y,z)]).  Pure data movement:
+    the kernel reads exactly the values the hashed lookup would.  -> (dense [cells,4] | None, offs, dims)"""
+    T = 1 << log2T
+    table = table.detach().to("cpu", torch.float32)
+    chunks, offs, dims, cur = [], [], [], 0
+    for l in range(min(scalings.numel(), max_levels)):
+        dim = int(scalings[l].item()) + 1
+        if dim ** 3 * 16 > max_level_bytes:
+            break
+        ax = torch.arange(dim, dtype=torch.int64)
+        z, y, x = torch.meshgrid(ax, ax, ax, indexing="ij")           # x fastest after flatten
+        hy, hz = y * _HASH_P1, z * _HASH_P2
+        i0 = ((x ^ hy ^ hz) & (T - 1)).reshape(-1) + l * T
+        i1 = ((torch.clamp(x + 1, max=dim - 1) ^ hy ^ hz) & (T - 1)).reshape(-1) + l * T
+        chunks.append(torch.cat([table[i0], table[i1]], dim=-1))
+        offs.append(cur)
+        dims.append(dim)
+        cur += dim ** 3
+    if not chunks:
+        return None, [], []
+    return torch.cat(chunks, dim=0).contiguous(), offs, dims
+
+
 @dataclass
 class DensityNetDev:
     """Device-resident proposal network (hash grid + Linear-ReLU-Linear), weights transposed."""
@@ -117,15 +146,25 @@ class DensityNetDev:
     b0: torch.Tensor
     w1t: torch.Tensor
     b1: torch.Tensor
+    dense: Optional[torch.Tensor] = None
+    dense_off: Tuple[int, ...] = ()
+    dense_dim: Tuple[int, ...] = ()
+    use_dense: bool = True
 
     @classmethod
     def from_torch(cls, table, scalings, log2T, w0, b0, w1, b1, device):
         f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
-        return cls(f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1))
+        dense, offs, dims = build_dense_pairs(table, scalings.detach().cpu(), int(log2T))
+        return cls(f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
+                   None if dense is None else f(dense), tuple(offs), tuple(dims))
 
     def cstruct(self) -> _l.DensityNet:
+        nd = len(self.dense_off) if (self.use_dense and self.dense is not None) else 0
+        offs = (C.c_int * 8)(*(list(self.dense_off[:nd]) + [0] * (8 - nd)))
+        dims = (C.c_int * 8)(*(list(self.dense_dim[:nd]) + [0] * (8 - nd)))
         return _l.DensityNet(_p(self.table), _p(self.scalings), self.scalings.numel(), self.log2T, _p(self.w0t),
-                             _p(self.b0), _p(self.w1t), _p(self.b1), self.b0.numel())
+                             _p(self.b0), _p(self.w1t), _p(self.b1), self.b0.numel(),
+                             _p(self.dense) if nd else None, nd, offs, dims)
 
 
 @dataclass
