@@ -27,19 +27,47 @@ class UnerfError(RuntimeError):
     pass
 
 
+def _source_digest() -> str:
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "unerf_common.hpp"),
+                                                          os.path.join(INCLUDE, "unerf.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into csrc/libunerf.so (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "unerf_common.hpp"), os.path.join(INCLUDE, "unerf.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    """Compile csrc/*.hip for gfx950 into csrc/libunerf.so (cross-compiles without a GPU).
+    Up-to-date-ness is a content hash of sources + flags (mtimes do not survive being copied to the GPU
+    box); concurrent callers (one process per GPU) serialise on a lock file and the library is
+    replaced atomically, so nobody dlopens a half-written file."""
+    import fcntl
+    digest, stamp = _source_digest(), LIB_PATH + ".sha256"
+
+    def fresh():
+        return os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+
+    if not force and fresh():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise UnerfError("hipcc failed:\n" + res.stdout + res.stderr)
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():   # another rank built it while we waited
+                return LIB_PATH
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
+            cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise UnerfError("hipcc failed:\n" + res.stdout + res.stderr)
+            os.replace(tmp, LIB_PATH)
+            with open(stamp, "w") as f:
+                f.write(digest)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
