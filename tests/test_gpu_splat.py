@@ -141,3 +141,49 @@ def test_active_splatfacto_full_pipeline(dev):
         bad = np.abs(g - r) > atol + rtol * np.abs(r)
         assert bad.mean() <= 5e-3, f"{k}: {bad.mean():.2e} of pixels off, worst {np.abs(g - r).max():.2e}"
     assert out["rgb"].max() <= 1.0
+
+
+def test_full_size_splat_frame_properties(dev):
+    """BASELINE size (N = 1 M splats, 1920x1080): size-independent properties of the bookkeeping --
+    sorted keys, bins that tile the intersection list exactly, every listed splat really overlaps its
+    tile, alpha in [0,1], finite images -- and idempotence (two renders are bit-identical)."""
+    from uncertainty_nerf_gs_amd import ops, splat, synthetic
+    N, H, W = 1_000_000, 1080, 1920
+    gp = {k: v.to(dev) for k, v in synthetic.make_splat_tensors(seed=7, N=N).items()}
+    c2w = synthetic.orbit_c2w(0.3, radius=2.5, height=0.5)
+    fx = fy = 1111.0
+    V = splat.viewmat_from_c2w(c2w)
+    quats = (gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True)).contiguous()
+    xys, depths, radii, conics, comp, tiles, _ = ops.splat_project(gp["means"], torch.exp(gp["scales"]), 1.0, quats, V[:3],
+                                                                  fx, fy, W / 2, H / 2, H, W)
+    I, cum, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W)
+    assert I == int(tiles.sum().item()) and I > 0 and int(cum[-1]) == I
+    assert torch.all(keys[1:] >= keys[:-1]), "intersection keys must be sorted (tile, then depth)"
+    tbx, tby = (W + 15) // 16, (H + 15) // 16
+    tile_of = (keys >> 32)
+    assert int(tile_of.max()) < tbx * tby
+    # bins: [start,end) per tile; non-empty bins are disjoint, ordered and cover [0,I)
+    b = bins.long()
+    nonempty = b[:, 1] > b[:, 0]
+    assert int((b[nonempty, 1] - b[nonempty, 0]).sum()) == I
+    starts = b[nonempty, 0]
+    assert torch.all(starts[1:] >= b[nonempty, 1][:-1])
+    # every entry of a bin belongs to that tile
+    tid = torch.arange(tbx * tby, device=dev)[nonempty]
+    assert torch.equal(tile_of[starts], tid) and torch.equal(tile_of[b[nonempty, 1] - 1], tid)
+    # depth bits inside a tile are ascending (front to back)
+    d_sorted = depths[gids.long()]
+    same_tile = tile_of[1:] == tile_of[:-1]
+    assert torch.all(d_sorted[1:][same_tile] >= d_sorted[:-1][same_tile])
+    bg = torch.tensor([0.2, 0.4, 0.6], device=dev)
+    out1 = splat.active_splatfacto_outputs(gp, c2w, fx, fy, W / 2, H / 2, H, W, bg)
+    out2 = splat.active_splatfacto_outputs(gp, c2w, fx, fy, W / 2, H / 2, H, W, bg)
+    for k in ("rgb", "depth", "accumulation", "uncertainty", "depth_var"):
+        assert torch.isfinite(out1[k]).all(), k
+        assert torch.equal(out1[k], out2[k]), f"{k}: not deterministic"
+    assert out1["accumulation"].min() >= 0 and out1["accumulation"].max() <= 1
+    assert out1["rgb"].max() <= 1 and out1["rgb"].min() >= 0
+    assert (out1["uncertainty"] >= 0).all() and (out1["depth_var"] >= 0).all()
+    empty = out1["accumulation"][..., 0] == 0
+    if empty.any():   # untouched pixels show the background exactly
+        assert torch.equal(out1["rgb"][empty], bg.expand_as(out1["rgb"][empty]))
