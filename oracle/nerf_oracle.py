@@ -360,16 +360,18 @@ def mc_keep_mask(seed: int, pass_idx: int, sample_idx: np.ndarray, stream: int, 
 
 
 def normal_noise(seed: int, draw: int, sample_idx: np.ndarray) -> np.ndarray:
-    """Box-Muller standard normal per (draw, sample), fp32 -- twin of the kernel's generator
-    used when no explicit noise tensor is supplied (laplace depth draws)."""
-    base = mc_base(seed, draw, sample_idx)
+    """Box-Muller standard normal per (draw, sample), fp32 -- twin of the kernel's generator used when
+    no explicit noise tensor is supplied (laplace depth draws).  Draws come in pairs: the pair index
+    draw>>1 keys the two uniforms, the even draw takes the cosine branch, the odd one the sine."""
+    base = mc_base(seed, draw >> 1, sample_idx)
     with np.errstate(over="ignore"):
         r1 = _hash32(base + GOLDEN)
         r2 = _hash32(base + np.uint32(2) * GOLDEN)
     u1 = ((r1 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
     u2 = ((r2 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
     rad = np.sqrt(np.float32(-2.0) * np.log(u1)).astype(np.float32)
-    return (rad * np.cos(np.float32(2.0 * math.pi) * u2)).astype(np.float32)
+    ang = np.float32(2.0 * math.pi) * u2
+    return (rad * (np.sin(ang) if (draw & 1) else np.cos(ang))).astype(np.float32)
 
 
 # --------------------------------------------------------------------------

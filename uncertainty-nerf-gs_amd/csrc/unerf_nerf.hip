@@ -939,7 +939,10 @@ __device__ __forceinline__ void mf_lap_head(const float* __restrict__ lap, int q
         for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[16 + r], s1[r], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float p = SIGMOID ? unerf_sigmoid(acc[r]) : expf(acc[r]);
+            // hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1e-6 relative) instead of the ~25-instruction exact
+            // expf / division: 16 activations follow every 32 MFMAs here and would otherwise take as long as
+            // the matrix work.  The results only enter means / variances over the n_lap samples.
+            float p = SIGMOID ? __builtin_amdgcn_rcpf(1.f + __expf(-acc[r])) : __expf(acc[r]);
             sum1 += p;
             sum2 += p * p;
         }
@@ -1440,11 +1443,35 @@ struct LapDepthArgs {
     float* out;
 };
 
-__device__ __forceinline__ float unerf_normal_from_hash(uint32_t base) {
+// Box-Muller on two hashed uniforms; BOTH outputs are used (cos for even draws, sin for odd ones of
+// a draw pair), with the hardware log / sin / cos (twin: oracle normal_noise)
+__device__ __forceinline__ void unerf_normal_pair_from_hash(uint32_t base, float& z0, float& z1) {
     uint32_t r1 = unerf_hash32(base + UNERF_GOLDEN), r2 = unerf_hash32(base + 2u * UNERF_GOLDEN);
     float u1 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
     float u2 = ((float)(r2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    float rad = sqrtf(-2.f * __logf(u1));
+    z0 = rad * __cosf(6.283185307179586f * u2);
+    z1 = rad * __sinf(6.283185307179586f * u2);
+}
+
+// get_weights for the Monte-Carlo depth draws: hardware exp (the 100-draw mean absorbs its ~1e-7 error)
+template <int SPL>
+__device__ __forceinline__ void group_weights_fast(const float (&dens)[SPL], const float (&delta)[SPL], int l16,
+                                                   float (&w)[SPL]) {
+    float dd[SPL], lex[SPL], ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        dd[e] = delta[e] * dens[e];
+        lex[e] = ls;
+        ls += dd[e];
+    }
+    float carry = group_excl_scan<16>(ls, l16);
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        float alpha = 1.f - __expf(-dd[e]);
+        float T = __expf(-(carry + lex[e]));
+        w[e] = unerf_nan_to_num(alpha * T);
+    }
 }
 
 template <int SPL>
@@ -1466,18 +1493,30 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
         sd[e] = (s != s) ? 1e-10f : fmaxf(s, 1e-10f);
         wsum[e] = 0.f;
     }
-    for (int d = 0; d < a.D; ++d) {
-        const uint32_t key = unerf_mc_key(a.seed, (uint32_t)d);
+    for (int d0 = 0; d0 < a.D; d0 += 2) {
+        float z[2][SPL];
+        if (a.noise) {
 #pragma unroll
-        for (int e = 0; e < SPL; ++e) {
-            float z;
-            if (a.noise) z = a.noise[((int64_t)d * a.R + r) * S + k0 + e];
-            else z = unerf_normal_from_hash(unerf_mc_base(key, (uint32_t)((a.ray_offset + r) * S + k0 + e)));
-            dens[e] = fmaxf(mu[e] + sd[e] * z, 0.f);
+            for (int e = 0; e < SPL; ++e) {
+                z[0][e] = a.noise[((int64_t)d0 * a.R + r) * S + k0 + e];
+                z[1][e] = (d0 + 1 < a.D) ? a.noise[((int64_t)(d0 + 1) * a.R + r) * S + k0 + e] : 0.f;
+            }
+        } else {
+            const uint32_t key = unerf_mc_key(a.seed, (uint32_t)(d0 >> 1));
+#pragma unroll
+            for (int e = 0; e < SPL; ++e)
+                unerf_normal_pair_from_hash(unerf_mc_base(key, (uint32_t)((a.ray_offset + r) * S + k0 + e)), z[0][e], z[1][e]);
         }
-        group_weights<SPL>(dens, delta, l16, w);
 #pragma unroll
-        for (int e = 0; e < SPL; ++e) wsum[e] += w[e];
+        for (int q = 0; q < 2; ++q) {
+            if (d0 + q < a.D) {
+#pragma unroll
+                for (int e = 0; e < SPL; ++e) dens[e] = fmaxf(mu[e] + sd[e] * z[q][e], 0.f);
+                group_weights_fast<SPL>(dens, delta, l16, w);
+#pragma unroll
+                for (int e = 0; e < SPL; ++e) wsum[e] += w[e];
+            }
+        }
     }
     if (ok) {
 #pragma unroll
