@@ -479,15 +479,16 @@ __device__ __forceinline__ void dense_lds(const float* __restrict__ Wt, const fl
     }
 }
 
-// same, with an inverted-dropout mask on the 64 inputs (pairs share one hash draw)
+// same, with an inverted-dropout mask on the 64 inputs (mask words: unerf_mask_word0 / unerf_xorshift32)
 template <int OUT>
 __device__ __forceinline__ void dense_lds_dropout(const float* __restrict__ Wt, const float* __restrict__ b,
-                                                  const float* act, int lane, uint32_t base, uint32_t stream_id,
-                                                  uint32_t thr, float scale, float (&acc)[OUT]) {
+                                                  const float* act, int lane, uint32_t base0, int pass,
+                                                  uint32_t stream_id, uint32_t thr, float scale, float (&acc)[OUT]) {
 #pragma unroll
     for (int o = 0; o < OUT; ++o) acc[o] = b[o];
     for (int j = 0; j < 32; ++j) {
-        uint32_t rnd = unerf_hash32(base + (stream_id * 32u + (uint32_t)j + 1u) * UNERF_GOLDEN);
+        uint32_t rnd = unerf_mask_word0(base0, stream_id, (uint32_t)j);
+        for (int q = 0; q < pass; ++q) rnd = unerf_xorshift32(rnd);
         float x0 = act[(2 * j) * 64 + lane];
         float x1 = act[(2 * j + 1) * 64 + lane];
         x0 = ((rnd & 0xFFFFu) < thr) ? x0 * scale : 0.f;
@@ -578,9 +579,9 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
         const int passes = a.p.K > 0 ? a.p.K : 1;
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         for (int k = 0; k < passes; ++k) {
-            const uint32_t base = unerf_mc_base(unerf_mc_key(a.p.seed, (uint32_t)k), sidx);
+            const uint32_t base = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
             float o1[16];
-            if (a.p.K > 0) dense_lds_dropout<16>(a.p.w1t, a.p.b1, A, lane, base, 0u, a.keep_thr, a.drop_scale, o1);
+            if (a.p.K > 0) dense_lds_dropout<16>(a.p.w1t, a.p.b1, A, lane, base, k, 0u, a.keep_thr, a.drop_scale, o1);
             else dense_lds<64, 16>(a.p.w1t, a.p.b1, A, lane, o1);
             float density = a.p.average_init_density * expf(o1[0]) * sel;
             store_act<16>(Bf, lane, sh, 0, false);
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
             dense_lds<64, 64>(a.p.h1t, a.p.hb1, Bf, lane, acc);
             store_act<64>(Bf, lane, acc, 0, true);
             float c[3];
-            if (a.p.K > 0) dense_lds_dropout<3>(a.p.h2t, a.p.hb2, Bf, lane, base, 1u, a.keep_thr, a.drop_scale, c);
+            if (a.p.K > 0) dense_lds_dropout<3>(a.p.h2t, a.p.hb2, Bf, lane, base, k, 1u, a.keep_thr, a.drop_scale, c);
             else dense_lds<64, 3>(a.p.h2t, a.p.hb2, Bf, lane, c);
             if (valid) {
                 int64_t q = (int64_t)k * N + n;
@@ -699,16 +700,25 @@ __device__ __forceinline__ f32x16 mf_slab(const float* lds, int frag0, int lane,
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[(frag0 + r) * 64 + lane], src[r], acc, 0, 0, 0);
     return acc;
 }
-// inverted dropout on one accumulator block (units 32*blk + row(r,h)); register pairs (r, r+1)
-// are units (u, u+1) = one hash draw, exactly like dense_lds_dropout / oracle mc_keep_mask
-__device__ __forceinline__ f32x16 mf_dropout(f32x16 v, int blk, int h, uint32_t base, uint32_t stream_id,
-                                             uint32_t thr, float scale) {
+// inverted dropout on one accumulator block (units 32*blk + row(r,h)).  Register pairs (r, r+1) are
+// units (u, u+1) = one mask word; the lane keeps its 8 words per block in `st` across the passes.
+__device__ __forceinline__ void mf_mask_init(uint32_t (&st)[8], int blk, int h, uint32_t base0, uint32_t stream_id) {
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
+    for (int q = 0; q < 8; ++q) {
+        const int r = 2 * q;
         uint32_t u = 32u * blk + (r & 3) + 8 * (r >> 2) + 4 * h;
-        uint32_t rnd = unerf_hash32(base + (stream_id * 32u + (u >> 1) + 1u) * UNERF_GOLDEN);
-        v[r] = ((rnd & 0xFFFFu) < thr) ? v[r] * scale : 0.f;
-        v[r + 1] = ((rnd >> 16) < thr) ? v[r + 1] * scale : 0.f;
+        st[q] = unerf_mask_word0(base0, stream_id, u >> 1);
+    }
+}
+__device__ __forceinline__ void mf_mask_step(uint32_t (&st)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st[q] = unerf_xorshift32(st[q]);
+}
+__device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], uint32_t thr, float scale) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        v[2 * q] = ((st[q] & 0xFFFFu) < thr) ? v[2 * q] * scale : 0.f;
+        v[2 * q + 1] = ((st[q] >> 16) < thr) ? v[2 * q + 1] * scale : 0.f;
     }
     return v;
 }
@@ -836,13 +846,26 @@ __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t nu
         const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
         const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.p.K > 0;
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
+        uint32_t mk0[8], mk1[8], mk2[8], mk3[8];  // this lane's mask words: trunk blk 0/1, head blk 0/1
+        if (drop) {
+            const uint32_t base0 = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
+            mf_mask_init(mk0, 0, h, base0, 0u);
+            mf_mask_init(mk1, 1, h, base0, 0u);
+            mf_mask_init(mk2, 0, h, base0, 1u);
+            mf_mask_init(mk3, 1, h, base0, 1u);
+        }
         for (int k = 0; k < passes; ++k) {
             asm volatile("" : "+v"(lane));  // same reason: keep the fragment reads inside the pass
-            const uint32_t base = unerf_mc_base(unerf_mc_key(a.p.seed, (uint32_t)k), sidx);
             f32x16 m0 = hid0, m1 = hid1;
             if (drop) {
-                m0 = mf_dropout(hid0, 0, h, base, 0u, a.keep_thr, a.drop_scale);
-                m1 = mf_dropout(hid1, 1, h, base, 0u, a.keep_thr, a.drop_scale);
+                if (k > 0) {
+                    mf_mask_step(mk0);
+                    mf_mask_step(mk1);
+                    mf_mask_step(mk2);
+                    mf_mask_step(mk3);
+                }
+                m0 = mf_dropout(hid0, mk0, a.keep_thr, a.drop_scale);
+                m1 = mf_dropout(hid1, mk1, a.keep_thr, a.drop_scale);
             }
             // trunk out: 64 -> out1 (rows >= out1 are zero-padded): row 0 density, 1..15 geo, 16 beta
             f32x16 t = mf_bias(lds, 2, h);
@@ -866,8 +889,8 @@ __global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t nu
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
             if (drop) {
-                d0 = mf_dropout(d0, 0, h, base, 1u, a.keep_thr, a.drop_scale);
-                d1 = mf_dropout(d1, 1, h, base, 1u, a.keep_thr, a.drop_scale);
+                d0 = mf_dropout(d0, mk2, a.keep_thr, a.drop_scale);
+                d1 = mf_dropout(d1, mk3, a.keep_thr, a.drop_scale);
             }
             // colour 2: 64 -> 3 on the VALU: each half sums its 32 units, halves meet by one shuffle
             float rgbv[3];
