@@ -95,30 +95,59 @@ __device__ __forceinline__ float unerf_normalize_position(float& x, float& y, fl
 
 // ---- one level of the nerfstudio torch HashEncoding ---------------------------------
 // corner order ccc,cfc,ffc,fcc,ccf,cff,fff,fcf; every level hashed; primes 1,2654435761,805459861.
+// Returns BYTE offsets of the 8 corner rows inside the level (row index * 8, 8-byte fp32x2 rows):
+// (hx ^ hy ^ hz) & mask, then << 3, equals ((hx<<3) ^ (hy<<3) ^ (hz<<3)) & (mask<<3), and
+// (v * prime) << 3 == v * (prime << 3) mod 2^32, so the shift is folded into the constants and a
+// corner costs one v_bitop3; the loads then take a uniform (SGPR) level base + this 32-bit VGPR
+// offset, with no 64-bit address arithmetic per corner.  Needs log2T <= 28.
 __device__ __forceinline__ void unerf_hash_corners(float px, float py, float pz, float scale, uint32_t mask,
-                                                   uint32_t (&idx)[8], float& ox, float& oy, float& oz) {
+                                                   uint32_t (&off)[8], float& ox, float& oy, float& oz) {
     float sx = px * scale, sy = py * scale, sz = pz * scale;
     int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
     int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
     ox = sx - (float)fx;
     oy = sy - (float)fy;
     oz = sz - (float)fz;
-    uint32_t hcx = (uint32_t)cx, hfx = (uint32_t)fx;
+    const uint32_t P1 = 2654435761u << 3, P2 = 805459861u << 3, m8 = mask << 3;
+    uint32_t hcx = (uint32_t)cx << 3, hfx = (uint32_t)fx << 3;
     // ceil = floor + 1 unless the coordinate is an exact integer, so the ceil products are the floor
     // products plus the prime (mod 2^32): two quarter-rate v_mul_lo_u32 per level instead of four
-    uint32_t hfy = (uint32_t)fy * 2654435761u, hfz = (uint32_t)fz * 805459861u;
-    uint32_t hcy = hfy + (cy != fy ? 2654435761u : 0u), hcz = hfz + (cz != fz ? 805459861u : 0u);
-    idx[0] = (hcx ^ hcy ^ hcz) & mask;
-    idx[1] = (hcx ^ hfy ^ hcz) & mask;
-    idx[2] = (hfx ^ hfy ^ hcz) & mask;
-    idx[3] = (hfx ^ hcy ^ hcz) & mask;
-    idx[4] = (hcx ^ hcy ^ hfz) & mask;
-    idx[5] = (hcx ^ hfy ^ hfz) & mask;
-    idx[6] = (hfx ^ hfy ^ hfz) & mask;
-    idx[7] = (hfx ^ hcy ^ hfz) & mask;
+    uint32_t hfy = (uint32_t)fy * P1, hfz = (uint32_t)fz * P2;
+    uint32_t hcy = hfy + (cy != fy ? P1 : 0u), hcz = hfz + (cz != fz ? P2 : 0u);
+    off[0] = (hcx ^ hcy ^ hcz) & m8;
+    off[1] = (hcx ^ hfy ^ hcz) & m8;
+    off[2] = (hfx ^ hfy ^ hcz) & m8;
+    off[3] = (hfx ^ hcy ^ hcz) & m8;
+    off[4] = (hcx ^ hcy ^ hfz) & m8;
+    off[5] = (hcx ^ hfy ^ hfz) & m8;
+    off[6] = (hfx ^ hfy ^ hfz) & m8;
+    off[7] = (hfx ^ hcy ^ hfz) & m8;
 }
 
+// Trilinear blend, the reference's lerp order (x, then y, then z; a*o + b*(1-o)).  Both features of a
+// row ride one packed fp32 pair (v_pk_mul_f32 / v_pk_add_f32 round each half exactly like the scalar
+// op): 21 packed instructions per level.  Left as scalar code the SLP vectoriser paired (f0*ox, f3*mx)
+// instead and spent a half-wasted horizontal v_pk_add plus ~25 register moves per level.
+typedef float unerf_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 unerf_blend8(const float2 (&f)[8], float ox, float oy, float oz) {
+    const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+    unerf_v2f v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = unerf_v2f{f[k].x, f[k].y};
+    unerf_v2f f03 = v[0] * ox + v[3] * mx;
+    unerf_v2f f12 = v[1] * ox + v[2] * mx;
+    unerf_v2f f56 = v[5] * ox + v[6] * mx;
+    unerf_v2f f47 = v[4] * ox + v[7] * mx;
+    unerf_v2f f0312 = f03 * oy + f12 * my;
+    unerf_v2f f4756 = f47 * oy + f56 * my;
+    unerf_v2f r = f0312 * oz + f4756 * mz;
+    return make_float2(r.x, r.y);
+}
+
+// Scalar statement of the same blend (identical roundings) for the MFMA field kernels, which are bound
+// by the gather rather than by VALU issue: the packed form's aligned register pairs cost them ~18 VGPRs
+// and with that the third wave per SIMD.
+__device__ __forceinline__ float2 unerf_blend8_scalar(const float2 (&f)[8], float ox, float oy, float oz) {
     float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
     float2 r;
     {
@@ -146,19 +175,20 @@ __device__ __forceinline__ float2 unerf_blend8(const float2 (&f)[8], float ox, f
 // (r1, MI355X): fetching x-neighbour rows (idx, idx^1 for even floor(x)) as one 16-B load plus a
 // predicated 8-B load for the odd case -- the divergent second load serialises into four dependent
 // round trips per level and ran 1.6-2.1x slower; the neighbour row is an L1 hit anyway.
-__device__ __forceinline__ void unerf_fetch_corners(const float2* __restrict__ lvl, const uint32_t (&idx)[8],
+__device__ __forceinline__ void unerf_fetch_corners(const float2* __restrict__ lvl, const uint32_t (&off)[8],
                                                     float2 (&f)[8]) {
+    const char* base = reinterpret_cast<const char*>(lvl);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = lvl[idx[k]];
+    for (int k = 0; k < 8; ++k) f[k] = *reinterpret_cast<const float2*>(base + off[k]);
 }
 
 __device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lvl, float px, float py, float pz,
                                                    float scale, uint32_t mask) {
-    uint32_t idx[8];
+    uint32_t off[8];
     float ox, oy, oz;
-    unerf_hash_corners(px, py, pz, scale, mask, idx, ox, oy, oz);
+    unerf_hash_corners(px, py, pz, scale, mask, off, ox, oy, oz);
     float2 f[8];
-    unerf_fetch_corners(lvl, idx, f);
+    unerf_fetch_corners(lvl, off, f);
     return unerf_blend8(f, ox, oy, oz);
 }
 
@@ -171,10 +201,15 @@ __device__ __forceinline__ float2 unerf_dense_level(const float4* __restrict__ c
     int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
     int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
     float ox = sx - (float)fx, oy = sy - (float)fy, oz = sz - (float)fz;
-    const float4 pcc = cells[(cz * dim + cy) * dim + fx];
-    const float4 pfc = cells[(cz * dim + fy) * dim + fx];
-    const float4 pcf = cells[(fz * dim + cy) * dim + fx];
-    const float4 pff = cells[(fz * dim + fy) * dim + fx];
+    // 32-bit byte offsets off a uniform base (dim <= 129: the whole level is < 2^32 bytes)
+    const char* base = reinterpret_cast<const char*>(cells);
+    const uint32_t udim = (uint32_t)dim;
+    const uint32_t rowc = (uint32_t)cz * udim, rowf = (uint32_t)fz * udim;
+    const uint32_t x16 = (uint32_t)fx << 4, d16 = udim << 4;
+    const float4 pcc = *reinterpret_cast<const float4*>(base + ((rowc + (uint32_t)cy) * d16 + x16));
+    const float4 pfc = *reinterpret_cast<const float4*>(base + ((rowc + (uint32_t)fy) * d16 + x16));
+    const float4 pcf = *reinterpret_cast<const float4*>(base + ((rowf + (uint32_t)cy) * d16 + x16));
+    const float4 pff = *reinterpret_cast<const float4*>(base + ((rowf + (uint32_t)fy) * d16 + x16));
     const bool step = cx != fx;  // false only when the scaled x is an exact integer (ceil == floor)
     float2 f[8];
     f[3] = make_float2(pcc.x, pcc.y);

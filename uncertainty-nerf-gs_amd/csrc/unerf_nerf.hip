@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(const float* __restrict__
             float ox, oy, oz;
             unerf_hash_corners(px, py, pz, scalings[l], mask, idx, ox, oy, oz);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) out_idx[(n * L + l) * 8 + k] = (int32_t)(idx[k] + ((uint32_t)l << log2T));
+            for (int k = 0; k < 8; ++k) out_idx[(n * L + l) * 8 + k] = (int32_t)((idx[k] >> 3) + ((uint32_t)l << log2T));
         }
     }
 }
@@ -251,6 +251,9 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
     UNERF_REQUIRE(net->log2T >= 1 && net->log2T <= 24, "proposal_density: bad log2T");
     UNERF_REQUIRE(net->n_dense >= 0 && net->n_dense <= 8 && net->n_dense <= net->L && (net->n_dense == 0 || net->dense),
                   "proposal_density: bad dense level description");
+    for (int l = 0; l < net->n_dense; ++l)  // a level is addressed with 32-bit byte offsets
+        UNERF_REQUIRE(net->dense_dim[l] >= 2 && net->dense_dim[l] <= 512, "proposal_density: dense_dim[%d]=%d", l,
+                      net->dense_dim[l]);
     if (R == 0) return UNERF_OK;
     PropArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.sstride = sbins_stride; a.R = R; a.n = n;
@@ -737,13 +740,13 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int lev = 8 * h + 4 * hb + q;
-            uint32_t idx[8];
-            unerf_hash_corners(px, py, pz, a.p.scalings[lev], mask, idx, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+            uint32_t off[8];
+            unerf_hash_corners(px, py, pz, a.p.scalings[lev], mask, off, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+            // lev differs between the wave's halves: keep the table base uniform (SGPR) and put the
+            // level into the 32-bit lane offset (whole table < 2^32 bytes: L * 2^(log2T+3))
+            const uint32_t lbase = (uint32_t)lev << (a.p.log2T + 3);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t off = ((((uint32_t)lev) << a.p.log2T) + idx[k]) * 8u;
-                cd[8 * q + k] = *reinterpret_cast<const float2*>(tbase + off);
-            }
+            for (int k = 0; k < 8; ++k) cd[8 * q + k] = *reinterpret_cast<const float2*>(tbase + (lbase | off[k]));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -751,7 +754,7 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
             float2 c8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
-            float2 f = unerf_blend8(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+            float2 f = unerf_blend8_scalar(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
             feat[2 * (4 * hb + q)] = f.x;
             feat[2 * (4 * hb + q) + 1] = f.y;
         }
@@ -761,7 +764,11 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
 }
 
 template <int MODE, bool FEAT_IN>
-__global__ __launch_bounds__(256) void field_kernel_mfma(FieldArgs a, int64_t num_tiles) {
+// ACTIVE is bound by the gather (texture-address unit): three waves per SIMD (<= 168 VGPRs) hide more of
+// its latency than two (measured 21.7 vs 23.7 ms/frame when a 176-VGPR build lost the third wave); the
+// K-pass mode needs the registers instead.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == UNERF_FIELD_ACTIVE ? 3 : 2)))
+void field_kernel_mfma(FieldArgs a, int64_t num_tiles) {
     extern __shared__ float lds[];
     {
         const float4* src = reinterpret_cast<const float4*>(a.p.mfma_blob);
