@@ -132,6 +132,30 @@ def test_weights_pdf_resample_matches_oracle(dev, n, m):
         assert abs(clip[c, 1].item() - rows.max().item()) <= 1e-6 * rows.max().item()
 
 
+@pytest.mark.parametrize("chunk,offset", [(10, 7), (4, 0), (1, 3), (1000, 123)])
+def test_pdf_clip_bounds_across_chunk_borders(dev, chunk, offset):
+    """A block reduces the clip bounds of 32 rays before touching memory; chunk borders that fall inside a
+    block (or inside one wave's ray sequence) must still land in the right [chunk] row, exactly."""
+    from uncertainty_nerf_gs_amd import ops, render
+    g = torch.Generator().manual_seed(chunk)
+    R, n, m = 157, 96, 48
+    dens = torch.exp(torch.randn(R, n, generator=g) * 2.5)
+    sb = torch.sort(torch.rand(R, n + 1, generator=g), dim=-1).values
+    n_chunks = (offset + R + chunk - 1) // chunk
+    clip = torch.empty(n_chunks, 2, device=dev)
+    clip[:, 0], clip[:, 1] = float("inf"), 0.0
+    new, _, _ = ops.weights_pdf_resample(dens.to(dev), sb.to(dev), render._pdf_u(m).to(dev), NEAR, FAR,
+                                         clip_minmax=clip, ray_offset=offset, chunk_rays=chunk)
+    eb = O.spacing_to_euclidean(new.cpu(), NEAR, FAR)
+    first, last = (eb[:, 0] + eb[:, 1]) / 2, (eb[:, -2] + eb[:, -1]) / 2
+    want = torch.empty(n_chunks, 2)
+    want[:, 0], want[:, 1] = float("inf"), 0.0
+    for r in range(R):
+        c = (offset + r) // chunk
+        want[c, 0], want[c, 1] = min(want[c, 0], first[r]), max(want[c, 1], last[r])
+    torch.testing.assert_close(clip.cpu(), want, rtol=1e-6, atol=0)
+
+
 def test_weights_pdf_resample_shared_initial_bins(dev):
     from uncertainty_nerf_gs_amd import ops, render
     g = torch.Generator().manual_seed(5)

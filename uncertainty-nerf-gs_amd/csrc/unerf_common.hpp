@@ -100,8 +100,10 @@ __device__ __forceinline__ float unerf_normalize_position(float& x, float& y, fl
 // (v * prime) << 3 == v * (prime << 3) mod 2^32, so the shift is folded into the constants and a
 // corner costs one v_bitop3; the loads then take a uniform (SGPR) level base + this 32-bit VGPR
 // offset, with no 64-bit address arithmetic per corner.  Needs log2T <= 28.
+template <bool WITH_BASE = false>
 __device__ __forceinline__ void unerf_hash_corners(float px, float py, float pz, float scale, uint32_t mask,
-                                                   uint32_t (&off)[8], float& ox, float& oy, float& oz) {
+                                                   uint32_t (&off)[8], float& ox, float& oy, float& oz,
+                                                   uint32_t base = 0u) {
     float sx = px * scale, sy = py * scale, sz = pz * scale;
     int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
     int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
@@ -109,19 +111,35 @@ __device__ __forceinline__ void unerf_hash_corners(float px, float py, float pz,
     oy = sy - (float)fy;
     oz = sz - (float)fz;
     const uint32_t P1 = 2654435761u << 3, P2 = 805459861u << 3, m8 = mask << 3;
-    uint32_t hcx = (uint32_t)cx << 3, hfx = (uint32_t)fx << 3;
+    uint32_t hfx = (uint32_t)fx << 3, hcx = (uint32_t)cx << 3;
     // ceil = floor + 1 unless the coordinate is an exact integer, so the ceil products are the floor
     // products plus the prime (mod 2^32): two quarter-rate v_mul_lo_u32 per level instead of four
     uint32_t hfy = (uint32_t)fy * P1, hfz = (uint32_t)fz * P2;
     uint32_t hcy = hfy + (cy != fy ? P1 : 0u), hcz = hfz + (cz != fz ? P2 : 0u);
-    off[0] = (hcx ^ hcy ^ hcz) & m8;
-    off[1] = (hcx ^ hfy ^ hcz) & m8;
-    off[2] = (hfx ^ hfy ^ hcz) & m8;
-    off[3] = (hfx ^ hcy ^ hcz) & m8;
-    off[4] = (hcx ^ hcy ^ hfz) & m8;
-    off[5] = (hcx ^ hfy ^ hfz) & m8;
-    off[6] = (hfx ^ hfy ^ hfz) & m8;
-    off[7] = (hfx ^ hcy ^ hfz) & m8;
+    if (!WITH_BASE) {  // 4 pair xors + one v_bitop3 ((t ^ z) & m8) per corner
+        off[0] = (hcx ^ hcy ^ hcz) & m8;
+        off[1] = (hcx ^ hfy ^ hcz) & m8;
+        off[2] = (hfx ^ hfy ^ hcz) & m8;
+        off[3] = (hfx ^ hcy ^ hcz) & m8;
+        off[4] = (hcx ^ hcy ^ hfz) & m8;
+        off[5] = (hcx ^ hfy ^ hfz) & m8;
+        off[6] = (hfx ^ hfy ^ hfz) & m8;
+        off[7] = (hfx ^ hcy ^ hfz) & m8;
+        return;
+    }
+    // with a level offset to merge in (`base`: bits above the mask), mask the three terms once (6 ops,
+    // base rides in on the z term); every corner is then a single three-input xor
+    hfx &= m8; hcx &= m8; hfy &= m8; hcy &= m8;
+    hfz = (hfz & m8) | base;
+    hcz = (hcz & m8) | base;
+    off[0] = hcx ^ hcy ^ hcz;
+    off[1] = hcx ^ hfy ^ hcz;
+    off[2] = hfx ^ hfy ^ hcz;
+    off[3] = hfx ^ hcy ^ hcz;
+    off[4] = hcx ^ hcy ^ hfz;
+    off[5] = hcx ^ hfy ^ hfz;
+    off[6] = hfx ^ hfy ^ hfz;
+    off[7] = hfx ^ hcy ^ hfz;
 }
 
 // Trilinear blend, the reference's lerp order (x, then y, then z; a*o + b*(1-o)).  Both features of a

@@ -224,17 +224,26 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
     const float* __restrict__ w0t = a.net.w0t;
     const float* __restrict__ b0 = a.net.b0;
     const float* __restrict__ w1t = a.net.w1t;
-    float h[HID];
+    // two hidden units per v_pk_fma_f32 (each half is an IEEE fma, same bits as fmaf): the kernel is
+    // VALU-issue-bound, and the MLP was a third of its instructions.  Weights arrive as SGPR pairs.
+    static_assert(HID % 2 == 0, "hidden width must be even");
+    const unerf_v2f* __restrict__ w0p = reinterpret_cast<const unerf_v2f*>(w0t);
+    const unerf_v2f* __restrict__ b0p = reinterpret_cast<const unerf_v2f*>(b0);
+    unerf_v2f h2[HID / 2];
 #pragma unroll
-    for (int j = 0; j < HID; ++j) h[j] = b0[j];
+    for (int j = 0; j < HID / 2; ++j) h2[j] = b0p[j];
 #pragma unroll
     for (int k = 0; k < 2 * L; ++k) {
+        const unerf_v2f fk = {feat[k], feat[k]};
 #pragma unroll
-        for (int j = 0; j < HID; ++j) h[j] = fmaf(feat[k], w0t[k * HID + j], h[j]);
+        for (int j = 0; j < HID / 2; ++j) h2[j] = __builtin_elementwise_fma(fk, w0p[k * (HID / 2) + j], h2[j]);
     }
     float o = a.net.b1[0];
 #pragma unroll
-    for (int j = 0; j < HID; ++j) o = fmaf(fmaxf(h[j], 0.f), w1t[j], o);
+    for (int j = 0; j < HID / 2; ++j) {  // ReLU as an integer max on the bit pattern (one op, see mf_relu)
+        o = fmaf(__int_as_float(max(__float_as_int(h2[j].x), 0)), w1t[2 * j], o);
+        o = fmaf(__int_as_float(max(__float_as_int(h2[j].y), 0)), w1t[2 * j + 1], o);
+    }
     a.out[idx] = a.avg * expf(o) * sel;
 }
 
@@ -295,19 +304,46 @@ struct PdfArgs {
 
 #define PDF_MAXN 256
 
+#define PDF_RAYS_PER_BLOCK 32
+
+// Each wave of the pdf kernel works on its own LDS rows, and a wave's DS operations complete in issue
+// order, so a compiler-level fence is all the "barrier" it needs; the four waves of a block are then
+// free to drift apart and hide one another's latency (s_barrier kept them in lock-step).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Thousands of rays share one chunk word: peek first (L2-coherent relaxed load) and only send the atomic
+// when it can still win -- a stale peek merely costs a redundant atomic, never a wrong result.
+__device__ __forceinline__ void pdf_clip_commit(float* clip, int64_t chunk, unsigned int lo, unsigned int hi) {
+    unsigned int* c = reinterpret_cast<unsigned int*>(clip) + chunk * 2;
+    if (lo < __hip_atomic_load(c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(c + 0, lo);
+    if (hi > __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(c + 1, hi);
+}
+
 template <int EPL>
 __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
     __shared__ float s_sb[4][PDF_MAXN + 4];
     __shared__ float s_cdf[4][PDF_MAXN + 4];
     __shared__ float s_nb[4][PDF_MAXN + 4];
+    __shared__ unsigned int s_clip[4][2];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t r = (int64_t)blockIdx.x * 4 + wv;
-    const bool ray_ok = r < a.R;
-    if (!ray_ok) r = a.R - 1;  // keep all waves alive for the block barriers
     const int n = a.n, nb = a.m + 1;
+    // A block walks PDF_RAYS_PER_BLOCK consecutive rays, four (one per wave) at a time, and keeps the
+    // running min/max of the first/last sample positions in registers: one peek + atomic per block and
+    // chunk instead of one per ray (2 M same-address L2 reads per frame made this kernel 3.5 ms).
+    int64_t cur_chunk = -1;
+    unsigned int cmin = 0x7F800000u, cmax = 0u;
+    for (int it = 0; it < PDF_RAYS_PER_BLOCK / 4; ++it) {
+    int64_t r = (int64_t)blockIdx.x * PDF_RAYS_PER_BLOCK + it * 4 + wv;
+    const bool ray_ok = r < a.R;
+    if (!ray_ok) r = a.R - 1;  // keep the wave alive for the block barrier at the end
+    wave_lds_sync();           // previous ray's LDS rows are free again
     const float* sb = a.sbins + r * a.sstride;
     for (int k = lane; k <= n; k += 64) s_sb[wv][k] = sb[k];
-    __syncthreads();
+    wave_lds_sync();
 
     float eu[EPL + 1], w[EPL], dd[EPL];
     const int k0 = lane * EPL;
@@ -378,7 +414,7 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e)
         if (k0 + e < n) s_cdf[wv][k0 + e + 1] = fminf(1.f, cb + lcdf[e]);
-    __syncthreads();
+    wave_lds_sync();
 
     for (int j = lane; j < nb; j += 64) {
         float u = a.u[j];
@@ -399,19 +435,38 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
         if (ray_ok) a.sbins_out[r * nb + j] = v;
     }
     if (a.clip) {
-        __syncthreads();
-        if (lane == 0 && ray_ok) {
+        wave_lds_sync();
+        if (ray_ok) {  // wave-uniform
             float f0 = unerf_s2e(s_nb[wv][0], a.s_near, a.s_far), f1 = unerf_s2e(s_nb[wv][1], a.s_near, a.s_far);
             float l0 = unerf_s2e(s_nb[wv][nb - 2], a.s_near, a.s_far), l1 = unerf_s2e(s_nb[wv][nb - 1], a.s_near, a.s_far);
             float first = (f0 + f1) / 2.f, last = (l0 + l1) / 2.f;
-            int64_t chunk = (a.ray_offset + r) / a.chunk_rays;
-            unsigned int* c = reinterpret_cast<unsigned int*>(a.clip) + chunk * 2;
-            // positive floats order like their bit patterns.  Thousands of rays share one chunk word:
-            // peek first (L2-coherent relaxed load) and only send the atomic when it can still win --
-            // a stale peek merely costs a redundant atomic, never a wrong result.
-            unsigned int fb = __float_as_uint(first), lb = __float_as_uint(last);
-            if (fb < __hip_atomic_load(c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(c + 0, fb);
-            if (lb > __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(c + 1, lb);
+            const int64_t chunk = (a.ray_offset + r) / a.chunk_rays;
+            if (chunk != cur_chunk) {
+                if (cur_chunk >= 0 && lane == 0) pdf_clip_commit(a.clip, cur_chunk, cmin, cmax);
+                cur_chunk = chunk;
+                cmin = 0x7F800000u;
+                cmax = 0u;
+            }
+            // positive floats order like their bit patterns
+            cmin = min(cmin, __float_as_uint(first));
+            cmax = max(cmax, __float_as_uint(last));
+        }
+    }
+    }  // rays of this block
+    if (a.clip) {
+        // the four waves normally sit in one chunk: merge them through LDS and send one update
+        const int64_t blk_chunk = (a.ray_offset + (int64_t)blockIdx.x * PDF_RAYS_PER_BLOCK) / a.chunk_rays;
+        const bool mergeable = cur_chunk == blk_chunk;  // this wave never left the block's first chunk
+        if (lane == 0) {
+            s_clip[wv][0] = mergeable ? cmin : 0x7F800000u;
+            s_clip[wv][1] = mergeable ? cmax : 0u;
+            if (!mergeable && cur_chunk >= 0) pdf_clip_commit(a.clip, cur_chunk, cmin, cmax);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int lo = min(min(s_clip[0][0], s_clip[1][0]), min(s_clip[2][0], s_clip[3][0]));
+            unsigned int hi = max(max(s_clip[0][1], s_clip[1][1]), max(s_clip[2][1], s_clip[3][1]));
+            if (lo != 0x7F800000u || hi != 0u) pdf_clip_commit(a.clip, blk_chunk, lo, hi);
         }
     }
 }
@@ -433,7 +488,7 @@ extern "C" int unerf_weights_pdf_resample(const float* density, const float* sbi
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
     a.u = u; a.m = m; a.pad = histogram_padding; a.eps = eps; a.sbins_out = sbins_out; a.prop_depth = prop_depth_out;
     a.weights_out = weights_out; a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays;
-    dim3 grid(blocks_for(R, 4)), block(256);
+    dim3 grid(blocks_for(R, PDF_RAYS_PER_BLOCK)), block(256);
     hipStream_t st = (hipStream_t)stream;
     int epl = (n + 63) / 64;
     switch (epl) {
@@ -730,6 +785,10 @@ __device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], 
 // Two batches of 4 levels: all 32 corner rows of a batch are requested back to back (uniform table
 // base + 32-bit byte offset per lane), THEN blended.  Left to itself the compiler interleaves
 // address math, 4-load groups and waits (about 20 dependent round trips per tile in the r1 ISA).
+// PACKED picks the fp32x2 blend (fewer VALU issues, ~18 more VGPRs): right for the K-pass and Laplace
+// kernels, which sit at 2 waves/SIMD anyway; the ACTIVE kernel keeps the scalar blend and its third wave
+// (packed + 168-VGPR cap: 20 B of scratch, 22.2 vs 21.8 ms/frame).
+template <bool PACKED>
 __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, float py, float pz, int h, uint32_t mask) {
     f32x16 feat;
     const char* tbase = reinterpret_cast<const char*>(a.p.table);
@@ -741,12 +800,12 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
         for (int q = 0; q < 4; ++q) {
             const int lev = 8 * h + 4 * hb + q;
             uint32_t off[8];
-            unerf_hash_corners(px, py, pz, a.p.scalings[lev], mask, off, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
-            // lev differs between the wave's halves: keep the table base uniform (SGPR) and put the
-            // level into the 32-bit lane offset (whole table < 2^32 bytes: L * 2^(log2T+3))
-            const uint32_t lbase = (uint32_t)lev << (a.p.log2T + 3);
+            // lev differs between the wave's halves: the table base stays uniform (SGPR) and the level
+            // goes into the 32-bit lane offset (whole table < 2^32 bytes: L * 2^(log2T+3))
+            unerf_hash_corners<true>(px, py, pz, a.p.scalings[lev], mask, off, of[3 * q], of[3 * q + 1], of[3 * q + 2],
+                                     (uint32_t)lev << (a.p.log2T + 3));
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cd[8 * q + k] = *reinterpret_cast<const float2*>(tbase + (lbase | off[k]));
+            for (int k = 0; k < 8; ++k) cd[8 * q + k] = *reinterpret_cast<const float2*>(tbase + off[k]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -754,7 +813,8 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
             float2 c8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
-            float2 f = unerf_blend8_scalar(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+            float2 f = PACKED ? unerf_blend8(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2])
+                              : unerf_blend8_scalar(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
             feat[2 * (4 * hb + q)] = f.x;
             feat[2 * (4 * hb + q) + 1] = f.y;
         }
@@ -821,7 +881,7 @@ void field_kernel_mfma(FieldArgs a, int64_t num_tiles) {
                 feat[2 * l + 1] = f.y;
             }
         } else {
-            feat = mf_gather_feats(a, px, py, pz, h, mask);
+            feat = mf_gather_feats<MODE != UNERF_FIELD_ACTIVE>(a, px, py, pz, h, mask);
         }
         // Colour layer 0 sees [geo(15) | SH(16)]; the SH half does not depend on the MC pass, so its
         // 16 MFMAs (+ bias) are done once per tile and every pass starts from that partial sum.
@@ -1023,7 +1083,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, in
         float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
         float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
         (void)unerf_normalize_position(px, py, pz);  // the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
-        f32x16 feat = mf_gather_feats(a, px, py, pz, h, mask);
+        f32x16 feat = mf_gather_feats<true>(a, px, py, pz, h, mask);
 
         // base_mlp is a bare Linear: no ReLU (utils.py:22-23)
         f32x16 hb0 = mf_slab(lds, 0, lane, feat, mf_bias(lds, 0, h));
