@@ -41,6 +41,28 @@ extern "C" int unerf_device_count(void) {
 
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
+// Division of an index < 2^31 by a launch-invariant divisor (samples per ray): one multiply-high and a
+// shift instead of the ~30 issue slots of the generic 32-bit division (Granlund-Montgomery, N = 31:
+// m = floor(2^(31+l) / d) + 1 with l = ceil(log2 d) satisfies 2^(31+l) < m d <= 2^(31+l) + 2^l).
+struct FastDiv {
+    uint32_t magic;  // 0: d == 1
+    uint32_t shift;
+    uint32_t d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f{0u, 0u, d};
+    if (d > 1u) {
+        uint32_t l = 0;
+        while ((1ull << l) < d) ++l;
+        f.magic = (uint32_t)((1ull << (31 + l)) / d + 1ull);
+        f.shift = l - 1;
+    }
+    return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t x, const FastDiv& f) {
+    return f.magic ? (__umulhi(x, f.magic) >> f.shift) : x;
+}
+
 // ======================================================================================
 // wave / group helpers
 // ======================================================================================
@@ -190,14 +212,24 @@ struct PropArgs {
     unerf_density_net net;
     float avg;
     float* out;
+    FastDiv fd;  // by n; used when R * n < 2^31
+    int small;
 };
 
 template <int L, int HID>
 __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.R * a.n) return;
-    int64_t r = idx / a.n;
-    int i = (int)(idx - r * a.n);
+    int64_t r;
+    int i;
+    if (a.small) {  // uniform
+        const uint32_t r32 = fastdiv((uint32_t)idx, a.fd);
+        r = r32;
+        i = (int)((uint32_t)idx - r32 * (uint32_t)a.n);
+    } else {
+        r = idx / a.n;
+        i = (int)(idx - r * a.n);
+    }
     const float* sb = a.sbins + r * a.sstride;
     float e0 = unerf_s2e(sb[i], a.s_near, a.s_far);
     float e1 = unerf_s2e(sb[i + 1], a.s_near, a.s_far);
@@ -268,6 +300,7 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.sstride = sbins_stride; a.R = R; a.n = n;
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
     a.net = *net; a.avg = average_init_density; a.out = density_out;
+    a.fd = make_fastdiv((uint32_t)n); a.small = (R * (int64_t)n < (1ll << 31)) ? 1 : 0;
     dim3 grid(blocks_for(R * (int64_t)n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (net->L == 5 && net->hidden == 16) hipLaunchKernelGGL((prop_density_kernel<5, 16>), grid, block, 0, st, a);
@@ -828,7 +861,7 @@ template <int MODE, bool FEAT_IN>
 // its latency than two (measured 21.7 vs 23.7 ms/frame when a 176-VGPR build lost the third wave); the
 // K-pass mode needs the registers instead.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == UNERF_FIELD_ACTIVE ? 3 : 2)))
-void field_kernel_mfma(FieldArgs a, int64_t num_tiles) {
+void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
         const float4* src = reinterpret_cast<const float4*>(a.p.mfma_blob);
@@ -836,16 +869,17 @@ void field_kernel_mfma(FieldArgs a, int64_t num_tiles) {
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    const int lane_c = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // wave index as a scalar: the tile walk and its divisions then run on the scalar unit
+    const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane_c & 31, h = lane_c >> 5;
     const int64_t N = a.R * (int64_t)a.S;
     const uint32_t mask = (1u << a.p.log2T) - 1u;
     // XCD-aware persistent walk: blocks b and b+8 share an XCD (L2); give each XCD one contiguous
     // eighth of the tiles so neighbouring rays (same coarse hash cells) meet in the same L2.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const int64_t tpx = (num_tiles + 7) / 8;
-    const int64_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
-    for (int64_t tile = xcd * tpx + (int64_t)slot * 4 + wv; tile < tile_end; tile += (int64_t)bpx * 4) {
+    const uint32_t tpx = (num_tiles + 7u) / 8u;  // num_tiles < 2^28 (the RNG counter bound in unerf_field_fwd)
+    const uint32_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
+    for (uint32_t tile = xcd * tpx + (uint32_t)slot * 4u + (uint32_t)wv; tile < tile_end; tile += (uint32_t)bpx * 4u) {
         // The LDS fragment reads are invariant across tiles; left alone, LICM hoists all 160 of
         // them into registers (490 VGPR+AGPR, scratch spills).  An opaque copy of the lane index
         // keeps them inside the iteration, where each read is consumed by the next MFMA.
@@ -855,9 +889,9 @@ void field_kernel_mfma(FieldArgs a, int64_t num_tiles) {
         // sample slot of 32 adjacent pixels, which sit in the same or neighbouring grid cells, so a gather
         // instruction presents few distinct lines to the texture-address unit (it retires ~1 divergent
         // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_03)
-        const int64_t rb = tile / a.S;
-        const int s = (int)(tile - rb * a.S);
-        int64_t r = rb * 32 + j;
+        const uint32_t rb = fastdiv(tile, div_s);
+        const int s = (int)(tile - rb * (uint32_t)a.S);
+        int64_t r = (int64_t)rb * 32 + j;
         const bool valid = r < a.R;
         if (!valid) r = a.R - 1;
         const int64_t n = r * a.S + s;
@@ -1046,7 +1080,7 @@ __device__ __forceinline__ void mf_lap_head(const float* __restrict__ lap, int q
     sum2 += __shfl_xor(sum2, 32, 64);
 }
 
-__global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, int64_t num_tiles) {
+__global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
         const float4* src = reinterpret_cast<const float4*>(a.p.mfma_blob);
@@ -1054,24 +1088,25 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, in
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    const int lane_c = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // wave index as a scalar: the tile walk and its divisions then run on the scalar unit
+    const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane_c & 31, h = lane_c >> 5;
     const int64_t N = a.R * (int64_t)a.S;
     const uint32_t mask = (1u << a.p.log2T) - 1u;
     const float inv_n = 1.f / (float)a.p.n_lap;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const int64_t tpx = (num_tiles + 7) / 8;
-    const int64_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
-    for (int64_t tile = xcd * tpx + (int64_t)slot * 4 + wv; tile < tile_end; tile += (int64_t)bpx * 4) {
+    const uint32_t tpx = (num_tiles + 7u) / 8u;  // num_tiles < 2^28 (the RNG counter bound in unerf_field_fwd)
+    const uint32_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
+    for (uint32_t tile = xcd * tpx + (uint32_t)slot * 4u + (uint32_t)wv; tile < tile_end; tile += (uint32_t)bpx * 4u) {
         int lane = lane_c;  // opaque per iteration: keeps the (tile-invariant) fragment reads in the loop
         asm volatile("" : "+v"(lane));
         // tile -> (block of 32 neighbouring rays, sample index s): the 32 columns of a tile are the SAME
         // sample slot of 32 adjacent pixels, which sit in the same or neighbouring grid cells, so a gather
         // instruction presents few distinct lines to the texture-address unit (it retires ~1 divergent
         // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_03)
-        const int64_t rb = tile / a.S;
-        const int s = (int)(tile - rb * a.S);
-        int64_t r = rb * 32 + j;
+        const uint32_t rb = fastdiv(tile, div_s);
+        const int s = (int)(tile - rb * (uint32_t)a.S);
+        int64_t r = (int64_t)rb * 32 + j;
         const bool valid = r < a.R;
         if (!valid) r = a.R - 1;
         const int64_t n = r * a.S + s;
@@ -1248,10 +1283,10 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid(tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
                 else
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid(tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_ACTIVE>), grid, block, 64 * 64 * 4, st, a);
             }
@@ -1263,10 +1298,10 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid(tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
                 else
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid(tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, tiles);
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
             }
@@ -1277,7 +1312,7 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 hipLaunchKernelGGL(field_kernel_mfma_laplace, dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
-                                   st, a, tiles);
+                                   st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_LAPLACE>), grid, block, 64 * 64 * 4, st, a);
             }
