@@ -1,0 +1,45 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence behind bench.py's numbers on the GPU box (run through gpurun):
+#   bash benchmarks/collect_profiles.sh <tag>          e.g. r1_05
+# Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ and the condensed, tracked-size files under
+# gpurun_out/profiles_<tag>/ (copy those into profiles/ and commit).  Kernel-trace/--stats and every
+# --pmc counter set run as SEPARATE passes (never combined with other trace domains); the profiled
+# program is `python3 bench.py ...` directly after `--`.
+set -u
+TAG=${1:-r1_xx}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+DST=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p "$OUT" "$DST"
+export TMPDIR=/tmp
+cd /tmp
+
+stats() {  # method, extra bench args...
+    local m=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${m}_stats" -- \
+        python3 "$ROOT/bench.py" --method "$m" --steps 4 --warmup 1 --no-cpu-baseline "$@" > "$OUT/${m}_stats.log" 2>&1
+    local f
+    f=$(find "$OUT/${m}_stats" -name '*kernel_stats.csv' | head -1)
+    [ -n "$f" ] && cp "$f" "$DST/${TAG}_${m}_kernel_stats.csv"
+    grep -a "^{\"metric\"" "$OUT/${m}_stats.log" | tail -1 > "$DST/${TAG}_${m}_bench_under_rocprof.json"
+}
+
+pmc() {  # method, set name, counters...
+    local m=$1 name=$2; shift 2
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/${m}_pmc_$name" -- \
+        python3 "$ROOT/bench.py" --method "$m" --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/${m}_pmc_$name.log" 2>&1
+    local f
+    f=$(find "$OUT/${m}_pmc_$name" -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && python3 "$ROOT/benchmarks/summarize_pmc.py" reduce "$f" "$DST/${TAG}_${m}_pmc_$name.csv"
+}
+
+for m in active mcdropout laplace splat; do stats $m; done
+for m in active mcdropout; do
+    pmc $m fetch FETCH_SIZE
+    pmc $m write WRITE_SIZE
+done
+pmc active sq SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
+pmc active ta TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
+pmc active tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+python3 "$ROOT/benchmarks/summarize_pmc.py" summary "$DST" "$TAG"
+ls -la "$DST"
