@@ -177,6 +177,20 @@ int unerf_laplace_depth_weights(const float* density_mu, const float* density_va
                                 int64_t R, int S, float near_plane, float far_plane, const float* noise, int D,
                                 uint32_t seed, int64_t ray_offset, float* weights_out, void* stream);
 
+/* Laplace GGN fitting: NerfactoLaplaceModel.compute_hessian_naive (models/laplace/laplace_model.py:343-400),
+ * one batch of rays.  Adds (+=) the batch's diagonal generalised Gauss-Newton of the summed-MSE loss w.r.t.
+ * mlp_density (ggn_density[65]: weight[64], bias) and mlp_rgb_ll (ggn_rgb[195]: weight[3][64] row-major,
+ * bias[3]) -- the layout of field.mlp_density_ggn / field.mlp_rgb_ggn (laplace_field.py:231-238).
+ * Forward = the deterministic is_inference=False path (laplace_field.py:317-345, 462-465) rendered with the
+ * eval-mode RGB renderer.  p: mode LAPLACE with mfma_blob; p->ws_density[65] / p->ws_rgb[195] hold the MEAN
+ * last layers ([out,in] row-major, then bias); n_lap / lap_blob are ignored.  sbins [R,S+1] as for
+ * unerf_field_fwd, S <= 64.  workspace: unerf_laplace_ggn_workspace_bytes(R, S) bytes of device scratch. */
+size_t unerf_laplace_ggn_workspace_bytes(int64_t R, int S);
+int unerf_laplace_ggn_diag(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
+                           float near_plane, float far_plane, const unerf_field_params* p /* host struct */,
+                           void* workspace, size_t workspace_bytes, float* ggn_density, float* ggn_rgb,
+                           void* stream);
+
 /* ------------------------------------------------- composite + variance --
  * Replaces RaySamples.get_weights + RGB/Accumulation/Depth(median,expected)/Uncertainty
  * renderers + the depth-variance sum at models/activenerfacto/activenerfacto_model.py:94-112

@@ -524,6 +524,39 @@ def laplace_field_deterministic(origins, directions, euclid_bins, fp: FieldParam
     return density, rgb.view(R, S, 3)
 
 
+def laplace_ggn_diag(scene: "NerfScene", origins, directions):
+    """[REF laplace_model.py:343-400 compute_hessian_naive, one batch]  Diagonal of the generalised
+    Gauss-Newton matrix of the summed-MSE loss w.r.t. the two last layers (mlp_density: 64+1, mlp_rgb_ll:
+    3*64+3 parameters, torch parameter order: weight row-major, then bias).  The reference obtains it from
+    one GGN-vector product per unit vector (backpack); the loss Hessian w.r.t. the rendered pixel is 2 I,
+    so diag = 2 * sum_{ray, channel} (d pred_rgb / d theta)^2 -- formed here with plain autograd, one
+    backward per rendered value.  Forward = the is_inference=False path (`laplace_model.py:208-226`) with
+    the eval-mode RGB renderer (eval_setup puts the pipeline in eval mode).  -> (ggn_density [65], ggn_rgb [195])"""
+    import copy
+    fp = copy.copy(scene.field)
+    fp.density_w = scene.field.density_w.clone().requires_grad_(True)
+    fp.density_b = scene.field.density_b.clone().requires_grad_(True)
+    fp.head_w = list(scene.field.head_w)
+    fp.head_b = list(scene.field.head_b)
+    fp.head_w[2] = scene.field.head_w[2].clone().requires_grad_(True)
+    fp.head_b[2] = scene.field.head_b[2].clone().requires_grad_(True)
+    params = [fp.density_w, fp.density_b, fp.head_w[2], fp.head_b[2]]
+    with torch.no_grad():
+        eb, _, _ = _sample(scene, origins, directions)
+    density, rgb = laplace_field_deterministic(origins, directions, eb, fp)
+    w = get_weights(density, eb[..., 1:] - eb[..., :-1])
+    pred = render_rgb(rgb, w)
+    diag = [torch.zeros_like(q) for q in params]
+    flat = pred.reshape(-1)
+    for i in range(flat.numel()):
+        g = torch.autograd.grad(flat[i], params, retain_graph=True, allow_unused=True)
+        for d, gi in zip(diag, g):
+            if gi is not None:
+                d += 2.0 * gi.detach() ** 2
+    return (torch.cat([diag[0].reshape(-1), diag[1].reshape(-1)]),
+            torch.cat([diag[2].reshape(-1), diag[3].reshape(-1)]))
+
+
 @dataclass
 class NerfScene:
     """Everything a nerfacto-family model needs at eval."""

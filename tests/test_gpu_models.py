@@ -120,6 +120,36 @@ def test_laplace_model_unc_render_matches_oracle(dev):
         assert bad.double().mean() <= 5e-3, (k, (got - want).abs().max().item())
 
 
+def test_laplace_compute_hessian_naive_matches_autograd_oracle(dev):
+    """GGN fitting (laplace_model.py:343-400): closed-form Jacobian kernels vs one autograd backward per
+    rendered value on the CPU oracle, through the Model method the eval script calls."""
+    from uncertainty_nerf_gs_amd import plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=4, kind="laplace", log2T=14, prop_log2T=12)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["nerfacto-laplace"]())
+    model = cfg._target(cfg, num_train_data=4)
+    model.load_state_dict(_state_dict_from_tensors(t, "laplace"))
+    sc = O.scene_from_tensors(t)
+    batches, want_d, want_r = [], torch.zeros(65), torch.zeros(195)
+    for theta, (H, W) in ((2.0, (6, 8)), (0.4, (5, 9))):   # 48 + 45 rays: the second batch is not a multiple of 32
+        cam = _camera(H, W, theta)
+        o, d, _ = O.generate_rays(cam.camera_to_worlds[0], 0.9 * W, 0.9 * W, W / 2, H / 2, H, W)
+        o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+        gd, gr = O.laplace_ggn_diag(sc, o, d)
+        want_d += gd
+        want_r += gr
+        batches.append((o, d))
+    with torch.cuda.device(dev):
+        got_d, got_r = model.compute_hessian_naive(n_iters=5, ray_batches=batches)
+    assert model.field.mlp_density_ggn is got_d and got_d.shape == (65,) and got_r.shape == (195,)
+    # sums of squares of fp32 Jacobians; the sampler's parallel cumsum moves a few samples by an ulp
+    torch.testing.assert_close(got_d.cpu(), want_d, rtol=2e-3, atol=1e-6 * want_d.max().item())
+    torch.testing.assert_close(got_r.cpu(), want_r, rtol=2e-3, atol=1e-6 * want_r.max().item())
+    # accumulates over calls: a second pass over the same batches doubles nothing in place (fresh buffers) ...
+    with torch.cuda.device(dev):
+        again_d, _ = model.compute_hessian_naive(n_iters=2, ray_batches=batches)
+    assert torch.equal(again_d, got_d), "the reduction order is fixed: refitting is bit-reproducible"
+
+
 def test_ensemble_aggregate_on_hip_moments(dev):
     from uncertainty_nerf_gs_amd import ensemble
     g = torch.Generator().manual_seed(12)

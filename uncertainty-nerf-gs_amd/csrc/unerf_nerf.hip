@@ -1080,6 +1080,27 @@ __device__ __forceinline__ void mf_lap_head(const float* __restrict__ lap, int q
     sum2 += __shfl_xor(sum2, 32, 64);
 }
 
+// store one accumulator block (rows = units 32*blk + (r&3) + 8*(r>>2) + 4h of sample n) to a [N][64] plane
+__device__ __forceinline__ void mf_store_units(float* plane, int64_t n, int blk, int h, const f32x16& v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(plane + n * 64 + 32 * blk + 8 * q + 4 * h) =
+            make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+// this lane's half of a 64-wide dot product with a weight row in global memory (mean last layer)
+__device__ __forceinline__ float mf_half_dot(const float* __restrict__ w, int h, const f32x16& v0, const f32x16& v1) {
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = fmaf(v0[r], w[(r & 3) + 8 * (r >> 2) + 4 * h], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = fmaf(v1[r], w[32 + (r & 3) + 8 * (r >> 2) + 4 * h], acc);
+    return acc + __shfl_xor(acc, 32, 64);
+}
+
+// CAPTURE = the deterministic (is_inference=False) forward for GGN fitting: ws_density / ws_rgb hold the MEAN
+// last layers, density = exp(.) * selector (laplace_field.py:317-345), rgb = sigmoid(.), and the inputs of the
+// two last layers (base_mlp output, colour hidden) are written to [N][64] planes a.aux / a.aux2.
+template <bool CAPTURE>
 __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
@@ -1117,7 +1138,8 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         float px = a.origins[r * 3 + 0] + dxr * t01 / 2.f;
         float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
         float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
-        (void)unerf_normalize_position(px, py, pz);  // the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
+        // inference: the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
+        const float sel = unerf_normalize_position(px, py, pz);
         f32x16 feat = mf_gather_feats<true>(a, px, py, pz, h, mask);
 
         // base_mlp is a bare Linear: no ReLU (utils.py:22-23)
@@ -1128,9 +1150,19 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         t = mf_slab(lds, 32, lane, hb0, t);
         t = mf_slab(lds, 48, lane, hb1, t);
         // density head: mean / variance of exp(w_s . hb + b_s) over the n_lap sampled rows
-        float d1, d2;
-        mf_lap_head<false>(a.p.lap_blob, 0, lane, h, hb0, hb1, d1, d2);
-        const float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
+        float mu_d, mu2_d = 0.f;
+        if (CAPTURE) {
+            mu_d = expf(mf_half_dot(a.p.ws_density, h, hb0, hb1) + a.p.ws_density[64]) * sel;
+            if (valid) {
+                mf_store_units(a.aux, n, 0, h, hb0);
+                mf_store_units(a.aux, n, 1, h, hb1);
+            }
+        } else {
+            float d1, d2;
+            mf_lap_head<false>(a.p.lap_blob, 0, lane, h, hb0, hb1, d1, d2);
+            mu_d = d1 * inv_n;
+            mu2_d = d2 * inv_n;
+        }
 
         // colour trunk
         f32x16 c0 = mf_bias(lds, 3, h), c1 = mf_bias(lds, 4, h);
@@ -1167,17 +1199,29 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         x1 = mf_relu(x1);
         // colour head: per channel mean / variance of sigmoid(w_s . x + b_s)
         float mu_c[3], vsum = 0.f;
+        if (CAPTURE) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float c1s, c2s;
-            mf_lap_head<true>(a.p.lap_blob, 1 + c, lane, h, x0, x1, c1s, c2s);
-            mu_c[c] = c1s * inv_n;
-            vsum += fmaxf(c2s * inv_n - mu_c[c] * mu_c[c], 0.f);
+            for (int c = 0; c < 3; ++c)
+                mu_c[c] = unerf_sigmoid(mf_half_dot(a.p.ws_rgb + c * 64, h, x0, x1) + a.p.ws_rgb[192 + c]);
+            if (valid) {
+                mf_store_units(a.aux2, n, 0, h, x0);
+                mf_store_units(a.aux2, n, 1, h, x1);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float c1s, c2s;
+                mf_lap_head<true>(a.p.lap_blob, 1 + c, lane, h, x0, x1, c1s, c2s);
+                mu_c[c] = c1s * inv_n;
+                vsum += fmaxf(c2s * inv_n - mu_c[c] * mu_c[c], 0.f);
+            }
         }
         if (valid && h == 0) {
             a.density[n] = mu_d;
-            a.aux[n] = mu2_d - mu_d * mu_d;
-            a.aux2[n] = vsum / 3.f;
+            if (!CAPTURE) {
+                a.aux[n] = mu2_d - mu_d * mu_d;
+                a.aux2[n] = vsum / 3.f;
+            }
             a.rgb[n * 3 + 0] = mu_c[0];
             a.rgb[n * 3 + 1] = mu_c[1];
             a.rgb[n * 3 + 2] = mu_c[2];
@@ -1311,7 +1355,7 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
             if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
-                hipLaunchKernelGGL(field_kernel_mfma_laplace, dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
+                hipLaunchKernelGGL((field_kernel_mfma_laplace<false>), dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
                                    st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_LAPLACE>), grid, block, 64 * 64 * 4, st, a);
@@ -1322,6 +1366,160 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             return UNERF_ERR_ARG;
     }
     return unerf_check_launch("field_fwd");
+}
+
+// --------------------------------------------------------------------------------------
+// 5d. Laplace GGN fitting (NerfactoLaplaceModel.compute_hessian_naive, laplace_model.py:343-400).
+// The reference multiplies the GGN onto each of the 260 unit vectors (one double-backward per
+// parameter per batch).  The loss is the summed MSE, so its Hessian w.r.t. a rendered pixel is 2 I
+// and the diagonal is 2 * sum_{ray,channel} J^2 with the Jacobian of the rendered colour
+//   C_c = sum_i w_i c_ic + (1 - sum_i w_i) c_{S-1,c}          (background = last sample)
+// in closed form.  Last colour layer, row c, input unit k (h = colour hidden, s' = c(1-c)):
+//   dC_c/dW_ck = sum_i (w_i + [i = S-1] T_end) s'_ic h_ik
+// density layer, unit k (x = base_mlp output, sigma = exp(.) * selector so dsigma/dpre = sigma):
+//   dC_c/dw_k = sum_i delta_i [ (1 - alpha_i) T_i c_ic - sum_{j>i} w_j c_jc - T_end c_{S-1,c} ] sigma_i x_ik
+// (bias: x = h = 1).  One wave per ray: lane i prepares sample i's scalars with wave scans, then lane k
+// accumulates unit k over the samples.  Per-wave partial sums, reduced in a fixed order (deterministic).
+// --------------------------------------------------------------------------------------
+#define GGN_PARAMS 260
+struct GgnArgs {
+    const float* sbins;
+    int64_t R;
+    int S;
+    float s_near, s_far;
+    const float* sigma;  // [R,S]
+    const float* rgb;    // [R,S,3]
+    const float* X;      // [R,S,64] base_mlp output
+    const float* Hc;     // [R,S,64] colour hidden (input of mlp_rgb_ll)
+    float* partials;     // [waves][260]
+};
+
+__global__ __launch_bounds__(256) void laplace_ggn_kernel(GgnArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+    const int S = a.S;
+    const bool in = lane < S;
+    float acc_d = 0.f, acc_db = 0.f, acc_r[3] = {0.f, 0.f, 0.f}, acc_rb[3] = {0.f, 0.f, 0.f};
+    for (int64_t r = gw; r < a.R; r += nw) {
+        const float* sb = a.sbins + r * (S + 1);
+        const int i = in ? lane : S - 1;
+        const float e0 = unerf_s2e(sb[i], a.s_near, a.s_far), e1 = unerf_s2e(sb[i + 1], a.s_near, a.s_far);
+        const float delta = e1 - e0;
+        const float sig = in ? a.sigma[r * S + i] : 0.f;
+        float c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] = unerf_nan_to_num(a.rgb[(r * S + i) * 3 + k]);
+        const float dd = in ? delta * sig : 0.f;
+        const float em = expf(-dd);  // 1 - alpha
+        const float T = expf(-group_excl_scan<64>(dd, lane));
+        const float w = in ? unerf_nan_to_num((1.f - em) * T) : 0.f;
+        const float Tf = 1.f - group_sum<64>(w);
+        float g[3], q[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float bg = __shfl(c[k], S - 1, 64);
+            const float wc = w * c[k];
+            const float incl = group_incl_scan<64>(wc, lane);
+            const float tot = __shfl(incl, 63, 64);
+            const float pred = tot + Tf * bg;
+            // eval-mode renderer clamps to [0,1]: the gradient passes only inside (torch.clamp backward)
+            const float live = (pred >= 0.f && pred <= 1.f && in) ? 1.f : 0.f;
+            g[k] = live * delta * (em * T * c[k] - (tot - incl) - Tf * bg) * sig;
+            const float wt = w + (lane == S - 1 ? Tf : 0.f);
+            q[k] = live * wt * c[k] * (1.f - c[k]);
+        }
+        float M[3] = {0.f, 0.f, 0.f}, N[3] = {0.f, 0.f, 0.f};
+        const float* xr = a.X + r * S * 64 + lane;
+        const float* hr = a.Hc + r * S * 64 + lane;
+        for (int s = 0; s < S; ++s) {
+            const float x = xr[s * 64], hh = hr[s * 64];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                M[k] = fmaf(__shfl(g[k], s, 64), x, M[k]);
+                N[k] = fmaf(__shfl(q[k], s, 64), hh, N[k]);
+            }
+        }
+        acc_d += 2.f * (M[0] * M[0] + M[1] * M[1] + M[2] * M[2]);
+        float mb2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            acc_r[k] += 2.f * N[k] * N[k];
+            const float mb = group_sum<64>(g[k]), nb = group_sum<64>(q[k]);
+            mb2 += mb * mb;
+            acc_rb[k] += 2.f * nb * nb;
+        }
+        acc_db += 2.f * mb2;
+    }
+    float* out = a.partials + gw * GGN_PARAMS;
+    out[lane] = acc_d;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[65 + k * 64 + lane] = acc_r[k];
+    if (lane == 0) {
+        out[64] = acc_db;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[65 + 192 + k] = acc_rb[k];
+    }
+}
+
+__global__ void laplace_ggn_reduce_kernel(const float* partials, int waves, float* ggn_density, float* ggn_rgb) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= GGN_PARAMS) return;
+    float sum = 0.f;
+    for (int w = 0; w < waves; ++w) sum += partials[(size_t)w * GGN_PARAMS + t];
+    if (t < 65) ggn_density[t] += sum;
+    else ggn_rgb[t - 65] += sum;
+}
+
+static int ggn_blocks(int64_t R) {
+    int64_t b = (R + 3) / 4;
+    return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+extern "C" size_t unerf_laplace_ggn_workspace_bytes(int64_t R, int S) {
+    if (R <= 0 || S <= 0) return 0;
+    const size_t N = (size_t)R * (size_t)S;
+    return (N * (64 + 64 + 1 + 3) + (size_t)ggn_blocks(R) * 4 * GGN_PARAMS) * sizeof(float);
+}
+
+extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directions, const float* sbins, int64_t R,
+                                      int S, float near_plane, float far_plane, const unerf_field_params* p,
+                                      void* workspace, size_t workspace_bytes, float* ggn_density, float* ggn_rgb,
+                                      void* stream) {
+    UNERF_REQUIRE(R >= 0 && S >= 1 && S <= 64, "laplace_ggn_diag: S=%d outside [1,64]", S);
+    if (R == 0) return UNERF_OK;
+    UNERF_REQUIRE(origins && directions && sbins && p && workspace && ggn_density && ggn_rgb,
+                  "laplace_ggn_diag: null pointer");
+    UNERF_REQUIRE(p->mode == UNERF_FIELD_LAPLACE && p->out1 == 15 && p->L == 16 && p->mfma_blob && p->ws_density &&
+                      p->ws_rgb && p->table && p->scalings,
+                  "laplace_ggn_diag: needs a LAPLACE field with mfma_blob and the mean last layers in ws_density[65] / "
+                  "ws_rgb[195]");
+    UNERF_REQUIRE(p->log2T >= 1 && p->log2T <= 24, "laplace_ggn_diag: bad log2T=%d", p->log2T);
+    UNERF_REQUIRE((uint64_t)R * (uint64_t)S < (1ull << 32), "laplace_ggn_diag: R*S exceeds 32 bits, split the batch");
+    UNERF_REQUIRE(workspace_bytes >= unerf_laplace_ggn_workspace_bytes(R, S),
+                  "laplace_ggn_diag: workspace %zu < %zu bytes", workspace_bytes,
+                  unerf_laplace_ggn_workspace_bytes(R, S));
+    const size_t N = (size_t)R * (size_t)S;
+    float* X = static_cast<float*>(workspace);
+    float* Hc = X + N * 64;
+    float* sigma = Hc + N * 64;
+    float* col = sigma + N;
+    float* partials = col + N * 3;
+    hipStream_t st = (hipStream_t)stream;
+    FieldArgs a;
+    a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
+    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = 0;
+    a.p = *p; a.density = sigma; a.rgb = col; a.aux = X; a.aux2 = Hc; a.features = nullptr;
+    a.keep_thr = 0; a.drop_scale = 1.f;
+    const int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+    hipLaunchKernelGGL((field_kernel_mfma_laplace<true>), dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
+                       st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+    GgnArgs g;
+    g.sbins = sbins; g.R = R; g.S = S; g.s_near = a.s_near; g.s_far = a.s_far;
+    g.sigma = sigma; g.rgb = col; g.X = X; g.Hc = Hc; g.partials = partials;
+    const int blocks = ggn_blocks(R);
+    hipLaunchKernelGGL(laplace_ggn_kernel, dim3(blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(laplace_ggn_reduce_kernel, dim3(2), dim3(256), 0, st, partials, blocks * 4, ggn_density, ggn_rgb);
+    return unerf_check_launch("laplace_ggn_diag");
 }
 
 // ======================================================================================

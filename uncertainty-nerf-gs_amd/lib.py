@@ -112,6 +112,9 @@ SIGNATURES = {
                              _vp]),
     "unerf_field_gather": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
     "unerf_laplace_depth_weights": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp, _i, _u32, _i64, _vp, _vp]),
+    "unerf_laplace_ggn_workspace_bytes": (C.c_size_t, [_i64, _i]),
+    "unerf_laplace_ggn_diag": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, C.POINTER(FieldParams), _vp, C.c_size_t, _vp, _vp,
+                                    _vp]),
     "unerf_composite_var": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp]),
     "unerf_composite_moments": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp, _vp]),
     "unerf_moments": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),

@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import fields as F
-from . import render, splat
+from . import ops, render, splat
 from .render import NerfSceneDev
 
 
@@ -262,6 +262,48 @@ class NerfactoLaplaceModel(_NerfactoBase):
 
     def _render_kwargs(self):
         return {"depth_draws": 100, "depth_seed": self.depth_seed}  # num_samples = 100 (laplace_model.py:487)
+
+    @torch.no_grad()
+    def compute_hessian_naive(self, pipeline=None, n_iters: int = 1000, ray_batches=None, device=None):
+        """laplace_model.py:343-400: fit the diagonal GGN of the two last layers over `n_iters` training
+        batches and store it in `field.mlp_density_ggn` / `field.mlp_rgb_ggn` (what `ggn_{n_iters}.pt` holds,
+        eval_uncertainty.py:1104-1116).  The reference runs one GGN-vector product per parameter (260
+        double-backwards per batch); here a batch is one deterministic forward plus the closed-form Jacobian
+        of the rendered colour (unerf_laplace_ggn_diag).  The GGN of a summed-MSE loss does not depend on the
+        target image, so only the rays of a batch are used.
+
+        Batches come from `pipeline.datamanager.next_train(i)` -> (ray_bundle, batch) like the reference, or
+        from `ray_batches`, an iterable of (origins [B,3], directions [B,3])."""
+        from torch.nn.utils import parameters_to_vector
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        c = self.config
+        fd = self.field.to_device(device)
+        scene = NerfSceneDev(field=fd, props=[p.to_device(device) for p in self.proposal_networks], near=c.near_plane,
+                             far=c.far_plane, num_prop=tuple(c.num_proposal_samples_per_ray),
+                             num_nerf=c.num_nerf_samples_per_ray, prop_average_init_density=c.average_init_density,
+                             chunk_rays=c.eval_num_rays_per_chunk)
+        dm = parameters_to_vector(self.field.mlp_density.parameters()).detach()
+        rm = parameters_to_vector(self.field.mlp_rgb_ll.parameters()).detach()
+        gd = torch.zeros(dm.numel(), device=device, dtype=torch.float32)
+        gr = torch.zeros(rm.numel(), device=device, dtype=torch.float32)
+        it = iter(ray_batches) if ray_batches is not None else None
+        for i in range(n_iters):
+            if it is not None:
+                try:
+                    o, d = next(it)
+                except StopIteration:
+                    break
+            else:
+                bundle, _batch = pipeline.datamanager.next_train(i)
+                o, d = bundle.origins, bundle.directions
+            o = o.reshape(-1, 3).to(device=device, dtype=torch.float32).contiguous()
+            d = d.reshape(-1, 3).to(device=device, dtype=torch.float32).contiguous()
+            sb, _ = render.sample_rays(scene, o, d, None, want_prop_depth=False)
+            ops.laplace_ggn_diag(o, d, sb, fd, dm, rm, c.near_plane, c.far_plane, gd, gr)
+        self.field.mlp_density_ggn = gd
+        self.field.mlp_rgb_ggn = gr
+        self.invalidate()
+        return gd, gr
 
 
 # ------------------------------------------------------------------ splats --------------------

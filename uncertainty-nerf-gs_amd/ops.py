@@ -418,6 +418,31 @@ def laplace_depth_weights(density_mu, density_var, sbins, near: float, far: floa
     return out
 
 
+def laplace_ggn_diag(origins, directions, sbins, field: FieldDev, density_mean: torch.Tensor, rgb_mean: torch.Tensor,
+                     near: float, far: float, ggn_density: torch.Tensor, ggn_rgb: torch.Tensor) -> None:
+    """One batch of NerfactoLaplaceModel.compute_hessian_naive (laplace_model.py:343-400): adds the batch's
+    diagonal GGN of the summed-MSE loss to ggn_density [65] / ggn_rgb [195] in place.  density_mean [65] and
+    rgb_mean [195] are the flattened mean last layers (weight row-major, then bias)."""
+    lib = _l.load()
+    if field.mode != _l.FIELD_LAPLACE:
+        raise _l.UnerfError("laplace_ggn_diag needs a LAPLACE field")
+    R, S = sbins.shape[0], sbins.shape[1] - 1
+    dev = origins.device
+    cs = field.cstruct()
+    dm = density_mean.detach().to(device=dev, dtype=torch.float32).contiguous()
+    rm = rgb_mean.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if dm.numel() != 65 or rm.numel() != 195:
+        raise _l.UnerfError("laplace_ggn_diag: density_mean must have 65 and rgb_mean 195 entries")
+    cs.ws_density, cs.ws_rgb, cs.n_lap = _p(dm), _p(rm), 1
+    cs.mfma_blob = _p(field.mfma_blob)
+    nbytes = lib.unerf_laplace_ggn_workspace_bytes(R, S)
+    ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+    with _ctx(dev):
+        _run("laplace_ggn_diag", lambda: lib.unerf_laplace_ggn_diag(_p(origins), _p(directions), _p(sbins), R, S, near, far,
+                                                                   C.byref(cs), _p(ws), nbytes, _p(ggn_density),
+                                                                   _p(ggn_rgb), _stream()))
+
+
 def composite_var(density, rgb, sbins, near: float, far: float, beta=None, weights_alt=None, clip_minmax=None,
                   ray_offset: int = 0, chunk_rays: int = 1 << 15) -> torch.Tensor:
     """density [B,R,S] -> out [B,R,8] = rgb3, accumulation, depth, expected_depth, rgb_var, depth_var"""
