@@ -10,8 +10,9 @@ the images (:1069-1077) and writes the same `metrics.json` envelope (:1156-1169)
 Differences, on purpose: SSIM / LPIPS (torchmetrics / torchvision networks, absent here) are not
 computed; no plots; and `num_rays_per_sec` is reported twice -- `num_rays_per_sec` covers render +
 metrics like the reference's counter (so numbers stay comparable with its metrics.json), while
-`render_rays_per_sec` times the render alone (HIP-synchronised).  Depth metrics need the dataset's
-`depth_gt_XX.npy` / `scale_parameters.txt` files (eval_uncertainty.py:415-644) and are a "next" row.
+`render_rays_per_sec` times the render alone (HIP-synchronised).  Depth metrics (`depth_metrics_unc`,
+eval_uncertainty.py:415-644) take the dataset's `depth_gt_XX.npy` map and `scale_parameters.txt` factor,
+read by `load_depth_gt`; pass `depth_gt_fn` to `get_average_uncertainty_metrics` to include them.
 """
 from __future__ import annotations
 
@@ -61,13 +62,66 @@ def image_metrics_unc(outputs: Dict[str, torch.Tensor], gt_image: torch.Tensor, 
     return md, curves
 
 
+def load_depth_gt(dataset_path: str, img_num: int) -> Tuple[np.ndarray, float]:
+    """the two files get_unc_metrics_depth reads (eval_uncertainty.py:432-437): -> (depth_gt [H,W], scale a)"""
+    a = float(np.loadtxt(os.path.join(str(dataset_path), "scale_parameters.txt"), delimiter=","))
+    return np.load(os.path.join(str(dataset_path), "depth_gt_{:02d}.npy".format(img_num))), a
+
+
+def depth_metrics_unc(outputs: Dict[str, torch.Tensor], depth_gt, scale: float, min_depth_std_for_nll: float = 1.0):
+    """get_unc_metrics_depth (eval_uncertainty.py:415-644) without the plots, plus the key renaming of
+    get_image_metrics_and_images_unc (:702-733).  depth / depth_std are resized to the GT map if the shapes
+    differ (torchvision `resize` on a tensor = bilinear `interpolate`, no antialias), scaled by `scale`;
+    NLL uses the prediction clipped to [1e-3, max GT] on the full image and is then masked by `GT > 0`;
+    errors, AUSE and AUCE use the masked, clipped prediction.  -> (metrics_dict, curves)"""
+    depth = outputs["depth"].squeeze(-1).to(torch.float32)
+    depth_std = outputs["depth_std"].squeeze(-1).to(torch.float32)
+    gt = torch.as_tensor(depth_gt, device=depth.device)
+
+    def _fit(x):
+        if gt.shape[-2:] == x.shape[-2:]:
+            return x
+        return torch.nn.functional.interpolate(x[None, None], size=tuple(gt.shape[-2:]), mode="bilinear",
+                                               align_corners=False, antialias=False)[0, 0]
+
+    depth, depth_std = _fit(depth), _fit(depth_std)
+    lo, hi = 1e-3, gt.max().float()
+    depth = scale * depth
+    depth_std = scale * depth_std
+    clipped = torch.minimum(torch.clamp_min(depth, lo), hi)
+    nll_img = M.negative_gaussian_loglikelihood(clipped.unsqueeze(-1), gt.unsqueeze(-1), depth_std.unsqueeze(-1),
+                                                eps=min_depth_std_for_nll).reshape(clipped.shape)
+    mask = gt > 0
+    d, g, sd = clipped[mask], gt[mask], depth_std[mask]
+    sq, ab, var = (g - d) ** 2, (g - d).abs(), sd ** 2
+    md: Dict[str, float] = {}
+    curves: Dict[str, np.ndarray] = {}
+    for et, err in (("mse", sq), ("mae", ab), ("rmse", sq)):
+        _, e, ev, a = M.ause(var, err, et)
+        md[f"depth_ause_{et}"] = float(a)
+        curves[f"depth_all_ause_{et}"], curves[f"depth_all_var_ause_{et}"] = e, ev
+    md["depth_mse"] = float(sq.mean().item())
+    md["depth_rmse"] = float(np.sqrt(sq.mean().item()))
+    md["depth_nll"] = float(nll_img[mask].mean().item())
+    md["depth_avg_var"] = float(var.mean().item())
+    a = M.auce(d.flatten().cpu().numpy(), sd.flatten().cpu().numpy(), g.flatten().cpu().numpy())
+    md["depth_auc_abs_error"], md["depth_auc_length"] = a["auc_abs_error_values"], a["auc_length_values"]
+    md["depth_auc_neg_error"] = a["auc_neg_error_values"]
+    for k in ("coverage_values", "avg_length_values", "coverage_error_values", "abs_coverage_error_values",
+              "neg_coverage_error_values"):
+        curves[f"depth_all_auce_{k}"] = a[k]
+    return md, curves
+
+
 def get_average_uncertainty_metrics(get_outputs_for_camera: Callable, eval_set: Iterable[Tuple[object, torch.Tensor]],
                                     eval_rgb_unc: bool = True, min_rgb_std_for_nll: float = 3e-2,
-                                    composite_gt: Optional[Callable] = None):
-    """eval_uncertainty.py:816-1079.  -> (averaged metrics dict, averaged curves dict)"""
+                                    composite_gt: Optional[Callable] = None, depth_gt_fn: Optional[Callable] = None,
+                                    min_depth_std_for_nll: float = 1.0):
+    """eval_uncertainty.py:816-1079.  -> (averaged metrics dict, averaged curves dict).
+    depth_gt_fn(image_index) -> (depth_gt [H,W], scale) switches the depth metrics on (eval_depth_unc)."""
     rows: List[Dict[str, float]] = []
     sums: Dict[str, np.ndarray] = {}
-    for camera, gt in eval_set:
+    for img_num, (camera, gt) in enumerate(eval_set):
         inner_start = time.time()
         outputs = get_outputs_for_camera(camera)
         if torch.cuda.is_available():
@@ -75,6 +129,11 @@ def get_average_uncertainty_metrics(get_outputs_for_camera: Callable, eval_set: 
         render_s = time.time() - inner_start
         H, W = outputs["rgb"].shape[:2]
         md, curves = image_metrics_unc(outputs, gt, eval_rgb_unc, min_rgb_std_for_nll, composite_gt)
+        if depth_gt_fn is not None:
+            dgt, scale = depth_gt_fn(img_num)
+            dmd, dcurves = depth_metrics_unc(outputs, dgt, scale, min_depth_std_for_nll)
+            md.update(dmd)
+            curves.update(dcurves)
         md["num_rays_per_sec"] = H * W / (time.time() - inner_start)
         md["fps"] = md["num_rays_per_sec"] / (H * W)
         md["render_rays_per_sec"] = H * W / render_s
