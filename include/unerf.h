@@ -240,7 +240,10 @@ int unerf_splat_sh_colors(int degree, const float* means3d, const float* cam_pos
  * rasterize_gaussians calls :260,:289,:306,:343).  cum_tiles_hit [N] i32 (inclusive scan,
  * output), isect_ids [I] i64 + gaussian_ids [I] i32 sorted outputs, tile_bins [tiles,2] i32.
  * Two-step use: call unerf_splat_count_intersects (async; writes the scan and *num_intersects
- * on device), read it back, size the buffers, then unerf_splat_bin_sort. */
+ * on device), read it back, size the buffers, then unerf_splat_bin_sort.
+ * The sorted order is that of gsplat's stable sort of (tile << 32 | depth bits) keys; it is produced by
+ * ordering the N splats by depth first and then sorting the intersections by tile id only (stable).
+ * isect_ids_sorted may be NULL (the rasteriser needs only gaussian_ids_sorted and tile_bins). */
 int64_t unerf_splat_sort_workspace_bytes(int64_t N, int64_t num_intersects);
 int unerf_splat_count_intersects(const int32_t* num_tiles_hit, int64_t N, int32_t* cum_tiles_hit,
                                  void* workspace, int64_t workspace_bytes, void* stream);

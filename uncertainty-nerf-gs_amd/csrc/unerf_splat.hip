@@ -228,22 +228,47 @@ extern "C" int unerf_splat_sh_colors(int degree, const float* means3d, const flo
 // ======================================================================================
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
-static int sort_bits(int H, int W, int bw) {
+static int tile_bits(int H, int W, int bw) {
     int64_t tiles = (int64_t)((W + bw - 1) / bw) * ((H + bw - 1) / bw);
     int b = 1;
     while (((int64_t)1 << b) < tiles) ++b;
-    return 32 + b;
+    return b;
+}
+
+// Workspace of unerf_splat_count_intersects / unerf_splat_bin_sort.  bin_sort orders the N splats by depth
+// first (32-bit keys, small), emits the intersections in that order and then needs only a STABLE sort by
+// tile id (13 bits at 1080p, 16-bit keys): two 6-byte-per-entry radix passes over the I intersections
+// instead of six 12-byte passes over 64-bit (tile | depth) keys.  Same final order, bit for bit: ties in
+// depth keep the splat-index order in both schemes.
+struct SortWs {
+    int64_t tmp, dkey_in, dkey_out, id_in, order, counts, cum, tkey_in, tkey_out, val_in, total;
+};
+static SortWs sort_ws_layout(int64_t N, int64_t I) {
+    size_t scan_tmp = 0, sortN_tmp = 0, sortI_tmp = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, (const int32_t*)nullptr, (int32_t*)nullptr, (int)N);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sortN_tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                             (const int32_t*)nullptr, (int32_t*)nullptr, (int)N, 0, 32);
+    if (I > 0)
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sortI_tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                 (const int32_t*)nullptr, (int32_t*)nullptr, (int)I, 0, 32);
+    (void)hipGetLastError();
+    size_t tmp = scan_tmp > sortN_tmp ? scan_tmp : sortN_tmp;
+    tmp = tmp > sortI_tmp ? tmp : sortI_tmp;
+    SortWs w;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t o = off; off += align256(bytes); return o; };
+    w.tmp = take((int64_t)tmp);
+    w.dkey_in = take(N * 4); w.dkey_out = take(N * 4); w.id_in = take(N * 4); w.order = take(N * 4);
+    w.counts = take(N * 4); w.cum = take(N * 4);
+    w.tkey_in = take(I * 4); w.tkey_out = take(I * 4); w.val_in = take(I * 4);
+    w.total = off + 1024;
+    return w;
 }
 
 extern "C" int64_t unerf_splat_sort_workspace_bytes(int64_t N, int64_t I) {
-    size_t scan_tmp = 0, sort_tmp = 0;
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, (const int32_t*)nullptr, (int32_t*)nullptr, (int)N);
-    if (I > 0)
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const int64_t*)nullptr, (int64_t*)nullptr,
-                                                 (const int32_t*)nullptr, (int32_t*)nullptr, (int)I, 0, 64);
-    (void)hipGetLastError();
-    int64_t tmp = (int64_t)(scan_tmp > sort_tmp ? scan_tmp : sort_tmp);
-    return align256(tmp) + align256(I * 8) + align256(I * 4) + 1024;
+    if (N < 1) N = 1;
+    if (I < 0) I = 0;
+    return sort_ws_layout(N, I).total;
 }
 
 extern "C" int unerf_splat_count_intersects(const int32_t* num_tiles_hit, int64_t N, int32_t* cum_tiles_hit,
@@ -260,37 +285,63 @@ extern "C" int unerf_splat_count_intersects(const int32_t* num_tiles_hit, int64_
     return unerf_check_launch("splat_count_intersects");
 }
 
-__global__ __launch_bounds__(256) void map_intersects_kernel(const float* __restrict__ xys,
-                                                             const float* __restrict__ depths,
-                                                             const int32_t* __restrict__ radii,
-                                                             const int32_t* __restrict__ cum, int64_t N, int bw, int tbx,
-                                                             int tby, int64_t* __restrict__ keys,
-                                                             int32_t* __restrict__ vals) {
+// depth key of every splat (culled ones last) + identity payload
+__global__ __launch_bounds__(256) void depth_keys_kernel(const float* __restrict__ depths,
+                                                         const int32_t* __restrict__ radii, int64_t N,
+                                                         uint32_t* __restrict__ keys, int32_t* __restrict__ ids) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    keys[i] = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
+    ids[i] = (int32_t)i;
+}
+
+// tiles hit by the j-th splat in depth order (num_tiles_hit recovered from its inclusive scan)
+__global__ __launch_bounds__(256) void sorted_counts_kernel(const int32_t* __restrict__ order,
+                                                            const int32_t* __restrict__ radii,
+                                                            const int32_t* __restrict__ cum, int64_t N,
+                                                            int32_t* __restrict__ counts) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const int32_t i = order[j];
+    counts[j] = radii[i] > 0 ? cum[i] - (i == 0 ? 0 : cum[i - 1]) : 0;
+}
+
+template <typename TKey>
+__global__ __launch_bounds__(256) void map_intersects_kernel(const float* __restrict__ xys,
+                                                             const int32_t* __restrict__ radii,
+                                                             const int32_t* __restrict__ order,
+                                                             const int32_t* __restrict__ cum_sorted, int64_t N, int bw,
+                                                             int tbx, int tby, TKey* __restrict__ tkeys,
+                                                             int32_t* __restrict__ vals) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const int32_t i = order[j];
     if (radii[i] <= 0) return;
     int x0, y0, x1, y1;
-    tile_bbox(xys[i * 2], xys[i * 2 + 1], (float)radii[i], bw, tbx, tby, x0, y0, x1, y1);
-    int64_t cur = (i == 0) ? 0 : cum[i - 1];
-    int64_t depth_id = (int64_t)(uint32_t)__float_as_int(depths[i]);
+    tile_bbox(xys[(int64_t)i * 2], xys[(int64_t)i * 2 + 1], (float)radii[i], bw, tbx, tby, x0, y0, x1, y1);
+    int64_t cur = (j == 0) ? 0 : cum_sorted[j - 1];
     for (int ty = y0; ty < y1; ++ty)
         for (int tx = x0; tx < x1; ++tx) {
-            int64_t tile_id = (int64_t)ty * tbx + tx;
-            keys[cur] = (tile_id << 32) | depth_id;
-            vals[cur] = (int32_t)i;
+            tkeys[cur] = (TKey)(ty * tbx + tx);
+            vals[cur] = i;
             ++cur;
         }
 }
 
-__global__ __launch_bounds__(256) void tile_edges_kernel(const int64_t* __restrict__ keys, int64_t I,
-                                                         int32_t* __restrict__ bins) {
+// tile ranges + the gsplat-style 64-bit ids (tile << 32 | depth bits) of the sorted intersections
+template <typename TKey>
+__global__ __launch_bounds__(256) void tile_edges_kernel(const TKey* __restrict__ tkeys,
+                                                         const int32_t* __restrict__ gids,
+                                                         const float* __restrict__ depths, int64_t I,
+                                                         int32_t* __restrict__ bins, int64_t* __restrict__ isect_ids) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= I) return;
-    int32_t cur = (int32_t)(keys[i] >> 32);
+    const int32_t cur = (int32_t)tkeys[i];
+    if (isect_ids) isect_ids[i] = ((int64_t)cur << 32) | (int64_t)(uint32_t)__float_as_int(depths[gids[i]]);
     if (i == 0) bins[cur * 2] = 0;
     if (i == I - 1) bins[cur * 2 + 1] = (int32_t)I;
     if (i > 0) {
-        int32_t prev = (int32_t)(keys[i - 1] >> 32);
+        const int32_t prev = (int32_t)tkeys[i - 1];
         if (prev != cur) {
             bins[prev * 2 + 1] = (int32_t)i;
             bins[cur * 2] = (int32_t)i;
@@ -298,36 +349,77 @@ __global__ __launch_bounds__(256) void tile_edges_kernel(const int64_t* __restri
     }
 }
 
+template <typename TKey>
+static int bin_sort_impl(const float* xys, const float* depths, const int32_t* radii, const int32_t* order,
+                         const int32_t* cum_sorted, int64_t N, int64_t I, int bw, int tbx, int tby, int bits,
+                         int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted, int32_t* tile_bins, char* ws,
+                         const SortWs& L, size_t tmp_bytes, hipStream_t st) {
+    TKey* tk_in = reinterpret_cast<TKey*>(ws + L.tkey_in);
+    TKey* tk_out = reinterpret_cast<TKey*>(ws + L.tkey_out);
+    int32_t* v_in = reinterpret_cast<int32_t*>(ws + L.val_in);
+    hipLaunchKernelGGL((map_intersects_kernel<TKey>), dim3(blocks_for(N, 256)), dim3(256), 0, st, xys, radii, order,
+                       cum_sorted, N, bw, tbx, tby, tk_in, v_in);
+    int rc = unerf_check_launch("splat_bin_sort map");
+    if (rc) return rc;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(ws + L.tmp, tmp_bytes, tk_in, tk_out, v_in, gaussian_ids_sorted,
+                                                      (int)I, 0, bits, st);
+    if (e != hipSuccess) {
+        unerf_set_error("splat_bin_sort: tile sort: %s", hipGetErrorString(e));
+        return UNERF_ERR_HIP;
+    }
+    hipLaunchKernelGGL((tile_edges_kernel<TKey>), dim3(blocks_for(I, 256)), dim3(256), 0, st, tk_out,
+                       gaussian_ids_sorted, depths, I, tile_bins, isect_ids_sorted);
+    return unerf_check_launch("splat_bin_sort edges");
+}
+
 extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const int32_t* radii,
                                     const int32_t* cum_tiles_hit, int64_t N, int64_t I, int H, int W, int block_width,
                                     int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted, int32_t* tile_bins,
                                     void* workspace, int64_t workspace_bytes, void* stream) {
     UNERF_REQUIRE(xys && depths && radii && cum_tiles_hit && tile_bins && workspace, "splat_bin_sort: null pointer");
-    UNERF_REQUIRE(N >= 1 && I >= 0 && I < (1ll << 31), "splat_bin_sort: bad N/I");
+    UNERF_REQUIRE(N >= 1 && N < (1ll << 31) && I >= 0 && I < (1ll << 31), "splat_bin_sort: bad N/I");
     hipStream_t st = (hipStream_t)stream;
     int tbx = (W + block_width - 1) / block_width, tby = (H + block_width - 1) / block_width;
     if (hipMemsetAsync(tile_bins, 0, (size_t)tbx * tby * 2 * sizeof(int32_t), st) != hipSuccess)
         return unerf_check_launch("splat_bin_sort memset");
     if (I == 0) return UNERF_OK;
-    UNERF_REQUIRE(isect_ids_sorted && gaussian_ids_sorted, "splat_bin_sort: null output");
+    UNERF_REQUIRE(gaussian_ids_sorted, "splat_bin_sort: null output");
+    const SortWs L = sort_ws_layout(N, I);
+    UNERF_REQUIRE(workspace_bytes >= L.total, "splat_bin_sort: workspace %lld < %lld bytes (unerf_splat_sort_workspace_bytes)",
+                  (long long)workspace_bytes, (long long)L.total);
     char* ws = (char*)workspace;
-    int64_t off_keys = 0, off_vals = align256(I * 8), off_tmp = off_vals + align256(I * 4);
-    UNERF_REQUIRE(workspace_bytes > off_tmp, "splat_bin_sort: workspace too small");
-    int64_t* keys = (int64_t*)(ws + off_keys);
-    int32_t* vals = (int32_t*)(ws + off_vals);
-    hipLaunchKernelGGL(map_intersects_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, xys, depths, radii,
-                       cum_tiles_hit, N, block_width, tbx, tby, keys, vals);
-    int rc = unerf_check_launch("splat_bin_sort map");
-    if (rc) return rc;
-    size_t tmp = (size_t)(workspace_bytes - off_tmp);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(ws + off_tmp, tmp, keys, isect_ids_sorted, vals,
-                                                      gaussian_ids_sorted, (int)I, 0, sort_bits(H, W, block_width), st);
+    size_t tmp_bytes = (size_t)(L.dkey_in - L.tmp);
+    uint32_t* dk_in = reinterpret_cast<uint32_t*>(ws + L.dkey_in);
+    uint32_t* dk_out = reinterpret_cast<uint32_t*>(ws + L.dkey_out);
+    int32_t* id_in = reinterpret_cast<int32_t*>(ws + L.id_in);
+    int32_t* order = reinterpret_cast<int32_t*>(ws + L.order);
+    int32_t* counts = reinterpret_cast<int32_t*>(ws + L.counts);
+    int32_t* cum_sorted = reinterpret_cast<int32_t*>(ws + L.cum);
+    // 1. splats in depth order (stable: equal depths keep their index order)
+    hipLaunchKernelGGL(depth_keys_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, depths, radii, N, dk_in, id_in);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(ws + L.tmp, tmp_bytes, dk_in, dk_out, id_in,
+                                                      order, (int)N, 0, 32, st);
     if (e != hipSuccess) {
-        unerf_set_error("splat_bin_sort: radix sort: %s", hipGetErrorString(e));
+        unerf_set_error("splat_bin_sort: depth sort: %s", hipGetErrorString(e));
         return UNERF_ERR_HIP;
     }
-    hipLaunchKernelGGL(tile_edges_kernel, dim3(blocks_for(I, 256)), dim3(256), 0, st, isect_ids_sorted, I, tile_bins);
-    return unerf_check_launch("splat_bin_sort edges");
+    // 2. where each depth-ordered splat's intersections start
+    hipLaunchKernelGGL(sorted_counts_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, order, radii, cum_tiles_hit, N,
+                       counts);
+    tmp_bytes = (size_t)(L.dkey_in - L.tmp);
+    e = hipcub::DeviceScan::InclusiveSum(ws + L.tmp, tmp_bytes, counts, cum_sorted, (int)N, st);
+    if (e != hipSuccess) {
+        unerf_set_error("splat_bin_sort: scan: %s", hipGetErrorString(e));
+        return UNERF_ERR_HIP;
+    }
+    // 3. emit in depth order, stable sort by tile, edges + ids
+    const int bits = tile_bits(H, W, block_width);
+    tmp_bytes = (size_t)(L.dkey_in - L.tmp);
+    if (bits <= 16)
+        return bin_sort_impl<uint16_t>(xys, depths, radii, order, cum_sorted, N, I, block_width, tbx, tby, bits,
+                                       isect_ids_sorted, gaussian_ids_sorted, tile_bins, ws, L, tmp_bytes, st);
+    return bin_sort_impl<uint32_t>(xys, depths, radii, order, cum_sorted, N, I, block_width, tbx, tby, bits,
+                                   isect_ids_sorted, gaussian_ids_sorted, tile_bins, ws, L, tmp_bytes, st);
 }
 
 // ======================================================================================
@@ -442,14 +534,23 @@ extern "C" int unerf_splat_rasterize(const int32_t* gaussian_ids_sorted, const i
 // ======================================================================================
 // alpha normalisation and per-splat depth difference
 // ======================================================================================
+// grid-stride max with one atomic per workgroup (one per wave cost 370 us on a 1080p image: 32 K atomics
+// serialise on a single L2 word)
 __global__ __launch_bounds__(256) void chan_max_kernel(const float* __restrict__ img, int stride, int ch, int64_t HW,
                                                        unsigned int* __restrict__ mx) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float v = (i < HW) ? img[i * stride + ch] : 0.f;
-    v = fmaxf(v, 0.f);
+    __shared__ float s_max[4];
+    float v = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256)
+        v = fmaxf(v, img[i * stride + ch]);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(mx, __float_as_uint(v));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        const unsigned int bits = __float_as_uint(v);  // v >= 0: bit patterns order like the values
+        if (bits > __hip_atomic_load(mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mx, bits);
+    }
 }
 
 __global__ __launch_bounds__(256) void alpha_norm_kernel(float* __restrict__ img, int stride, int ch,
@@ -470,7 +571,9 @@ extern "C" int unerf_splat_alpha_normalize(float* img, int stride, int ch, const
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(scratch_max, 0, sizeof(float), st) != hipSuccess)
         return unerf_check_launch("splat_alpha_normalize memset");
-    hipLaunchKernelGGL(chan_max_kernel, dim3(blocks_for(HW, 256)), dim3(256), 0, st, img, stride, ch, HW,
+    const unsigned max_blocks = 2048;  // 8 workgroups per CU
+    const unsigned nblk = blocks_for(HW, 256) < max_blocks ? blocks_for(HW, 256) : max_blocks;
+    hipLaunchKernelGGL(chan_max_kernel, dim3(nblk), dim3(256), 0, st, img, stride, ch, HW,
                        reinterpret_cast<unsigned int*>(scratch_max));
     hipLaunchKernelGGL(alpha_norm_kernel, dim3(blocks_for(HW, 256)), dim3(256), 0, st, img, stride, ch, final_T, HW,
                        scratch_max);
