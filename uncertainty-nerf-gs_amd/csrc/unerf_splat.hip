@@ -441,8 +441,9 @@ struct RasterArgs {
 
 template <int C>
 __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
-    __shared__ float s_xyo[256 * 3];
-    __shared__ float s_con[256 * 3];
+    // one 16-byte + one 8-byte broadcast read per splat instead of six 4-byte ones
+    __shared__ float4 s_geo[256];  // x, y, opacity, conic a
+    __shared__ float2 s_bc[256];   // conic b, c
     __shared__ float s_col[256 * C];
     const int bw = a.bw;
     const int tbx = (a.W + bw - 1) / bw;
@@ -466,20 +467,18 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
         const int idx = start + tr;
         if (idx < r1) {
             int g = a.ids[idx];
-            s_xyo[tr * 3 + 0] = a.xys[g * 2];
-            s_xyo[tr * 3 + 1] = a.xys[g * 2 + 1];
-            s_xyo[tr * 3 + 2] = a.opac[g];
-            s_con[tr * 3 + 0] = a.conics[g * 3];
-            s_con[tr * 3 + 1] = a.conics[g * 3 + 1];
-            s_con[tr * 3 + 2] = a.conics[g * 3 + 2];
+            s_geo[tr] = make_float4(a.xys[g * 2], a.xys[g * 2 + 1], a.opac[g], a.conics[g * 3]);
+            s_bc[tr] = make_float2(a.conics[g * 3 + 1], a.conics[g * 3 + 2]);
 #pragma unroll
             for (int c = 0; c < C; ++c) s_col[tr * C + c] = a.colors[(int64_t)g * C + c];
         }
         __syncthreads();
         const int bsz = min(256, r1 - start);
         for (int t = 0; t < bsz && !done; ++t) {
-            float dx = s_xyo[t * 3] - px, dy = s_xyo[t * 3 + 1] - py, op = s_xyo[t * 3 + 2];
-            float ca = s_con[t * 3], cb = s_con[t * 3 + 1], cc = s_con[t * 3 + 2];
+            const float4 ge = s_geo[t];
+            const float2 bc = s_bc[t];
+            float dx = ge.x - px, dy = ge.y - py, op = ge.z;
+            float ca = ge.w, cb = bc.x, cc = bc.y;
             float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
             float alpha = fminf(0.999f, op * __expf(-sigma));
             if (sigma < 0.f || alpha < 1.f / 255.f) continue;

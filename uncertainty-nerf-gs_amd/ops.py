@@ -514,9 +514,12 @@ def splat_sh_colors(degree: int, means3d, cam_pos: torch.Tensor, sh_coeffs, log_
     return colors, beta
 
 
-def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_width: int = 16):
-    """-> (num_intersects, cum_tiles_hit, isect_ids_sorted, gaussian_ids_sorted, tile_bins [tiles,2])
-    One host read-back (num_intersects) sizes the buffers, as gsplat's compute_cumulative_intersects does."""
+def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_width: int = 16,
+                   want_isect_ids: bool = True):
+    """-> (num_intersects, cum_tiles_hit, isect_ids_sorted | None, gaussian_ids_sorted, tile_bins [tiles,2])
+    One host read-back (num_intersects) sizes the buffers, as gsplat's compute_cumulative_intersects does.
+    The 64-bit isect ids are gsplat's by-product; the rasteriser does not read them (want_isect_ids=False
+    skips their gather + 8-byte store per intersection)."""
     lib = _l.load()
     N, dev = xys.shape[0], xys.device
     tbx, tby = (W + block_width - 1) // block_width, (H + block_width - 1) // block_width
@@ -527,13 +530,13 @@ def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_widt
                                                   _p(ws0, torch.uint8), ws0.numel(), _stream()))
         I = int(cum[-1].item())
         ws = torch.empty(int(lib.unerf_splat_sort_workspace_bytes(N, I)), device=dev, dtype=torch.uint8)
-        ids = torch.empty(max(I, 1), device=dev, dtype=torch.int64)
+        ids = torch.empty(max(I, 1), device=dev, dtype=torch.int64) if want_isect_ids else None
         gids = torch.empty(max(I, 1), device=dev, dtype=torch.int32)
         bins = torch.empty(tbx * tby, 2, device=dev, dtype=torch.int32)
         _run("splat_bin_sort", lambda: lib.unerf_splat_bin_sort(_p(xys), _p(depths), _p(radii, torch.int32), _p(cum, torch.int32), N, I, H,
                                           W, block_width, _p(ids, torch.int64), _p(gids, torch.int32),
                                           _p(bins, torch.int32), _p(ws, torch.uint8), ws.numel(), _stream()))
-    return I, cum, ids[:I], gids[:I], bins
+    return I, cum, (ids[:I] if ids is not None else None), gids[:I], bins
 
 
 def splat_rasterize(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, H: int, W: int,

@@ -50,7 +50,7 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     elif rasterize_mode != "classic":
         raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
     opac = opac.contiguous()
-    I, _cum, _keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, block_width)
+    I, _cum, _keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, block_width, want_isect_ids=False)
     cols = torch.cat([rgbs, beta[:, None], depths[:, None]], dim=1).contiguous()
     bg5 = torch.cat([background.to(dev, torch.float32), torch.zeros(2, device=dev)])
     img, fT, _ = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg5, block_width)
