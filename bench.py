@@ -296,6 +296,19 @@ def bench_splat(args, rank, world, dev, dist):
     if rank == 0:
         ksum = timer.summary()
         dom = max(ksum, key=lambda k: ksum[k]["total_ms"])
+        # algorithmic bytes of one frame: splat parameters in, projection record out and back in,
+        # the sort's key/payload traffic as the reference's 64-bit-key radix sort would move it (I x 96 B),
+        # the rasteriser's per-intersection reads (twice: 5-channel pass + depth-variance pass) and the images.
+        from uncertainty_nerf_gs_amd.splat import viewmat_from_c2w
+        q = gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True)
+        pr = ops.splat_project(gp["means"].contiguous(), torch.exp(gp["scales"]), 1.0, q.contiguous(),
+                               viewmat_from_c2w(poses[0])[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)
+        n_isect = int(pr[5].sum().item())
+        N = args.splats
+        frame_bytes = N * 240 + 2 * N * 36 + n_isect * 96 + 2 * n_isect * 36 + H * W * 7 * 4
+        sort_bytes = n_isect * 96
+        kbytes = {"splat_bin_sort": sort_bytes, "splat_rasterize": n_isect * 36 + H * W * 4 * 4}
+        ach = kbytes.get(dom, 0) / (ksum[dom]["avg_ms"] * 1e-3) / 1e9 if dom in kbytes else None
         line = {
             "metric": "Mrays/s (+var) [pixels of an active-splatfacto frame], 1080p", "value": H * W * args.steps * world / elapsed / 1e6,
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -303,8 +316,11 @@ def bench_splat(args, rank, world, dev, dist):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"active-splatfacto {W}x{H}, N={args.splats} splats, rgb+beta+depth+depth_var",
                        "parallelism": f"views x{world}" if world > 1 else "single"},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                         "traffic": None, "avg_launch_ms": ksum[dom]["avg_ms"],
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if ach is None else ach / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": ksum[dom]["avg_ms"], "num_intersects": n_isect,
+                         "frame_algorithmic_bytes": frame_bytes,
+                         "frame_frac_of_hbm_peak": frame_bytes * args.steps * world / elapsed / 1e9 / HBM_PEAK_GBS,
                          "per_kernel_ms_per_frame": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(ksum.items())}},
             "cpu_baseline": None,
         }
