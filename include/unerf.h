@@ -58,6 +58,27 @@ int unerf_generate_rays(const float* c2w_host, float fx, float fy, float cx, flo
 int unerf_hashgrid_fwd(const float* xyz, const float* table, const float* scalings, int64_t N, int L,
                        int log2T, float* out, int32_t* out_idx, void* stream);
 
+/* tiny-cuda-nn `HashGrid` layout, as nerfstudio's HashEncoding(implementation="tcnn") configures it (the
+ * reference's default, models/activenerfacto/activenerfacto_field.py:89,146): `table` is then the flat fp32
+ * `tcnn_encoding.params` vector viewed as rows of 2 features, and level l is described by one record
+ * (host helper: uncertainty-nerf-gs_amd/ops.py::tcnn_grid_levels):
+ *   scale  = exp2f(l * log2f(per_level_scale)) * base_res - 1     res = ceilf(scale) + 1
+ *   size   = min(next_multiple(res^3, 8), 2^log2_hashmap_size)    rows of this level
+ *   offset = sum of the sizes of the levels below                  dense = (res^3 <= size)
+ * Lookup: pos = x*scale + 0.5, cell = floor(pos), w = pos - cell; corner k (bit d of k = +1 along dim d) has
+ * row (x + y res + z res^2) mod size when dense, else (x ^ y*2654435761 ^ z*805459861) mod size, and weight
+ * prod_d (bit ? w_d : 1 - w_d); the 8 corners are accumulated in corner order.  fp32 throughout (tcnn itself
+ * interpolates fp16 copies of the same fp32 master parameters: documented divergence). */
+typedef struct {
+    float scale;
+    uint32_t res, offset, size, dense;
+} unerf_tcnn_level;
+
+/* xyz [N,3] in [0,1]; params = tcnn_encoding.params (fp32, [rows][2]); levels_host [L]; out [N,2L];
+ * out_idx (may be NULL) [N,L,8] int32 = absolute row indices in corner order k = 0..7. */
+int unerf_hashgrid_fwd_tcnn(const float* xyz, const float* params, const unerf_tcnn_level* levels_host, int64_t N,
+                            int L, float* out, int32_t* out_idx, void* stream);
+
 /* hash grid + small MLP (torch nn.Linear weights pre-transposed to [in][out]). */
 typedef struct {
     const float* table;      /* [L<<log2T][2] */
@@ -77,6 +98,9 @@ typedef struct {
     int n_dense;
     int dense_off[8];
     int dense_dim[8];
+    /* NULL: nerfstudio torch HashEncoding (above).  Else DEVICE array [L] of level records: `table` is a
+       tcnn-layout parameter vector (`scalings`, `log2T`, `dense*` are ignored). */
+    const unerf_tcnn_level* tcnn_levels;
 } unerf_density_net;
 
 /* -------------------------------------------------- proposal density --
@@ -147,6 +171,9 @@ typedef struct {
     /* Optional (LAPLACE, with mfma_blob): the n_lap <= 128 sampled last-layer rows of both heads as MFMA A
        fragments (ops.py::pack_laplace_heads, UNERF_LAP_BLOB_FLOATS floats; streamed from L2, not LDS). */
     const float* lap_blob;
+    /* NULL: nerfstudio torch HashEncoding.  Else DEVICE array [16] of tcnn level records: `table` is the flat
+       tcnn-layout parameter vector of the main grid (`scalings` / `log2T` ignored). */
+    const unerf_tcnn_level* tcnn_levels;
 } unerf_field_params;
 #define UNERF_MFMA_BLOB_FLOATS 10660
 #define UNERF_LAP_BLOB_FLOATS 33280

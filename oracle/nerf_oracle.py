@@ -84,6 +84,84 @@ def hash_encode(x: torch.Tensor, table: torch.Tensor, scalings: torch.Tensor, lo
 
 
 # --------------------------------------------------------------------------
+# L0.1b tiny-cuda-nn HashGrid, as HashEncoding(implementation="tcnn") configures it
+#                                         [UPSTREAM-RECALL tiny-cuda-nn, SURVEY.md A.6]
+# --------------------------------------------------------------------------
+
+def tcnn_grid_levels(num_levels: int, base_res: int, per_level_scale: float, log2_hashmap_size: int):
+    """scale_l = exp2f(l * log2f(per_level_scale)) * base_res - 1 (float32); res_l = ceil(scale_l) + 1;
+    rows_l = min(next_multiple(res_l^3, 8), 2^log2_hashmap_size); levels concatenated.
+    -> [(scale, res, offset, size, dense)] with offset / size in rows of 2 features."""
+    log2_pls = np.float32(np.log2(np.float32(per_level_scale)))
+    out, offset = [], 0
+    for l in range(num_levels):
+        scale = np.float32(np.float32(np.exp2(np.float32(np.float32(l) * log2_pls))) * np.float32(base_res) - np.float32(1))
+        res = int(np.ceil(scale)) + 1
+        size = min(-(-res ** 3 // 8) * 8, 1 << log2_hashmap_size)
+        out.append((float(scale), res, offset, size, int(res ** 3 <= size)))
+        offset += size
+    return out
+
+
+def tcnn_hash_indices(x: torch.Tensor, levels):
+    """x [N,3] in [0,1] -> (rows [N,L,8] int64 absolute row per corner, w [N,L,3] interpolation weights).
+    pos = fma(scale, x, 0.5); cell = floor(pos); corner k steps +1 along dim d where bit d of k is set;
+    dense levels: (x + y res + z res^2) mod size; hashed: (x ^ y*2654435761 ^ z*805459861) mod size (uint32)."""
+    rows, ws = [], []
+    x64 = x.double()
+    for scale, res, offset, size, dense in levels:
+        pos = (x64 * float(np.float32(scale)) + 0.5).float()   # fp32 product is exact in fp64: one rounding = fmaf
+        cell = torch.floor(pos)
+        ws.append(pos - cell)
+        c = cell.long()
+        per = []
+        for k in range(8):
+            cx, cy, cz = c[:, 0] + (k & 1), c[:, 1] + ((k >> 1) & 1), c[:, 2] + ((k >> 2) & 1)
+            if dense:
+                idx = (cx + cy * res + cz * res * res) % size
+            else:
+                M = 0xFFFFFFFF
+                idx = ((cx & M) ^ ((cy * 2654435761) & M) ^ ((cz * 805459861) & M)) % size
+            per.append(idx + offset)
+        rows.append(torch.stack(per, dim=-1))
+    return torch.stack(rows, dim=1), torch.stack(ws, dim=1)
+
+
+def tcnn_hash_encode(x: torch.Tensor, params: torch.Tensor, levels) -> torch.Tensor:
+    """-> [N, 2L], level-major.  Corner weight = prod_d (bit ? w_d : 1 - w_d); the 8 corners are accumulated in
+    corner order with a fused multiply-add (float64 product + sum rounded once to float32).  fp32 values; tcnn
+    itself interpolates fp16 copies of these fp32 master parameters (documented divergence)."""
+    rows, w = tcnn_hash_indices(x, levels)
+    tab = params.reshape(-1, 2)
+    N, L = x.shape[0], len(levels)
+    out = torch.zeros(N, L, 2, dtype=torch.float32)
+    for k in range(8):
+        wk = torch.ones(N, L, dtype=torch.float32)
+        for d in range(3):
+            wd = w[..., d]
+            wk = wk * (wd if (k >> d) & 1 else (1.0 - wd))
+        val = tab[rows[..., k]]
+        out = (wk[..., None].double() * val.double() + out.double()).float()
+    return out.reshape(N, 2 * L)
+
+
+def unpack_tcnn_mlp(params: torch.Tensor, in_dim: int, width: int, n_hidden_layers: int, out_dim: int):
+    """tcnn FullyFusedMLP parameter vector -> torch-layout [out,in] weight matrices (no biases).
+    Layout: first layer [width, pad16(in_dim)], (n_hidden_layers - 1) x [width, width], last [pad16(out_dim), width],
+    each row-major, concatenated; padded input columns / output rows are dropped."""
+    pad = lambda n: -(-n // 16) * 16
+    ws, o = [], 0
+    shapes = [(width, pad(in_dim))] + [(width, width)] * (n_hidden_layers - 1) + [(pad(out_dim), width)]
+    for r, c in shapes:
+        ws.append(params[o:o + r * c].reshape(r, c))
+        o += r * c
+    assert o == params.numel(), (o, params.numel())
+    ws[0] = ws[0][:, :in_dim]
+    ws[-1] = ws[-1][:out_dim]
+    return [w_.contiguous() for w_ in ws]
+
+
+# --------------------------------------------------------------------------
 # L0.2-L0.5 small pieces                                  [UPSTREAM nerfstudio]
 # --------------------------------------------------------------------------
 
@@ -244,6 +322,13 @@ class GridMLP:
     log2_T: int
     weights: List[torch.Tensor]
     biases: List[torch.Tensor]
+    tcnn_levels: Optional[list] = None   # set: `table` is a tcnn-layout parameter vector (tcnn_grid_levels)
+
+
+def grid_encode(x: torch.Tensor, g: "GridMLP") -> torch.Tensor:
+    if g.tcnn_levels is not None:
+        return tcnn_hash_encode(x, g.table, g.tcnn_levels)
+    return hash_encode(x, g.table, g.scalings, g.log2_T)
 
 
 def sample_positions(origins, directions, euclid_bins):
@@ -256,7 +341,7 @@ def density_field(positions: torch.Tensor, net: GridMLP, average_init_density: f
     """HashMLPDensityField.get_density on explicit positions [R,n,3] -> [R,n]."""
     shp = positions.shape[:-1]
     p, sel = normalized_positions(positions)
-    h = hash_encode(p.reshape(-1, 3), net.table, net.scalings, net.log2_T)
+    h = grid_encode(p.reshape(-1, 3), net)
     out = mlp_forward(h, net.weights, net.biases).view(*shp)
     return average_init_density * torch.exp(out) * sel
 
@@ -407,13 +492,17 @@ class FieldParams:
     average_init_density: float = 1.0
     beta_min: float = 0.01
     geo_feat_dim: int = 15
+    sh_remap: bool = False             # tcnn SphericalHarmonics maps its [0,1] input back to [-1,1]
 
 
-def _color_inputs(directions: torch.Tensor, S: int, geo: torch.Tensor, appearance: torch.Tensor):
+def _color_inputs(directions: torch.Tensor, S: int, geo: torch.Tensor, appearance: torch.Tensor,
+                  sh_remap: bool = False):
     """[UPSTREAM NerfactoField.get_outputs; re-implemented by the reference at
     laplace_field.py:378-398, 451-459]  directions [R,3], geo [R,S,15] -> h [R*S,63]"""
     R = directions.shape[0]
     dn = (directions + 1.0) / 2.0
+    if sh_remap:   # tcnn SphericalHarmonics: x * 2 - 1 on its [0,1] input
+        dn = dn * 2.0 - 1.0
     d = sh16(dn)[:, None, :].expand(R, S, 16)
     app = appearance.view(1, 1, -1).expand(R, S, -1)
     return torch.cat([d, geo, app], dim=-1).reshape(R * S, -1)
@@ -424,13 +513,13 @@ def active_field(origins, directions, euclid_bins, fp: FieldParams):
     R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
     pos = sample_positions(origins, directions, euclid_bins)
     p, sel = normalized_positions(pos)
-    feat = hash_encode(p.reshape(-1, 3), fp.grid.table, fp.grid.scalings, fp.grid.log2_T)
+    feat = grid_encode(p.reshape(-1, 3), fp.grid)
     h = mlp_forward(feat, fp.grid.weights, fp.grid.biases).view(R, S, -1)
     g = fp.geo_feat_dim
     dens_pre, geo, unc_pre = h[..., 0], h[..., 1:1 + g], h[..., 1 + g]
     density = fp.average_init_density * torch.exp(dens_pre) * sel
     beta = F.softplus(unc_pre) + fp.beta_min
-    rgb = mlp_forward(_color_inputs(directions, S, geo, fp.appearance), fp.head_w, fp.head_b, "sigmoid")
+    rgb = mlp_forward(_color_inputs(directions, S, geo, fp.appearance, fp.sh_remap), fp.head_w, fp.head_b, "sigmoid")
     return density, rgb.view(R, S, 3), beta
 
 
@@ -443,7 +532,7 @@ def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trun
     scale = 1.0 / (1.0 - p_drop)
     pos = sample_positions(origins, directions, euclid_bins)
     p, sel = normalized_positions(pos)
-    feat = hash_encode(p.reshape(-1, 3), fp.grid.table, fp.grid.scalings, fp.grid.log2_T)
+    feat = grid_encode(p.reshape(-1, 3), fp.grid)
     h = F.relu(F.linear(feat, fp.grid.weights[0], fp.grid.biases[0]))
     if keep_trunk is not None:
         h = h * keep_trunk.to(h.dtype) * scale
@@ -451,7 +540,7 @@ def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trun
     g = fp.geo_feat_dim
     density = fp.average_init_density * torch.exp(out[..., 0]) * sel
     geo = out[..., 1:1 + g]
-    x = _color_inputs(directions, S, geo, fp.appearance)
+    x = _color_inputs(directions, S, geo, fp.appearance, fp.sh_remap)
     x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
     x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
     if keep_head is not None:
@@ -496,11 +585,11 @@ def laplace_field(origins, directions, euclid_bins, fp: FieldParams, ws_density:
     R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
     pos = sample_positions(origins, directions, euclid_bins)
     p, _sel = normalized_positions(pos)
-    feat = hash_encode(p.reshape(-1, 3), fp.grid.table, fp.grid.scalings, fp.grid.log2_T)
+    feat = grid_encode(p.reshape(-1, 3), fp.grid)
     hb = F.linear(feat, fp.grid.weights[0], fp.grid.biases[0])
     geo = F.linear(hb, fp.hidden_w, fp.hidden_b).view(R, S, -1)
     mu_d, var_d = sample_laplace(ws_density, "exp", hb, 1)
-    x = _color_inputs(directions, S, geo, fp.appearance)
+    x = _color_inputs(directions, S, geo, fp.appearance, fp.sh_remap)
     x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
     x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
     mu_rgb, var_rgb = sample_laplace(ws_rgb, "sigmoid", x, 3)
@@ -513,11 +602,11 @@ def laplace_field_deterministic(origins, directions, euclid_bins, fp: FieldParam
     R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
     pos = sample_positions(origins, directions, euclid_bins)
     p, sel = normalized_positions(pos)
-    feat = hash_encode(p.reshape(-1, 3), fp.grid.table, fp.grid.scalings, fp.grid.log2_T)
+    feat = grid_encode(p.reshape(-1, 3), fp.grid)
     hb = F.linear(feat, fp.grid.weights[0], fp.grid.biases[0])
     geo = F.linear(hb, fp.hidden_w, fp.hidden_b).view(R, S, -1)
     density = torch.exp(F.linear(hb, fp.density_w, fp.density_b)).view(R, S) * sel
-    x = _color_inputs(directions, S, geo, fp.appearance)
+    x = _color_inputs(directions, S, geo, fp.appearance, fp.sh_remap)
     x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
     x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
     rgb = torch.sigmoid(F.linear(x, fp.head_w[2], fp.head_b[2]))
@@ -717,7 +806,7 @@ def scene_from_tensors(t: dict) -> NerfScene:
         if "w1" in d and d.get("w1") is not None and not d.get("_laplace", False):
             ws.append(d["w1"])
             bs.append(d["b1"])
-        return GridMLP(d["table"], d["scalings"], int(d["log2T"]), ws, bs)
+        return GridMLP(d["table"], d["scalings"], int(d["log2T"]), ws, bs, tcnn_levels=d.get("tcnn_levels"))
 
     f = t["field"]
     lap = t["kind"] == "laplace"
@@ -725,7 +814,7 @@ def scene_from_tensors(t: dict) -> NerfScene:
     fd["_laplace"] = lap
     fp = FieldParams(grid=grid(fd), head_w=list(f["head_w"]), head_b=list(f["head_b"]), appearance=f["appearance"],
                      average_init_density=float(f.get("average_init_density", 1.0)),
-                     beta_min=float(f.get("beta_min", 0.01)))
+                     beta_min=float(f.get("beta_min", 0.01)), sh_remap=bool(f.get("sh_remap", False)))
     if lap:
         fp.hidden_w, fp.hidden_b = f["w1"], f["b1"]
         fp.density_w, fp.density_b = f["density_w"], f["density_b"]

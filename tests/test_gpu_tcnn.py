@@ -1,0 +1,124 @@
+"""tcnn-layout grids on the GPU (`implementation="tcnn"` checkpoints): the lookup against
+its CPU restatement (row indices bit-exact, fp32 blend to an ulp-level tolerance), and the three NeRF methods
+end to end with tcnn-layout tables in the main field and both proposal networks.
+[UPSTREAM-RECALL tiny-cuda-nn, SURVEY.md A.6: parity unpinned.]"""
+import math
+
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from test_gpu_nerf_e2e import _cam, _gates, _img_close, _oracle_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("L,base,max_res,log2T", [(16, 16, 2048, 14), (5, 16, 128, 12), (5, 16, 256, 17), (16, 16, 2048, 19)])
+def test_tcnn_hashgrid_rows_bit_exact_and_features(dev, L, base, max_res, log2T):
+    from uncertainty_nerf_gs_amd import ops
+    growth = math.exp((math.log(max_res) - math.log(base)) / (L - 1))
+    lv = ops.tcnn_grid_levels(L, base, growth, log2T)
+    rows = lv[-1][2] + lv[-1][3]
+    g = torch.Generator().manual_seed(L + log2T)
+    table = (torch.rand(rows, 2, generator=g) * 2 - 1)
+    x = torch.rand(3000, 3, generator=g)
+    x[:40] = torch.tensor([0.0, 0.5, 1.0])[torch.randint(0, 3, (40, 3), generator=g)]   # box faces / corners
+    x[40:80] = torch.round(x[40:80] * 15) / 15                                            # exact level-0 lattice points
+    out, idx = ops.hashgrid_fwd_tcnn(x.to(dev), table.to(dev), lv, return_indices=True)
+    ref_idx, _ = O.tcnn_hash_indices(x, lv)
+    assert torch.equal(idx.cpu().long(), ref_idx), "row indices must match bit for bit"
+    ref = O.tcnn_hash_encode(x, table, lv)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-6, atol=2e-7)
+    assert ops.hashgrid_fwd_tcnn(x[:0].to(dev), table.to(dev), lv).shape == (0, 2 * L)
+
+
+@pytest.mark.parametrize("kind", ["active", "mcdropout", "laplace"])
+def test_tcnn_layout_camera_parity(dev, kind):
+    from uncertainty_nerf_gs_amd import ops, render, synthetic
+    t = synthetic.make_scene_tensors(seed=5, kind=kind, log2T=14, prop_log2T=12, grid="tcnn")
+    sc = O.scene_from_tensors(t)
+    assert sc.field.grid.tcnn_levels is not None and sc.field.sh_remap
+    H, W = 28, 36
+    cam, c2w = _cam(H, W), synthetic.orbit_c2w(1.3)
+    o, d = _oracle_rays(c2w, cam)
+    if kind == "active":
+        sd = synthetic.scene_to_device(t, dev)
+        sd.chunk_rays = 512
+        out = render.render_camera(sd, c2w, rays_per_launch=1024, keep_density=True, **cam)
+        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=512)
+    elif kind == "mcdropout":
+        sd = synthetic.scene_to_device(t, dev, K=3, seed=9, p_drop=0.2)
+        sd.chunk_rays = 512
+        out = render.render_camera(sd, c2w, rays_per_launch=1024, **cam)
+        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 3, 9, 0.2, ray_offset=off), o, d, chunk=512)
+    else:
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+        sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+        noise = torch.randn(100, H * W, 48, generator=torch.Generator().manual_seed(8))
+        od, dd_, _ = ops.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, dev)
+        out = {k: v.view(H, W, -1) for k, v in render.render_rays(sd, od, dd_, depth_noise=noise.to(dev)).items()}
+        ref = {k: v.view(H, W, -1) for k, v in
+               O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise).items()}
+    assert sd.field.tcnn_levels is not None and sd.props[0].tcnn_levels is not None and sd.field.sh_remap == 1
+    _gates(f"tcnn_{kind}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb")
+    _img_close(out["rgb_std"], ref["rgb_std"], 2e-5, 5e-3, "rgb_std", max_bad_frac=2e-3)
+    _img_close(out["accumulation"], ref["accumulation"], 3e-4, 0, "accumulation")
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 2e-3, "expected_depth", max_bad_frac=5e-3)
+
+
+def test_valu_field_kernel_agrees_with_mfma_kernel_on_tcnn_grid(dev):
+    from uncertainty_nerf_gs_amd import ops, render, synthetic
+    t = synthetic.make_scene_tensors(seed=6, kind="active", log2T=14, prop_log2T=12, grid="tcnn")
+    sd = synthetic.scene_to_device(t, dev)
+    H, W = 16, 20
+    o, d, _ = ops.generate_rays(synthetic.orbit_c2w(0.2), 18.0, 18.0, W / 2, H / 2, H, W, dev)
+    sb, _ = render.sample_rays(sd, o, d, None, want_prop_depth=False)
+    a = ops.field_fwd(o, d, sb, sd.field, sd.near, sd.far)
+    sd.field.use_mfma = False
+    b = ops.field_fwd(o, d, sb, sd.field, sd.near, sd.far)
+    for x, y, name in zip(a[:3], b[:3], ("density", "rgb", "beta")):
+        torch.testing.assert_close(x, y, rtol=2e-4, atol=2e-6, msg=name)
+
+
+def test_model_from_tcnn_layout_checkpoint(dev):
+    """a checkpoint with tinycudann parameter vectors loads by name and renders the same image as the direct
+    pipeline built from the unpacked weights"""
+    from uncertainty_nerf_gs_amd import fields as F
+    from uncertainty_nerf_gs_amd import models, plugin, render, synthetic
+    t = synthetic.make_scene_tensors(seed=7, kind="active", log2T=14, prop_log2T=12, grid="tcnn")
+    for blk in [t["field"]] + t["props"]:
+        for k in ("b0", "b1"):
+            blk[k] = torch.zeros_like(blk[k])          # tcnn MLPs carry no biases
+    t["field"]["head_b"] = [torch.zeros_like(b) for b in t["field"]["head_b"]]
+
+    def pack(ws, in_dim, out_dim):   # inverse of unpack_tcnn_mlp
+        pad = lambda n: -(-n // 16) * 16
+        first = torch.zeros(ws[0].shape[0], pad(in_dim))
+        first[:, :in_dim] = ws[0]
+        last = torch.zeros(pad(out_dim), ws[-1].shape[1])
+        last[:out_dim] = ws[-1]
+        return torch.cat([first.reshape(-1)] + [w.reshape(-1) for w in ws[1:-1]] + [last.reshape(-1)])
+
+    f = t["field"]
+    sd_ckpt = {"field.mlp_base_grid.tcnn_encoding.params": f["table"].reshape(-1),
+               "field.mlp_base_mlp.tcnn_encoding.params": pack([f["w0"], f["w1"]], 32, 17),
+               "field.mlp_head.tcnn_encoding.params": pack(list(f["head_w"]), 63, 3),
+               "field.embedding_appearance.embedding.weight": f["appearance"][None]}   # one image: its mean is exact
+    for i, p in enumerate(t["props"]):
+        sd_ckpt[f"proposal_networks.{i}.encoding.tcnn_encoding.params"] = p["table"].reshape(-1)
+        sd_ckpt[f"proposal_networks.{i}.mlp_base.1.tcnn_encoding.params"] = pack([p["w0"], p["w1"]], 10, 1)
+    cfg = plugin.MODEL_CONFIGS["active-nerfacto"]()
+    cfg.implementation, cfg.log2_hashmap_size = "tcnn", 14
+    cfg.proposal_net_args_list = [dict(a, log2_hashmap_size=12) for a in cfg.proposal_net_args_list]
+    model = cfg._target(cfg, num_train_data=1)
+    model.load_state_dict({"_model." + k: v for k, v in sd_ckpt.items()})
+    H, W = 24, 32
+    cam = models.Camera(camera_to_worlds=synthetic.orbit_c2w(0.9)[None], fx=torch.tensor([0.9 * W]),
+                        fy=torch.tensor([0.9 * W]), cx=W / 2, cy=H / 2, height=H, width=W)
+    with torch.cuda.device(dev):
+        out = model.get_outputs_for_camera(cam)
+    direct = render.render_camera(synthetic.scene_to_device(t, dev), cam.camera_to_worlds[0], fx=0.9 * W, fy=0.9 * W,
+                                  cx=W / 2, cy=H / 2, H=H, W=W, keep_density=True)
+    for k in direct:
+        assert torch.equal(out[k], direct[k]), k

@@ -241,6 +241,61 @@ __device__ __forceinline__ float2 unerf_dense_level(const float4* __restrict__ c
     return unerf_blend8(f, ox, oy, oz);
 }
 
+// ---- one level of a tiny-cuda-nn HashGrid (include/unerf.h: unerf_tcnn_level) ----------------------
+// rows[k] = absolute row (level offset included) of corner k; bit d of k steps +1 along dim d.
+__device__ __forceinline__ void unerf_tcnn_corners(const unerf_tcnn_level& lv, float px, float py, float pz,
+                                                   uint32_t (&rows)[8], float& wx, float& wy, float& wz) {
+    const float fx = fmaf(lv.scale, px, 0.5f), fy = fmaf(lv.scale, py, 0.5f), fz = fmaf(lv.scale, pz, 0.5f);
+    const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+    wx = fx - gx;
+    wy = fy - gy;
+    wz = fz - gz;
+    const uint32_t x0 = (uint32_t)(int)gx, y0 = (uint32_t)(int)gy, z0 = (uint32_t)(int)gz;
+    if (lv.dense) {
+        // (x + y res + z res^2) mod size; the index stays below 2 size (size >= res^3, coordinates <= res)
+        const uint32_t r = lv.res, r2 = lv.res * lv.res;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t i = (x0 + (k & 1)) + (y0 + ((k >> 1) & 1)) * r + (z0 + ((k >> 2) & 1)) * r2;
+            i = i >= lv.size ? i - lv.size : i;
+            rows[k] = lv.offset + i;
+        }
+    } else {
+        // hashed levels have size = 2^log2_hashmap_size
+        const uint32_t m = lv.size - 1u;
+        const uint32_t hy0 = y0 * 2654435761u, hz0 = z0 * 805459861u;
+        const uint32_t hy1 = hy0 + 2654435761u, hz1 = hz0 + 805459861u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t hx = x0 + (k & 1), hy = (k & 2) ? hy1 : hy0, hz = (k & 4) ? hz1 : hz0;
+            rows[k] = lv.offset + ((hx ^ hy ^ hz) & m);
+        }
+    }
+}
+__device__ __forceinline__ float2 unerf_tcnn_blend(const float2 (&f)[8], float wx, float wy, float wz) {
+    float2 r = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float w = 1.f;
+        w *= (k & 1) ? wx : 1.f - wx;
+        w *= (k & 2) ? wy : 1.f - wy;
+        w *= (k & 4) ? wz : 1.f - wz;
+        r.x = fmaf(w, f[k].x, r.x);
+        r.y = fmaf(w, f[k].y, r.y);
+    }
+    return r;
+}
+__device__ __forceinline__ float2 unerf_tcnn_level_feat(const float2* __restrict__ params, const unerf_tcnn_level& lv,
+                                                        float px, float py, float pz) {
+    uint32_t rows[8];
+    float wx, wy, wz;
+    unerf_tcnn_corners(lv, px, py, pz, rows, wx, wy, wz);
+    float2 f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = params[rows[k]];
+    return unerf_tcnn_blend(f, wx, wy, wz);
+}
+
 // ---- real SH, 4 levels (components_from_spherical_harmonics) -------------------------
 __device__ __forceinline__ void unerf_sh16(float x, float y, float z, float (&c)[16]) {
     float xx = x * x, yy = y * y, zz = z * z;

@@ -39,6 +39,10 @@ extern "C" int unerf_device_count(void) {
     return n;
 }
 
+struct TcnnLevels {
+    unerf_tcnn_level v[32];
+};
+
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 // Division of an index < 2^31 by a launch-invariant divisor (samples per ray): one multiply-high and a
@@ -198,6 +202,46 @@ extern "C" int unerf_hashgrid_fwd(const float* xyz, const float* table, const fl
     return unerf_check_launch("hashgrid_fwd");
 }
 
+__global__ __launch_bounds__(256) void hashgrid_tcnn_kernel(const float* __restrict__ xyz,
+                                                            const float* __restrict__ params, TcnnLevels lv, int64_t N,
+                                                            int L, float* __restrict__ out, int32_t* __restrict__ out_idx) {
+    int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float px = xyz[n * 3 + 0], py = xyz[n * 3 + 1], pz = xyz[n * 3 + 2];
+    for (int l = 0; l < L; ++l) {
+        uint32_t rows[8];
+        float wx, wy, wz;
+        unerf_tcnn_corners(lv.v[l], px, py, pz, rows, wx, wy, wz);
+        float2 f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = reinterpret_cast<const float2*>(params)[rows[k]];
+        float2 r = unerf_tcnn_blend(f, wx, wy, wz);
+        out[n * (2 * L) + 2 * l + 0] = r.x;
+        out[n * (2 * L) + 2 * l + 1] = r.y;
+        if (out_idx) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out_idx[(n * L + l) * 8 + k] = (int32_t)rows[k];
+        }
+    }
+}
+
+extern "C" int unerf_hashgrid_fwd_tcnn(const float* xyz, const float* params, const unerf_tcnn_level* levels_host,
+                                       int64_t N, int L, float* out, int32_t* out_idx, void* stream) {
+    UNERF_REQUIRE(L >= 1 && L <= 32 && N >= 0, "hashgrid_fwd_tcnn: bad L=%d", L);
+    if (N == 0) return UNERF_OK;
+    UNERF_REQUIRE(xyz && params && levels_host && out, "hashgrid_fwd_tcnn: null pointer");
+    TcnnLevels lv;
+    for (int l = 0; l < L; ++l) {
+        lv.v[l] = levels_host[l];
+        UNERF_REQUIRE(lv.v[l].res >= 2 && lv.v[l].size >= 8 && (lv.v[l].dense || (lv.v[l].size & (lv.v[l].size - 1)) == 0),
+                      "hashgrid_fwd_tcnn: level %d: res=%u size=%u (hashed levels need a power-of-two size)", l,
+                      lv.v[l].res, lv.v[l].size);
+    }
+    hipLaunchKernelGGL(hashgrid_tcnn_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, xyz, params,
+                       lv, N, L, out, out_idx);
+    return unerf_check_launch("hashgrid_fwd_tcnn");
+}
+
 // ======================================================================================
 // 3. proposal density: positions -> contraction -> hash grid (L levels) -> MLP(2L->HID->1)
 // ======================================================================================
@@ -243,7 +287,9 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         float2 f;
-        if (l < a.net.n_dense) {  // wave-uniform: coarse level with a dense, x-paired copy
+        if (a.net.tcnn_levels) {  // uniform: tcnn-layout grid
+            f = unerf_tcnn_level_feat(reinterpret_cast<const float2*>(a.net.table), a.net.tcnn_levels[l], px, py, pz);
+        } else if (l < a.net.n_dense) {  // wave-uniform: coarse level with a dense, x-paired copy
             f = unerf_dense_level(reinterpret_cast<const float4*>(a.net.dense) + a.net.dense_off[l], a.net.dense_dim[l],
                                   px, py, pz, a.net.scalings[l]);
         } else {
@@ -284,12 +330,12 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
                                       const unerf_density_net* net, float average_init_density, float* density_out,
                                       void* stream) {
     UNERF_REQUIRE(origins && directions && sbins && net && density_out, "proposal_density: null pointer");
-    UNERF_REQUIRE(net->table && net->scalings && net->w0t && net->b0 && net->w1t && net->b1,
+    UNERF_REQUIRE(net->table && (net->scalings || net->tcnn_levels) && net->w0t && net->b0 && net->w1t && net->b1,
                   "proposal_density: null pointer inside unerf_density_net");
     UNERF_REQUIRE(R >= 0 && n >= 1, "proposal_density: bad R/n");
     UNERF_REQUIRE(sbins_stride == 0 || sbins_stride >= n + 1, "proposal_density: sbins_stride %lld < n+1",
                   (long long)sbins_stride);
-    UNERF_REQUIRE(net->log2T >= 1 && net->log2T <= 24, "proposal_density: bad log2T");
+    UNERF_REQUIRE(net->tcnn_levels || (net->log2T >= 1 && net->log2T <= 24), "proposal_density: bad log2T");
     UNERF_REQUIRE(net->n_dense >= 0 && net->n_dense <= 8 && net->n_dense <= net->L && (net->n_dense == 0 || net->dense),
                   "proposal_density: bad dense level description");
     for (int l = 0; l < net->n_dense; ++l)  // a level is addressed with 32-bit byte offsets
@@ -622,8 +668,13 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
     const uint32_t mask = (1u << a.p.log2T) - 1u;
 #pragma unroll 4
     for (int l = 0; l < 16; ++l) {
-        const float2* lvl = reinterpret_cast<const float2*>(a.p.table) + ((size_t)l << a.p.log2T);
-        float2 f = unerf_hash_level(lvl, px, py, pz, a.p.scalings[l], mask);
+        float2 f;
+        if (a.p.tcnn_levels) {
+            f = unerf_tcnn_level_feat(reinterpret_cast<const float2*>(a.p.table), a.p.tcnn_levels[l], px, py, pz);
+        } else {
+            const float2* lvl = reinterpret_cast<const float2*>(a.p.table) + ((size_t)l << a.p.log2T);
+            f = unerf_hash_level(lvl, px, py, pz, a.p.scalings[l], mask);
+        }
         A[(2 * l) * 64 + lane] = f.x;
         A[(2 * l + 1) * 64 + lane] = f.y;
     }
@@ -821,9 +872,37 @@ __device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], 
 // PACKED picks the fp32x2 blend (fewer VALU issues, ~18 more VGPRs): right for the K-pass and Laplace
 // kernels, which sit at 2 waves/SIMD anyway; the ACTIVE kernel keeps the scalar blend and its third wave
 // (packed + 168-VGPR cap: 20 B of scratch, 22.2 vs 21.8 ms/frame).
-template <bool PACKED>
+template <bool PACKED, bool TCNN>
 __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, float py, float pz, int h, uint32_t mask) {
     f32x16 feat;
+    if (TCNN) {  // tcnn-layout grid: same batching (4 levels = 32 corner rows in flight), tcnn indexing + blend
+        const float2* params = reinterpret_cast<const float2*>(a.p.table);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            float2 cd[32];
+            float wf[12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unerf_tcnn_level lv = a.p.tcnn_levels[8 * h + 4 * hb + q];
+                uint32_t rows[8];
+                unerf_tcnn_corners(lv, px, py, pz, rows, wf[3 * q], wf[3 * q + 1], wf[3 * q + 2]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cd[8 * q + k] = params[rows[k]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float2 c8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
+                float2 f = unerf_tcnn_blend(c8, wf[3 * q], wf[3 * q + 1], wf[3 * q + 2]);
+                feat[2 * (4 * hb + q)] = f.x;
+                feat[2 * (4 * hb + q) + 1] = f.y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return feat;
+    }
     const char* tbase = reinterpret_cast<const char*>(a.p.table);
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
@@ -856,11 +935,11 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
     return feat;
 }
 
-template <int MODE, bool FEAT_IN>
+template <int MODE, bool FEAT_IN, bool TCNN = false>
 // ACTIVE is bound by the gather (texture-address unit): three waves per SIMD (<= 168 VGPRs) hide more of
 // its latency than two (measured 21.7 vs 23.7 ms/frame when a 176-VGPR build lost the third wave); the
 // K-pass mode needs the registers instead.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == UNERF_FIELD_ACTIVE ? 3 : 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && !TCNN) ? 3 : 2)))
 void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
@@ -915,7 +994,7 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 feat[2 * l + 1] = f.y;
             }
         } else {
-            feat = mf_gather_feats<MODE != UNERF_FIELD_ACTIVE>(a, px, py, pz, h, mask);
+            feat = mf_gather_feats<(MODE != UNERF_FIELD_ACTIVE), TCNN>(a, px, py, pz, h, mask);
         }
         // Colour layer 0 sees [geo(15) | SH(16)]; the SH half does not depend on the MC pass, so its
         // 16 MFMAs (+ bias) are done once per tile and every pass starts from that partial sum.
@@ -1100,7 +1179,7 @@ __device__ __forceinline__ float mf_half_dot(const float* __restrict__ w, int h,
 // CAPTURE = the deterministic (is_inference=False) forward for GGN fitting: ws_density / ws_rgb hold the MEAN
 // last layers, density = exp(.) * selector (laplace_field.py:317-345), rgb = sigmoid(.), and the inputs of the
 // two last layers (base_mlp output, colour hidden) are written to [N][64] planes a.aux / a.aux2.
-template <bool CAPTURE>
+template <bool CAPTURE, bool TCNN = false>
 __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
@@ -1140,7 +1219,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
         // inference: the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
         const float sel = unerf_normalize_position(px, py, pz);
-        f32x16 feat = mf_gather_feats<true>(a, px, py, pz, h, mask);
+        f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask);
 
         // base_mlp is a bare Linear: no ReLU (utils.py:22-23)
         f32x16 hb0 = mf_slab(lds, 0, lane, feat, mf_bias(lds, 0, h));
@@ -1300,13 +1379,14 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                                const float* features, float* density, float* rgb, float* aux, float* aux2,
                                void* stream) {
     UNERF_REQUIRE(origins && directions && sbins && p && density && rgb, "field_fwd: null pointer");
-    UNERF_REQUIRE(p->table && p->scalings && p->w0t && p->b0 && p->w1t && p->b1 && p->h0t && p->hb0 && p->h1t &&
-                      p->hb1 && p->h2t && p->hb2,
+    UNERF_REQUIRE(p->table && (p->scalings || p->tcnn_levels) && p->w0t && p->b0 && p->w1t && p->b1 && p->h0t &&
+                      p->hb0 && p->h1t && p->hb1 && p->h2t && p->hb2,
                   "field_fwd: null weight pointer");
     UNERF_REQUIRE(p->L == 16, "field_fwd: L=%d (only the nerfacto 16-level grid is built)", p->L);
     UNERF_REQUIRE(!features || (p->mfma_blob && p->mode != UNERF_FIELD_LAPLACE),
                   "field_fwd: pre-gathered features are consumed by the MFMA kernel only (ACTIVE/MCDROPOUT with mfma_blob)");
-    UNERF_REQUIRE(p->log2T >= 1 && p->log2T <= 24, "field_fwd: bad log2T=%d", p->log2T);
+    UNERF_REQUIRE(p->tcnn_levels || (p->log2T >= 1 && p->log2T <= 24), "field_fwd: bad log2T=%d", p->log2T);
+    UNERF_REQUIRE(!(p->tcnn_levels && features), "field_fwd: pre-gathered feature planes are built for the torch-layout grid only");
     UNERF_REQUIRE(R >= 0 && S >= 1, "field_fwd: bad R/S");
     UNERF_REQUIRE((uint64_t)(ray_offset + R) * (uint64_t)S < (1ull << 32),
                   "field_fwd: sample index exceeds 32 bits (RNG counter)");
@@ -1328,6 +1408,10 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid(tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                else if (p->tcnn_levels)
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false, true>), dim3(mfma_grid(tiles)),
+                                       dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
+                                       make_fastdiv((uint32_t)S));
                 else
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid(tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
@@ -1343,6 +1427,10 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid(tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                else if (p->tcnn_levels)
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, true>), dim3(mfma_grid(tiles)),
+                                       dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
+                                       make_fastdiv((uint32_t)S));
                 else
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid(tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
@@ -1355,7 +1443,11 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
             if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
-                hipLaunchKernelGGL((field_kernel_mfma_laplace<false>), dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
+                if (p->tcnn_levels)
+                    hipLaunchKernelGGL((field_kernel_mfma_laplace<false, true>), dim3(mfma_grid(tiles)), dim3(256),
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                else
+                    hipLaunchKernelGGL((field_kernel_mfma_laplace<false>), dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
                                    st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_LAPLACE>), grid, block, 64 * 64 * 4, st, a);
@@ -1490,10 +1582,10 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     UNERF_REQUIRE(origins && directions && sbins && p && workspace && ggn_density && ggn_rgb,
                   "laplace_ggn_diag: null pointer");
     UNERF_REQUIRE(p->mode == UNERF_FIELD_LAPLACE && p->out1 == 15 && p->L == 16 && p->mfma_blob && p->ws_density &&
-                      p->ws_rgb && p->table && p->scalings,
+                      p->ws_rgb && p->table && (p->scalings || p->tcnn_levels),
                   "laplace_ggn_diag: needs a LAPLACE field with mfma_blob and the mean last layers in ws_density[65] / "
                   "ws_rgb[195]");
-    UNERF_REQUIRE(p->log2T >= 1 && p->log2T <= 24, "laplace_ggn_diag: bad log2T=%d", p->log2T);
+    UNERF_REQUIRE(p->tcnn_levels || (p->log2T >= 1 && p->log2T <= 24), "laplace_ggn_diag: bad log2T=%d", p->log2T);
     UNERF_REQUIRE((uint64_t)R * (uint64_t)S < (1ull << 32), "laplace_ggn_diag: R*S exceeds 32 bits, split the batch");
     UNERF_REQUIRE(workspace_bytes >= unerf_laplace_ggn_workspace_bytes(R, S),
                   "laplace_ggn_diag: workspace %zu < %zu bytes", workspace_bytes,
@@ -1511,7 +1603,11 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     a.p = *p; a.density = sigma; a.rgb = col; a.aux = X; a.aux2 = Hc; a.features = nullptr;
     a.keep_thr = 0; a.drop_scale = 1.f;
     const int64_t tiles = ((R + 31) / 32) * (int64_t)S;
-    hipLaunchKernelGGL((field_kernel_mfma_laplace<true>), dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
+    if (p->tcnn_levels)
+        hipLaunchKernelGGL((field_kernel_mfma_laplace<true, true>), dim3(mfma_grid(tiles)), dim3(256),
+                           UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+    else
+        hipLaunchKernelGGL((field_kernel_mfma_laplace<true>), dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
                        st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
     GgnArgs g;
     g.sbins = sbins; g.R = R; g.S = S; g.s_near = a.s_near; g.s_far = a.s_far;

@@ -27,30 +27,90 @@ from .synthetic import hash_scalings
 from .utils import create_mlp
 
 
+class _TcnnParams(nn.Module):
+    """what a tinycudann module exposes to the state dict: one flat fp32 `params` vector"""
+
+    def __init__(self, n: int, init_scale: float):
+        super().__init__()
+        self.params = nn.Parameter((torch.rand(n) * 2 - 1) * init_scale)
+
+
+def _pad16(n: int) -> int:
+    return -(-n // 16) * 16
+
+
+def unpack_tcnn_mlp(params: torch.Tensor, in_dim: int, width: int, num_layers: int, out_dim: int):
+    """tiny-cuda-nn FullyFusedMLP parameter vector -> torch-layout [out,in] weights (tcnn MLPs have no biases).
+    Layout [UPSTREAM-RECALL tiny-cuda-nn, SURVEY.md A.6]: first layer [width, pad16(in_dim)], then
+    (num_layers - 2) x [width, width], last [pad16(out_dim), width]; row-major, concatenated."""
+    shapes = [(width, _pad16(in_dim))] + [(width, width)] * (num_layers - 2) + [(_pad16(out_dim), width)]
+    need = sum(r * c for r, c in shapes)
+    if params.numel() != need:
+        raise ValueError(f"tcnn MLP params: {params.numel()} values, expected {need} for {in_dim}->{width}x"
+                         f"{num_layers - 1}->{out_dim}")
+    ws, o = [], 0
+    for r, c in shapes:
+        ws.append(params[o:o + r * c].reshape(r, c))
+        o += r * c
+    ws[0] = ws[0][:, :in_dim]
+    ws[-1] = ws[-1][:out_dim]
+    return ws
+
+
 class HashEncoding(nn.Module):
-    """nerfstudio HashEncoding (torch implementation): parameter `hash_table` [L*T, F]."""
+    """nerfstudio HashEncoding.  implementation="torch": parameter `hash_table` [L*T, F] (every level hashed).
+    implementation="tcnn": parameter `tcnn_encoding.params`, the flat fp32 vector of a tiny-cuda-nn HashGrid
+    (dense coarse levels, +0.5 cell shift; include/unerf.h: unerf_tcnn_level) -- the layout the reference's
+    default configuration trains with (activenerfacto_field.py:89)."""
 
     def __init__(self, num_levels=16, min_res=16, max_res=1024, log2_hashmap_size=19, features_per_level=2,
-                 hash_init_scale=0.001):
+                 hash_init_scale=0.001, implementation="torch"):
         super().__init__()
         assert features_per_level == 2, "the HIP kernels are built for F=2"
-        self.num_levels, self.log2_hashmap_size = num_levels, log2_hashmap_size
+        assert implementation in ("torch", "tcnn")
+        self.num_levels, self.log2_hashmap_size, self.implementation = num_levels, log2_hashmap_size, implementation
         self.register_buffer("scalings", hash_scalings(num_levels, min_res, max_res), persistent=False)
-        table = (torch.rand((1 << log2_hashmap_size) * num_levels, features_per_level) * 2 - 1) * hash_init_scale
-        self.hash_table = nn.Parameter(table)
+        self.tcnn_levels = None
+        if implementation == "tcnn":
+            import math
+            growth = math.exp((math.log(max_res) - math.log(min_res)) / (num_levels - 1)) if num_levels > 1 else 1.0
+            self.tcnn_levels = ops.tcnn_grid_levels(num_levels, min_res, growth, log2_hashmap_size)
+            rows = self.tcnn_levels[-1][2] + self.tcnn_levels[-1][3]
+            self.tcnn_encoding = _TcnnParams(rows * 2, 1e-4)
+        else:
+            table = (torch.rand((1 << log2_hashmap_size) * num_levels, features_per_level) * 2 - 1) * hash_init_scale
+            self.hash_table = nn.Parameter(table)
+
+    @property
+    def table(self) -> torch.Tensor:
+        return self.tcnn_encoding.params if self.implementation == "tcnn" else self.hash_table
 
     def get_out_dim(self) -> int:
         return self.num_levels * 2
 
 
 class MLP(nn.Module):
-    """nerfstudio MLP (torch implementation): `layers` ModuleList of Linear, ReLU between."""
+    """nerfstudio MLP.  implementation="torch": `layers` ModuleList of Linear, ReLU between.
+    implementation="tcnn": `tcnn_encoding.params` of a FullyFusedMLP (no biases, padded to multiples of 16)."""
 
-    def __init__(self, in_dim, num_layers, layer_width, out_dim):
+    def __init__(self, in_dim, num_layers, layer_width, out_dim, implementation="torch"):
         super().__init__()
+        assert implementation in ("torch", "tcnn")
         self.in_dim, self.num_layers, self.layer_width, self.out_dim = in_dim, num_layers, layer_width, out_dim
+        self.implementation = implementation
         dims = [in_dim] + [layer_width] * (num_layers - 1) + [out_dim]
-        self.layers = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(num_layers)])
+        if implementation == "tcnn":
+            n = layer_width * _pad16(in_dim) + (num_layers - 2) * layer_width ** 2 + _pad16(out_dim) * layer_width
+            self.tcnn_encoding = _TcnnParams(n, (6.0 / (2 * layer_width)) ** 0.5)
+        else:
+            self.layers = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(num_layers)])
+
+    def linear_layers(self):
+        """-> [(weight [out,in], bias [out])] of the Linear layers, whichever way they are stored"""
+        if self.implementation == "tcnn":
+            ws = unpack_tcnn_mlp(self.tcnn_encoding.params, self.in_dim, self.layer_width, self.num_layers, self.out_dim)
+            return [(w, torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)) for w in ws]
+        return [(l.weight, l.bias) for l in self.layers]
 
 
 class Embedding(nn.Module):
@@ -68,32 +128,38 @@ class HashMLPDensityField(nn.Module):
     """Proposal network.  Keys: encoding.hash_table (= mlp_base.0.hash_table), mlp_base.1.layers.{0,1}.*"""
 
     def __init__(self, num_layers=2, hidden_dim=16, num_levels=5, max_res=128, base_res=16, log2_hashmap_size=17,
-                 average_init_density=1.0):
+                 average_init_density=1.0, implementation="torch"):
         super().__init__()
         assert num_layers == 2, "proposal kernels are built for Linear-ReLU-Linear"
         self.average_init_density = average_init_density
-        self.encoding = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size)
-        self.mlp_base = nn.Sequential(self.encoding, MLP(self.encoding.get_out_dim(), num_layers, hidden_dim, 1))
+        self.encoding = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, implementation=implementation)
+        self.mlp_base = nn.Sequential(self.encoding, MLP(self.encoding.get_out_dim(), num_layers, hidden_dim, 1,
+                                                         implementation=implementation))
 
     def to_device(self, device) -> ops.DensityNetDev:
-        m = self.mlp_base[1].layers
-        return ops.DensityNetDev.from_torch(self.encoding.hash_table, self.encoding.scalings,
-                                            self.encoding.log2_hashmap_size, m[0].weight, m[0].bias, m[1].weight,
-                                            m[1].bias, device)
+        (w0, b0), (w1, b1) = self.mlp_base[1].linear_layers()
+        return ops.DensityNetDev.from_torch(self.encoding.table, self.encoding.scalings, self.encoding.log2_hashmap_size,
+                                            w0, b0, w1, b1, device, tcnn_levels=self.encoding.tcnn_levels)
 
 
 class _NerfactoFieldBase(nn.Module):
     """Pieces shared with nerfstudio NerfactoField: colour head input = SH16 + geo15 + appearance32."""
 
     def __init__(self, num_images, geo_feat_dim=15, appearance_embedding_dim=32,
-                 use_average_appearance_embedding=False):
+                 use_average_appearance_embedding=False, implementation="torch"):
         super().__init__()
+        assert implementation in ("torch", "tcnn")
+        self.implementation = implementation
         assert geo_feat_dim == 15 and appearance_embedding_dim == 32, "kernels are built for the nerfacto widths"
         self.geo_feat_dim = geo_feat_dim
         self.appearance_embedding_dim = appearance_embedding_dim
         self.use_average_appearance_embedding = use_average_appearance_embedding
         self.embedding_appearance = Embedding(num_images, appearance_embedding_dim)
         self.average_init_density = 1.0
+
+    def _grid_kw(self, grid: HashEncoding):
+        """tcnn layout of the grid + tcnn's SphericalHarmonics convention (it maps the (d+1)/2 input back to [-1,1])"""
+        return {"tcnn_levels": grid.tcnn_levels, "sh_remap": 1 if self.implementation == "tcnn" else 0}
 
     def eval_appearance(self) -> torch.Tensor:
         """constant eval embedding: mean of the table or zeros (laplace_field.py:386-398)"""
@@ -109,22 +175,27 @@ class ActiveNerfactoField(_NerfactoFieldBase):
                  base_res=16, max_res=2048, log2_hashmap_size=19, num_layers_color=3, features_per_level=2,
                  hidden_dim_color=64, appearance_embedding_dim=32, use_average_appearance_embedding=False,
                  spatial_distortion=None, implementation="torch", beta_min=0.01, **_unused):
-        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding)
+        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
+                         implementation)
         assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
         self.beta_min = beta_min
-        self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level)
-        self.mlp_base_mlp = MLP(self.mlp_base_grid.get_out_dim(), num_layers, hidden_dim, 1 + geo_feat_dim + 1)
+        self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
+                                          implementation=implementation)
+        self.mlp_base_mlp = MLP(self.mlp_base_grid.get_out_dim(), num_layers, hidden_dim, 1 + geo_feat_dim + 1,
+                                implementation=implementation)
         self.mlp_base = nn.Sequential(self.mlp_base_grid, self.mlp_base_mlp)  # alias keys mlp_base.{0,1}.*
-        self.mlp_head = MLP(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color, hidden_dim_color, 3)
+        self.mlp_head = MLP(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color, hidden_dim_color, 3,
+                            implementation=implementation)
         self.average_init_density = 1.0  # activenerfacto_field.py:159
 
     def to_device(self, device, **kw) -> ops.FieldDev:
-        t, h = self.mlp_base_mlp.layers, self.mlp_head.layers
+        (w0, b0), (w1, b1) = self.mlp_base_mlp.linear_layers()
+        h = self.mlp_head.linear_layers()
+        g = self.mlp_base_grid
         return ops.FieldDev.from_torch(
-            _l.FIELD_ACTIVE, self.mlp_base_grid.hash_table, self.mlp_base_grid.scalings,
-            self.mlp_base_grid.log2_hashmap_size, t[0].weight, t[0].bias, t[1].weight, t[1].bias,
-            [l.weight for l in h], [l.bias for l in h], self.eval_appearance(), device,
-            average_init_density=self.average_init_density, beta_min=self.beta_min, **kw)
+            _l.FIELD_ACTIVE, g.table, g.scalings, g.log2_hashmap_size, w0, b0, w1, b1,
+            [w for w, _ in h], [b for _, b in h], self.eval_appearance(), device,
+            average_init_density=self.average_init_density, beta_min=self.beta_min, **self._grid_kw(g), **kw)
 
 
 class NerfactoMCDropoutField(_NerfactoFieldBase):
@@ -135,13 +206,15 @@ class NerfactoMCDropoutField(_NerfactoFieldBase):
                  hidden_dim_color=64, appearance_embedding_dim=32, use_average_appearance_embedding=False,
                  spatial_distortion=None, implementation="torch", dropout_rate=0.2,
                  rgb_dropout_layers: Optional[List[int]] = None, density_dropout_layers=True, **_unused):
-        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding)
+        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
+                         implementation)
         assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
         rgb_dropout_layers = [-1] if rgb_dropout_layers is None else rgb_dropout_layers
         assert density_dropout_layers and list(rgb_dropout_layers) == [-1], \
             "kernels implement the reference default: dropout before the last Linear of trunk and head"
         self.dropout_rate = dropout_rate
-        self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level)
+        self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
+                                          implementation=implementation)
         self.mlp_base = create_mlp(self.mlp_base_grid.get_out_dim(), num_layers, hidden_dim, 1 + geo_feat_dim,
                                    activation=nn.ReLU, dropout_layers=[-1], dropout_rate=dropout_rate)
         self.mlp_head = create_mlp(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color, hidden_dim_color, 3,
@@ -151,10 +224,11 @@ class NerfactoMCDropoutField(_NerfactoFieldBase):
     def to_device(self, device, mc_samples=10, seed=0, **kw) -> ops.FieldDev:
         b, h = self.mlp_base, self.mlp_head
         return ops.FieldDev.from_torch(
-            _l.FIELD_MCDROPOUT, self.mlp_base_grid.hash_table, self.mlp_base_grid.scalings,
+            _l.FIELD_MCDROPOUT, self.mlp_base_grid.table, self.mlp_base_grid.scalings,
             self.mlp_base_grid.log2_hashmap_size, b[0].weight, b[0].bias, b[3].weight, b[3].bias,
             [h[0].weight, h[2].weight, h[5].weight], [h[0].bias, h[2].bias, h[5].bias], self.eval_appearance(), device,
-            average_init_density=self.average_init_density, K=mc_samples, seed=seed, p_drop=self.dropout_rate, **kw)
+            average_init_density=self.average_init_density, K=mc_samples, seed=seed, p_drop=self.dropout_rate,
+            **self._grid_kw(self.mlp_base_grid), **kw)
 
 
 class NerfactoLaplaceField(_NerfactoFieldBase):
@@ -166,14 +240,16 @@ class NerfactoLaplaceField(_NerfactoFieldBase):
                  base_res=16, max_res=2048, log2_hashmap_size=19, num_layers_color=3, features_per_level=2,
                  hidden_dim_color=64, appearance_embedding_dim=32, use_average_appearance_embedding=False,
                  spatial_distortion=None, implementation="torch", density_activation="trunc_exp", **_unused):
-        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding)
+        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
+                         implementation)
         assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
         assert density_activation == "trunc_exp", "softplus density activation is not built"
         self.register_buffer("aabb", torch.zeros(2, 3) if aabb is None else aabb)
         self.register_buffer("max_res", torch.tensor(max_res))
         self.register_buffer("num_levels", torch.tensor(num_levels))
         self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
-        self.base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level)
+        self.base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
+                                      implementation=implementation)
         # num_layers-1 == 1 -> a bare Linear: activation AND out_activation are dropped (utils.py:22-23)
         self.base_mlp = create_mlp(self.base_grid.get_out_dim(), num_layers - 1, hidden_dim, hidden_dim,
                                    activation=nn.ReLU, out_activation=nn.ReLU)
@@ -204,7 +280,8 @@ class NerfactoLaplaceField(_NerfactoFieldBase):
         h = self.mlp_head
         f = lambda t: None if t is None else t.detach().to(device=device, dtype=torch.float32).contiguous()
         return ops.FieldDev.from_torch(
-            _l.FIELD_LAPLACE, self.base_grid.hash_table, self.base_grid.scalings, self.base_grid.log2_hashmap_size,
+            _l.FIELD_LAPLACE, self.base_grid.table, self.base_grid.scalings, self.base_grid.log2_hashmap_size,
             self.base_mlp[0].weight, self.base_mlp[0].bias, self.mlp_hidden.weight, self.mlp_hidden.bias,
             [h[0].weight, h[2].weight, self.mlp_rgb_ll.weight], [h[0].bias, h[2].bias, self.mlp_rgb_ll.bias],
-            self.eval_appearance(), device, ws_density=f(ws_density), ws_rgb=f(ws_rgb), **kw)
+            self.eval_appearance(), device, ws_density=f(ws_density), ws_rgb=f(ws_rgb),
+            **self._grid_kw(self.base_grid), **kw)

@@ -71,11 +71,18 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+class TcnnLevel(C.Structure):
+    """include/unerf.h: unerf_tcnn_level"""
+    _fields_ = [("scale", C.c_float), ("res", C.c_uint32), ("offset", C.c_uint32), ("size", C.c_uint32),
+                ("dense", C.c_uint32)]
+
+
 class DensityNet(C.Structure):
     _fields_ = [
         ("table", C.c_void_p), ("scalings", C.c_void_p), ("L", C.c_int), ("log2T", C.c_int),
         ("w0t", C.c_void_p), ("b0", C.c_void_p), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("hidden", C.c_int),
         ("dense", C.c_void_p), ("n_dense", C.c_int), ("dense_off", C.c_int * 8), ("dense_dim", C.c_int * 8),
+        ("tcnn_levels", C.c_void_p),
     ]
 
 
@@ -90,6 +97,7 @@ class FieldParams(C.Structure):
         ("K", C.c_int), ("seed", C.c_uint32), ("p_drop", C.c_float),
         ("ws_density", C.c_void_p), ("ws_rgb", C.c_void_p), ("n_lap", C.c_int),
         ("mfma_blob", C.c_void_p), ("lap_blob", C.c_void_p),
+        ("tcnn_levels", C.c_void_p),
     ]
 
 
@@ -105,6 +113,7 @@ SIGNATURES = {
     "unerf_device_count": (_i, []),
     "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "unerf_hashgrid_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "unerf_hashgrid_fwd_tcnn": (_i, [_vp, _vp, C.POINTER(TcnnLevel), _i64, _i, _vp, _vp, _vp]),
     "unerf_proposal_density": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, C.POINTER(DensityNet), _f, _vp, _vp]),
     "unerf_weights_pdf_resample": (_i, [_vp, _vp, _i64, _i64, _i, _f, _f, _vp, _i, _f, _f, _vp, _vp, _vp, _vp,
                                         _i64, _i64, _vp]),

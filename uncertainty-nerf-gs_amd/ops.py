@@ -105,6 +105,49 @@ def hashgrid_fwd(xyz: torch.Tensor, table: torch.Tensor, scalings: torch.Tensor,
     return (out, idx) if return_indices else out
 
 
+# ---- tiny-cuda-nn HashGrid layout (include/unerf.h: unerf_tcnn_level) -------------------------------
+
+def tcnn_grid_levels(num_levels: int, base_res: int, per_level_scale: float, log2_hashmap_size: int):
+    """Level records of a tcnn `HashGrid` encoding, computed the way tcnn does (float32 log2f / exp2f):
+    -> list of (scale, res, offset, size, dense) with offset/size in rows of 2 features.
+    nerfstudio's HashEncoding(implementation="tcnn") passes per_level_scale = exp((ln max_res - ln min_res)/(L-1))."""
+    import numpy as np
+    log2_pls = np.log2(np.float32(per_level_scale)).astype(np.float32)
+    out, offset = [], 0
+    for l in range(num_levels):
+        scale = np.float32(np.exp2(np.float32(l) * log2_pls).astype(np.float32) * np.float32(base_res) - np.float32(1.0))
+        res = int(np.ceil(scale)) + 1
+        cube = res ** 3
+        size = min((cube + 7) // 8 * 8, 1 << log2_hashmap_size)
+        out.append((float(scale), res, offset, size, 1 if cube <= size else 0))
+        offset += size
+    return out
+
+
+def tcnn_levels_ctypes(levels):
+    return (_l.TcnnLevel * len(levels))(*[_l.TcnnLevel(*lv) for lv in levels])
+
+
+def tcnn_levels_tensor(levels, device) -> torch.Tensor:
+    """the same records as a device buffer (5 x 4 bytes per level) for unerf_density_net / unerf_field_params"""
+    import struct
+    raw = b"".join(struct.pack("<fIIII", *lv) for lv in levels)
+    return torch.frombuffer(bytearray(raw), dtype=torch.int32).clone().to(device)
+
+
+def hashgrid_fwd_tcnn(xyz: torch.Tensor, params: torch.Tensor, levels, return_indices: bool = False):
+    """tcnn-layout lookup: params = flat fp32 `tcnn_encoding.params`, levels from tcnn_grid_levels"""
+    lib = _l.load()
+    N, L = xyz.shape[0], len(levels)
+    out = torch.empty(N, 2 * L, device=xyz.device, dtype=torch.float32)
+    idx = torch.empty(N, L, 8, device=xyz.device, dtype=torch.int32) if return_indices else None
+    lv = tcnn_levels_ctypes(levels)
+    with _ctx(xyz.device):
+        _run("hashgrid_fwd_tcnn", lambda: lib.unerf_hashgrid_fwd_tcnn(_p(xyz, name="xyz"), _p(params, name="params"), lv, N, L,
+                                                                     _p(out), _p(idx, torch.int32), _stream()))
+    return (out, idx) if return_indices else out
+
+
 # --------------------------------------------------------- parameter packs --------------
 
 _HASH_P1, _HASH_P2 = 2654435761, 805459861
@@ -150,21 +193,26 @@ class DensityNetDev:
     dense_off: Tuple[int, ...] = ()
     dense_dim: Tuple[int, ...] = ()
     use_dense: bool = True
+    tcnn_levels: Optional[torch.Tensor] = None   # device records: `table` is then a tcnn-layout parameter vector
 
     @classmethod
-    def from_torch(cls, table, scalings, log2T, w0, b0, w1, b1, device):
+    def from_torch(cls, table, scalings, log2T, w0, b0, w1, b1, device, tcnn_levels=None):
         f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        if tcnn_levels is not None:
+            sc = torch.zeros(len(tcnn_levels))
+            return cls(f(table.reshape(-1, 2)), f(sc), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
+                       tcnn_levels=tcnn_levels_tensor(tcnn_levels, device))
         dense, offs, dims = build_dense_pairs(table, scalings.detach().cpu(), int(log2T))
         return cls(f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
                    None if dense is None else f(dense), tuple(offs), tuple(dims))
 
     def cstruct(self) -> _l.DensityNet:
-        nd = len(self.dense_off) if (self.use_dense and self.dense is not None) else 0
+        nd = len(self.dense_off) if (self.use_dense and self.dense is not None and self.tcnn_levels is None) else 0
         offs = (C.c_int * 8)(*(list(self.dense_off[:nd]) + [0] * (8 - nd)))
         dims = (C.c_int * 8)(*(list(self.dense_dim[:nd]) + [0] * (8 - nd)))
         return _l.DensityNet(_p(self.table), _p(self.scalings), self.scalings.numel(), self.log2T, _p(self.w0t),
                              _p(self.b0), _p(self.w1t), _p(self.b1), self.b0.numel(),
-                             _p(self.dense) if nd else None, nd, offs, dims)
+                             _p(self.dense) if nd else None, nd, offs, dims, _p(self.tcnn_levels, torch.int32))
 
 
 @dataclass
@@ -197,12 +245,19 @@ class FieldDev:
     mfma_blob: Optional[torch.Tensor] = None
     lap_blob: Optional[torch.Tensor] = None
     use_mfma: bool = True
+    tcnn_levels: Optional[torch.Tensor] = None   # device records: `table` is then a tcnn-layout parameter vector
 
     @classmethod
-    def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device, **kw):
+    def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device,
+                   tcnn_levels=None, **kw):
         f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
-        h0 = head_w[0].detach().to(torch.float32)
-        hb0 = head_b[0].detach().to(torch.float32) + h0[:, 31:] @ appearance.detach().to(torch.float32)
+        if tcnn_levels is not None:
+            table, scalings = table.reshape(-1, 2), torch.zeros(len(tcnn_levels))
+            kw["tcnn_levels"] = tcnn_levels_tensor(tcnn_levels, device)
+        h0 = head_w[0].detach().to(torch.float32).contiguous()
+        # appearance block folded into the bias; accumulated in float64 so the result does not depend on the
+        # memory layout the weights arrived in (a strided view takes a different CPU matmul path)
+        hb0 = (head_b[0].detach().double() + h0[:, 31:].double() @ appearance.detach().double()).to(torch.float32)
         lap = mode == _l.FIELD_LAPLACE
         blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
                                  geo_first_unit=0 if lap else 1))
@@ -220,7 +275,8 @@ class FieldDev:
             _p(self.h0t), _p(self.hb0), _p(self.h1t), _p(self.hb1), _p(self.h2t), _p(self.hb2),
             self.average_init_density, self.beta_min, self.sh_remap, self.K, self.seed & 0xFFFFFFFF, self.p_drop,
             _p(self.ws_density), _p(self.ws_rgb), 0 if self.ws_density is None else self.ws_density.shape[0],
-            _p(self.mfma_blob) if self.use_mfma else None, _p(self.lap_blob) if self.use_mfma else None)
+            _p(self.mfma_blob) if self.use_mfma else None, _p(self.lap_blob) if self.use_mfma else None,
+            _p(self.tcnn_levels, torch.int32))
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------

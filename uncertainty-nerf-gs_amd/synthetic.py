@@ -38,15 +38,28 @@ def _grid(gen, num_levels, min_res, max_res, log2T, table_scale):
     return {"table": table, "scalings": hash_scalings(num_levels, min_res, max_res), "log2T": log2T}
 
 
+def _grid_tcnn(gen, num_levels, min_res, max_res, log2T, table_scale):
+    """tcnn-layout grid as nerfstudio's HashEncoding(implementation="tcnn") sets it up: per_level_scale =
+    exp((ln max_res - ln min_res) / (L - 1)); `table` is the flat parameter vector viewed as [rows, 2]."""
+    growth = math.exp((math.log(max_res) - math.log(min_res)) / (num_levels - 1))
+    levels = ops.tcnn_grid_levels(num_levels, min_res, growth, log2T)
+    rows = levels[-1][2] + levels[-1][3]
+    table = (torch.rand(rows, 2, generator=gen) * 2 - 1) * table_scale
+    return {"table": table, "scalings": torch.zeros(num_levels), "log2T": log2T, "tcnn_levels": levels}
+
+
 def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, prop_log2T: int = 17,
                        max_res: int = 2048, table_scale: float = 0.5, density_gain: float = 16.0,
-                       density_bias: float = -2.0, color_gain: float = 4.0, beta_gain: float = 12.0) -> Dict:
+                       density_bias: float = -2.0, color_gain: float = 4.0, beta_gain: float = 12.0,
+                       grid: str = "torch") -> Dict:
     """Random-init nerfacto-shaped scene.  Tables U(-1,1)*table_scale; Linear layers
     Kaiming-uniform like nn.Linear; the density row is gained up so accumulation, depth and the
     variances vary over the image instead of saturating."""
-    assert kind in ("active", "mcdropout", "laplace")
+    assert kind in ("active", "mcdropout", "laplace") and grid in ("torch", "tcnn")
     gen = torch.Generator().manual_seed(seed)
-    f = _grid(gen, 16, 16, max_res, log2T, table_scale)
+    make_grid = _grid_tcnn if grid == "tcnn" else _grid
+    f = make_grid(gen, 16, 16, max_res, log2T, table_scale)
+    f["sh_remap"] = grid == "tcnn"   # tcnn's SphericalHarmonics encoding maps (d+1)/2 back to [-1,1]
     f["w0"], f["b0"] = _linear(gen, 64, 32)
     out1 = {"active": 17, "mcdropout": 16, "laplace": 15}[kind]
     f["w1"], f["b1"] = _linear(gen, out1, 64)
@@ -73,7 +86,7 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
             f["b1"][16] = -2.0
     props = []
     for mr in (128, 256):
-        p = _grid(gen, 5, 16, mr, prop_log2T, table_scale)
+        p = make_grid(gen, 5, 16, mr, prop_log2T, table_scale)
         p["w0"], p["b0"] = _linear(gen, 16, 10)
         p["w1"], p["b1"] = _linear(gen, 1, 16)
         p["w1"][0] *= density_gain
@@ -91,9 +104,10 @@ def scene_to_device(t: Dict, device, **field_kw) -> NerfSceneDev:
     fd = ops.FieldDev.from_torch(_MODE[t["kind"]], f["table"], f["scalings"], f["log2T"], f["w0"], f["b0"], f["w1"],
                                  f["b1"], f["head_w"], f["head_b"], f["appearance"], device,
                                  average_init_density=float(f["average_init_density"]),
-                                 beta_min=float(f["beta_min"]), **field_kw)
+                                 beta_min=float(f["beta_min"]), tcnn_levels=f.get("tcnn_levels"),
+                                 sh_remap=int(bool(f.get("sh_remap", False))), **field_kw)
     props = [ops.DensityNetDev.from_torch(p["table"], p["scalings"], p["log2T"], p["w0"], p["b0"], p["w1"], p["b1"],
-                                          device) for p in t["props"]]
+                                          device, tcnn_levels=p.get("tcnn_levels")) for p in t["props"]]
     return NerfSceneDev(field=fd, props=props, near=float(t["near"]), far=float(t["far"]),
                         num_prop=tuple(t["num_prop"]), num_nerf=int(t["num_nerf"]),
                         prop_average_init_density=float(t["prop_average_init_density"]))
