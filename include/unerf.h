@@ -174,6 +174,15 @@ typedef struct {
     /* NULL: nerfstudio torch HashEncoding.  Else DEVICE array [16] of tcnn level records: `table` is the flat
        tcnn-layout parameter vector of the main grid (`scalings` / `log2T` ignored). */
     const unerf_tcnn_level* tcnn_levels;
+    /* Optional, preferred when present (all modes): the dense layers as SPLIT-F16 matrix operands
+       (ops.py::pack_field_mfma16, same size as mfma_blob; LAPLACE additionally lap16_blob,
+       ops.py::pack_laplace_heads16, UNERF_LAP_BLOB_FLOATS floats).  Every fp32 weight and activation is carried
+       as hi = f16(x), lo = f16(x - hi) and hi*hi + hi*lo + lo*hi is accumulated in fp32 on
+       v_mfma_f32_32x32x16_f16: fp32-equivalent results (relative deviation ~1e-7 from the exact kernels) at a
+       third of the matrix-pipe time of the fp32-input MFMA, which runs at the vector rate.  NULL selects the
+       exact-fp32 kernels above. */
+    const float* mfma16_blob;
+    const float* lap16_blob;
 } unerf_field_params;
 #define UNERF_MFMA_BLOB_FLOATS 10660
 #define UNERF_LAP_BLOB_FLOATS 33280

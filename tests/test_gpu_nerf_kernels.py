@@ -172,11 +172,15 @@ def _final_bins(sc, o, d):
     return bins.contiguous()
 
 
-@pytest.mark.parametrize("use_mfma", [True, False], ids=["mfma", "valu"])
-def test_field_active_matches_oracle(dev, use_mfma):
+_KERNELS = [(True, "f16x2"), (True, "fp32"), (False, "fp32")]
+_KERNEL_IDS = ["mfma-f16x2", "mfma-fp32", "valu"]
+
+
+@pytest.mark.parametrize("use_mfma,precision", _KERNELS, ids=_KERNEL_IDS)
+def test_field_active_matches_oracle(dev, use_mfma, precision):
     from uncertainty_nerf_gs_amd import ops
     t, sc, sd = _scene("active", dev)
-    sd.field.use_mfma = use_mfma
+    sd.field.use_mfma, sd.field.precision = use_mfma, precision
     o, d = _rays()
     sb = _final_bins(sc, o, d)
     eb = O.spacing_to_euclidean(sb, NEAR, FAR)
@@ -201,19 +205,20 @@ def test_field_level_major_gather_equals_fused_lookup(dev, kind, kw):
     p, _ = O.normalized_positions(O.sample_positions(o, d, eb))
     ref = O.hash_encode(p.reshape(-1, 3), sc.field.grid.table, sc.field.grid.scalings, sc.field.grid.log2_T)
     assert torch.equal(feats.permute(1, 0, 2).reshape(-1, 32).cpu(), ref)
+    sd.field.precision = "fp32"   # feature planes feed the exact-fp32 MFMA kernel
     a = ops.field_fwd(od, dd, sbd, sd.field, NEAR, FAR, ray_offset=3)
     b = ops.field_fwd(od, dd, sbd, sd.field, NEAR, FAR, ray_offset=3, features=feats)
     for x, y in zip(a, b):
         assert (x is None and y is None) or torch.equal(x, y)
 
 
-@pytest.mark.parametrize("use_mfma", [True, False], ids=["mfma", "valu"])
+@pytest.mark.parametrize("use_mfma,precision", _KERNELS, ids=_KERNEL_IDS)
 @pytest.mark.parametrize("K", [0, 3])
-def test_field_mcdropout_matches_oracle(dev, K, use_mfma):
+def test_field_mcdropout_matches_oracle(dev, K, use_mfma, precision):
     from uncertainty_nerf_gs_amd import ops
     seed, p = 1234, 0.2
     t, sc, sd = _scene("mcdropout", dev, K=K, seed=seed, p_drop=p)
-    sd.field.use_mfma = use_mfma
+    sd.field.use_mfma, sd.field.precision = use_mfma, precision
     o, d = _rays(16, 24)
     sb = _final_bins(sc, o, d)
     eb = O.spacing_to_euclidean(sb, NEAR, FAR)
@@ -396,3 +401,24 @@ def test_laplace_ggn_diag_kernels_match_autograd(dev):
     from uncertainty_nerf_gs_amd import lib as L
     with pytest.raises(L.UnerfError):
         ops.laplace_ggn_diag(o.to(dev), d.to(dev), bins.to(dev).contiguous(), sd.field, dm[:10], rm, sc.near, sc.far, gd, gr)
+
+
+@pytest.mark.parametrize("kind,kw", [("active", {}), ("mcdropout", dict(K=4, seed=3, p_drop=0.2))])
+def test_split_f16_matrix_kernels_are_fp32_equivalent(dev, kind, kw):
+    """The split-f16 kernels (hi/lo halves, three products, fp32 accumulate) against the exact fp32-MFMA kernels
+    on identical inputs: the deviation must stay at the level of fp32 rounding itself, far inside the tolerance
+    either kernel is held to against the oracle."""
+    from uncertainty_nerf_gs_amd import ops
+    t, sc, sd = _scene(kind, dev, **kw)
+    o, d = _rays(24, 32)
+    sb = _final_bins(sc, o, d)
+    args = (o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
+    sd.field.precision = "fp32"
+    exact = ops.field_fwd(*args, ray_offset=77)
+    sd.field.precision = "f16x2"
+    split = ops.field_fwd(*args, ray_offset=77)
+    dens_e, dens_s = exact[0].double(), split[0].double()
+    assert ((dens_s - dens_e).abs() <= 3e-6 * dens_e.abs() + 1e-9).all(), ((dens_s - dens_e).abs() / (dens_e.abs() + 1e-9)).max()
+    assert (split[1] - exact[1]).abs().max() <= 1e-6, (split[1] - exact[1]).abs().max()
+    if kind == "active":
+        assert (split[2] - exact[2]).abs().max() <= 2e-6 * exact[2].abs().max()

@@ -1099,6 +1099,206 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 }
 
 // --------------------------------------------------------------------------------------
+// 5b''. Split-f16 variant of 5b (ACTIVE, MCDROPOUT): the same network, same tile mapping, same gathers and
+// epilogues, but the dense layers run on v_mfma_f32_32x32x16_f16 with every fp32 operand carried as two
+// halves (hi = f16(x), lo = f16(x - hi): 22 mantissa bits) and hi*hi + hi*lo + lo*hi accumulated in fp32.
+// Why: the fp32-input MFMA runs at the fp32 VECTOR rate and does not overlap with VALU work (rocprof
+// r1_05: MFMA-busy 58 % + VALU-busy 35 % = the elapsed cycles), so the exact-fp32 kernel spends 10.2 k of
+// its 17.4 k cycles per tile in 160 MFMAs.  The f16 matrix pipe is 16x faster per k-step; three products
+// per step leave 60 MFMAs x ~36 cycles = 2.2 k cycles, plus ~3 VALU per activation element for the split.
+// Accuracy: dropped lo*lo term and the rounding of lo are each <= 2^-22 relative per product, i.e. the
+// result is fp32-equivalent (|d rgb| ~ 1e-7; tests/test_gpu_nerf_kernels.py bounds it against the exact
+// kernel, the e2e PSNR / AUSE gates are unchanged).  f16 subnormal inputs are honoured by the MFMA
+// (benchmarks/mfma_f16_probe.hip); operands must stay below 65504 in magnitude (checked for the weights at
+// pack time; activations of a trained nerfacto field are orders of magnitude smaller).
+// Operand order: accumulator registers 8s..8s+7 of a lane in half g are layer units
+// 16s + 4g + (e&3) + 8(e>>2) -- the k order of the next layer's B operand, hence the order
+// ops.pack_field_mfma16 packs the A slabs in.  LDS blob: 20 slabs x (hi|lo) x 64 lanes x 16 B = 40 KiB, then
+// the same bias rows / rgb layer as the fp32 blob (same offsets, same total size).
+// --------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void mf16_split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)x[e];
+        hi[e] = hh;
+        lo[e] = (_Float16)(x[e] - (float)hh);
+    }
+}
+__device__ __forceinline__ void mf16_split(const f32x16& v, int s, f16x8& hi, f16x8& lo) {
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = v[8 * s + e];
+    mf16_split8(x, hi, lo);
+}
+// acc += W(slab) x B: small terms first
+__device__ __forceinline__ f32x16 mf16_mac(const float* lds, int slab, int lane, const f16x8& bhi, const f16x8& blo,
+                                           f32x16 acc) {
+    const f16x8 ahi = *reinterpret_cast<const f16x8*>(lds + slab * 512 + lane * 4);
+    const f16x8 alo = *reinterpret_cast<const f16x8*>(lds + slab * 512 + 256 + lane * 4);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
+    return acc;
+}
+// a 64-wide layer input held as two accumulator blocks (units 0..31 in v0, 32..63 in v1) against the
+// 4 k-steps x NB row blocks of slabs starting at `slab0` (slab = slab0 + NB*step + block)
+template <int NB>
+__device__ __forceinline__ void mf16_layer64(const float* lds, int slab0, int lane, const f32x16& v0, const f32x16& v1,
+                                             f32x16& o0, f32x16& o1) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        f16x8 bhi, blo;
+        mf16_split(s < 2 ? v0 : v1, s & 1, bhi, blo);
+        o0 = mf16_mac(lds, slab0 + NB * s, lane, bhi, blo, o0);
+        if (NB == 2) o1 = mf16_mac(lds, slab0 + NB * s + 1, lane, bhi, blo, o1);
+    }
+}
+
+template <int MODE, bool TCNN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && !TCNN) ? 3 : 2)))
+void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
+    extern __shared__ float lds[];
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.p.mfma16_blob);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane_c & 31, h = lane_c >> 5;
+    const int64_t N = a.R * (int64_t)a.S;
+    const uint32_t mask = (1u << a.p.log2T) - 1u;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const uint32_t tpx = (num_tiles + 7u) / 8u;
+    const uint32_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
+    for (uint32_t tile = xcd * tpx + (uint32_t)slot * 4u + (uint32_t)wv; tile < tile_end; tile += (uint32_t)bpx * 4u) {
+        int lane = lane_c;  // opaque per iteration: keeps the (tile-invariant) LDS operand reads inside the loop
+        asm volatile("" : "+v"(lane));
+        const uint32_t rb = fastdiv(tile, div_s);
+        const int s = (int)(tile - rb * (uint32_t)a.S);
+        int64_t r = (int64_t)rb * 32 + j;
+        const bool valid = r < a.R;
+        if (!valid) r = a.R - 1;
+        const int64_t n = r * a.S + s;
+        const float* sb = a.sbins + r * (a.S + 1);
+        float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+        float t01 = e0 + e1;
+        float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
+        float px = a.origins[r * 3 + 0] + dxr * t01 / 2.f;
+        float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
+        float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
+        const float sel = unerf_normalize_position(px, py, pz);
+        const f32x16 feat = mf_gather_feats<(MODE != UNERF_FIELD_ACTIVE), TCNN>(a, px, py, pz, h, mask);
+
+        // colour layer 0, SH half (pass-invariant): components 8h..8h+7 of this lane half, one k-step
+        f32x16 csh0 = mf_bias(lds, 3, h), csh1 = mf_bias(lds, 4, h);
+        {
+            float sh[16];
+            float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
+            if (a.p.sh_remap) {
+                ux = ux * 2.f - 1.f;
+                uy = uy * 2.f - 1.f;
+                uz = uz * 2.f - 1.f;
+            }
+            unerf_sh16(ux, uy, uz, sh);
+            const uint32_t hm = 0u - (uint32_t)h;
+            float mine[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                mine[q] = __uint_as_float((__float_as_uint(sh[8 + q]) & hm) | (__float_as_uint(sh[q]) & ~hm));
+            f16x8 bhi, blo;
+            mf16_split8(mine, bhi, blo);
+            csh0 = mf16_mac(lds, 10, lane, bhi, blo, csh0);
+            csh1 = mf16_mac(lds, 11, lane, bhi, blo, csh1);
+        }
+
+        // layer 0: 32 -> 64 (this half's 16 features = two k-steps), ReLU
+        f32x16 hid0 = mf_bias(lds, 0, h), hid1 = mf_bias(lds, 1, h);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f16x8 bhi, blo;
+            mf16_split(feat, st, bhi, blo);
+            hid0 = mf16_mac(lds, 2 * st, lane, bhi, blo, hid0);
+            hid1 = mf16_mac(lds, 2 * st + 1, lane, bhi, blo, hid1);
+        }
+        hid0 = mf_relu(hid0);
+        hid1 = mf_relu(hid1);
+
+        const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
+        const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.p.K > 0;
+        const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
+        uint32_t mk0[8], mk1[8], mk2[8], mk3[8];
+        if (drop) {
+            const uint32_t base0 = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
+            mf_mask_init(mk0, 0, h, base0, 0u);
+            mf_mask_init(mk1, 1, h, base0, 0u);
+            mf_mask_init(mk2, 0, h, base0, 1u);
+            mf_mask_init(mk3, 1, h, base0, 1u);
+        }
+        for (int k = 0; k < passes; ++k) {
+            asm volatile("" : "+v"(lane));
+            f32x16 m0 = hid0, m1 = hid1;
+            if (drop) {
+                if (k > 0) {
+                    mf_mask_step(mk0);
+                    mf_mask_step(mk1);
+                    mf_mask_step(mk2);
+                    mf_mask_step(mk3);
+                }
+                m0 = mf_dropout(hid0, mk0, a.keep_thr, a.drop_scale);
+                m1 = mf_dropout(hid1, mk1, a.keep_thr, a.drop_scale);
+            }
+            // trunk out: 64 -> out1 rows (row 0 density, 1..15 geo, 16 beta)
+            f32x16 t = mf_bias(lds, 2, h), unused = t;
+            mf16_layer64<1>(lds, 4, lane, m0, m1, t, unused);
+            // colour 0: geo rows of t (registers 0..7 = one k-step) on top of the SH partial sum, ReLU
+            f32x16 c0 = csh0, c1 = csh1;
+            {
+                f16x8 bhi, blo;
+                mf16_split(t, 0, bhi, blo);
+                c0 = mf16_mac(lds, 8, lane, bhi, blo, c0);
+                c1 = mf16_mac(lds, 9, lane, bhi, blo, c1);
+            }
+            c0 = mf_relu(c0);
+            c1 = mf_relu(c1);
+            // colour 1: 64 -> 64, ReLU
+            f32x16 d0 = mf_bias(lds, 5, h), d1 = mf_bias(lds, 6, h);
+            mf16_layer64<2>(lds, 12, lane, c0, c1, d0, d1);
+            d0 = mf_relu(d0);
+            d1 = mf_relu(d1);
+            if (drop) {
+                d0 = mf_dropout(d0, mk2, a.keep_thr, a.drop_scale);
+                d1 = mf_dropout(d1, mk3, a.keep_thr, a.drop_scale);
+            }
+            // colour 2: 64 -> 3 on the VALU in fp32 (as in the exact kernel)
+            float rgbv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* w0p = lds + MF_H2_OFF + ((0 * 2 + h) * 3 + c) * 16;
+                const float* w1p = lds + MF_H2_OFF + ((1 * 2 + h) * 3 + c) * 16;
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = fmaf(d0[q], w0p[q], acc);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = fmaf(d1[q], w1p[q], acc);
+                acc += __shfl_xor(acc, 32, 64);
+                rgbv[c] = unerf_sigmoid(acc + lds[MF_H2_OFF + 192 + c]);
+            }
+            if (valid && h == 0) {
+                int64_t q = (int64_t)k * N + n;
+                a.density[q] = a.p.average_init_density * expf(t[0]) * sel;
+                a.rgb[q * 3 + 0] = rgbv[0];
+                a.rgb[q * 3 + 1] = rgbv[1];
+                a.rgb[q * 3 + 2] = rgbv[2];
+                if (MODE == UNERF_FIELD_ACTIVE) a.aux[n] = unerf_softplus(t[8]) + a.p.beta_min;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // 5b'. LAPLACE on the matrix cores.  The reference evaluates the two sampled last layers in a
 // 100-iteration Python loop of GEMVs (laplace_field.py:553-560); as a matrix product the weight
 // SAMPLES are the output rows: density head 128(100) x 64, colour head 3 x 128(100) x 64 per
@@ -1403,7 +1603,11 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     switch (p->mode) {
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
-            if (p->mfma_blob) {
+            if (p->mfma16_blob && !features && !p->tcnn_levels) {  // tcnn-layout grids stay on the exact kernels
+                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+                hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid(tiles)), dim3(256),
+                                   UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+            } else if (p->mfma_blob) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid(tiles)), dim3(256),
@@ -1422,7 +1626,12 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_MCDROPOUT:
             UNERF_REQUIRE(p->out1 == 16, "field_fwd MCDROPOUT: out1 must be 16");
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
-            if (p->mfma_blob) {
+            if (p->mfma16_blob && !features && !p->tcnn_levels) {
+                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+                hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid(tiles)),
+                                   dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
+                                   make_fastdiv((uint32_t)S));
+            } else if (p->mfma_blob) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid(tiles)), dim3(256),

@@ -98,6 +98,7 @@ class FieldParams(C.Structure):
         ("ws_density", C.c_void_p), ("ws_rgb", C.c_void_p), ("n_lap", C.c_int),
         ("mfma_blob", C.c_void_p), ("lap_blob", C.c_void_p),
         ("tcnn_levels", C.c_void_p),
+        ("mfma16_blob", C.c_void_p), ("lap16_blob", C.c_void_p),
     ]
 
 

@@ -246,6 +246,9 @@ class FieldDev:
     lap_blob: Optional[torch.Tensor] = None
     use_mfma: bool = True
     tcnn_levels: Optional[torch.Tensor] = None   # device records: `table` is then a tcnn-layout parameter vector
+    mfma16_blob: Optional[torch.Tensor] = None   # split-f16 operands of the dense layers (pack_field_mfma16)
+    lap16_blob: Optional[torch.Tensor] = None
+    precision: str = "f16x2"                     # "f16x2": split-f16 matrix kernels (fp32-equivalent); "fp32": exact
 
     @classmethod
     def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device,
@@ -261,6 +264,8 @@ class FieldDev:
         lap = mode == _l.FIELD_LAPLACE
         blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
                                  geo_first_unit=0 if lap else 1))
+        kw["mfma16_blob"] = f(pack_field_mfma16(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2],
+                                                head_b[2], geo_first_unit=0 if lap else 1))
         lap_blob = None
         if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
             lap_blob = f(pack_laplace_heads(kw["ws_density"], kw["ws_rgb"]))
@@ -276,7 +281,9 @@ class FieldDev:
             self.average_init_density, self.beta_min, self.sh_remap, self.K, self.seed & 0xFFFFFFFF, self.p_drop,
             _p(self.ws_density), _p(self.ws_rgb), 0 if self.ws_density is None else self.ws_density.shape[0],
             _p(self.mfma_blob) if self.use_mfma else None, _p(self.lap_blob) if self.use_mfma else None,
-            _p(self.tcnn_levels, torch.int32))
+            _p(self.tcnn_levels, torch.int32),
+            _p(self.mfma16_blob) if (self.use_mfma and self.precision == "f16x2") else None,
+            _p(self.lap16_blob) if (self.use_mfma and self.precision == "f16x2") else None)
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------
@@ -345,6 +352,65 @@ def pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit: i
                 hh2[blk, hh, c] = h2[c, 32 * blk + _mfma_unit(r16, hh)]
     blob[MFMA_H2_OFF + 192:MFMA_H2_OFF + 195] = hb2
     return blob
+
+
+# ---- split-f16 operand packing for field_kernel_mfma16 --------------------------------------------
+# v_mfma_f32_32x32x16_f16 (gfx950): D[32x32] += A[32x16] B[16x32] with fp32 accumulation; lane l holds
+# A[row l&31][k = 8(l>>5) + e], B[k = 8(l>>5) + e][col l&31], e = 0..7 (one 16-byte register quad each).
+# Every fp32 weight w is stored as two halves hi = f16(w), lo = f16(w - hi) (22 mantissa bits together) and
+# the kernel splits the activations the same way; hi*hi + hi*lo + lo*hi is accumulated in fp32 (the dropped
+# lo*lo term is 2^-22 relative).  Three f16 MFMAs at 16x the fp32-MFMA rate replace eight fp32 MFMAs.
+# The accumulator registers 8s..8s+7 of a lane in half g hold layer units 16s + 4g + (e&3) + 8(e>>2): that is
+# the k order of the next layer's B operand, so it is the k order the A fragments are packed in.
+MF16_SLABS = 20            # L0: 4 (step, block), trunk-out: 4 steps, colour-0: 4 (geo|SH, block), colour-1: 8
+MF16_SLAB_FLOATS = 512     # 64 lanes x 8 halves x (hi, lo) = 2 KiB
+
+
+def _mf16_unit(s, g, e):
+    """layer unit held by accumulator register 8s+e of a lane in half g"""
+    return 16 * s + 4 * g + (e & 3) + 8 * (e >> 2)
+
+
+def _split_f16(w: torch.Tensor):
+    hi = w.to(torch.float16)
+    lo = (w - hi.to(torch.float32)).to(torch.float16)
+    return hi, lo
+
+
+def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit: int = 1) -> torch.Tensor:
+    """Same arguments and same blob size as pack_field_mfma; the first 10240 floats hold the 20 split-f16
+    A-operand slabs [slab][hi|lo][lane][8 halves], the bias rows and the rgb layer follow unchanged (fp32)."""
+    f = lambda t: t.detach().to("cpu", torch.float32)
+    w0f, w1f, h0f, h1f = map(f, (w0, w1, h0, h1))
+    out1 = w1f.shape[0]
+    assert w0f.shape == (64, 32) and w1f.shape[1] == 64 and out1 <= 32 and h0f.shape == (64, 31) and h1f.shape == (64, 64)
+    assert abs(w0f).max() < 6e4 and abs(w1f).max() < 6e4 and abs(h0f).max() < 6e4 and abs(h1f).max() < 6e4, \
+        "weights outside the f16 range"
+    lane = torch.arange(64)
+    row, g = (lane & 31)[:, None], (lane >> 5)[:, None]
+    e = torch.arange(8)[None, :]
+    w1p = torch.zeros(32, 64)
+    w1p[:out1] = w1f
+    slabs = torch.zeros(MF16_SLABS, 64, 8)
+    for s in range(2):                                   # L0: half g feeds inputs 16g + (8s + e)
+        for b in range(2):
+            slabs[2 * s + b] = w0f[32 * b + row, 16 * g + 8 * s + e]
+    for s in range(4):                                   # trunk-out: 64 hidden units, accumulator order
+        slabs[4 + s] = w1p[row, 32 * (s >> 1) + _mf16_unit(s & 1, g, e)]
+    for b in range(2):
+        gi = _mf16_unit(0, g, e) - geo_first_unit          # colour-0, geo rows of the trunk output (regs 0..7)
+        ok = (gi >= 0) & (gi < 15)
+        slabs[8 + b] = torch.where(ok, h0f[32 * b + row, (16 + gi).clamp(16, 30)], torch.zeros(64, 8))
+        slabs[10 + b] = h0f[32 * b + row, 8 * g + e]       # colour-0, SH components 8g + e
+    for s in range(4):                                   # colour-1
+        for b in range(2):
+            slabs[12 + 2 * s + b] = h1f[32 * b + row, 32 * (s >> 1) + _mf16_unit(s & 1, g, e)]
+    hi, lo = _split_f16(slabs)
+    frag = torch.stack([hi, lo], dim=1).contiguous()      # [slab][hi|lo][lane][8]
+    head = frag.view(torch.int16).reshape(-1).view(torch.float32)
+    assert head.numel() == MF16_SLABS * MF16_SLAB_FLOATS == MFMA_BIAS_OFF
+    tail = pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit)[MFMA_BIAS_OFF:]
+    return torch.cat([head, tail])
 
 
 # sampled last layers of the Laplace field as MFMA A fragments: rows = weight samples (padded to 128

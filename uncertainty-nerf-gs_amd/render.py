@@ -95,7 +95,8 @@ def _unpack(out: torch.Tensor) -> Dict[str, torch.Tensor]:
 
 def _uses_split(scene: NerfSceneDev) -> bool:
     f = scene.field
-    return bool(scene.split_gather and f.mode != _l.FIELD_LAPLACE and f.use_mfma and f.mfma_blob is not None)
+    return bool(scene.split_gather and f.mode != _l.FIELD_LAPLACE and f.use_mfma and f.mfma_blob is not None
+                and f.tcnn_levels is None)
 
 
 def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: int):
