@@ -240,15 +240,17 @@ def test_field_mcdropout_matches_oracle(dev, K, use_mfma, precision):
         assert not torch.equal(dens[0], dens[1]), "passes must use different masks"
 
 
-@pytest.mark.parametrize("use_mfma,n_samples", [(True, 100), (False, 100), (True, 37), (True, 128)],
-                         ids=["mfma-100", "valu-100", "mfma-37", "mfma-128"])
-def test_field_laplace_matches_oracle(dev, use_mfma, n_samples):
+@pytest.mark.parametrize("use_mfma,precision,n_samples",
+                         [(True, "f16x2", 100), (True, "fp32", 100), (False, "fp32", 100), (True, "f16x2", 37),
+                          (True, "fp32", 37), (True, "f16x2", 128), (True, "f16x2", 4)],
+                         ids=["mfma16-100", "mfma32-100", "valu-100", "mfma16-37", "mfma32-37", "mfma16-128", "mfma16-4"])
+def test_field_laplace_matches_oracle(dev, use_mfma, precision, n_samples):
     from uncertainty_nerf_gs_amd import ops, synthetic
     t, sc, _ = _scene("laplace", dev)
     wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=n_samples)
     sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
-    sd.field.use_mfma = use_mfma
-    assert sd.field.lap_blob is not None
+    sd.field.use_mfma, sd.field.precision = use_mfma, precision
+    assert sd.field.lap_blob is not None and sd.field.lap16_blob is not None
     o, d = _rays(12, 16)
     sb = _final_bins(sc, o, d)
     eb = O.spacing_to_euclidean(sb, NEAR, FAR)

@@ -1509,6 +1509,170 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
 }
 
 // --------------------------------------------------------------------------------------
+// 5b-3. Split-f16 variant of the LAPLACE kernel (inference): base network as in field_kernel_mfma16, the 4 x 128
+// sampled last-layer rows as 16 (head, block) groups of 4 k-steps x 3 products = 12 MFMAs (instead of 32),
+// operands streamed from L2 as 16-byte quads (ops.pack_laplace_heads16), one block prefetched ahead.  With the
+// matrix work cut 5x the exp / rcp epilogues (quarter-rate transcendentals) are the larger half, so register
+// quads that only hold padding rows (rows >= n_lap) are skipped.
+// --------------------------------------------------------------------------------------
+template <bool SIGMOID>
+__device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int q, int n_lap, int lane,
+                                              const f16x8 (&bhi)[4], const f16x8 (&blo)[4], int h, float& sum1,
+                                              float& sum2) {
+    sum1 = 0.f;
+    sum2 = 0.f;
+    f16x8 cur[8], nxt[8];
+    {
+        const float* f = lap + (size_t)((q * LAP_BLOCKS + 0) * 8) * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = *reinterpret_cast<const f16x8*>(f + i * 256);
+    }
+#pragma unroll
+    for (int b = 0; b < LAP_BLOCKS; ++b) {
+        if (b + 1 < LAP_BLOCKS) {
+            const float* f = lap + (size_t)((q * LAP_BLOCKS + b + 1) * 8) * 256 + lane * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nxt[i] = *reinterpret_cast<const f16x8*>(f + i * 256);
+        }
+        const float4* bp = reinterpret_cast<const float4*>(lap + LAP_BIAS_OFF + ((q * LAP_BLOCKS + b) * 2 + h) * 16);
+        float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {  // cur[2 st] = hi, cur[2 st + 1] = lo of k-step st
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st + 1], bhi[st], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st], blo[st], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st], bhi[st], acc, 0, 0, 0);
+        }
+        // register quad qd holds rows 8 qd + 4 h + (0..3) of this block: skip quads that are padding in both halves
+        const int rows = n_lap - 32 * b;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            if (8 * qd < rows) {  // uniform
+#pragma unroll
+                for (int r = 4 * qd; r < 4 * qd + 4; ++r) {
+                    float p = SIGMOID ? __builtin_amdgcn_rcpf(1.f + __expf(-acc[r])) : __expf(acc[r]);
+                    sum1 += p;
+                    sum2 += p * p;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 1 < LAP_BLOCKS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        }
+    }
+    sum1 += __shfl_xor(sum1, 32, 64);
+    sum2 += __shfl_xor(sum2, 32, 64);
+}
+
+__global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
+    extern __shared__ float lds[];
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.p.mfma16_blob);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane_c & 31, h = lane_c >> 5;
+    const uint32_t mask = (1u << a.p.log2T) - 1u;
+    const float inv_n = 1.f / (float)a.p.n_lap;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const uint32_t tpx = (num_tiles + 7u) / 8u;
+    const uint32_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
+    for (uint32_t tile = xcd * tpx + (uint32_t)slot * 4u + (uint32_t)wv; tile < tile_end; tile += (uint32_t)bpx * 4u) {
+        int lane = lane_c;
+        asm volatile("" : "+v"(lane));
+        const uint32_t rb = fastdiv(tile, div_s);
+        const int s = (int)(tile - rb * (uint32_t)a.S);
+        int64_t r = (int64_t)rb * 32 + j;
+        const bool valid = r < a.R;
+        if (!valid) r = a.R - 1;
+        const int64_t n = r * a.S + s;
+        const float* sb = a.sbins + r * (a.S + 1);
+        float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+        float t01 = e0 + e1;
+        float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
+        float px = a.origins[r * 3 + 0] + dxr * t01 / 2.f;
+        float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
+        float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
+        (void)unerf_normalize_position(px, py, pz);  // the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
+        const f32x16 feat = mf_gather_feats<true, false>(a, px, py, pz, h, mask);
+
+        // base_mlp: bare Linear 32 -> 64 (no ReLU, utils.py:22-23)
+        f32x16 hb0 = mf_bias(lds, 0, h), hb1 = mf_bias(lds, 1, h);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f16x8 bhi, blo;
+            mf16_split(feat, st, bhi, blo);
+            hb0 = mf16_mac(lds, 2 * st, lane, bhi, blo, hb0);
+            hb1 = mf16_mac(lds, 2 * st + 1, lane, bhi, blo, hb1);
+        }
+        // the 64 base outputs feed both mlp_hidden (geo) and the sampled density rows: split them once
+        f16x8 xhi[4], xlo[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) mf16_split(st < 2 ? hb0 : hb1, st & 1, xhi[st], xlo[st]);
+        f32x16 t = mf_bias(lds, 2, h);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) t = mf16_mac(lds, 4 + st, lane, xhi[st], xlo[st], t);
+        float d1, d2;
+        mf16_lap_head<false>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
+        const float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
+
+        // colour trunk: [geo15 | SH16] -> 64 -> 64
+        f32x16 c0 = mf_bias(lds, 3, h), c1 = mf_bias(lds, 4, h);
+        {
+            f16x8 bhi, blo;
+            mf16_split(t, 0, bhi, blo);
+            c0 = mf16_mac(lds, 8, lane, bhi, blo, c0);
+            c1 = mf16_mac(lds, 9, lane, bhi, blo, c1);
+            float sh[16];
+            float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
+            if (a.p.sh_remap) {
+                ux = ux * 2.f - 1.f;
+                uy = uy * 2.f - 1.f;
+                uz = uz * 2.f - 1.f;
+            }
+            unerf_sh16(ux, uy, uz, sh);
+            const uint32_t hm = 0u - (uint32_t)h;
+            float mine[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                mine[q] = __uint_as_float((__float_as_uint(sh[8 + q]) & hm) | (__float_as_uint(sh[q]) & ~hm));
+            mf16_split8(mine, bhi, blo);
+            c0 = mf16_mac(lds, 10, lane, bhi, blo, c0);
+            c1 = mf16_mac(lds, 11, lane, bhi, blo, c1);
+        }
+        c0 = mf_relu(c0);
+        c1 = mf_relu(c1);
+        f32x16 x0 = mf_bias(lds, 5, h), x1 = mf_bias(lds, 6, h);
+        mf16_layer64<2>(lds, 12, lane, c0, c1, x0, x1);
+        x0 = mf_relu(x0);
+        x1 = mf_relu(x1);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) mf16_split(st < 2 ? x0 : x1, st & 1, xhi[st], xlo[st]);
+        float mu_c[3], vsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float c1s, c2s;
+            mf16_lap_head<true>(a.p.lap16_blob, 1 + c, a.p.n_lap, lane, xhi, xlo, h, c1s, c2s);
+            mu_c[c] = c1s * inv_n;
+            vsum += fmaxf(c2s * inv_n - mu_c[c] * mu_c[c], 0.f);
+        }
+        if (valid && h == 0) {
+            a.density[n] = mu_d;
+            a.aux[n] = mu2_d - mu_d * mu_d;
+            a.aux2[n] = vsum / 3.f;
+            a.rgb[n * 3 + 0] = mu_c[0];
+            a.rgb[n * 3 + 1] = mu_c[1];
+            a.rgb[n * 3 + 2] = mu_c[2];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // 5c. level-major hash-grid gather.  One level of the main grid is 2^19 x 8 B = 4 MiB -- exactly
 // one XCD's L2.  Sample-major lookup (all 16 levels per sample) keeps 64 MiB live and runs at the
 // Infinity-Cache random-64-B-request rate (40 ms/frame inside the fused kernel, 5.05 ms per 2^18
@@ -1650,7 +1814,11 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_LAPLACE:
             UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
-            if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
+            if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS && !p->tcnn_levels) {
+                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+                hipLaunchKernelGGL(field_kernel_mfma16_laplace, dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
+                                   st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+            } else if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (p->tcnn_levels)
                     hipLaunchKernelGGL((field_kernel_mfma_laplace<false, true>), dim3(mfma_grid(tiles)), dim3(256),

@@ -269,6 +269,7 @@ class FieldDev:
         lap_blob = None
         if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
             lap_blob = f(pack_laplace_heads(kw["ws_density"], kw["ws_rgb"]))
+            kw["lap16_blob"] = f(pack_laplace_heads16(kw["ws_density"], kw["ws_rgb"]))
         return cls(mode, f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
                    f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
                    mfma_blob=blob, lap_blob=lap_blob, **kw)
@@ -449,6 +450,32 @@ def pack_laplace_heads(ws_density: torch.Tensor, ws_rgb: torch.Tensor) -> torch.
             for hh in range(2):
                 bias[q, b, hh] = bv[32 * b + _mfma_unit(r16, hh)]
     return blob
+
+
+def pack_laplace_heads16(ws_density: torch.Tensor, ws_rgb: torch.Tensor) -> torch.Tensor:
+    """Split-f16 form of pack_laplace_heads (same size, same bias region): fragments
+    [head q][block b][k-step s][hi|lo][lane][8 halves], k order = accumulator order of the 64 hidden units."""
+    wd = ws_density.detach().to("cpu", torch.float32)
+    wr = ws_rgb.detach().to("cpu", torch.float32)
+    n = wd.shape[0]
+    assert wd.shape == (n, 65) and wr.shape == (n, 195) and 1 <= n <= 32 * LAP_BLOCKS
+    assert abs(wd).max() < 6e4 and abs(wr).max() < 6e4, "sampled weights outside the f16 range"
+    heads_w = [wd[:, :64]] + [wr[:, c * 64:(c + 1) * 64] for c in range(3)]
+    lane = torch.arange(64)
+    row, g = (lane & 31)[:, None], (lane >> 5)[:, None]
+    e = torch.arange(8)[None, :]
+    slabs = torch.zeros(4, LAP_BLOCKS, 4, 64, 8)
+    for q in range(4):
+        W = torch.zeros(32 * LAP_BLOCKS, 64)
+        W[:n] = heads_w[q]
+        for b in range(LAP_BLOCKS):
+            for st in range(4):
+                slabs[q, b, st] = W[32 * b + row, 32 * (st >> 1) + _mf16_unit(st & 1, g, e)]
+    hi, lo = _split_f16(slabs)
+    frag = torch.stack([hi, lo], dim=3).contiguous()       # [q][b][s][hi|lo][lane][8]
+    head = frag.view(torch.int16).reshape(-1).view(torch.float32)
+    assert head.numel() == LAP_BIAS_OFF
+    return torch.cat([head, pack_laplace_heads(ws_density, ws_rgb)[LAP_BIAS_OFF:]])
 
 
 # ------------------------------------------------------- proposal sampling -------------
