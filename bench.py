@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_PEAK_TFLOPS = 157.3       # fp32 vector = fp32-input MFMA peak (the field MLP computes in fp32)
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector = fp32-input MFMA peak (the exact-fp32 field kernels, --exact-fp32)
+F16_PEAK_TFLOPS = 2500.0       # dense f16/bf16 MFMA peak (the split-f16 field kernels issue 3 f16 products per fp32 MAC)
 
 # algorithmic work per ray (SURVEY.md 8d / DESIGN.md "Kernels"): bytes the algorithm must touch
 def _alg(kind, K):
@@ -68,6 +69,8 @@ def main():
     ap.add_argument("--rays-per-launch", type=int, default=1 << 18)
     ap.add_argument("--overlap", action="store_true", help="sampling / shading stages on two HIP streams (experiment)")
     ap.add_argument("--split-gather", action="store_true", help="level-major gather kernel + feature planes (experiment)")
+    ap.add_argument("--exact-fp32", action="store_true",
+                    help="dense layers on the exact fp32-input MFMA kernels instead of the split-f16 ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -104,6 +107,7 @@ def main():
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
         kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
     scene = synthetic.scene_to_device(t, dev, **kw)
+    scene.field.precision = "fp32" if (args.exact_fp32 or args.split_gather) else "f16x2"
     scene.split_gather = args.split_gather
     H, W = args.height, args.width
     cam = dict(synthetic.CAMERA_1080P)
@@ -149,17 +153,26 @@ def main():
         rays_per_launch = H * W * args.steps / ksum[dom]["launches"]
         avg_s = ksum[dom]["avg_ms"] * 1e-3
         a = alg.get(dom, {"bytes": 0, "flops": 0})
-        # both roofs for the dominant kernel; the binding one (larger fraction) is reported as `bound`
+        # both roofs for the dominant kernel; the binding one (larger fraction) is reported as `bound`.
+        # Matrix roof: the exact kernels run fp32-input MFMAs (peak = the fp32 vector peak); the split-f16 kernels
+        # issue three f16 products per algorithmic MAC on the f16 matrix pipe (peak 2.5 PFLOP/s dense).
+        split = scene.field.precision == "f16x2"
         hbm_ach = a["bytes"] * rays_per_launch / avg_s / 1e9
         mfma_ach = a["flops"] * rays_per_launch / avg_s / 1e12
-        if mfma_ach / FP32_PEAK_TFLOPS > hbm_ach / HBM_PEAK_GBS:
-            roof = {"kernel": dom, "bound": "mfma", "achieved": mfma_ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "note": "fp32 arithmetic: fp32-input MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)"}
+        mfma_peak = F16_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
+        mfma_issued = 3.0 * mfma_ach if split else mfma_ach
+        if mfma_issued / mfma_peak > hbm_ach / HBM_PEAK_GBS:
+            roof = {"kernel": dom, "bound": "mfma", "achieved": mfma_ach, "peak": mfma_peak, "unit": "TFLOP/s",
+                    "note": ("algorithmic flops; the kernel issues 3x as many on the f16 matrix pipe" if split else
+                             "fp32 arithmetic: fp32-input MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)")}
         else:
-            roof = {"kernel": dom, "bound": "hbm", "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            roof = {"kernel": dom, "bound": "hbm", "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "note": "algorithmic gather bytes (8 B per hash-grid corner); the tables are L2 / Infinity-Cache "
+                            "resident, so this rate can exceed the DRAM peak -- `traffic` is what reached the fabric"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["other_roof"] = {"hbm_GBps": hbm_ach, "hbm_frac": hbm_ach / HBM_PEAK_GBS, "fp32_TFLOPs": mfma_ach,
-                              "fp32_frac": mfma_ach / FP32_PEAK_TFLOPS}
+        roof["other_roof"] = {"hbm_GBps": hbm_ach, "hbm_frac": hbm_ach / HBM_PEAK_GBS,
+                              "algorithmic_TFLOPs": mfma_ach, "matrix_pipe": "f16 (3 products per MAC)" if split else "fp32",
+                              "issued_matrix_TFLOPs": mfma_issued, "matrix_frac": mfma_issued / mfma_peak}
         roof["algorithmic_bytes_per_ray"] = a["bytes"]
         roof["algorithmic_flops_per_ray"] = a["flops"]
         roof["traffic"] = None
@@ -191,6 +204,9 @@ def main():
                                    + (f", K={K} MC-dropout passes" if K else "")
                                    + (", 100 last-layer Laplace samples" if args.method == "laplace" else ""),
                        "rays_per_step": H * W, "samples_per_ray": [256, 96, 48], "hash_grid": "16x2^19x2 fp32",
+                       "dense_layers": ("fp32 operands split into two f16 halves, 3 products on v_mfma_f32_32x32x16_f16, "
+                                        "fp32 accumulate (fp32-equivalent, DESIGN.md 4.6)" if split else
+                                        "exact fp32 (v_mfma_f32_32x32x2_f32)"),
                        "parallelism": f"views x{world}" if world > 1 else "single"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -36,7 +36,8 @@ def reduce(src, dst):
             w.writerow([k, c, n, f"{v / n:.6f}", f"{d / n:.3f}"])
 
 
-FIELD_KERNELS = {"active": "field_kernel_mfma<0, false>", "mcdropout": "field_kernel_mfma<1, false>"}
+FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false>", "field_kernel_mfma<0, false, false>", "field_kernel_mfma<0, false>"),
+                 "mcdropout": ("field_kernel_mfma16<1, false>", "field_kernel_mfma<1, false, false>", "field_kernel_mfma<1, false>")}
 
 
 def summary(d, tag):
@@ -58,8 +59,8 @@ def summary(d, tag):
                "kernels": kernels}
         with open(os.path.join(d, f"{tag}_{method}_pmc_summary.json"), "w") as f:
             json.dump(out, f, indent=1)
-        fk = FIELD_KERNELS[method]
-        if fk in kernels and "FETCH_SIZE" in kernels[fk] and "WRITE_SIZE" in kernels[fk]:
+        fk = next((k for k in FIELD_KERNELS[method] if k in kernels), None)
+        if fk and "FETCH_SIZE" in kernels[fk] and "WRITE_SIZE" in kernels[fk]:
             t = {"method": method, "K": 8 if method == "mcdropout" else 0, "rays_per_launch": 262144,
                  "source": f"profiles/{tag}_{method}_pmc_fetch.csv + {tag}_{method}_pmc_write.csv "
                            "(separate rocprofv3 --pmc passes)",

@@ -3,6 +3,9 @@
 // gfx950 only; wave = 64.  See include/unerf.h for the contract of each entry point.
 #include "unerf_common.hpp"
 
+#include <mutex>
+#include <unordered_map>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1118,13 +1121,31 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 // --------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// Two elements per step: hi = v_cvt_pk_f16_f32(x0, x1) (round to nearest even), then each residual
+// x - float(hi) is formed and rounded to f16 inside ONE mixed-precision fma (v_fma_mixlo/mixhi_f16: f16 and f32
+// sources, exact internal product and sum): 1.5 VALU per element instead of the ~3 of convert-back / subtract /
+// convert (the kernels are VALU-issue-bound once the matrix work is on the f16 pipe).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mf16_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const f16x2 hh = {(_Float16)x0, (_Float16)x1};
+    hi = __builtin_bit_cast(uint32_t, hh);
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+    lo = l;
+}
 __device__ __forceinline__ void mf16_split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+    u32x4 hv, lv;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 hh = (_Float16)x[e];
-        hi[e] = hh;
-        lo[e] = (_Float16)(x[e] - (float)hh);
+    for (int p = 0; p < 4; ++p) {
+        uint32_t hq, lq;
+        mf16_split2(x[2 * p], x[2 * p + 1], hq, lq);
+        hv[p] = hq;
+        lv[p] = lq;
     }
+    hi = __builtin_bit_cast(f16x8, hv);
+    lo = __builtin_bit_cast(f16x8, lv);
 }
 __device__ __forceinline__ void mf16_split(const f32x16& v, int s, f16x8& hi, f16x8& lo) {
     float x[8];
@@ -1190,7 +1211,8 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
         float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
         const float sel = unerf_normalize_position(px, py, pz);
-        const f32x16 feat = mf_gather_feats<(MODE != UNERF_FIELD_ACTIVE), TCNN>(a, px, py, pz, h, mask);
+        // packed fp32x2 blend: this kernel has the registers for it (123 VGPRs without) in every mode
+        const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask);
 
         // colour layer 0, SH half (pass-invariant): components 8h..8h+7 of this lane half, one k-step
         f32x16 csh0 = mf_bias(lds, 3, h), csh1 = mf_bias(lds, 4, h);
@@ -1731,9 +1753,32 @@ extern "C" int unerf_field_gather(const float* origins, const float* directions,
     return unerf_check_launch("field_gather");
 }
 
-static int mfma_grid(int64_t num_tiles) {
+// Persistent grid of the matrix kernels: exactly as many workgroups as are co-resident (occupancy x CUs, a
+// multiple of the 8 XCDs).  The ACTIVE kernels fit 3 per CU (42.6 KB LDS, <= 168 VGPRs), the K-pass and Laplace
+// kernels 2; launching 3 per CU for those left a third of the tiles to a half-empty second round.
+template <typename Kern>
+static int mfma_grid_for(Kern kernel, int64_t num_tiles) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> cache;
+    int cap = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find(reinterpret_cast<const void*>(kernel));
+        if (it != cache.end()) cap = it->second;
+    }
+    if (cap == 0) {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, UNERF_MFMA_BLOB_FLOATS * 4) != hipSuccess ||
+            per_cu < 1)
+            per_cu = 2;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipGetLastError();
+        cap = per_cu * cus;
+        if (getenv("UNERF_DEBUG_GRID")) fprintf(stderr, "[unerf] persistent grid: %d workgroups/CU x %d CUs\n", per_cu, cus);
+        std::lock_guard<std::mutex> lock(mu);
+        cache[reinterpret_cast<const void*>(kernel)] = cap;
+    }
     int64_t blocks = (num_tiles + 3) / 4;
-    const int64_t cap = 256 * 3;  // 3 workgroups of 4 waves per CU: 42.6 KB LDS each, <=168 VGPRs
     if (blocks > cap) blocks = cap;
     return (int)((blocks + 7) / 8 * 8);
 }
@@ -1769,19 +1814,19 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
             if (p->mfma16_blob && !features && !p->tcnn_levels) {  // tcnn-layout grids stay on the exact kernels
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
-                hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid(tiles)), dim3(256),
+                hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), tiles)), dim3(256),
                                    UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else if (p->mfma_blob) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (features)
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid(tiles)), dim3(256),
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
                 else if (p->tcnn_levels)
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false, true>), dim3(mfma_grid(tiles)),
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_ACTIVE, false, true>), tiles)),
                                        dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
                                        make_fastdiv((uint32_t)S));
                 else
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid(tiles)), dim3(256),
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_ACTIVE, false>), tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_ACTIVE>), grid, block, 64 * 64 * 4, st, a);
@@ -1792,20 +1837,20 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
             if (p->mfma16_blob && !features && !p->tcnn_levels) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
-                hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid(tiles)),
+                hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), tiles)),
                                    dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
                                    make_fastdiv((uint32_t)S));
             } else if (p->mfma_blob) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (features)
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid(tiles)), dim3(256),
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
                 else if (p->tcnn_levels)
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, true>), dim3(mfma_grid(tiles)),
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, true>), tiles)),
                                        dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
                                        make_fastdiv((uint32_t)S));
                 else
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid(tiles)), dim3(256),
+                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>), tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
@@ -1816,15 +1861,15 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
             if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS && !p->tcnn_levels) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
-                hipLaunchKernelGGL(field_kernel_mfma16_laplace, dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
+                hipLaunchKernelGGL(field_kernel_mfma16_laplace, dim3(mfma_grid_for(field_kernel_mfma16_laplace, tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
                                    st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
                 int64_t tiles = ((R + 31) / 32) * (int64_t)S;
                 if (p->tcnn_levels)
-                    hipLaunchKernelGGL((field_kernel_mfma_laplace<false, true>), dim3(mfma_grid(tiles)), dim3(256),
+                    hipLaunchKernelGGL((field_kernel_mfma_laplace<false, true>), dim3(mfma_grid_for((field_kernel_mfma_laplace<false, true>), tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
                 else
-                    hipLaunchKernelGGL((field_kernel_mfma_laplace<false>), dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
+                    hipLaunchKernelGGL((field_kernel_mfma_laplace<false>), dim3(mfma_grid_for((field_kernel_mfma_laplace<false>), tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
                                    st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_LAPLACE>), grid, block, 64 * 64 * 4, st, a);
@@ -1981,10 +2026,10 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     a.keep_thr = 0; a.drop_scale = 1.f;
     const int64_t tiles = ((R + 31) / 32) * (int64_t)S;
     if (p->tcnn_levels)
-        hipLaunchKernelGGL((field_kernel_mfma_laplace<true, true>), dim3(mfma_grid(tiles)), dim3(256),
+        hipLaunchKernelGGL((field_kernel_mfma_laplace<true, true>), dim3(mfma_grid_for((field_kernel_mfma_laplace<true, true>), tiles)), dim3(256),
                            UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
     else
-        hipLaunchKernelGGL((field_kernel_mfma_laplace<true>), dim3(mfma_grid(tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
+        hipLaunchKernelGGL((field_kernel_mfma_laplace<true>), dim3(mfma_grid_for((field_kernel_mfma_laplace<true>), tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
                        st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
     GgnArgs g;
     g.sbins = sbins; g.R = R; g.S = S; g.s_near = a.s_near; g.s_far = a.s_far;
