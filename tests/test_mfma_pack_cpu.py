@@ -187,3 +187,124 @@ def test_laplace_packed_heads_reproduce_sample_laplace():
         pc = torch.sigmoid(F.linear(x, ws_r[:, ch * 64:(ch + 1) * 64].double(), ws_r[:, 192 + ch].double()))
         np.testing.assert_allclose(mu_c[:, ch], pc.mean(1).numpy(), rtol=1e-9)
         np.testing.assert_allclose(var_c[:, ch], ((pc ** 2).mean(1) - pc.mean(1) ** 2).numpy(), rtol=1e-6, atol=1e-12)
+
+
+# ---- split-f16 slabs (ops.pack_field_mfma16 / pack_laplace_heads16, field_kernel_mfma16*) --------------------
+# v_mfma_f32_32x32x16_f16 lane maps: A[row l&31][k = 8(l>>5) + e], B[k = 8(l>>5) + e][col l&31], e = 0..7;
+# D as for the other 32x32 forms.  The emulation recombines hi + lo in float64, i.e. it checks the ORDER the
+# operands are packed in and that hi/lo carry the weights to ~2^-22; the three-product arithmetic itself is
+# checked on the GPU against the exact kernels.
+
+def _slabs16(blob, n_slabs):
+    raw = blob[:n_slabs * ops.MF16_SLAB_FLOATS].contiguous().view(torch.int16).view(torch.float16)
+    fr = raw.view(n_slabs, 2, 64, 8).to(torch.float64).numpy()
+    return fr[:, 0] + fr[:, 1]                      # [slab][lane][8]: hi + lo
+
+
+def mfma16(a_slab, b_vals, acc):
+    """a_slab [64 lanes, 8], b_vals [64 lanes, 8] (this lane's 8 k-values of its column) -> acc [16, 64]"""
+    A = np.zeros((32, 16))
+    B = np.zeros((16, 32))
+    for e in range(8):
+        A[I_, 8 * H_ + e] = a_slab[:, e]
+        B[8 * H_ + e, I_] = b_vals[:, e]
+    D = A @ B
+    out = acc.copy()
+    for r in range(16):
+        out[r] += D[unit(r, H_), I_]
+    return out
+
+
+def _regs(acc, s):
+    """the B operand a lane builds from accumulator registers 8s..8s+7"""
+    return np.stack([acc[8 * s + e] for e in range(8)], axis=1)
+
+
+def test_split_f16_slabs_reproduce_the_mlp():
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g) * 0.3
+    w0, b0, w1, b1 = rnd(64, 32), rnd(64), rnd(17, 64), rnd(17)
+    h0, hb0, h1, hb1, h2, hb2 = rnd(64, 31), rnd(64), rnd(64, 64), rnd(64), rnd(3, 64), rnd(3)
+    blob = ops.pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2)
+    assert blob.numel() == ops.MFMA_BLOB_FLOATS
+    # the tail (bias rows, rgb layer) is the fp32 blob's tail
+    assert torch.equal(blob[ops.MFMA_BIAS_OFF:], ops.pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2)[ops.MFMA_BIAS_OFF:])
+    sl = _slabs16(blob, ops.MF16_SLABS)
+    bias = blob[ops.MFMA_BIAS_OFF:ops.MFMA_H2_OFF].numpy().astype(np.float64).reshape(7, 2, 16)
+    binit = lambda k: np.stack([bias[k, H_, r] for r in range(16)])
+    feats, sh = rnd(32, 32).double().numpy(), rnd(32, 16).double().numpy()
+    j = I_
+    feat = np.stack([feats[j, 16 * H_ + s] for s in range(16)])                  # lane (j,h): features 16h + 0..15
+    hid = [binit(0), binit(1)]
+    for st in range(2):
+        for b in range(2):
+            hid[b] = mfma16(sl[2 * st + b], _regs(feat, st), hid[b])
+    hid = [np.maximum(a, 0) for a in hid]
+    t = binit(2)
+    for st in range(4):
+        t = mfma16(sl[4 + st], _regs(hid[st >> 1], st & 1), t)
+    shv = np.stack([sh[j, 8 * H_ + e] for e in range(8)], axis=1)
+    c = [binit(3), binit(4)]
+    for b in range(2):
+        c[b] = mfma16(sl[8 + b], _regs(t, 0), c[b])
+        c[b] = mfma16(sl[10 + b], shv, c[b])
+    c = [np.maximum(a, 0) for a in c]
+    d = [binit(5), binit(6)]
+    for st in range(4):
+        for b in range(2):
+            d[b] = mfma16(sl[12 + 2 * st + b], _regs(c[st >> 1], st & 1), d[b])
+    trunk = np.zeros((32, 32))
+    hidden2 = np.zeros((32, 64))
+    for r in range(16):
+        trunk[j, unit(r, H_)] = t[r]
+        for b in range(2):
+            hidden2[j, 32 * b + unit(r, H_)] = np.maximum(d[b][r], 0)
+    hid_ref = F.relu(F.linear(torch.from_numpy(feats), w0.double(), b0.double()))
+    t_ref = F.linear(hid_ref, w1.double(), b1.double())
+    x = torch.cat([torch.from_numpy(sh), t_ref[:, 1:16]], dim=-1)
+    x = F.relu(F.linear(x, h0.double(), hb0.double()))
+    x = F.relu(F.linear(x, h1.double(), hb1.double()))
+    # hi + lo carries each weight to ~2^-22: sums of 64 products agree to ~1e-6
+    np.testing.assert_allclose(trunk[:, :17], t_ref.numpy(), rtol=0, atol=3e-6)
+    assert np.all(trunk[:, 17:] == 0)
+    np.testing.assert_allclose(hidden2, x.numpy(), rtol=0, atol=5e-6)
+
+
+def test_split_f16_halves_are_a_22_bit_representation():
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(4096, generator=g) * torch.logspace(-3, 2, 4096)
+    hi, lo = ops._split_f16(w)
+    err = (w.double() - (hi.double() + lo.double())).abs()
+    assert (err <= w.abs().double() * 2.0 ** -21 + 3.1e-8).all()
+    # weights beyond the f16 range make the packer decline (the caller stays on the exact kernels)
+    big = torch.randn(64, 32, generator=g)
+    big[3, 5] = 7.0e4
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    assert ops.pack_field_mfma16(big, rnd(64), rnd(16, 64), rnd(16), rnd(64, 31), rnd(64), rnd(64, 64), rnd(64), rnd(3, 64), rnd(3)) is None
+
+
+def test_split_f16_laplace_heads_layout():
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g) * 0.3
+    n = 100
+    ws_d, ws_r = rnd(n, 65), rnd(n, 195)
+    lap = ops.pack_laplace_heads16(ws_d, ws_r)
+    assert lap.numel() == ops.LAP_BLOB_FLOATS
+    assert torch.equal(lap[ops.LAP_BIAS_OFF:], ops.pack_laplace_heads(ws_d, ws_r)[ops.LAP_BIAS_OFF:])
+    sl = _slabs16(lap, 4 * ops.LAP_BLOCKS * 4).reshape(4, ops.LAP_BLOCKS, 4, 64, 8)
+    x = rnd(32, 64).double().numpy()                      # 64 hidden units of 32 samples
+    xin = [np.zeros((16, 64)), np.zeros((16, 64))]        # as two accumulator blocks
+    for b in range(2):
+        for r in range(16):
+            xin[b][r] = x[I_, 32 * b + unit(r, H_)]
+    for q, W in enumerate([ws_d[:, :64]] + [ws_r[:, c * 64:(c + 1) * 64] for c in range(3)]):
+        for blk in range(ops.LAP_BLOCKS):
+            acc = np.zeros((16, 64))
+            for st in range(4):
+                acc = mfma16(sl[q, blk, st], _regs(xin[st >> 1], st & 1), acc)
+            rows = np.zeros((32, 32))                     # [sample, row-in-block]
+            for r in range(16):
+                rows[I_, unit(r, H_)] = acc[r]
+            Wp = np.zeros((128, 64))
+            Wp[:n] = W.double().numpy()
+            np.testing.assert_allclose(rows, x @ Wp[32 * blk:32 * blk + 32].T, rtol=0, atol=3e-6)

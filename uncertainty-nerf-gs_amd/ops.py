@@ -264,12 +264,14 @@ class FieldDev:
         lap = mode == _l.FIELD_LAPLACE
         blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
                                  geo_first_unit=0 if lap else 1))
-        kw["mfma16_blob"] = f(pack_field_mfma16(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2],
-                                                head_b[2], geo_first_unit=0 if lap else 1))
+        blob16 = pack_field_mfma16(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
+                                   geo_first_unit=0 if lap else 1)
+        kw["mfma16_blob"] = None if blob16 is None else f(blob16)   # None (weights beyond the f16 range): exact kernels
         lap_blob = None
         if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
             lap_blob = f(pack_laplace_heads(kw["ws_density"], kw["ws_rgb"]))
-            kw["lap16_blob"] = f(pack_laplace_heads16(kw["ws_density"], kw["ws_rgb"]))
+            lap16 = pack_laplace_heads16(kw["ws_density"], kw["ws_rgb"])
+            kw["lap16_blob"] = None if lap16 is None else f(lap16)
         return cls(mode, f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
                    f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
                    mfma_blob=blob, lap_blob=lap_blob, **kw)
@@ -363,6 +365,7 @@ def pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit: i
 # lo*lo term is 2^-22 relative).  Three f16 MFMAs at 16x the fp32-MFMA rate replace eight fp32 MFMAs.
 # The accumulator registers 8s..8s+7 of a lane in half g hold layer units 16s + 4g + (e&3) + 8(e>>2): that is
 # the k order of the next layer's B operand, so it is the k order the A fragments are packed in.
+F16_OPERAND_LIMIT = 6.0e4  # |operand| must stay below f16 max (65504) for the hi half to be finite
 MF16_SLABS = 20            # L0: 4 (step, block), trunk-out: 4 steps, colour-0: 4 (geo|SH, block), colour-1: 8
 MF16_SLAB_FLOATS = 512     # 64 lanes x 8 halves x (hi, lo) = 2 KiB
 
@@ -385,8 +388,8 @@ def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit:
     w0f, w1f, h0f, h1f = map(f, (w0, w1, h0, h1))
     out1 = w1f.shape[0]
     assert w0f.shape == (64, 32) and w1f.shape[1] == 64 and out1 <= 32 and h0f.shape == (64, 31) and h1f.shape == (64, 64)
-    assert abs(w0f).max() < 6e4 and abs(w1f).max() < 6e4 and abs(h0f).max() < 6e4 and abs(h1f).max() < 6e4, \
-        "weights outside the f16 range"
+    if max(float(abs(w).max()) for w in (w0f, w1f, h0f, h1f)) >= F16_OPERAND_LIMIT:
+        return None   # outside the f16 operand range: the caller stays on the exact fp32 kernels
     lane = torch.arange(64)
     row, g = (lane & 31)[:, None], (lane >> 5)[:, None]
     e = torch.arange(8)[None, :]
@@ -459,7 +462,8 @@ def pack_laplace_heads16(ws_density: torch.Tensor, ws_rgb: torch.Tensor) -> torc
     wr = ws_rgb.detach().to("cpu", torch.float32)
     n = wd.shape[0]
     assert wd.shape == (n, 65) and wr.shape == (n, 195) and 1 <= n <= 32 * LAP_BLOCKS
-    assert abs(wd).max() < 6e4 and abs(wr).max() < 6e4, "sampled weights outside the f16 range"
+    if max(float(abs(wd).max()), float(abs(wr).max())) >= F16_OPERAND_LIMIT:
+        return None
     heads_w = [wd[:, :64]] + [wr[:, c * 64:(c + 1) * 64] for c in range(3)]
     lane = torch.arange(64)
     row, g = (lane & 31)[:, None], (lane >> 5)[:, None]
