@@ -1119,6 +1119,20 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 // ops.pack_field_mfma16 packs the A slabs in.  LDS blob: 20 slabs x (hi|lo) x 64 lanes x 16 B = 40 KiB, then
 // the same bias rows / rgb layer as the fp32 blob (same offsets, same total size).
 // --------------------------------------------------------------------------------------
+// dropout mask only: the inverted-dropout scale 1/(1-p) is folded into the weights of the layer that follows
+// (ops.pack_field_mfma16(drop_scale=...)), which saves one multiply per hidden unit and pass
+__device__ __forceinline__ f32x16 mf_dropout_mask(f32x16 v, const uint32_t (&st)[8], uint32_t thr) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        v[2 * q] = ((st[q] & 0xFFFFu) < thr) ? v[2 * q] : 0.f;
+        v[2 * q + 1] = ((st[q] >> 16) < thr) ? v[2 * q + 1] : 0.f;
+    }
+    return v;
+}
+// sigmoid on the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1e-7 relative each) instead of the ~25-instruction
+// exact expf + IEEE division
+__device__ __forceinline__ float mf_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Two elements per step: hi = v_cvt_pk_f16_f32(x0, x1) (round to nearest even), then each residual
@@ -1269,8 +1283,8 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                     mf_mask_step(mk2);
                     mf_mask_step(mk3);
                 }
-                m0 = mf_dropout(hid0, mk0, a.keep_thr, a.drop_scale);
-                m1 = mf_dropout(hid1, mk1, a.keep_thr, a.drop_scale);
+                m0 = mf_dropout_mask(hid0, mk0, a.keep_thr);
+                m1 = mf_dropout_mask(hid1, mk1, a.keep_thr);
             }
             // trunk out: 64 -> out1 rows (row 0 density, 1..15 geo, 16 beta)
             f32x16 t = mf_bias(lds, 2, h), unused = t;
@@ -1291,10 +1305,10 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
             if (drop) {
-                d0 = mf_dropout(d0, mk2, a.keep_thr, a.drop_scale);
-                d1 = mf_dropout(d1, mk3, a.keep_thr, a.drop_scale);
+                d0 = mf_dropout_mask(d0, mk2, a.keep_thr);
+                d1 = mf_dropout_mask(d1, mk3, a.keep_thr);
             }
-            // colour 2: 64 -> 3 on the VALU in fp32 (as in the exact kernel)
+            // colour 2: 64 -> 3 on the VALU in fp32 (weights pre-scaled by the dropout scale when masks are on)
             float rgbv[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -1306,7 +1320,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc = fmaf(d1[q], w1p[q], acc);
                 acc += __shfl_xor(acc, 32, 64);
-                rgbv[c] = unerf_sigmoid(acc + lds[MF_H2_OFF + 192 + c]);
+                rgbv[c] = mf_sigmoid_fast(acc + lds[MF_H2_OFF + 192 + c]);
             }
             if (valid && h == 0) {
                 int64_t q = (int64_t)k * N + n;

@@ -264,8 +264,10 @@ class FieldDev:
         lap = mode == _l.FIELD_LAPLACE
         blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
                                  geo_first_unit=0 if lap else 1))
+        masks_on = mode == _l.FIELD_MCDROPOUT and int(kw.get("K", 0)) > 0
         blob16 = pack_field_mfma16(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
-                                   geo_first_unit=0 if lap else 1)
+                                   geo_first_unit=0 if lap else 1,
+                                   drop_scale=1.0 / (1.0 - float(kw.get("p_drop", 0.2))) if masks_on else 1.0)
         kw["mfma16_blob"] = None if blob16 is None else f(blob16)   # None (weights beyond the f16 range): exact kernels
         lap_blob = None
         if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
@@ -381,11 +383,15 @@ def _split_f16(w: torch.Tensor):
     return hi, lo
 
 
-def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit: int = 1) -> torch.Tensor:
+def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit: int = 1,
+                      drop_scale: float = 1.0) -> torch.Tensor:
     """Same arguments and same blob size as pack_field_mfma; the first 10240 floats hold the 20 split-f16
-    A-operand slabs [slab][hi|lo][lane][8 halves], the bias rows and the rgb layer follow unchanged (fp32)."""
+    A-operand slabs [slab][hi|lo][lane][8 halves], the bias rows and the rgb layer follow (fp32).
+    drop_scale = 1/(1-p) when MC-dropout masks are applied in front of the trunk-out and rgb layers: the
+    inverted-dropout scale is folded into those two weight matrices (the kernel then only zeroes units)."""
     f = lambda t: t.detach().to("cpu", torch.float32)
     w0f, w1f, h0f, h1f = map(f, (w0, w1, h0, h1))
+    w1f = w1f * float(drop_scale)
     out1 = w1f.shape[0]
     assert w0f.shape == (64, 32) and w1f.shape[1] == 64 and out1 <= 32 and h0f.shape == (64, 31) and h1f.shape == (64, 64)
     if max(float(abs(w).max()) for w in (w0f, w1f, h0f, h1f)) >= F16_OPERAND_LIMIT:
@@ -413,7 +419,7 @@ def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit:
     frag = torch.stack([hi, lo], dim=1).contiguous()      # [slab][hi|lo][lane][8]
     head = frag.view(torch.int16).reshape(-1).view(torch.float32)
     assert head.numel() == MF16_SLABS * MF16_SLAB_FLOATS == MFMA_BIAS_OFF
-    tail = pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit)[MFMA_BIAS_OFF:]
+    tail = pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, f(h2) * float(drop_scale), hb2, geo_first_unit)[MFMA_BIAS_OFF:]
     return torch.cat([head, tail])
 
 
