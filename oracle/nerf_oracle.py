@@ -463,8 +463,8 @@ def normal_noise(seed: int, draw: int, sample_idx: np.ndarray) -> np.ndarray:
     draw>>1 keys the two uniforms, the even draw takes the cosine branch, the odd one the sine."""
     base = mc_base(seed, draw >> 1, sample_idx)
     with np.errstate(over="ignore"):
-        r1 = _hash32(base + GOLDEN)
-        r2 = _hash32(base + np.uint32(2) * GOLDEN)
+        r1 = base                      # the keyed sample hash is the first uniform's word ...
+        r2 = _hash32(base + GOLDEN)    # ... one more hash gives the second (two hashes per draw pair)
     u1 = ((r1 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
     u2 = ((r2 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
     rad = np.sqrt(np.float32(-2.0) * np.log(u1)).astype(np.float32)

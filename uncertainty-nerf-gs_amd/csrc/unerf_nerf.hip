@@ -2299,9 +2299,10 @@ struct LapDepthArgs {
 };
 
 // Box-Muller on two hashed uniforms; BOTH outputs are used (cos for even draws, sin for odd ones of
-// a draw pair), with the hardware log / sin / cos (twin: oracle normal_noise)
+// a draw pair), with the hardware log / sin / cos (twin: oracle normal_noise).  `base` = mc_base(key, sample)
+// is itself the first uniform's word; the second is one more hash of it (two hashes per draw PAIR).
 __device__ __forceinline__ void unerf_normal_pair_from_hash(uint32_t base, float& z0, float& z1) {
-    uint32_t r1 = unerf_hash32(base + UNERF_GOLDEN), r2 = unerf_hash32(base + 2u * UNERF_GOLDEN);
+    const uint32_t r1 = base, r2 = unerf_hash32(base + UNERF_GOLDEN);
     float u1 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
     float u2 = ((float)(r2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
     float rad = sqrtf(-2.f * __logf(u1));
@@ -2309,24 +2310,31 @@ __device__ __forceinline__ void unerf_normal_pair_from_hash(uint32_t base, float
     z1 = rad * __sinf(6.283185307179586f * u2);
 }
 
-// get_weights for the Monte-Carlo depth draws: hardware exp (the 100-draw mean absorbs its ~1e-7 error)
+// get_weights for the Monte-Carlo depth draws on the hardware exp, ONE per sample: with e_i = exp(-delta_i
+// sigma_i) the weights are (1 - e_i) * prod_{j<i} e_j -- the transmittance as a running product (a 16-lane
+// multiplicative scan) instead of a second exp of the running sum.  The 100-draw mean absorbs the ~1e-6
+// difference from get_weights' exp(-cumsum) form (tests/test_gpu_nerf_kernels.py: explicit-noise parity).
 template <int SPL>
 __device__ __forceinline__ void group_weights_fast(const float (&dens)[SPL], const float (&delta)[SPL], int l16,
                                                    float (&w)[SPL]) {
-    float dd[SPL], lex[SPL], ls = 0.f;
+    float em[SPL], lex[SPL], lp = 1.f;
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
-        dd[e] = delta[e] * dens[e];
-        lex[e] = ls;
-        ls += dd[e];
+        em[e] = __expf(-(delta[e] * dens[e]));
+        lex[e] = lp;      // product of this lane's earlier samples
+        lp *= em[e];
     }
-    float carry = group_excl_scan<16>(ls, l16);
+    // exclusive multiplicative scan over the 16 lanes of the ray
+    float incl = lp;
 #pragma unroll
-    for (int e = 0; e < SPL; ++e) {
-        float alpha = 1.f - __expf(-dd[e]);
-        float T = __expf(-(carry + lex[e]));
-        w[e] = unerf_nan_to_num(alpha * T);
+    for (int d = 1; d < 16; d <<= 1) {
+        float t = __shfl_up(incl, d, 16);
+        if (l16 >= d) incl *= t;
     }
+    float carry = __shfl_up(incl, 1, 16);
+    carry = l16 == 0 ? 1.f : carry;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) w[e] = unerf_nan_to_num((1.f - em[e]) * (carry * lex[e]));
 }
 
 template <int SPL>
