@@ -831,7 +831,7 @@ __device__ __forceinline__ f32x16 mf_bias(const float* lds, int k, int h) {
 }
 // ReLU as a signed-integer max on the bit pattern: one v_max_i32 per element.  fmaxf() costs two
 // VALU ops here (a canonicalising v_max before the real one, IEEE maxnum), and with ~10 VALU per
-// MFMA the K-pass kernel is issue-bound (rocprof r1_03: MFMA busy 61 % + VALU busy 38 %).
+// MFMA the K-pass kernel is issue-bound (rocprof r1_04: MFMA busy 61 % + VALU busy 38 %).
 // Negative floats (incl. -0.0) have negative bit patterns -> 0; non-negative ones pass unchanged.
 __device__ __forceinline__ f32x16 mf_relu(f32x16 v) {
 #pragma unroll
@@ -970,7 +970,7 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         // tile -> (block of 32 neighbouring rays, sample index s): the 32 columns of a tile are the SAME
         // sample slot of 32 adjacent pixels, which sit in the same or neighbouring grid cells, so a gather
         // instruction presents few distinct lines to the texture-address unit (it retires ~1 divergent
-        // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_03)
+        // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_04)
         const uint32_t rb = fastdiv(tile, div_s);
         const int s = (int)(tile - rb * (uint32_t)a.S);
         int64_t r = (int64_t)rb * 32 + j;
@@ -1439,7 +1439,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         // tile -> (block of 32 neighbouring rays, sample index s): the 32 columns of a tile are the SAME
         // sample slot of 32 adjacent pixels, which sit in the same or neighbouring grid cells, so a gather
         // instruction presents few distinct lines to the texture-address unit (it retires ~1 divergent
-        // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_03)
+        // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_04)
         const uint32_t rb = fastdiv(tile, div_s);
         const int s = (int)(tile - rb * (uint32_t)a.S);
         int64_t r = (int64_t)rb * 32 + j;

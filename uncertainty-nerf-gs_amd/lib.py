@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(CSRC, "libunerf.so")
 SOURCES = ["unerf_nerf.hip", "unerf_splat.hip"]
 # -amdgpu-mfma-vgpr-form: gfx950 has one unified register file; let the MFMAs write their accumulators to
 # ordinary VGPRs so ReLU / dropout / the next layer's B operand read them without v_accvgpr_read copies
-# (97 copies per tile in the K-pass kernel, which is VALU-issue-bound; rocprof r1_03).
+# (97 copies per tile in the K-pass kernel, which is VALU-issue-bound; rocprof r1_04).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
