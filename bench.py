@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--split-gather", action="store_true", help="level-major gather kernel + feature planes (experiment)")
     ap.add_argument("--exact-fp32", action="store_true",
                     help="dense layers on the exact fp32-input MFMA kernels instead of the split-f16 ones")
+    ap.add_argument("--no-exact-check", action="store_true",
+                    help="skip the extra exact-fp32 frames rendered after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -146,6 +148,28 @@ def main():
     rays = H * W * args.steps * world
     mrays = rays / elapsed / 1e6
 
+    # Reported next to the headline, outside its timed region: the same frames with the dense layers on the
+    # exact fp32-input MFMA kernels, and how far the split-f16 image is from that exact-fp32 image.
+    exact = None
+    if scene.field.precision == "f16x2" and not args.no_exact_check:
+        scene.field.precision = "fp32"
+        n_alt = max(1, min(args.steps, 3))
+        ref = frame(args.warmup + args.steps - 1)          # also warms the exact kernels up
+        sync_all()
+        t1 = time.perf_counter()
+        for i in range(n_alt):
+            frame(args.warmup + i)
+        sync_all()
+        alt = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([alt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            alt = float(tt.item())
+        scene.field.precision = "f16x2"
+        exact = {"value": H * W * n_alt * world / alt / 1e6, "unit": "Mrays/s", "ms_per_step": alt / n_alt * 1e3,
+                 "steps": n_alt, "max_abs_rgb_diff_vs_split_f16": float((ref["rgb"] - out["rgb"]).abs().max()),
+                 "max_abs_rgb_std_diff_vs_split_f16": float((ref["rgb_std"] - out["rgb_std"]).abs().max())}
+
     if rank == 0:
         ksum = timer.summary()
         alg = _alg(args.method, K)
@@ -208,7 +232,7 @@ def main():
                                         "fp32 accumulate (fp32-equivalent, DESIGN.md 4.6)" if split else
                                         "exact fp32 (v_mfma_f32_32x32x2_f32)"),
                        "parallelism": f"views x{world}" if world > 1 else "single"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "exact_fp32_kernels": exact,
         }
         print(json.dumps(line))
     if dist is not None:

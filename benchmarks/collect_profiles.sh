@@ -17,7 +17,7 @@ cd /tmp
 stats() {  # method, extra bench args...
     local m=$1; shift
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${m}_stats" -- \
-        python3 "$ROOT/bench.py" --method "$m" --steps 4 --warmup 1 --no-cpu-baseline "$@" > "$OUT/${m}_stats.log" 2>&1
+        python3 "$ROOT/bench.py" --method "$m" --steps 4 --warmup 1 --no-cpu-baseline --no-exact-check "$@" > "$OUT/${m}_stats.log" 2>&1
     local f
     f=$(find "$OUT/${m}_stats" -name '*kernel_stats.csv' | head -1)
     [ -n "$f" ] && cp "$f" "$DST/${TAG}_${m}_kernel_stats.csv"
@@ -27,7 +27,7 @@ stats() {  # method, extra bench args...
 pmc() {  # method, set name, counters...
     local m=$1 name=$2; shift 2
     rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/${m}_pmc_$name" -- \
-        python3 "$ROOT/bench.py" --method "$m" --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/${m}_pmc_$name.log" 2>&1
+        python3 "$ROOT/bench.py" --method "$m" --steps 1 --warmup 1 --no-cpu-baseline --no-exact-check > "$OUT/${m}_pmc_$name.log" 2>&1
     local f
     f=$(find "$OUT/${m}_pmc_$name" -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && python3 "$ROOT/benchmarks/summarize_pmc.py" reduce "$f" "$DST/${TAG}_${m}_pmc_$name.csv"
