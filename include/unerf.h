@@ -183,6 +183,11 @@ typedef struct {
        exact-fp32 kernels above. */
     const float* mfma16_blob;
     const float* lap16_blob;
+    /* Scheduling hint, 0 = none: the rays [ray_offset, ray_offset + R) of this call are consecutive pixels of a
+       row-major image `image_width` wide.  The matrix kernels then take 8x4 pixel patches (instead of 32
+       consecutive pixels) as the 32 columns of a tile: fewer distinct cache lines per gather instruction.
+       Results are identical with and without the hint. */
+    int image_width;
 } unerf_field_params;
 #define UNERF_MFMA_BLOB_FLOATS 10660
 #define UNERF_LAP_BLOB_FLOATS 33280

@@ -424,3 +424,23 @@ def test_split_f16_matrix_kernels_are_fp32_equivalent(dev, kind, kw):
     assert (split[1] - exact[1]).abs().max() <= 1e-6, (split[1] - exact[1]).abs().max()
     if kind == "active":
         assert (split[2] - exact[2]).abs().max() <= 2e-6 * exact[2].abs().max()
+
+
+@pytest.mark.parametrize("kind,kw,precision", [("active", {}, "f16x2"), ("active", {}, "fp32"),
+                                               ("mcdropout", dict(K=2, seed=11, p_drop=0.2), "f16x2")])
+@pytest.mark.parametrize("W,R,offset", [(40, 40 * 9, 0), (37, 37 * 6 + 5, 37 * 3 + 11), (64, 300, 64 * 2), (8, 8 * 4, 8)])
+def test_pixel_patch_tiles_change_nothing(dev, kind, kw, precision, W, R, offset):
+    """image_width only regroups the 32 columns of a tile into 8x4 pixel patches (a locality hint): every
+    (ray, sample) result must be bit-identical, for ragged widths, partial bands and mid-row offsets."""
+    from uncertainty_nerf_gs_amd import ops
+    t, sc, sd = _scene(kind, dev, **kw)
+    sd.field.precision = precision
+    g = torch.Generator().manual_seed(W * 1000 + R)
+    o = torch.randn(R, 3, generator=g) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    sb = _final_bins(sc, o, d)
+    args = (o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
+    a = ops.field_fwd(*args, ray_offset=offset)
+    b = ops.field_fwd(*args, ray_offset=offset, image_width=W)
+    for x, y in zip(a, b):
+        assert (x is None and y is None) or torch.equal(x, y)

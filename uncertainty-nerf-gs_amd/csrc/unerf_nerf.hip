@@ -587,6 +587,19 @@ extern "C" int unerf_weights_pdf_resample(const float* density, const float* sbi
 //    [feature][lane] (bank-conflict free), weights stream through the scalar cache
 //    (uniform addresses -> s_load), accumulators are static registers.
 // ======================================================================================
+// Which 32 rays form the columns of a matrix-kernel tile.  Default: 32 consecutive rays.  When the caller says
+// that its rays are consecutive pixels of a row-major image (unerf_field_params.image_width), a tile is an
+// 8 x 4 PIXEL PATCH instead: neighbouring samples then sit in fewer distinct grid cells on the fine levels, so a
+// gather instruction touches fewer cache lines (the texture-address unit is what binds the split-f16 ACTIVE
+// kernel).  Pure scheduling: every (ray, sample) is computed exactly as before.
+struct TileMap {
+    uint32_t img_w;      // 0: consecutive rays
+    uint32_t pcols;      // 8-pixel patch columns per 4-row band
+    FastDiv div_pcols;
+    int64_t g0;          // index of local ray 0 in the image
+    int64_t first_row;   // first image row of the first band touched by this launch
+};
+
 struct FieldArgs {
     const float* origins;
     const float* dirs;
@@ -603,7 +616,39 @@ struct FieldArgs {
     uint32_t keep_thr;
     float drop_scale;
     const float* features;  // optional [16][N][2] level-major planes from unerf_field_gather (MFMA kernel)
+    TileMap tm;
 };
+
+// ray of column j of ray-block rb (a tile is (rb, sample index)); invalid columns are clamped by the caller
+__device__ __forceinline__ void tile_ray(const FieldArgs& a, uint32_t rb, int j, int64_t& r, bool& valid) {
+    if (a.tm.img_w == 0) {  // uniform
+        r = (int64_t)rb * 32 + j;
+        valid = r < a.R;
+    } else {
+        const uint32_t band = fastdiv(rb, a.tm.div_pcols), pc = rb - band * a.tm.pcols;
+        const uint32_t x = pc * 8u + (uint32_t)(j & 7);
+        const int64_t y = a.tm.first_row + (int64_t)band * 4 + (j >> 3);
+        r = y * (int64_t)a.tm.img_w + x - a.tm.g0;
+        valid = x < a.tm.img_w && r >= 0 && r < a.R;
+    }
+}
+
+// host side: fills a.tm and returns the number of tiles
+static int64_t make_tiles(FieldArgs& a, int image_width) {
+    a.tm.img_w = 0; a.tm.pcols = 0; a.tm.div_pcols = make_fastdiv(1); a.tm.g0 = 0; a.tm.first_row = 0;
+    if (image_width >= 8 && a.R >= 4 * (int64_t)image_width) {   // at least one full band, else 1-D tiles
+        const int64_t g0 = a.ray_offset, g1 = a.ray_offset + a.R - 1;
+        const int64_t band0 = (g0 / image_width) / 4, band1 = (g1 / image_width) / 4;
+        const int64_t pcols = (image_width + 7) / 8;
+        const int64_t tiles = (band1 - band0 + 1) * pcols * (int64_t)a.S;
+        if (tiles < (1ll << 28)) {
+            a.tm.img_w = (uint32_t)image_width; a.tm.pcols = (uint32_t)pcols; a.tm.div_pcols = make_fastdiv((uint32_t)pcols);
+            a.tm.g0 = g0; a.tm.first_row = band0 * 4;
+            return tiles;
+        }
+    }
+    return ((a.R + 31) / 32) * (int64_t)a.S;
+}
 
 // acc[o] = b[o] + sum_i act[i] * Wt[i][o]   (sequential over i, fused multiply-add)
 template <int IN, int OUT>
@@ -973,8 +1018,9 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_04)
         const uint32_t rb = fastdiv(tile, div_s);
         const int s = (int)(tile - rb * (uint32_t)a.S);
-        int64_t r = (int64_t)rb * 32 + j;
-        const bool valid = r < a.R;
+        int64_t r;
+        bool valid;
+        tile_ray(a, rb, j, r, valid);
         if (!valid) r = a.R - 1;
         const int64_t n = r * a.S + s;
         const float* sb = a.sbins + r * (a.S + 1);
@@ -1213,8 +1259,9 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         asm volatile("" : "+v"(lane));
         const uint32_t rb = fastdiv(tile, div_s);
         const int s = (int)(tile - rb * (uint32_t)a.S);
-        int64_t r = (int64_t)rb * 32 + j;
-        const bool valid = r < a.R;
+        int64_t r;
+        bool valid;
+        tile_ray(a, rb, j, r, valid);
         if (!valid) r = a.R - 1;
         const int64_t n = r * a.S + s;
         const float* sb = a.sbins + r * (a.S + 1);
@@ -1442,8 +1489,9 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_04)
         const uint32_t rb = fastdiv(tile, div_s);
         const int s = (int)(tile - rb * (uint32_t)a.S);
-        int64_t r = (int64_t)rb * 32 + j;
-        const bool valid = r < a.R;
+        int64_t r;
+        bool valid;
+        tile_ray(a, rb, j, r, valid);
         if (!valid) r = a.R - 1;
         const int64_t n = r * a.S + s;
         const float* sb = a.sbins + r * (a.S + 1);
@@ -1623,8 +1671,9 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         asm volatile("" : "+v"(lane));
         const uint32_t rb = fastdiv(tile, div_s);
         const int s = (int)(tile - rb * (uint32_t)a.S);
-        int64_t r = (int64_t)rb * 32 + j;
-        const bool valid = r < a.R;
+        int64_t r;
+        bool valid;
+        tile_ray(a, rb, j, r, valid);
         if (!valid) r = a.R - 1;
         const int64_t n = r * a.S + s;
         const float* sb = a.sbins + r * (a.S + 1);
@@ -1827,11 +1876,11 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
             if (p->mfma16_blob && !features && !p->tcnn_levels) {  // tcnn-layout grids stay on the exact kernels
-                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+                int64_t tiles = make_tiles(a, p->image_width);
                 hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), tiles)), dim3(256),
                                    UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else if (p->mfma_blob) {
-                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+                int64_t tiles = make_tiles(a, p->image_width);
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
@@ -1850,12 +1899,12 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->out1 == 16, "field_fwd MCDROPOUT: out1 must be 16");
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
             if (p->mfma16_blob && !features && !p->tcnn_levels) {
-                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+                int64_t tiles = make_tiles(a, p->image_width);
                 hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), tiles)),
                                    dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
                                    make_fastdiv((uint32_t)S));
             } else if (p->mfma_blob) {
-                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+                int64_t tiles = make_tiles(a, p->image_width);
                 if (features)
                     hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
@@ -1874,11 +1923,11 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
             if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS && !p->tcnn_levels) {
-                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+                int64_t tiles = make_tiles(a, p->image_width);
                 hipLaunchKernelGGL(field_kernel_mfma16_laplace, dim3(mfma_grid_for(field_kernel_mfma16_laplace, tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
                                    st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
-                int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+                int64_t tiles = make_tiles(a, p->image_width);
                 if (p->tcnn_levels)
                     hipLaunchKernelGGL((field_kernel_mfma_laplace<false, true>), dim3(mfma_grid_for((field_kernel_mfma_laplace<false, true>), tiles)), dim3(256),
                                        UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
@@ -2038,7 +2087,7 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = 0;
     a.p = *p; a.density = sigma; a.rgb = col; a.aux = X; a.aux2 = Hc; a.features = nullptr;
     a.keep_thr = 0; a.drop_scale = 1.f;
-    const int64_t tiles = ((R + 31) / 32) * (int64_t)S;
+    const int64_t tiles = make_tiles(a, 0);
     if (p->tcnn_levels)
         hipLaunchKernelGGL((field_kernel_mfma_laplace<true, true>), dim3(mfma_grid_for((field_kernel_mfma_laplace<true, true>), tiles)), dim3(256),
                            UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));

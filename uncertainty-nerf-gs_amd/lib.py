@@ -99,6 +99,7 @@ class FieldParams(C.Structure):
         ("mfma_blob", C.c_void_p), ("lap_blob", C.c_void_p),
         ("tcnn_levels", C.c_void_p),
         ("mfma16_blob", C.c_void_p), ("lap16_blob", C.c_void_p),
+        ("image_width", C.c_int),
     ]
 
 

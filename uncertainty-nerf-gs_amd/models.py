@@ -207,7 +207,7 @@ class _NerfactoBase(nn.Module):
         lists: Dict[str, List[torch.Tensor]] = {}
         for s in range(0, H * W, rpl):
             out = render.render_rays(scene, o[s:s + rpl], d[s:s + rpl], ray_offset=s, total_rays=H * W, clip=clip,
-                                     **self._render_kwargs())
+                                     image_width=W, **self._render_kwargs())
             for k, v in out.items():
                 lists.setdefault(k, []).append(v)
         return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}

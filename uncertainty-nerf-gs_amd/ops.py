@@ -288,7 +288,7 @@ class FieldDev:
             _p(self.mfma_blob) if self.use_mfma else None, _p(self.lap_blob) if self.use_mfma else None,
             _p(self.tcnn_levels, torch.int32),
             _p(self.mfma16_blob) if (self.use_mfma and self.precision == "f16x2") else None,
-            _p(self.lap16_blob) if (self.use_mfma and self.precision == "f16x2") else None)
+            _p(self.lap16_blob) if (self.use_mfma and self.precision == "f16x2") else None, 0)
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------
@@ -549,8 +549,9 @@ def field_gather(origins, directions, sbins, field: FieldDev, near: float, far: 
 
 
 def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0,
-              features: Optional[torch.Tensor] = None):
-    """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h)"""
+              features: Optional[torch.Tensor] = None, image_width: int = 0):
+    """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h).  image_width > 0 tells the kernel that
+    rays [ray_offset, ray_offset+R) are consecutive pixels of a row-major image (8x4-pixel tiles: same results)."""
     lib = _l.load()
     R, S = sbins.shape[0], sbins.shape[1] - 1
     B = max(field.K, 1) if field.mode == _l.FIELD_MCDROPOUT else 1
@@ -560,6 +561,7 @@ def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: flo
     aux = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
     aux2 = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode == _l.FIELD_LAPLACE else None
     cs = field.cstruct()
+    cs.image_width = int(image_width)
     with _ctx(dev):
         _run("field_fwd", lambda: lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, ray_offset,
                                      C.byref(cs), _p(features), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()))

@@ -108,9 +108,10 @@ def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: i
 
 def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, feats, clip, ray_offset: int = 0,
                   depth_noise: Optional[torch.Tensor] = None, depth_draws: int = 100, depth_seed: int = 0,
-                  keep_density: bool = False) -> Dict[str, torch.Tensor]:
+                  keep_density: bool = False, image_width: int = 0) -> Dict[str, torch.Tensor]:
     f = scene.field
-    density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset, features=feats)
+    density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset, features=feats,
+                                            image_width=image_width)
     kw = dict(clip_minmax=clip, ray_offset=ray_offset, chunk_rays=scene.chunk_rays)
     res: Dict[str, torch.Tensor] = {}
     if f.mode == _l.FIELD_ACTIVE:
@@ -183,7 +184,7 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
         if not overlap or len(starts) == 1:
             for start in starts:
                 o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start))
-                out = render_rays(scene, o, d, ray_offset=start, total_rays=total, clip=clip, **shade_kw)
+                out = render_rays(scene, o, d, ray_offset=start, total_rays=total, clip=clip, image_width=W, **shade_kw)
                 for k, v in out.items():
                     lists.setdefault(k, []).append(v)
         else:
@@ -201,7 +202,7 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
                             t.record_stream(s_shade)
                 with torch.cuda.stream(s_shade):
                     s_shade.wait_event(ev)
-                    out = shading_stage(scene, o, d, sb, pds, feats, clip, start, **shade_kw)
+                    out = shading_stage(scene, o, d, sb, pds, feats, clip, start, image_width=W, **shade_kw)
                     for v in out.values():
                         v.record_stream(cur)
                 for k, v in out.items():
