@@ -113,7 +113,11 @@ typedef struct {
 int unerf_proposal_density(const float* origins, const float* directions, const float* sbins,
                            int64_t sbins_stride, int64_t R, int n, float near_plane, float far_plane,
                            const unerf_density_net* net /* host struct of device ptrs */,
-                           float average_init_density, float* density_out, void* stream);
+                           float average_init_density, float* density_out,
+                           int64_t ray_offset, int image_width /* scheduling hint, 0 = none: rays [ray_offset,
+                           ray_offset + R) are consecutive pixels of a row-major image this wide; a wave then
+                           evaluates an 8x8 pixel patch at one sample index.  Same results either way. */,
+                           void* stream);
 
 /* ------------------------------------------- weights + PDF resampling --
  * Replaces RaySamples.get_weights + PDFSampler.generate_ray_samples (eval branch) inside

@@ -444,3 +444,21 @@ def test_pixel_patch_tiles_change_nothing(dev, kind, kw, precision, W, R, offset
     b = ops.field_fwd(*args, ray_offset=offset, image_width=W)
     for x, y in zip(a, b):
         assert (x is None and y is None) or torch.equal(x, y)
+
+
+@pytest.mark.parametrize("level", [0, 1])
+@pytest.mark.parametrize("W,R,offset", [(40, 40 * 17, 0), (37, 37 * 9 + 5, 37 * 3 + 11), (16, 16 * 8, 16 * 8)])
+def test_proposal_pixel_patch_schedule_changes_nothing(dev, level, W, R, offset):
+    """image_width only changes which (ray, sample) a thread evaluates (8x8 pixel patch x one sample index per
+    wave): bit-identical densities for ragged widths, partial bands, mid-row offsets, shared and per-ray bins."""
+    from uncertainty_nerf_gs_amd import ops
+    t, sc, sd = _scene("active", dev)
+    g = torch.Generator().manual_seed(W + R + level)
+    o = torch.randn(R, 3, generator=g) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    n = 256 if level == 0 else 96
+    sb = O.initial_spacing_bins(n) if level == 0 else torch.sort(torch.rand(R, n + 1, generator=g), dim=-1).values
+    args = (o.to(dev), d.to(dev), sb.contiguous().to(dev), sd.props[level], NEAR, FAR, 0.01)
+    a = ops.proposal_density(*args)
+    b = ops.proposal_density(*args, ray_offset=offset, image_width=W)
+    assert torch.equal(a, b)

@@ -261,15 +261,33 @@ struct PropArgs {
     float* out;
     FastDiv fd;  // by n; used when R * n < 2^31
     int small;
+    // Pixel-patch schedule (image_width hint): a workgroup = an 8x8 pixel patch x 4 consecutive sample indices,
+    // a wave = the 64 pixels of the patch at ONE sample index.  Neighbouring pixels at equal depth sit in the
+    // same one or two grid cells, so a gather instruction touches a handful of cache lines instead of the
+    // ~20 of 64 consecutive samples along one ray (the proposal kernels saturate the texture-address unit).
+    uint32_t img_w, pcols, nsg;   // img_w = 0: linear schedule; nsg = ceil(n / 4) sample groups
+    FastDiv div_nsg, div_pcols;
+    int64_t g0, first_row;
 };
 
 template <int L, int HID>
 __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.R * a.n) return;
     int64_t r;
     int i;
-    if (a.small) {  // uniform
+    if (a.img_w) {  // uniform
+        const uint32_t patch = fastdiv(blockIdx.x, a.div_nsg), sg = blockIdx.x - patch * a.nsg;
+        const uint32_t band = fastdiv(patch, a.div_pcols), pc = patch - band * a.pcols;
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t x = pc * 8u + (lane & 7u);
+        const int64_t y = a.first_row + (int64_t)band * 8 + (lane >> 3);
+        r = y * (int64_t)a.img_w + x - a.g0;
+        i = (int)(sg * 4u + (threadIdx.x >> 6));
+        if (x >= a.img_w || r < 0 || r >= a.R || i >= a.n) return;
+        idx = r * a.n + i;
+    } else if (idx >= a.R * a.n) {
+        return;
+    } else if (a.small) {  // uniform
         const uint32_t r32 = fastdiv((uint32_t)idx, a.fd);
         r = r32;
         i = (int)((uint32_t)idx - r32 * (uint32_t)a.n);
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
 extern "C" int unerf_proposal_density(const float* origins, const float* directions, const float* sbins,
                                       int64_t sbins_stride, int64_t R, int n, float near_plane, float far_plane,
                                       const unerf_density_net* net, float average_init_density, float* density_out,
-                                      void* stream) {
+                                      int64_t ray_offset, int image_width, void* stream) {
     UNERF_REQUIRE(origins && directions && sbins && net && density_out, "proposal_density: null pointer");
     UNERF_REQUIRE(net->table && (net->scalings || net->tcnn_levels) && net->w0t && net->b0 && net->w1t && net->b1,
                   "proposal_density: null pointer inside unerf_density_net");
@@ -350,7 +368,19 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
     a.net = *net; a.avg = average_init_density; a.out = density_out;
     a.fd = make_fastdiv((uint32_t)n); a.small = (R * (int64_t)n < (1ll << 31)) ? 1 : 0;
+    a.img_w = 0; a.pcols = 0; a.nsg = 0; a.div_nsg = a.div_pcols = make_fastdiv(1); a.g0 = 0; a.first_row = 0;
     dim3 grid(blocks_for(R * (int64_t)n, 256)), block(256);
+    if (image_width >= 8 && R >= 8 * (int64_t)image_width && ray_offset >= 0) {  // at least one full 8-row band
+        const int64_t band0 = (ray_offset / image_width) / 8, band1 = ((ray_offset + R - 1) / image_width) / 8;
+        const int64_t pcols = (image_width + 7) / 8, nsg = (n + 3) / 4;
+        const int64_t blocks = (band1 - band0 + 1) * pcols * nsg;
+        if (blocks < (1ll << 31)) {
+            a.img_w = (uint32_t)image_width; a.pcols = (uint32_t)pcols; a.nsg = (uint32_t)nsg;
+            a.div_nsg = make_fastdiv((uint32_t)nsg); a.div_pcols = make_fastdiv((uint32_t)pcols);
+            a.g0 = ray_offset; a.first_row = band0 * 8;
+            grid = dim3((unsigned)blocks);
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (net->L == 5 && net->hidden == 16) hipLaunchKernelGGL((prop_density_kernel<5, 16>), grid, block, 0, st, a);
     else if (net->L == 5 && net->hidden == 64) hipLaunchKernelGGL((prop_density_kernel<5, 64>), grid, block, 0, st, a);

@@ -116,7 +116,7 @@ SIGNATURES = {
     "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "unerf_hashgrid_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "unerf_hashgrid_fwd_tcnn": (_i, [_vp, _vp, C.POINTER(TcnnLevel), _i64, _i, _vp, _vp, _vp]),
-    "unerf_proposal_density": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, C.POINTER(DensityNet), _f, _vp, _vp]),
+    "unerf_proposal_density": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, C.POINTER(DensityNet), _f, _vp, _i64, _i, _vp]),
     "unerf_weights_pdf_resample": (_i, [_vp, _vp, _i64, _i64, _i, _f, _f, _vp, _i, _f, _f, _vp, _vp, _vp, _vp,
                                         _i64, _i64, _vp]),
     "unerf_field_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i64, C.POINTER(FieldParams), _vp, _vp, _vp, _vp, _vp,

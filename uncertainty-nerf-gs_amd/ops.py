@@ -491,8 +491,10 @@ def pack_laplace_heads16(ws_density: torch.Tensor, ws_rgb: torch.Tensor) -> torc
 # ------------------------------------------------------- proposal sampling -------------
 
 def proposal_density(origins, directions, sbins, net: DensityNetDev, near: float, far: float,
-                     average_init_density: float, n: Optional[int] = None) -> torch.Tensor:
-    """sbins: [n+1] shared row or [R,n+1] per ray -> density [R,n]"""
+                     average_init_density: float, n: Optional[int] = None, ray_offset: int = 0,
+                     image_width: int = 0) -> torch.Tensor:
+    """sbins: [n+1] shared row or [R,n+1] per ray -> density [R,n].  image_width > 0: the rays are pixels
+    [ray_offset, ray_offset + R) of a row-major image (8x8-pixel-patch schedule, same results)."""
     lib = _l.load()
     R = origins.shape[0]
     stride = 0 if sbins.dim() == 1 else sbins.shape[1]
@@ -501,7 +503,8 @@ def proposal_density(origins, directions, sbins, net: DensityNetDev, near: float
     cs = net.cstruct()
     with _ctx(origins.device):
         _run(f"proposal_density_{n}", lambda: lib.unerf_proposal_density(_p(origins), _p(directions), _p(sbins), stride, R, n, near, far,
-                                            C.byref(cs), average_init_density, _p(out), _stream()))
+                                            C.byref(cs), average_init_density, _p(out), ray_offset, image_width,
+                                            _stream()))
     return out
 
 

@@ -68,14 +68,14 @@ class NerfSceneDev:
 
 
 def sample_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Tensor, clip: Optional[torch.Tensor],
-                ray_offset: int = 0, want_prop_depth: bool = True):
+                ray_offset: int = 0, want_prop_depth: bool = True, image_width: int = 0):
     """ProposalNetworkSampler at eval.  -> (final spacing bins [R,S+1], [prop_depth_0, prop_depth_1])"""
     sb = scene.const("bins", scene.num_prop[0])
     prop_depths = []
     n_iter = len(scene.props)
     for lvl in range(n_iter):
         dens = ops.proposal_density(origins, directions, sb, scene.props[lvl], scene.near, scene.far,
-                                    scene.prop_average_init_density)
+                                    scene.prop_average_init_density, ray_offset=ray_offset, image_width=image_width)
         m = scene.num_prop[lvl + 1] if lvl + 1 < n_iter else scene.num_nerf
         last = lvl + 1 == n_iter
         sb, pd, _ = ops.weights_pdf_resample(dens, sb, scene.const("u", m), scene.near, scene.far,
@@ -99,9 +99,9 @@ def _uses_split(scene: NerfSceneDev) -> bool:
                 and f.tcnn_levels is None)
 
 
-def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: int):
+def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: int, image_width: int = 0):
     """-> (final spacing bins, prop depths, feature planes | None)"""
-    sb, prop_depths = sample_rays(scene, origins, directions, clip, ray_offset)
+    sb, prop_depths = sample_rays(scene, origins, directions, clip, ray_offset, image_width=image_width)
     feats = ops.field_gather(origins, directions, sb, scene.field, scene.near, scene.far) if _uses_split(scene) else None
     return sb, prop_depths, feats
 
@@ -162,7 +162,8 @@ def render_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Te
     R = origins.shape[0]
     if clip is None:
         clip = ops.new_clip_buffer((total_rays or (ray_offset + R)), scene.chunk_rays, origins.device)
-    sb, prop_depths, feats = sampling_stage(scene, origins, directions, clip, ray_offset)
+    sb, prop_depths, feats = sampling_stage(scene, origins, directions, clip, ray_offset,
+                                            image_width=shade_kw.get("image_width", 0))
     return shading_stage(scene, origins, directions, sb, prop_depths, feats, clip, ray_offset, **shade_kw)
 
 
@@ -194,7 +195,7 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
             for start in starts:
                 with torch.cuda.stream(s_samp):
                     o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start))
-                    sb, pds, feats = sampling_stage(scene, o, d, clip, start)
+                    sb, pds, feats = sampling_stage(scene, o, d, clip, start, image_width=W)
                     ev = torch.cuda.Event()
                     ev.record(s_samp)
                     for t in (o, d, sb, feats, *pds):   # handed to the other stream: keep the allocator honest
