@@ -47,7 +47,7 @@ def test_bad_shapes_are_rejected(lib):
     rc = h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, 4, 4, 10, 10, 1, 1, None, None)
     assert rc == -1 and b"outside" in h.unerf_last_error()
     net = lib.DensityNet(1, 1, 7, 17, 1, 1, 1, 1, 16, None, 0)
-    rc = h.unerf_proposal_density(1, 1, 1, 0, 4, 256, 0.05, 1000.0, C.byref(net), 0.01, 1, None)
+    rc = h.unerf_proposal_density(1, 1, 1, 0, 4, 256, 0.05, 1000.0, C.byref(net), 0.01, 1, 0, 0, None)
     assert rc == -1 and b"unsupported" in h.unerf_last_error()
     rc = h.unerf_weights_pdf_resample(1, 1, 0, 4, 300, 0.05, 1000.0, 1, 96, 0.01, 1e-5, 1, None, None, None, 0, 32768,
                                       None)
