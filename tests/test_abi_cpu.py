@@ -78,3 +78,33 @@ def test_product_package_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+def test_ctypes_structs_match_the_header_layout(lib, tmp_path):
+    """sizeof / offsetof of every parameter struct, as a C compiler sees include/unerf.h, against the ctypes
+    mirrors in lib.py (a silent mismatch would hand the kernels garbage pointers)."""
+    import os
+    import subprocess
+    structs = {"unerf_density_net": lib.DensityNet, "unerf_field_params": lib.FieldParams, "unerf_tcnn_level": lib.TcnnLevel}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "unerf.h"', 'int main(void) {']
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} SIZEOF %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-I", inc, "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for row in out.strip().splitlines():
+        cname, what, val = row.split()
+        ct = structs[cname]
+        if what == "SIZEOF":
+            assert C.sizeof(ct) == int(val), (cname, C.sizeof(ct), val)
+        else:
+            assert getattr(ct, what).offset == int(val), (cname, what, getattr(ct, what).offset, val)
+        seen += 1
+    assert seen == sum(len(ct._fields_) + 1 for ct in structs.values())
