@@ -73,19 +73,65 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, const FastDiv& f) {
 // ======================================================================================
 // wave / group helpers
 // ======================================================================================
+// Cross-lane traffic on DPP (data-parallel primitives: the lane permutation rides on the consuming VALU
+// instruction) instead of __shfl_* (which compile to ds_bpermute_b32 through the LDS crossbar plus address,
+// compare and select instructions: ~5 VALU + 1 LDS op per scan step).  The PDF, composite and depth-draw
+// kernels are VALU-bound and spend a fifth of their instructions in scans.  gfx9 DPP controls:
+// row_shr:n = 0x110+n (within a 16-lane row, zero fill), row_bcast:15 = 0x142, row_bcast:31 = 0x143,
+// wave_shr:1 = 0x138, quad_perm = 0x00-0xFF, row_half_mirror = 0x141, row_mirror = 0x140.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v) {  // lanes without a source (or masked-off rows) read 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f_or(float v, float fill) {  // lanes without a source lane read `fill`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
+}
+
+// sum over a WIDTH-lane group (16: one DPP row; 64: the wave), result in every lane
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, WIDTH);
+    static_assert(WIDTH == 16 || WIDTH == 64, "group width");
+    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);   // row_half_mirror
+    v += dpp_f<0x140>(v);   // row_mirror: every lane of a row holds the row sum
+    if (WIDTH == 64) {
+        v += dpp_f<0x142, 0xA>(v);   // rows 1,3 += row sums of rows 0,2
+        v += dpp_f<0x143, 0xC>(v);   // rows 2,3 += sum of rows 0,1  -> lane 63 holds the total
+        v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    }
     return v;
 }
-// inclusive scan over a WIDTH-lane group
 template <int WIDTH>
-__device__ __forceinline__ float group_incl_scan(float v, int lane_in_group) {
-#pragma unroll
-    for (int d = 1; d < WIDTH; d <<= 1) {
-        float t = __shfl_up(v, d, WIDTH);
-        if (lane_in_group >= d) v += t;
+__device__ __forceinline__ int group_sum_i(int v) {
+    static_assert(WIDTH == 16 || WIDTH == 64, "group width");
+    v += dpp_i<0xB1>(v);
+    v += dpp_i<0x4E>(v);
+    v += dpp_i<0x141>(v);
+    v += dpp_i<0x140>(v);
+    if (WIDTH == 64) {
+        v += dpp_i<0x142, 0xA>(v);
+        v += dpp_i<0x143, 0xC>(v);
+        v = __builtin_amdgcn_readlane(v, 63);
+    }
+    return v;
+}
+// inclusive scan over a WIDTH-lane group (Hillis-Steele inside the 16-lane rows, then the row totals)
+template <int WIDTH>
+__device__ __forceinline__ float group_incl_scan(float v, int /*lane_in_group*/) {
+    static_assert(WIDTH == 16 || WIDTH == 64, "group width");
+    v += dpp_f<0x111>(v);
+    v += dpp_f<0x112>(v);
+    v += dpp_f<0x114>(v);
+    v += dpp_f<0x118>(v);
+    if (WIDTH == 64) {
+        v += dpp_f<0x142, 0xA>(v);
+        v += dpp_f<0x143, 0xC>(v);
     }
     return v;
 }
@@ -94,9 +140,8 @@ __device__ __forceinline__ float group_incl_scan(float v, int lane_in_group) {
 // the low bits of small prefixes behind a large element and turns inf - inf into NaN.)
 template <int WIDTH>
 __device__ __forceinline__ float group_excl_scan(float v, int lane_in_group) {
-    float incl = group_incl_scan<WIDTH>(v, lane_in_group);
-    float up = __shfl_up(incl, 1, WIDTH);
-    return lane_in_group == 0 ? 0.f : up;
+    const float incl = group_incl_scan<WIDTH>(v, lane_in_group);
+    return WIDTH == 16 ? dpp_f<0x111>(incl) : dpp_f<0x138>(incl);   // row_shr:1 / wave_shr:1, zero fill
 }
 
 // ======================================================================================
@@ -490,8 +535,7 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
         int cnt = 0;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) cnt += (k0 + e < n && (cbase + lc[e]) < 0.5f) ? 1 : 0;
-#pragma unroll
-        for (int msk = 32; msk >= 1; msk >>= 1) cnt += __shfl_xor(cnt, msk, 64);
+        cnt = group_sum_i<64>(cnt);
         int idx = min(cnt, n - 1);
         int owner = idx / EPL, slot = idx - owner * EPL;
         float val = 0.f;
@@ -2221,15 +2265,13 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
         wt += wd[e] * steps[e];
     }
     float tot = group_incl_scan<16>(ls, l16);
-    float cbase = __shfl_up(tot, 1, 16);
-    if (l16 == 0) cbase = 0.f;
+    float cbase = dpp_f<0x111>(tot);   // row_shr:1, lane 0 of the group reads 0
     float acc = __shfl(tot, 15, 16);
     wt = group_sum<16>(wt);
     int cnt = 0;
 #pragma unroll
     for (int e = 0; e < SPL; ++e) cnt += ((cbase + lc[e]) < 0.5f) ? 1 : 0;
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 16);
+    cnt = group_sum_i<16>(cnt);
     int idx = min(cnt, S - 1);
     int owner = idx / SPL, slot = idx - owner * SPL;
     float depth = 0.f;
@@ -2404,14 +2446,13 @@ __device__ __forceinline__ void group_weights_fast(const float (&dens)[SPL], con
         lp *= em[e];
     }
     // exclusive multiplicative scan over the 16 lanes of the ray
+    // (DPP row shifts; lanes without a source lane keep the `old` operand = 1)
     float incl = lp;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        float t = __shfl_up(incl, d, 16);
-        if (l16 >= d) incl *= t;
-    }
-    float carry = __shfl_up(incl, 1, 16);
-    carry = l16 == 0 ? 1.f : carry;
+    incl *= dpp_f_or<0x111>(incl, 1.f);
+    incl *= dpp_f_or<0x112>(incl, 1.f);
+    incl *= dpp_f_or<0x114>(incl, 1.f);
+    incl *= dpp_f_or<0x118>(incl, 1.f);
+    const float carry = dpp_f_or<0x111>(incl, 1.f);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) w[e] = unerf_nan_to_num((1.f - em[e]) * (carry * lex[e]));
 }
