@@ -707,6 +707,34 @@ __device__ __forceinline__ void tile_ray(const FieldArgs& a, uint32_t rb, int j,
     }
 }
 
+// One column of a matrix-kernel tile: which (ray, sample) it is and where the sample sits (mid-point of its
+// spacing bin, euclidean, before contraction).  Shared by the four field_kernel_mfma* kernels.
+struct TileSample {
+    int64_t n;        // r * S + s
+    bool valid;       // column maps to a ray of this launch (else clamped to the last ray, results dropped)
+    float dx, dy, dz;
+    float px, py, pz;
+};
+__device__ __forceinline__ TileSample tile_sample(const FieldArgs& a, uint32_t tile, const FastDiv& div_s, int j) {
+    TileSample t;
+    const uint32_t rb = fastdiv(tile, div_s);
+    const int s = (int)(tile - rb * (uint32_t)a.S);
+    int64_t r;
+    tile_ray(a, rb, j, r, t.valid);
+    if (!t.valid) r = a.R - 1;
+    t.n = r * a.S + s;
+    const float* sb = a.sbins + r * (a.S + 1);
+    const float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+    const float t01 = e0 + e1;
+    t.dx = a.dirs[r * 3 + 0];
+    t.dy = a.dirs[r * 3 + 1];
+    t.dz = a.dirs[r * 3 + 2];
+    t.px = a.origins[r * 3 + 0] + t.dx * t01 / 2.f;
+    t.py = a.origins[r * 3 + 1] + t.dy * t01 / 2.f;
+    t.pz = a.origins[r * 3 + 2] + t.dz * t01 / 2.f;
+    return t;
+}
+
 // host side: fills a.tm and returns the number of tiles
 static int64_t make_tiles(FieldArgs& a, int image_width) {
     a.tm.img_w = 0; a.tm.pcols = 0; a.tm.div_pcols = make_fastdiv(1); a.tm.g0 = 0; a.tm.first_row = 0;
@@ -1090,20 +1118,11 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         // sample slot of 32 adjacent pixels, which sit in the same or neighbouring grid cells, so a gather
         // instruction presents few distinct lines to the texture-address unit (it retires ~1 divergent
         // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_04)
-        const uint32_t rb = fastdiv(tile, div_s);
-        const int s = (int)(tile - rb * (uint32_t)a.S);
-        int64_t r;
-        bool valid;
-        tile_ray(a, rb, j, r, valid);
-        if (!valid) r = a.R - 1;
-        const int64_t n = r * a.S + s;
-        const float* sb = a.sbins + r * (a.S + 1);
-        float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
-        float t01 = e0 + e1;
-        float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
-        float px = a.origins[r * 3 + 0] + dxr * t01 / 2.f;
-        float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
-        float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
+        const TileSample ts = tile_sample(a, tile, div_s, j);
+        const bool valid = ts.valid;
+        const int64_t n = ts.n;
+        const float dxr = ts.dx, dyr = ts.dy, dzr = ts.dz;
+        float px = ts.px, py = ts.py, pz = ts.pz;
         const float sel = unerf_normalize_position(px, py, pz);
 
         // hash grid: this half's 8 levels -> 16 features = the 16 k-steps of layer 0
@@ -1331,20 +1350,11 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     for (uint32_t tile = xcd * tpx + (uint32_t)slot * 4u + (uint32_t)wv; tile < tile_end; tile += (uint32_t)bpx * 4u) {
         int lane = lane_c;  // opaque per iteration: keeps the (tile-invariant) LDS operand reads inside the loop
         asm volatile("" : "+v"(lane));
-        const uint32_t rb = fastdiv(tile, div_s);
-        const int s = (int)(tile - rb * (uint32_t)a.S);
-        int64_t r;
-        bool valid;
-        tile_ray(a, rb, j, r, valid);
-        if (!valid) r = a.R - 1;
-        const int64_t n = r * a.S + s;
-        const float* sb = a.sbins + r * (a.S + 1);
-        float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
-        float t01 = e0 + e1;
-        float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
-        float px = a.origins[r * 3 + 0] + dxr * t01 / 2.f;
-        float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
-        float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
+        const TileSample ts = tile_sample(a, tile, div_s, j);
+        const bool valid = ts.valid;
+        const int64_t n = ts.n;
+        const float dxr = ts.dx, dyr = ts.dy, dzr = ts.dz;
+        float px = ts.px, py = ts.py, pz = ts.pz;
         const float sel = unerf_normalize_position(px, py, pz);
         // packed fp32x2 blend: this kernel has the registers for it (123 VGPRs without) in every mode
         const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask);
@@ -1561,20 +1571,11 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         // sample slot of 32 adjacent pixels, which sit in the same or neighbouring grid cells, so a gather
         // instruction presents few distinct lines to the texture-address unit (it retires ~1 divergent
         // lane per clock: TA_BUSY 74 % with 32 consecutive samples of one ray per tile, rocprof r1_04)
-        const uint32_t rb = fastdiv(tile, div_s);
-        const int s = (int)(tile - rb * (uint32_t)a.S);
-        int64_t r;
-        bool valid;
-        tile_ray(a, rb, j, r, valid);
-        if (!valid) r = a.R - 1;
-        const int64_t n = r * a.S + s;
-        const float* sb = a.sbins + r * (a.S + 1);
-        float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
-        float t01 = e0 + e1;
-        float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
-        float px = a.origins[r * 3 + 0] + dxr * t01 / 2.f;
-        float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
-        float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
+        const TileSample ts = tile_sample(a, tile, div_s, j);
+        const bool valid = ts.valid;
+        const int64_t n = ts.n;
+        const float dxr = ts.dx, dyr = ts.dy, dzr = ts.dz;
+        float px = ts.px, py = ts.py, pz = ts.pz;
         // inference: the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
         const float sel = unerf_normalize_position(px, py, pz);
         f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask);
@@ -1743,20 +1744,11 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
     for (uint32_t tile = xcd * tpx + (uint32_t)slot * 4u + (uint32_t)wv; tile < tile_end; tile += (uint32_t)bpx * 4u) {
         int lane = lane_c;
         asm volatile("" : "+v"(lane));
-        const uint32_t rb = fastdiv(tile, div_s);
-        const int s = (int)(tile - rb * (uint32_t)a.S);
-        int64_t r;
-        bool valid;
-        tile_ray(a, rb, j, r, valid);
-        if (!valid) r = a.R - 1;
-        const int64_t n = r * a.S + s;
-        const float* sb = a.sbins + r * (a.S + 1);
-        float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
-        float t01 = e0 + e1;
-        float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
-        float px = a.origins[r * 3 + 0] + dxr * t01 / 2.f;
-        float py = a.origins[r * 3 + 1] + dyr * t01 / 2.f;
-        float pz = a.origins[r * 3 + 2] + dzr * t01 / 2.f;
+        const TileSample ts = tile_sample(a, tile, div_s, j);
+        const bool valid = ts.valid;
+        const int64_t n = ts.n;
+        const float dxr = ts.dx, dyr = ts.dy, dzr = ts.dz;
+        float px = ts.px, py = ts.py, pz = ts.pz;
         (void)unerf_normalize_position(px, py, pz);  // the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
         const f32x16 feat = mf_gather_feats<true, false>(a, px, py, pz, h, mask);
 
