@@ -208,11 +208,26 @@ def golden_mc_aggregate():
     np.savez_compressed(os.path.join(OUT, "mc_aggregate.npz"), **res)
 
 
+def golden_eval_configs():
+    """field names and defaults of the eval script's configuration dataclasses (scripts/eval_configs.py)"""
+    import dataclasses
+    from nerfuncertainty.scripts import eval_configs as ec
+    out = {}
+    for name in ("EvalUncertainty", "LaplaceConfig", "EnsembleConfig", "MCDropoutConfig", "ActiveNerfactoConfig",
+                 "ActiveSplatfactoConfig"):
+        fields = {}
+        for f in dataclasses.fields(getattr(ec, name)):
+            d = None if f.default is dataclasses.MISSING else f.default
+            fields[f.name] = {"required": f.default is dataclasses.MISSING, "default": str(d) if d is not None and not isinstance(d, (bool, int, float)) else d}
+        out[name] = fields
+    json.dump(out, open(os.path.join(OUT, "eval_configs.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("/root/reference is not mounted: golden vectors can only be regenerated in the build container")
     install_stubs()
     for fn in (golden_create_mlp, golden_metrics, golden_sample_laplace, golden_get_weights, golden_ensemble,
-               golden_mc_aggregate):
+               golden_mc_aggregate, golden_eval_configs):
         fn()
         print("wrote", fn.__name__)

@@ -97,3 +97,82 @@ def test_depth_metrics_resize_prediction_to_gt_shape():
     out, gt, a = _depth_case(H=17, W=21, gh=18, gw=22)
     md, _ = E.depth_metrics_unc(out, gt, a)
     assert np.isfinite(list(md.values())).all()
+
+
+def test_eval_config_mirror_matches_reference_defaults():
+    """field names, order and defaults of the eval-script dataclasses vs tests/golden/eval_configs.json
+    (generated from the reference's scripts/eval_configs.py by tests/golden/make_golden.py)"""
+    import dataclasses
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "eval_configs.json")))
+    for name, fields in gold.items():
+        cls = getattr(E, name)
+        ours = dataclasses.fields(cls)
+        assert [f.name for f in ours] == list(fields), name
+        for f in ours:
+            want = fields[f.name]
+            if want["required"]:
+                continue          # the reference has no default; the mirror uses None so it can be built in tests
+            got = f.default
+            got = str(got) if got is not None and not isinstance(got, (bool, int, float)) else got
+            assert got == want["default"], (name, f.name, got, want["default"])
+
+
+def test_outputs_fn_dispatch_follows_the_eval_script(tmp_path):
+    """eval_uncertainty.py:1086-1134 with fake models: which callable each config selects and what it sets"""
+    calls = []
+
+    class FakeField:
+        mlp_density_ggn = None
+        mlp_rgb_ggn = None
+
+    class FakeModel:
+        def __init__(self):
+            self.config = type("C", (), {"mc_samples": 10})()
+            self.field = FakeField()
+
+        def invalidate(self):
+            calls.append("invalidate")
+
+        def get_outputs_for_camera(self, camera):
+            return {"who": "plain", "camera": camera}
+
+        def get_outputs_for_camera_unc(self, camera, **kw):
+            return {"who": "unc", "kw": kw}
+
+        def compute_hessian_naive(self, pipeline=None, n_iters=1000, ray_batches=None):
+            calls.append(("ggn", n_iters))
+            self.field.mlp_density_ggn, self.field.mlp_rgb_ggn = torch.ones(65), torch.ones(195)
+
+    m = FakeModel()
+    fn = E.outputs_fn_for(E.MCDropoutConfig(mc_samples=8), m)
+    assert m.config.mc_samples == 8 and fn("cam")["who"] == "plain" and calls == ["invalidate"]
+    m2 = FakeModel()
+    E.outputs_fn_for(E.MCDropoutConfig(), m2)
+    assert m2.config.mc_samples == 10            # None keeps the model's own setting
+    cfg = E.LaplaceConfig(load_config=tmp_path / "cfg" / "config.yml", n_iters=7, prior_precision=2.5, n_samples=50)
+    m3 = FakeModel()
+    fn = E.outputs_fn_for(cfg, m3)
+    out = fn("cam")
+    assert ("ggn", 7) in calls and (tmp_path / "cfg" / "ggn_7.pt").exists() and m3.prior_prec == 2.5
+    assert out["who"] == "unc" and out["kw"] == dict(is_inference=True, use_deterministic_density=False, prior_prec=2.5,
+                                                     n_samples=50)
+    calls.clear()
+    m4 = FakeModel()
+    E.outputs_fn_for(cfg, m4)                      # second time: the saved GGN is loaded instead of refitted
+    assert calls == [] and torch.equal(m4.field.mlp_rgb_ggn, torch.ones(195))
+    assert E.outputs_fn_for(E.ActiveNerfactoConfig(), m)("c")["who"] == "plain"
+    assert E.ActiveSplatfactoConfig().eval_depth is False and E.EvalUncertainty().min_depth_std_for_nll == 2.0
+
+
+def test_run_eval_writes_the_metrics_envelope(tmp_path):
+    items = _fake_eval_set(2, 12, 16)
+
+    class M:
+        def get_outputs_for_camera(self, cam):
+            return cam
+    cfg = E.ActiveNerfactoConfig(output_path=tmp_path / "o" / "metrics.json", eval_depth=False)
+    res = E.run_eval(cfg, M(), [(o, gt) for o, gt in items], experiment_name="garden", method_name="active-nerfacto",
+                     checkpoint="step-000029999.ckpt")
+    d = json.loads((tmp_path / "o" / "metrics.json").read_text())
+    assert d["method_name"] == "active-nerfacto" and d["results"]["psnr"] == res["psnr"] and "rgb_ause_mse" in res

@@ -19,7 +19,10 @@ from __future__ import annotations
 import json
 import os
 import time
-from typing import Callable, Dict, Iterable, List, Optional, Tuple
+from dataclasses import dataclass
+from functools import partial
+from pathlib import Path
+from typing import Callable, Dict, Iterable, List, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -150,3 +153,106 @@ def write_metrics_json(path: str, experiment_name: str, method_name: str, checkp
     with open(path, "w", encoding="utf8") as f:
         json.dump({"experiment_name": experiment_name, "method_name": method_name, "checkpoint": checkpoint,
                    "results": results}, f, indent=2)
+
+
+# ---- the eval script's configuration surface (scripts/eval_configs.py) and its per-method dispatch ----------
+
+@dataclass
+class EvalUncertainty:
+    """scripts/eval_configs.py:7-49 (field names and defaults; pinned by tests/golden/eval_configs.json)"""
+    load_config: Union[Path, List[Path], None] = None
+    dataset_path: Optional[Path] = None
+    output_path: Path = Path("output.json")
+    render_output_path: Optional[Path] = None
+    save_all_ause: bool = False
+    seed: int = 42
+    eval_depth: bool = True
+    eval_rgb: bool = True
+    plot_ause: bool = False
+    save_rendered_images: bool = False
+    min_rgb_std_for_nll: float = 3e-2
+    min_depth_std_for_nll: float = 2.0
+    unc_max: float = 1.0
+    unc_min: float = 0.0
+
+
+@dataclass
+class LaplaceConfig(EvalUncertainty):
+    prior_precision: float = 1.0
+    n_samples: int = 100
+    n_iters: int = 300
+    use_deterministic_density: bool = False
+
+
+@dataclass
+class EnsembleConfig(EvalUncertainty):
+    pass
+
+
+@dataclass
+class MCDropoutConfig(EvalUncertainty):
+    mc_samples: Optional[int] = None
+
+
+@dataclass
+class ActiveNerfactoConfig(EvalUncertainty):
+    eval_depth: bool = True
+
+
+@dataclass
+class ActiveSplatfactoConfig(EvalUncertainty):
+    eval_depth: bool = False
+
+
+EvalConfigs = Union[LaplaceConfig, EnsembleConfig, MCDropoutConfig, ActiveNerfactoConfig, ActiveSplatfactoConfig]
+
+
+def outputs_fn_for(eval_config: EvalConfigs, model, ggn_batches=None, pipeline=None) -> Callable:
+    """The per-method callable scripts/eval_uncertainty.py:1086-1134 selects, for this build's Model mirrors.
+    `model` is one Model, or a list of member Models for EnsembleConfig (single process; one member per rank goes
+    through ensemble.aggregate_distributed instead).  LaplaceConfig loads `ggn_{n_iters}.pt` next to load_config when
+    it exists, else fits the GGN (from `pipeline.datamanager` or `ggn_batches`) and saves it there (:1103-1116)."""
+    import torch
+    if isinstance(eval_config, EnsembleConfig):
+        from . import ensemble
+        members = list(model)
+        assert len(members) > 1, "Ensemble requires at least two models."
+        return lambda camera: ensemble.aggregate([m.get_outputs_for_camera(camera) for m in members])
+    if isinstance(eval_config, MCDropoutConfig):
+        model.config.mc_samples = eval_config.mc_samples if eval_config.mc_samples is not None else model.config.mc_samples
+        model.invalidate()
+        return model.get_outputs_for_camera
+    if isinstance(eval_config, LaplaceConfig):
+        hessian_path = None
+        if eval_config.load_config is not None:
+            hessian_path = Path(eval_config.load_config).parent / f"ggn_{eval_config.n_iters}.pt"
+        if hessian_path is not None and hessian_path.exists():
+            saved = torch.load(hessian_path)
+            model.field.mlp_density_ggn, model.field.mlp_rgb_ggn = saved["mlp_density_ggn"], saved["mlp_rgb_ggn"]
+        else:
+            model.compute_hessian_naive(pipeline=pipeline, n_iters=eval_config.n_iters, ray_batches=ggn_batches)
+            if hessian_path is not None:
+                hessian_path.parent.mkdir(parents=True, exist_ok=True)
+                torch.save({"mlp_density_ggn": model.field.mlp_density_ggn.cpu(),
+                            "mlp_rgb_ggn": model.field.mlp_rgb_ggn.cpu()}, hessian_path)
+        model.prior_prec = eval_config.prior_precision
+        return partial(model.get_outputs_for_camera_unc, is_inference=True,
+                       use_deterministic_density=eval_config.use_deterministic_density,
+                       prior_prec=eval_config.prior_precision, n_samples=eval_config.n_samples)
+    return model.get_outputs_for_camera          # ActiveNerfactoConfig, ActiveSplatfactoConfig
+
+
+def run_eval(eval_config: EvalConfigs, model, eval_set, experiment_name: str = "", method_name: str = "",
+             checkpoint: str = "", depth_gt_fn: Optional[Callable] = None, composite_gt: Optional[Callable] = None,
+             **fn_kw) -> Dict[str, float]:
+    """main() of scripts/eval_uncertainty.py:1082-1169 without nerfstudio's pipeline loading: pick the method's
+    callable, average the per-image metrics, write the metrics.json envelope to eval_config.output_path."""
+    fn = outputs_fn_for(eval_config, model, **fn_kw)
+    if eval_config.eval_depth and depth_gt_fn is None and eval_config.dataset_path is not None:
+        depth_gt_fn = lambda i: load_depth_gt(str(eval_config.dataset_path), i)
+    metrics, _curves = get_average_uncertainty_metrics(
+        fn, eval_set, eval_rgb_unc=eval_config.eval_rgb, min_rgb_std_for_nll=eval_config.min_rgb_std_for_nll,
+        composite_gt=composite_gt, depth_gt_fn=depth_gt_fn if eval_config.eval_depth else None,
+        min_depth_std_for_nll=eval_config.min_depth_std_for_nll)
+    write_metrics_json(str(eval_config.output_path), experiment_name, method_name, checkpoint, metrics)
+    return metrics
