@@ -167,6 +167,8 @@ typedef struct {
     const float* ws_density;  /* [n_lap][65]  */
     const float* ws_rgb;      /* [n_lap][195] */
     int n_lap;
+    int lap_mask_density;     /* 1: multiply the density mean by the box selector (the use_deterministic_density=True
+                                 path, laplace_field.py:501-506 / :317-345, fed with n_lap copies of the mean row) */
     /* Optional (ACTIVE / MCDROPOUT): the same MLP weights pre-arranged as fp32-MFMA A-operand
        fragments (layout: uncertainty-nerf-gs_amd/ops.py::pack_field_mfma, UNERF_MFMA_BLOB_FLOATS
        floats).  When non-NULL the fused kernel runs its dense layers on v_mfma_f32_32x32x2_f32

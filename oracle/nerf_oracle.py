@@ -736,21 +736,29 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
 
 
 def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
-                    depth_noise: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """[REF laplace_model.py:456-556] is_inference=True, use_deterministic_density=False.
-    depth_noise [D,R,S] = the standard-normal draw behind Normal(mu_d, sigma_d).sample((D,))."""
+                    depth_noise: Optional[torch.Tensor], use_deterministic_density: bool = False) -> Dict[str, torch.Tensor]:
+    """[REF laplace_model.py:456-556] is_inference=True.
+    use_deterministic_density=False: density = sampled-head mean (NOT selector-masked), depth from the mean of the
+    weights of D Normal(mu_d, sigma_d) density draws; depth_noise [D,R,S] = the standard-normal draw behind them.
+    use_deterministic_density=True (laplace_field.py:501-506): density = the plain mean head, selector-masked
+    (is_inference=False branch of get_density), colour still sampled, depth from the ordinary weights."""
     eb, wl, bl = _sample(scene, origins, directions)
     mu_d, var_d, mu_rgb, var_rgb = laplace_field(origins, directions, eb, scene.field, ws_density, ws_rgb)
+    if use_deterministic_density:
+        mu_d, _ = laplace_field_deterministic(origins, directions, eb, scene.field)
     deltas = eb[..., 1:] - eb[..., :-1]
     steps = (eb[..., :-1] + eb[..., 1:]) / 2
     w = get_weights(mu_d, deltas)
     rgb = render_rgb(mu_rgb, w)
     rgb_var = render_uncertainty(var_rgb, w ** 2)
-    sd = torch.maximum(var_d.sqrt(), torch.tensor([1e-10]))
-    sd = torch.nan_to_num(sd, nan=1e-10) if torch.isnan(sd).any() else sd
-    sampled = F.relu(mu_d[None] + sd[None] * depth_noise)
-    sw = torch.stack([get_weights(sampled[i], deltas) for i in range(sampled.shape[0])], dim=0)
-    wm = sw.mean(dim=0)
+    if use_deterministic_density:
+        wm = w
+    else:
+        sd = torch.maximum(var_d.sqrt(), torch.tensor([1e-10]))
+        sd = torch.nan_to_num(sd, nan=1e-10) if torch.isnan(sd).any() else sd
+        sampled = F.relu(mu_d[None] + sd[None] * depth_noise)
+        sw = torch.stack([get_weights(sampled[i], deltas) for i in range(sampled.shape[0])], dim=0)
+        wm = sw.mean(dim=0)
     depth = render_depth_median(wm, steps)
     depth_var = torch.sum(wm * (steps - depth) ** 2, dim=-1, keepdim=True) + 1e-5
     out = {

@@ -120,6 +120,38 @@ def test_laplace_model_unc_render_matches_oracle(dev):
         assert bad.double().mean() <= 5e-3, (k, (got - want).abs().max().item())
 
 
+def test_laplace_model_deterministic_density_matches_oracle(dev):
+    """LaplaceConfig.use_deterministic_density=True (laplace_field.py:501-506): plain selector-masked density,
+    sampled colour head, depth from the ordinary weights; the generator is consumed by the colour head only."""
+    from uncertainty_nerf_gs_amd import plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=4, kind="laplace", log2T=14, prop_log2T=12)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["nerfacto-laplace"]())
+    model = cfg._target(cfg, num_train_data=4)
+    model.load_state_dict(_state_dict_from_tensors(t, "laplace"))
+    g = torch.Generator().manual_seed(5)
+    model.field.mlp_density_ggn = torch.rand(65, generator=g) * 1e3
+    model.field.mlp_rgb_ggn = torch.rand(195, generator=g) * 1e3
+    H, W = 16, 24
+    cam = _camera(H, W, 2.0)
+    with torch.cuda.device(dev):
+        out = model.get_outputs_for_camera_unc(cam, is_inference=True, use_deterministic_density=True, prior_prec=1.0,
+                                               n_samples=100, generator=torch.Generator().manual_seed(9))
+    f = t["field"]
+    mu_r = torch.cat([f["head_w"][2].reshape(-1), f["head_b"][2].reshape(-1)])
+    mu_d = torch.cat([f["density_w"].reshape(-1), f["density_b"].reshape(-1)])
+    wsr = O.laplace_weight_samples(mu_r, model.field.mlp_rgb_ggn, 1.0, 1e-9,
+                                   torch.randn(100, 195, generator=torch.Generator().manual_seed(9)))
+    sc = O.scene_from_tensors(t)
+    o, d, _ = O.generate_rays(cam.camera_to_worlds[0], 0.9 * W, 0.9 * W, W / 2, H / 2, H, W)
+    ref = O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), mu_d.view(1, -1).repeat(100, 1), wsr, None,
+                            use_deterministic_density=True)
+    for k, atol, rtol in (("rgb", 5e-5, 0), ("rgb_std", 2e-5, 5e-3), ("accumulation", 3e-4, 0), ("expected_depth", 0, 2e-3),
+                          ("depth_std", 0, 1e-2)):
+        got, want = out[k].cpu().reshape(H * W, -1).double(), ref[k].double()
+        bad = (got - want).abs() > atol + rtol * want.abs()
+        assert bad.double().mean() <= 1e-2, (k, (got - want).abs().max().item())
+
+
 def test_laplace_compute_hessian_naive_matches_autograd_oracle(dev):
     """GGN fitting (laplace_model.py:343-400): closed-form Jacobian kernels vs one autograd backward per
     rendered value on the CPU oracle, through the Model method the eval script calls."""

@@ -91,4 +91,22 @@ def test_laplace_model_rejects_unbuilt_modes():
     cfg.proposal_net_args_list = [dict(a, log2_hashmap_size=5) for a in cfg.proposal_net_args_list]
     m = M.NerfactoLaplaceModel(cfg)
     with pytest.raises(NotImplementedError):
-        m.get_outputs_for_camera_unc(None, use_deterministic_density=True)
+        m.get_outputs_for_camera_unc(None, is_inference=False)   # the training forward is not a render path
+
+
+def test_laplace_deterministic_density_draws_only_the_colour_head():
+    """use_deterministic_density=True (laplace_field.py:501-506): no density draw is made, so the generator
+    reaches the colour head in its initial state; the density rows are copies of the mean parameters."""
+    from torch.nn.utils import parameters_to_vector
+    cfg = M.NerfactoLaplaceModelConfig(log2_hashmap_size=6)
+    cfg.proposal_net_args_list = [dict(a, log2_hashmap_size=5) for a in cfg.proposal_net_args_list]
+    f = M.NerfactoLaplaceModel(cfg).field
+    f.mlp_rgb_ggn = torch.rand(195) * 10
+    ws_d, ws_r = f.sample_last_layers(n_samples=100, generator=torch.Generator().manual_seed(3), deterministic_density=True)
+    mu_d = parameters_to_vector(f.mlp_density.parameters()).detach()
+    assert ws_d.shape == (100, 65) and torch.equal(ws_d, mu_d.view(1, -1).repeat(100, 1))
+    mu_r = parameters_to_vector(f.mlp_rgb_ll.parameters()).detach()
+    noise = torch.randn(100, 195, generator=torch.Generator().manual_seed(3))
+    torch.testing.assert_close(ws_r, mu_r.view(1, -1) + noise / torch.sqrt(f.mlp_rgb_ggn + 1.0 + 1e-9))
+    _, ws_r2 = f.sample_last_layers(n_samples=100, generator=torch.Generator().manual_seed(3))
+    assert not torch.equal(ws_r, ws_r2)   # with density sampling the colour head sees a later generator state

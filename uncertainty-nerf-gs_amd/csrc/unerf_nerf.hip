@@ -912,7 +912,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
         }
         mu /= (float)nl;
         mu2 /= (float)nl;
-        float var_d = mu2 - mu * mu;
+        float var_d = a.p.lap_mask_density ? 0.f : mu2 - mu * mu;
         store_act<16>(A, lane, sh, 0, false);
         store_act<15>(A, lane, geo, 16, false);
         dense_lds<31, 64>(a.p.h0t, a.p.hb0, A, lane, acc);
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
             vsum += fmaxf(m2[c] - m1[c] * m1[c], 0.f);
         }
         if (valid) {
-            a.density[n] = mu;  // NOT selector-masked (laplace_field.py:356-362)
+            a.density[n] = a.p.lap_mask_density ? mu * sel : mu;  // inference: NOT selector-masked (laplace_field.py:356-362)
             a.aux[n] = var_d;
             a.aux2[n] = vsum / 3.f;
             a.rgb[n * 3 + 0] = m1[0];
@@ -1600,6 +1600,10 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
             mf_lap_head<false>(a.p.lap_blob, 0, lane, h, hb0, hb1, d1, d2);
             mu_d = d1 * inv_n;
             mu2_d = d2 * inv_n;
+            if (a.p.lap_mask_density) {  // use_deterministic_density: selector-masked mean, no variance
+                mu_d *= sel;
+                mu2_d = mu_d * mu_d;
+            }
         }
 
         // colour trunk
@@ -1749,7 +1753,8 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         const int64_t n = ts.n;
         const float dxr = ts.dx, dyr = ts.dy, dzr = ts.dz;
         float px = ts.px, py = ts.py, pz = ts.pz;
-        (void)unerf_normalize_position(px, py, pz);  // the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
+        // inference: the returned mu_d is NOT selector-masked (laplace_field.py:356-362) unless lap_mask_density
+        const float sel = unerf_normalize_position(px, py, pz);
         const f32x16 feat = mf_gather_feats<true, false>(a, px, py, pz, h, mask);
 
         // base_mlp: bare Linear 32 -> 64 (no ReLU, utils.py:22-23)
@@ -1770,7 +1775,11 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         for (int st = 0; st < 4; ++st) t = mf16_mac(lds, 4 + st, lane, xhi[st], xlo[st], t);
         float d1, d2;
         mf16_lap_head<false>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
-        const float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
+        float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
+        if (a.p.lap_mask_density) {  // use_deterministic_density: selector-masked mean, no variance
+            mu_d *= sel;
+            mu2_d = mu_d * mu_d;
+        }
 
         // colour trunk: [geo15 | SH16] -> 64 -> 64
         f32x16 c0 = mf_bias(lds, 3, h), c1 = mf_bias(lds, 4, h);

@@ -95,7 +95,7 @@ class FieldParams(C.Structure):
         ("h2t", C.c_void_p), ("hb2", C.c_void_p),
         ("average_init_density", C.c_float), ("beta_min", C.c_float), ("sh_remap", C.c_int),
         ("K", C.c_int), ("seed", C.c_uint32), ("p_drop", C.c_float),
-        ("ws_density", C.c_void_p), ("ws_rgb", C.c_void_p), ("n_lap", C.c_int),
+        ("ws_density", C.c_void_p), ("ws_rgb", C.c_void_p), ("n_lap", C.c_int), ("lap_mask_density", C.c_int),
         ("mfma_blob", C.c_void_p), ("lap_blob", C.c_void_p),
         ("tcnn_levels", C.c_void_p),
         ("mfma16_blob", C.c_void_p), ("lap16_blob", C.c_void_p),

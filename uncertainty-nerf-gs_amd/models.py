@@ -245,19 +245,22 @@ class NerfactoLaplaceModel(_NerfactoBase):
 
     def _field_to_device(self, device):
         ws_d, ws_r = self._ws
-        return self.field.to_device(device, ws_density=ws_d, ws_rgb=ws_r)
+        return self.field.to_device(device, ws_density=ws_d, ws_rgb=ws_r,
+                                    lap_mask_density=int(getattr(self, "_deterministic_density", False)))
 
     @torch.no_grad()
     def get_outputs_for_camera_unc(self, camera, obb_box=None, is_inference: bool = True,
                                    use_deterministic_density: bool = False, prior_prec: float = 1.0,
                                    n_samples: int = 100, eps: float = 1e-9, generator=None):
         """laplace_model.py:403-415.  Draws the last-layer parameter samples on the host the way
-        `sample_laplace` does (one torch.randn per head), then renders with the fused kernels."""
-        if not is_inference or use_deterministic_density:
-            raise NotImplementedError("only is_inference=True, use_deterministic_density=False "
-                                      "(eval_configs.py:60 default) is built")
-        self._ws = self.field.sample_last_layers(n_samples=n_samples, prior_prec=prior_prec, eps=eps,
-                                                 generator=generator)
+        `sample_laplace` does (one torch.randn per head), then renders with the fused kernels.
+        use_deterministic_density=True (eval_configs.py LaplaceConfig): the density is the plain, selector-masked
+        mean head (no density samples, no depth draws); the colour head is still sampled."""
+        if not is_inference:
+            raise NotImplementedError("is_inference=False is the training forward (used by compute_hessian_naive only)")
+        self._ws = self.field.sample_last_layers(n_samples=n_samples, prior_prec=prior_prec, eps=eps, generator=generator,
+                                                 deterministic_density=use_deterministic_density)
+        self._deterministic_density = bool(use_deterministic_density)
         self.invalidate()
         return self.get_outputs_for_camera(camera, obb_box)
 

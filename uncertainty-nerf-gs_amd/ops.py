@@ -242,6 +242,7 @@ class FieldDev:
     p_drop: float = 0.2
     ws_density: Optional[torch.Tensor] = None
     ws_rgb: Optional[torch.Tensor] = None
+    lap_mask_density: int = 0     # 1: use_deterministic_density (ws_density = copies of the mean row, selector-masked)
     mfma_blob: Optional[torch.Tensor] = None
     lap_blob: Optional[torch.Tensor] = None
     use_mfma: bool = True
@@ -285,6 +286,7 @@ class FieldDev:
             _p(self.h0t), _p(self.hb0), _p(self.h1t), _p(self.hb1), _p(self.h2t), _p(self.hb2),
             self.average_init_density, self.beta_min, self.sh_remap, self.K, self.seed & 0xFFFFFFFF, self.p_drop,
             _p(self.ws_density), _p(self.ws_rgb), 0 if self.ws_density is None else self.ws_density.shape[0],
+            int(self.lap_mask_density),
             _p(self.mfma_blob) if self.use_mfma else None, _p(self.lap_blob) if self.use_mfma else None,
             _p(self.tcnn_levels, torch.int32),
             _p(self.mfma16_blob) if (self.use_mfma and self.precision == "f16x2") else None,

@@ -138,8 +138,9 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
             u = _unpack(ops.composite_var(density, rgb, sb, scene.near, scene.far, **kw)[0])
             res = {k: u[k] for k in ("rgb", "accumulation", "depth", "expected_depth")}
     else:
-        walt = ops.laplace_depth_weights(density[0], aux, sb, scene.near, scene.far, depth_noise, depth_draws,
-                                         depth_seed, ray_offset)
+        # use_deterministic_density (laplace_model.py:486-507 is skipped): depth from the ordinary weights
+        walt = None if f.lap_mask_density else ops.laplace_depth_weights(
+            density[0], aux, sb, scene.near, scene.far, depth_noise, depth_draws, depth_seed, ray_offset)
         out = ops.composite_var(density, rgb, sb, scene.near, scene.far, beta=aux2, weights_alt=walt, **kw)[0]
         u = _unpack(out)
         res = {"rgb": u["rgb"], "rgb_std": u["rgb_var"].sqrt(), "accumulation": u["accumulation"],
