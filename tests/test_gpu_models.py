@@ -86,6 +86,30 @@ def test_model_from_checkpoint_equals_direct_pipeline(dev, kind, method):
     assert out["rgb"].shape == (H, W, 3) and out["rgb_std"].shape == (H, W, 1)
 
 
+def test_get_outputs_on_a_ray_bundle_equals_the_oracle_chunk(dev):
+    """Model.get_outputs / forward on a flat bundle = one reference chunk (clip bounds of that bundle)."""
+    from types import SimpleNamespace
+    from uncertainty_nerf_gs_amd import plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=3, kind="active", log2T=14, prop_log2T=12)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["active-nerfacto"]())
+    model = cfg._target(cfg, num_train_data=4)
+    model.load_state_dict(_state_dict_from_tensors(t, "active"))
+    g = torch.Generator().manual_seed(1)
+    o = torch.randn(700, 3, generator=g) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(700, 3, generator=g), dim=-1)
+    with torch.cuda.device(dev):
+        out = model(SimpleNamespace(origins=o.to(dev), directions=d.to(dev)))
+        out2 = model.get_outputs((o.to(dev), d.to(dev)))
+    ref = O.active_outputs(O.scene_from_tensors(t), o, d)
+    assert set(ref) <= set(out)
+    for k in out:
+        assert torch.equal(out[k], out2[k])
+    for k, atol, rtol in (("rgb", 5e-5, 0), ("accumulation", 3e-4, 0), ("expected_depth", 0, 2e-3), ("rgb_std", 1e-5, 2e-3)):
+        got, want = out[k].cpu().double(), ref[k].double()
+        bad = (got - want).abs() > atol + rtol * want.abs()
+        assert bad.double().mean() <= 5e-3, (k, (got - want).abs().max().item())
+
+
 def test_laplace_model_unc_render_matches_oracle(dev):
     from uncertainty_nerf_gs_amd import plugin, synthetic
     t = synthetic.make_scene_tensors(seed=4, kind="laplace", log2T=14, prop_log2T=12)

@@ -213,6 +213,33 @@ class _NerfactoBase(nn.Module):
         return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}
 
 
+    @torch.no_grad()
+    def get_outputs(self, ray_bundle) -> Dict[str, torch.Tensor]:
+        """Model.get_outputs(ray_bundle) at eval (activenerfacto_model.py:83-152, mcdropout / laplace equivalents):
+        a flat bundle of rays -- any object with `.origins` / `.directions` [R,3] (a nerfstudio RayBundle), or an
+        (origins, directions) pair -- rendered as ONE reference chunk (the per-chunk expected-depth clip bounds are
+        those of this bundle, as in the reference when `forward` is called on a chunk)."""
+        if isinstance(ray_bundle, (tuple, list)):
+            o, d = ray_bundle
+        else:
+            o, d = ray_bundle.origins, ray_bundle.directions
+        scene = self.device_scene(o.device if o.is_cuda else None)
+        o = o.reshape(-1, 3).to(device=scene.device, dtype=torch.float32).contiguous()
+        d = d.reshape(-1, 3).to(device=scene.device, dtype=torch.float32).contiguous()
+        from .ops import new_clip_buffer
+        R = o.shape[0]
+        clip = new_clip_buffer(R, max(R, 1), o.device)                 # one chunk = the whole bundle
+        saved, scene.chunk_rays = scene.chunk_rays, max(R, 1)
+        try:
+            return render.render_rays(scene, o, d, ray_offset=0, total_rays=R, clip=clip, **self._render_kwargs())
+        finally:
+            scene.chunk_rays = saved
+
+    def forward(self, ray_bundle) -> Dict[str, torch.Tensor]:  # type: ignore[override]
+        """Model.forward: collider (near/far planes are the config's) + get_outputs"""
+        return self.get_outputs(ray_bundle)
+
+
 class ActiveNerfactoModel(_NerfactoBase):
     config: ActiveNerfactoModelConfig
 
