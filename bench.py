@@ -229,7 +229,7 @@ def main():
                                    + (", 100 last-layer Laplace samples" if args.method == "laplace" else ""),
                        "rays_per_step": H * W, "samples_per_ray": [256, 96, 48], "hash_grid": "16x2^19x2 fp32",
                        "dense_layers": ("fp32 operands split into two f16 halves, 3 products on v_mfma_f32_32x32x16_f16, "
-                                        "fp32 accumulate (fp32-equivalent, DESIGN.md 4.6)" if split else
+                                        "fp32 accumulate (fp32-equivalent, DESIGN.md 4.2)" if split else
                                         "exact fp32 (v_mfma_f32_32x32x2_f32)"),
                        "parallelism": f"views x{world}" if world > 1 else "single"},
             "roofline": roof, "cpu_baseline": cpu, "exact_fp32_kernels": exact,
