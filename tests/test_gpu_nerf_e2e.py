@@ -166,3 +166,36 @@ def test_full_1080p_frame_properties(dev):
         assert torch.equal(part[k], full), f"{k}: launch grouping changed the result"
     sb, _ = render.sample_rays(sd, o, d, None, a)
     assert torch.all(sb[:, 1:] >= sb[:, :-1]) and sb.min() >= 0 and sb.max() <= 1
+
+
+def test_full_size_mcdropout_and_laplace_degenerate_to_the_deterministic_render(dev):
+    """BASELINE size (full tables, 1080p): with the stochastic part switched off the uncertainty methods must
+    collapse onto their deterministic renders -- K identical MC passes (p = 0) have zero spread and equal the K = 0
+    render; Laplace with zero-variance last layers (all sampled rows = the mean row) has zero colour spread."""
+    from uncertainty_nerf_gs_amd import render, synthetic
+    cam, c2w = dict(synthetic.CAMERA_1080P), synthetic.orbit_c2w(1.0)
+    t = synthetic.make_scene_tensors(seed=2, kind="mcdropout")
+    base = render.render_camera(synthetic.scene_to_device(t, dev, K=0), c2w, **cam)
+    mc = render.render_camera(synthetic.scene_to_device(t, dev, K=3, seed=5, p_drop=0.0), c2w, **cam)
+    # (x + x + x) / 3 is x up to one rounding, so "zero spread" means a few ulp of the value
+    assert mc["rgb_std"].abs().max() <= 1e-6 and mc["depth_std"].abs().max() <= 1e-5 * mc["depth"].max()
+    assert mc["expected_depth_std"].abs().max() <= 1e-5 * mc["expected_depth"].max()
+    for k in ("rgb", "accumulation", "depth", "expected_depth"):
+        torch.testing.assert_close(mc[k], base[k], rtol=1e-6, atol=1e-7, msg=k)
+    # a real dropout rate produces a spread, and its mean stays close to the deterministic image
+    mc2 = render.render_camera(synthetic.scene_to_device(t, dev, K=4, seed=5, p_drop=0.2), c2w, **cam)
+    assert mc2["rgb_std"].mean() > 1e-3 and (mc2["rgb"] - base["rgb"]).abs().mean() < 0.1
+    del base, mc, mc2
+    tl = synthetic.make_scene_tensors(seed=3, kind="laplace")
+    f = tl["field"]
+    mu_d = torch.cat([f["density_w"].reshape(-1), f["density_b"].reshape(-1)]).view(1, -1).repeat(100, 1)
+    mu_r = torch.cat([f["head_w"][2].reshape(-1), f["head_b"][2].reshape(-1)]).view(1, -1).repeat(100, 1)
+    sd = synthetic.scene_to_device(tl, dev, ws_density=mu_d.to(dev), ws_rgb=mu_r.to(dev))
+    lap = render.render_camera(sd, c2w, **cam)
+    assert torch.isfinite(lap["rgb"]).all() and lap["rgb_std"].abs().max() <= 1e-3   # sqrt of E[p^2]-E[p]^2 rounding
+    sd.field.precision = "fp32"
+    lap_exact = render.render_camera(sd, c2w, **cam)
+    assert (lap["rgb"] - lap_exact["rgb"]).abs().max() <= 2e-6    # split-f16 vs exact kernels at full size
+    # accumulation comes from the depth draws Normal(mu_d, sqrt(var_d)): with identical rows var_d is pure rounding
+    # noise (E[p^2] - E[p]^2 ~ 1e-7 p^2) and its square root amplifies the difference between the two kernel sets
+    assert (lap["accumulation"] - lap_exact["accumulation"]).abs().max() <= 2e-4
