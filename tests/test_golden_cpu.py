@@ -116,3 +116,24 @@ def test_nll_matches_torch_normal():
     p, t, s = torch.rand(50, 3, generator=g), torch.rand(50, 3, generator=g), torch.rand(50, 1, generator=g) * 0.2
     ref = -torch.distributions.Normal(p, torch.clamp_min(s, 3e-2)).log_prob(t)
     torch.testing.assert_close(negative_gaussian_loglikelihood(p, t, s, 3e-2), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_auce_torch_equals_the_reference_pinned_loop():
+    """the one-sort device AUCE against metrics.auce (itself pinned to the reference by the golden vectors)"""
+    import torch
+    from uncertainty_nerf_gs_amd import metrics as M
+    g = torch.Generator().manual_seed(17)
+    for n, scale in ((5000, 1.0), (777, 0.2), (4096, 3.0)):
+        mean = torch.rand(n, 3, generator=g)
+        sigma = 0.02 + scale * 0.1 * torch.rand(n, 3, generator=g)
+        target = mean + sigma * torch.randn(n, 3, generator=g) * 1.3
+        sigma[:5] = 0.0                      # degenerate intervals: covered only when target == mean
+        target[:2] = mean[:2]
+        ref = M.auce(mean.numpy(), sigma.numpy(), target.numpy())
+        got = M.auce_torch(mean, sigma, target)
+        assert set(ref) == set(got)
+        np.testing.assert_array_equal(got["coverage_values"], ref["coverage_values"])
+        np.testing.assert_allclose(got["avg_length_values"], ref["avg_length_values"], rtol=1e-6)
+        for k in ("auc_abs_error_values", "auc_neg_error_values"):
+            assert abs(got[k] - ref[k]) < 1e-12
+        assert abs(got["auc_length_values"] - ref["auc_length_values"]) < 1e-6 * ref["auc_length_values"]

@@ -56,7 +56,7 @@ def image_metrics_unc(outputs: Dict[str, torch.Tensor], gt_image: torch.Tensor, 
                                                                eps=min_rgb_std_for_nll).mean().item())
         md["rgb_avg_var"] = float(var.mean().item())
         std3 = var.sqrt().unsqueeze(-1).repeat(1, 3)
-        a = M.auce(rgb.reshape(-1, 3).cpu().numpy(), std3.cpu().numpy(), image.reshape(-1, 3).cpu().numpy())
+        a = M.auce_torch(rgb.reshape(-1, 3), std3, image.reshape(-1, 3))   # = M.auce (reference loop), one sort on device
         md["rgb_auc_abs_error"], md["rgb_auc_length"] = a["auc_abs_error_values"], a["auc_length_values"]
         md["rgb_auc_neg_error"] = a["auc_neg_error_values"]
         for k in ("coverage_values", "avg_length_values", "coverage_error_values", "abs_coverage_error_values",
@@ -107,7 +107,7 @@ def depth_metrics_unc(outputs: Dict[str, torch.Tensor], depth_gt, scale: float, 
     md["depth_rmse"] = float(np.sqrt(sq.mean().item()))
     md["depth_nll"] = float(nll_img[mask].mean().item())
     md["depth_avg_var"] = float(var.mean().item())
-    a = M.auce(d.flatten().cpu().numpy(), sd.flatten().cpu().numpy(), g.flatten().cpu().numpy())
+    a = M.auce_torch(d.flatten(), sd.flatten(), g.flatten())
     md["depth_auc_abs_error"], md["depth_auc_length"] = a["auc_abs_error_values"], a["auc_length_values"]
     md["depth_auc_neg_error"] = a["auc_neg_error_values"]
     for k in ("coverage_values", "avg_length_values", "coverage_error_values", "abs_coverage_error_values",

@@ -76,6 +76,32 @@ def auce(mean_values: np.ndarray, sigma_values: np.ndarray, target_values: np.nd
     }
 
 
+def auce_torch(mean_values: torch.Tensor, sigma_values: torch.Tensor, target_values: torch.Tensor) -> Dict[str, np.ndarray]:
+    """`auce` on whatever device the tensors live on, in one sort: an interval [m - z s, m + z s] covers the
+    target iff |t - m| / s <= z, so the 99 coverages are 99 binary searches into the sorted standardised residuals
+    and the 99 mean interval lengths are 2 z mean(s).  Same dictionary as `auce` (the reference's 99-pass numpy
+    loop, metrics/auce.py:10-57, takes ~1 s per 1080p image and would dominate the eval loop's rays/s); float64
+    throughout, so the coverage counts agree with it except for residuals within 1e-16 of an interval edge."""
+    m, sg, t = (x.detach().reshape(-1).to(torch.float64) for x in (mean_values, sigma_values, target_values))
+    n = float(t.numel())
+    alphas = np.arange(start=0.01, stop=1.0, step=0.01)
+    z = torch.as_tensor(_norm_ppf(1.0 - alphas / 2), dtype=torch.float64, device=t.device)
+    r = (t - m).abs()
+    ratio = torch.where(sg > 0, r / sg, torch.where(r == 0, torch.zeros_like(r), torch.full_like(r, float("inf"))))
+    ratio, _ = torch.sort(ratio)
+    coverage = (torch.searchsorted(ratio, z, right=True).to(torch.float64) / n).cpu().numpy()
+    length = (2.0 * z * sg.mean()).cpu().numpy()
+    cov_err = coverage - (1.0 - alphas)
+    abs_err = np.abs(cov_err)
+    neg_err = (np.abs(cov_err) - cov_err) / 2.0
+    return {
+        "coverage_values": coverage, "avg_length_values": length, "coverage_error_values": cov_err,
+        "abs_coverage_error_values": abs_err, "neg_coverage_error_values": neg_err,
+        "auc_abs_error_values": _trapz(abs_err, alphas), "auc_length_values": _trapz(length, alphas),
+        "auc_neg_error_values": _trapz(neg_err, alphas),
+    }
+
+
 def psnr(pred: torch.Tensor, gt: torch.Tensor) -> float:
     """torchmetrics PeakSignalNoiseRatio(data_range=1.0) as used via model.psnr
     (scripts/eval_uncertainty.py:683): 10*log10(1/mse) over all elements."""
