@@ -245,7 +245,7 @@ int unerf_laplace_ggn_diag(const float* origins, const float* directions, const 
  * density [B,R,S], rgb [B,R,S,3], beta [B? no: R,S] (NULL -> rgb_var = 0);
  * weights_alt [R,S] (NULL or the laplace mean sampled weights: then accumulation, depth,
  * expected depth and depth_var use it while rgb and rgb_var use get_weights(density)).
- * clip_minmax as produced by unerf_weights_pdf_resample.
+ * clip_minmax as produced by unerf_weights_pdf_resample.  1 <= S <= 256, any value.
  * out [B,R,8] = rgb(3), accumulation, depth(median), expected_depth, rgb_var, depth_var(+1e-5). */
 int unerf_composite_var(const float* density, const float* rgb, const float* beta, const float* weights_alt,
                         const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane,

@@ -35,8 +35,8 @@ def test_null_pointers_are_rejected_before_launch(lib):
     rc = h.unerf_hashgrid_fwd(None, None, None, 10, 16, 19, None, None, None)
     assert rc == -1
     assert b"null pointer" in h.unerf_last_error()
-    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 47, 0.05, 1000.0, None, 0, 32768, 1, None)
-    assert rc == -1 and b"multiple of 16" in h.unerf_last_error()
+    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 300, 0.05, 1000.0, None, 0, 32768, 1, None)
+    assert rc == -1 and b"outside [1,256]" in h.unerf_last_error()
     rc = h.unerf_moments(None, 8, 4, 3, None, None, None)
     assert rc == -1
 

@@ -263,8 +263,10 @@ def test_field_laplace_matches_oracle(dev, use_mfma, precision, n_samples):
     _close(rvar, var_rgb, 0, 2e-6, "var_rgb")
 
 
-@pytest.mark.parametrize("B,S", [(1, 48), (3, 48), (1, 96), (2, 16), (1, 256)])
+@pytest.mark.parametrize("B,S", [(1, 48), (3, 48), (1, 96), (2, 16), (1, 256),
+                                 (1, 50), (2, 17), (1, 7), (1, 2), (1, 40), (1, 70), (1, 100), (1, 150), (1, 255)])
 def test_composite_var_matches_oracle(dev, B, S):
+    """S = 16 k: the aligned kernels; every other S: the RAGGED ones (masked trailing slots)"""
     from uncertainty_nerf_gs_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + S)
     R = 131
@@ -272,7 +274,7 @@ def test_composite_var_matches_oracle(dev, B, S):
     dens[:, 0] = 0.0
     dens[:, 1, S // 3:] = 1e5
     rgb = torch.rand(B, R, S, 3, generator=g)
-    rgb[0, 2, 3, 1] = float("nan")
+    rgb[0, 2, min(3, S - 1), 1] = float("nan")
     beta = torch.rand(R, S, generator=g) + 0.01
     sb = torch.sort(torch.rand(R, S + 1, generator=g), dim=-1).values
     eb = O.spacing_to_euclidean(sb, NEAR, FAR)
@@ -298,11 +300,12 @@ def test_composite_var_matches_oracle(dev, B, S):
         _close(out[b, :, 7:8][same], dv_ref[same], 5e-5, 1e-7, "depth_var")
 
 
-def test_composite_var_weights_alt(dev):
+@pytest.mark.parametrize("S", [48, 50, 21])
+def test_composite_var_weights_alt(dev, S):
     """laplace: rgb / rgb_var from get_weights(mu_d), depth-side outputs from the mean sampled weights"""
     from uncertainty_nerf_gs_amd import ops
     g = torch.Generator().manual_seed(77)
-    R, S = 64, 48
+    R = 64
     dens = torch.exp(torch.randn(1, R, S, generator=g))
     rgb = torch.rand(1, R, S, 3, generator=g)
     var = torch.rand(R, S, generator=g) * 0.01
@@ -319,11 +322,12 @@ def test_composite_var_weights_alt(dev):
     _close(out[:, 4:5], O.render_depth_median(walt, steps), 1e-6, 0, "depth(alt)", max_bad_frac=0.02)
 
 
+@pytest.mark.parametrize("S", [48, 50, 9])
 @pytest.mark.parametrize("explicit_noise", [True, False])
-def test_laplace_depth_weights_matches_oracle(dev, explicit_noise):
+def test_laplace_depth_weights_matches_oracle(dev, explicit_noise, S):
     from uncertainty_nerf_gs_amd import ops
     g = torch.Generator().manual_seed(3)
-    R, S, D = 40, 48, 100
+    R, D = 40, 100
     mu = torch.exp(torch.randn(R, S, generator=g))
     var = torch.rand(R, S, generator=g) * mu ** 2
     var[0, 0] = -1e-3   # sqrt -> NaN -> 1e-10 (laplace_model.py:489-494)
@@ -337,7 +341,7 @@ def test_laplace_depth_weights_matches_oracle(dev, explicit_noise):
     else:
         sidx = ((np.arange(R)[:, None] + off) * S + np.arange(S)[None]).reshape(-1)
         noise = torch.from_numpy(np.stack([O.normal_noise(seed, dd, sidx).reshape(R, S) for dd in range(D)]))
-        assert abs(noise.mean().item()) < 0.02 and abs(noise.std().item() - 1) < 0.02
+        assert abs(noise.mean().item()) < 0.03 and abs(noise.std().item() - 1) < 0.03
     sd = var.sqrt()
     sd = torch.where(torch.isnan(sd), torch.tensor(1e-10), torch.clamp_min(sd, 1e-10))
     samp = torch.relu(mu[None] + sd[None] * noise)
@@ -347,7 +351,7 @@ def test_laplace_depth_weights_matches_oracle(dev, explicit_noise):
     _close(got, ref, 3e-4 if not explicit_noise else 3e-5, 2e-7, "mean sampled weights")
 
 
-@pytest.mark.parametrize("B,S", [(8, 48), (2, 48), (16, 16), (1, 48)])
+@pytest.mark.parametrize("B,S", [(8, 48), (2, 48), (16, 16), (1, 48), (4, 50), (3, 5), (2, 130)])
 def test_composite_moments_equals_composite_then_moments(dev, B, S):
     """fused K-pass composite + mean/var == per-pass composite followed by torch mean / var"""
     from uncertainty_nerf_gs_amd import ops

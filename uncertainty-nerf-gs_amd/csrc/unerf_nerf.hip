@@ -2216,24 +2216,28 @@ struct CompArgs {
 };
 
 // one (pass b, ray r) composite, executed by a 16-lane group; g = b*R + r.  Results are replicated on all 16 lanes.
-template <int SPL>
+// RAGGED: S is not a multiple of 16 (SPL = ceil(S / 16)); the slots k >= S of the last lanes are masked: their bin
+// edges collapse onto edge S (delta = 0), density and weight are 0, and they are excluded from the median count
+// and from the "last sample" background colour.  The aligned instantiations are unchanged.
+template <int SPL, bool RAGGED = false>
 __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int64_t r, int l16, float (&o8)[8]) {
     const int S = a.S, k0 = l16 * SPL;
     const float* sb = a.sbins + r * (S + 1);
     float eu[SPL + 1], delta[SPL], steps[SPL], dens[SPL], w[SPL];
 #pragma unroll
-    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[k0 + e], a.s_near, a.s_far);
+    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[RAGGED ? min(k0 + e, S) : k0 + e], a.s_near, a.s_far);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
         delta[e] = eu[e + 1] - eu[e];
         steps[e] = (eu[e] + eu[e + 1]) / 2.f;
-        dens[e] = a.density[g * S + k0 + e];
+        dens[e] = (!RAGGED || k0 + e < S) ? a.density[g * S + k0 + e] : 0.f;
     }
     group_weights<SPL>(dens, delta, l16, w);
 
     float cr = 0.f, cg = 0.f, cb = 0.f, accw = 0.f, uvar = 0.f, lr = 0.f, lg = 0.f, lb = 0.f;
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
+        if (RAGGED && k0 + e >= S) continue;
         const float* c = a.rgb + (g * S + k0 + e) * 3;
         float r0 = unerf_nan_to_num(c[0]), g0 = unerf_nan_to_num(c[1]), b0 = unerf_nan_to_num(c[2]);
         cr += w[e] * r0;
@@ -2241,7 +2245,7 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
         cb += w[e] * b0;
         accw += w[e];
         if (a.beta) uvar += (w[e] * w[e]) * a.beta[r * S + k0 + e];
-        lr = r0; lg = g0; lb = b0;  // after the loop: this lane's last sample
+        lr = r0; lg = g0; lb = b0;  // after the loop: this lane's last (real) sample
     }
     cr = group_sum<16>(cr);
     cg = group_sum<16>(cg);
@@ -2249,7 +2253,8 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
     accw = group_sum<16>(accw);
     uvar = group_sum<16>(uvar);
     // background_color = "last_sample"
-    float bgr = __shfl(lr, 15, 16), bgg = __shfl(lg, 15, 16), bgb = __shfl(lb, 15, 16);
+    const int last_lane = RAGGED ? (S - 1) / SPL : 15;   // the lane that holds sample S-1
+    float bgr = __shfl(lr, last_lane, 16), bgg = __shfl(lg, last_lane, 16), bgb = __shfl(lb, last_lane, 16);
     cr = fminf(fmaxf(cr + bgr * (1.f - accw), 0.f), 1.f);
     cg = fminf(fmaxf(cg + bgg * (1.f - accw), 0.f), 1.f);
     cb = fminf(fmaxf(cb + bgb * (1.f - accw), 0.f), 1.f);
@@ -2257,7 +2262,8 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
     // depth-side weights: the laplace mean sampled weights when given
     float wd[SPL];
 #pragma unroll
-    for (int e = 0; e < SPL; ++e) wd[e] = a.walt ? a.walt[r * S + k0 + e] : w[e];
+    for (int e = 0; e < SPL; ++e)
+        wd[e] = (RAGGED && k0 + e >= S) ? 0.f : (a.walt ? a.walt[r * S + k0 + e] : w[e]);
     float ls = 0.f, lc[SPL], wt = 0.f;
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
@@ -2271,7 +2277,7 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
     wt = group_sum<16>(wt);
     int cnt = 0;
 #pragma unroll
-    for (int e = 0; e < SPL; ++e) cnt += ((cbase + lc[e]) < 0.5f) ? 1 : 0;
+    for (int e = 0; e < SPL; ++e) cnt += ((!RAGGED || k0 + e < S) && (cbase + lc[e]) < 0.5f) ? 1 : 0;
     cnt = group_sum_i<16>(cnt);
     int idx = min(cnt, S - 1);
     int owner = idx / SPL, slot = idx - owner * SPL;
@@ -2297,7 +2303,7 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
     o8[4] = depth; o8[5] = ed; o8[6] = uvar; o8[7] = dv;
 }
 
-template <int SPL>
+template <int SPL, bool RAGGED = false>
 __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
     const int l16 = threadIdx.x & 15;
     int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -2305,7 +2311,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
     const bool ok = g < G;
     if (!ok) g = G - 1;
     float o8[8];
-    composite_one<SPL>(a, g, g % a.R, l16, o8);
+    composite_one<SPL, RAGGED>(a, g, g % a.R, l16, o8);
     if (ok && l16 == 0) {
         float4* o = reinterpret_cast<float4*>(a.out + g * 8);
         o[0] = make_float4(o8[0], o8[1], o8[2], o8[3]);
@@ -2317,7 +2323,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
 // outputs, and the per-pixel mean and unbiased variance over the passes (two-pass, like
 // torch.stack(...).mean(0) / .var(0), mcdropout_models.py:121-126) come out of two group reductions:
 // the [B,R,8] per-pass images never touch HBM.
-template <int SPL>
+template <int SPL, bool RAGGED = false>
 __global__ __launch_bounds__(256) void composite_moments_kernel(CompArgs a, float* __restrict__ mean_out,
                                                                 float* __restrict__ var_out) {
     const int l16 = threadIdx.x & 15;
@@ -2329,7 +2335,7 @@ __global__ __launch_bounds__(256) void composite_moments_kernel(CompArgs a, floa
     for (int c = 0; c < 8; ++c) mine[c] = 0.f;
     for (int b = 0; b < a.B; ++b) {
         float o8[8];
-        composite_one<SPL>(a, (int64_t)b * a.R + r, r, l16, o8);
+        composite_one<SPL, RAGGED>(a, (int64_t)b * a.R + r, r, l16, o8);
         if (l16 == b) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) mine[c] = o8[c];
@@ -2354,18 +2360,35 @@ __global__ __launch_bounds__(256) void composite_moments_kernel(CompArgs a, floa
 }
 
 
+// Samples per lane: S = 16 * SPL for SPL in {1,2,3,4,6,8,16} (every nerfacto sample count) takes the aligned
+// kernels; any other 1 <= S <= 256 takes the RAGGED instantiation of the next SPL up, whose slots k >= S are masked.
+static inline int unerf_spl_for(int S) {
+    const int want = (S + 15) / 16;
+    for (int spl : {1, 2, 3, 4, 6, 8, 16})
+        if (spl >= want) return spl;
+    return 0;
+}
+#define UNERF_SPL_CASE(N, KERNEL, ...)                                                                              \
+    case N:                                                                                                         \
+        if (ragged_) hipLaunchKernelGGL((KERNEL<N, true>), __VA_ARGS__);                                            \
+        else hipLaunchKernelGGL((KERNEL<N, false>), __VA_ARGS__);                                                   \
+        break;
 #define UNERF_DISPATCH_SPL(S, KERNEL, ...)                                                                          \
-    switch ((S) / 16) {                                                                                             \
-        case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break;                                                \
-        case 2: hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__); break;                                                \
-        case 3: hipLaunchKernelGGL((KERNEL<3>), __VA_ARGS__); break;                                                \
-        case 4: hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__); break;                                                \
-        case 6: hipLaunchKernelGGL((KERNEL<6>), __VA_ARGS__); break;                                                \
-        case 8: hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__); break;                                                \
-        case 16: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;                                              \
-        default:                                                                                                    \
-            unerf_set_error("samples per ray S=%d unsupported (need S = 16*k, k in {1,2,3,4,6,8,16})", (S));        \
-            return UNERF_ERR_ARG;                                                                                   \
+    {                                                                                                               \
+        const int spl_ = unerf_spl_for(S);                                                                          \
+        const bool ragged_ = spl_ * 16 != (S);                                                                      \
+        switch (spl_) {                                                                                             \
+            UNERF_SPL_CASE(1, KERNEL, __VA_ARGS__)                                                                  \
+            UNERF_SPL_CASE(2, KERNEL, __VA_ARGS__)                                                                  \
+            UNERF_SPL_CASE(3, KERNEL, __VA_ARGS__)                                                                  \
+            UNERF_SPL_CASE(4, KERNEL, __VA_ARGS__)                                                                  \
+            UNERF_SPL_CASE(6, KERNEL, __VA_ARGS__)                                                                  \
+            UNERF_SPL_CASE(8, KERNEL, __VA_ARGS__)                                                                  \
+            UNERF_SPL_CASE(16, KERNEL, __VA_ARGS__)                                                                 \
+            default:                                                                                                \
+                unerf_set_error("samples per ray S=%d outside [1,256]", (S));                                       \
+                return UNERF_ERR_ARG;                                                                               \
+        }                                                                                                           \
     }
 
 extern "C" int unerf_composite_var(const float* density, const float* rgb, const float* beta, const float* weights_alt,
@@ -2374,7 +2397,7 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
                                    void* stream) {
     UNERF_REQUIRE(density && rgb && sbins && out, "composite_var: null pointer");
     UNERF_REQUIRE(B >= 1 && R >= 0, "composite_var: bad B/R");
-    UNERF_REQUIRE(S % 16 == 0, "composite_var: S=%d must be a multiple of 16", S);
+    UNERF_REQUIRE(S >= 1 && S <= 256, "composite_var: S=%d outside [1,256]", S);
     UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "composite_var: chunk_rays must be > 0 with clip_minmax");
     if (R == 0) return UNERF_OK;
     CompArgs a;
@@ -2392,7 +2415,7 @@ extern "C" int unerf_composite_moments(const float* density, const float* rgb, c
                                        int64_t chunk_rays, float* mean_out, float* var_out, void* stream) {
     UNERF_REQUIRE(density && rgb && sbins && mean_out && var_out, "composite_moments: null pointer");
     UNERF_REQUIRE(B >= 1 && B <= 16 && R >= 0, "composite_moments: B=%d outside [1,16] (use composite_var + moments)", B);
-    UNERF_REQUIRE(S % 16 == 0, "composite_moments: S=%d must be a multiple of 16", S);
+    UNERF_REQUIRE(S >= 1 && S <= 256, "composite_moments: S=%d outside [1,256]", S);
     UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "composite_moments: chunk_rays must be > 0 with clip_minmax");
     if (R == 0) return UNERF_OK;
     CompArgs a;
@@ -2458,7 +2481,7 @@ __device__ __forceinline__ void group_weights_fast(const float (&dens)[SPL], con
     for (int e = 0; e < SPL; ++e) w[e] = unerf_nan_to_num((1.f - em[e]) * (carry * lex[e]));
 }
 
-template <int SPL>
+template <int SPL, bool RAGGED = false>
 __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
     const int l16 = threadIdx.x & 15;
     int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -2468,13 +2491,14 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
     const float* sb = a.sbins + r * (S + 1);
     float eu[SPL + 1], delta[SPL], mu[SPL], sd[SPL], wsum[SPL], dens[SPL], w[SPL];
 #pragma unroll
-    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[k0 + e], a.s_near, a.s_far);
+    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[RAGGED ? min(k0 + e, S) : k0 + e], a.s_near, a.s_far);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
         delta[e] = eu[e + 1] - eu[e];
-        mu[e] = a.mu[r * S + k0 + e];
-        float s = sqrtf(a.var[r * S + k0 + e]);
-        sd[e] = (s != s) ? 1e-10f : fmaxf(s, 1e-10f);
+        const bool live = !RAGGED || k0 + e < S;   // masked slots: mu = sd = 0 -> density 0, delta 0
+        mu[e] = live ? a.mu[r * S + k0 + e] : 0.f;
+        float s = live ? sqrtf(a.var[r * S + k0 + e]) : 0.f;
+        sd[e] = !live ? 0.f : (s != s) ? 1e-10f : fmaxf(s, 1e-10f);
         wsum[e] = 0.f;
     }
     for (int d0 = 0; d0 < a.D; d0 += 2) {
@@ -2482,8 +2506,9 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
         if (a.noise) {
 #pragma unroll
             for (int e = 0; e < SPL; ++e) {
-                z[0][e] = a.noise[((int64_t)d0 * a.R + r) * S + k0 + e];
-                z[1][e] = (d0 + 1 < a.D) ? a.noise[((int64_t)(d0 + 1) * a.R + r) * S + k0 + e] : 0.f;
+                const bool live = !RAGGED || k0 + e < S;
+                z[0][e] = live ? a.noise[((int64_t)d0 * a.R + r) * S + k0 + e] : 0.f;
+                z[1][e] = (live && d0 + 1 < a.D) ? a.noise[((int64_t)(d0 + 1) * a.R + r) * S + k0 + e] : 0.f;
             }
         } else {
             const uint32_t key = unerf_mc_key(a.seed, (uint32_t)(d0 >> 1));
@@ -2504,7 +2529,8 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
     }
     if (ok) {
 #pragma unroll
-        for (int e = 0; e < SPL; ++e) a.out[r * S + k0 + e] = wsum[e] / (float)a.D;
+        for (int e = 0; e < SPL; ++e)
+            if (!RAGGED || k0 + e < S) a.out[r * S + k0 + e] = wsum[e] / (float)a.D;
     }
 }
 
@@ -2512,7 +2538,7 @@ extern "C" int unerf_laplace_depth_weights(const float* density_mu, const float*
                                            int64_t R, int S, float near_plane, float far_plane, const float* noise,
                                            int D, uint32_t seed, int64_t ray_offset, float* weights_out, void* stream) {
     UNERF_REQUIRE(density_mu && density_var && sbins && weights_out, "laplace_depth_weights: null pointer");
-    UNERF_REQUIRE(D >= 1 && R >= 0 && S % 16 == 0, "laplace_depth_weights: bad D/R/S");
+    UNERF_REQUIRE(D >= 1 && R >= 0 && S >= 1 && S <= 256, "laplace_depth_weights: bad D/R/S");
     if (R == 0) return UNERF_OK;
     LapDepthArgs a;
     a.mu = density_mu; a.var = density_var; a.sbins = sbins; a.R = R; a.S = S;
