@@ -23,7 +23,7 @@ def _fake_eval_set(n=3, H=20, W=24):
 def test_metric_keys_and_averaging(tmp_path):
     items = _fake_eval_set()
     avg, curves = E.get_average_uncertainty_metrics(lambda cam: cam, [(o, gt) for o, gt in items])
-    want = {"psnr", "rgb_ause_mse", "rgb_ause_mae", "rgb_ause_rmse", "rgb_mse", "rgb_rmse", "rgb_nll", "rgb_avg_var",
+    want = {"psnr", "ssim", "rgb_ause_mse", "rgb_ause_mae", "rgb_ause_rmse", "rgb_mse", "rgb_rmse", "rgb_nll", "rgb_avg_var",
             "rgb_auc_abs_error", "rgb_auc_length", "rgb_auc_neg_error", "num_rays_per_sec", "fps", "render_rays_per_sec"}
     assert set(avg) == want
     per = [E.image_metrics_unc(o, gt)[0] for o, gt in items]
@@ -176,3 +176,50 @@ def test_run_eval_writes_the_metrics_envelope(tmp_path):
                      checkpoint="step-000029999.ckpt")
     d = json.loads((tmp_path / "o" / "metrics.json").read_text())
     assert d["method_name"] == "active-nerfacto" and d["results"]["psnr"] == res["psnr"] and "rgb_ause_mse" in res
+
+
+def _ssim_scipy(pred, gt):
+    """independent restatement of the torchmetrics recipe with scipy filters ('mirror' = torch's reflect padding)"""
+    from scipy.ndimage import correlate1d
+    p, t = pred.double().numpy(), gt.double().numpy()            # [H,W,C]
+    dr = max(p.max() - p.min(), t.max() - t.min())
+    c1, c2 = (0.01 * dr) ** 2, (0.03 * dr) ** 2
+    d = np.arange(-5, 6, dtype=np.float64)
+    g = np.exp(-(d / 1.5) ** 2 / 2)
+    g /= g.sum()
+    blur = lambda x: correlate1d(correlate1d(x, g, axis=0, mode="mirror"), g, axis=1, mode="mirror")
+    mu_p, mu_t = blur(p), blur(t)
+    s_pp, s_tt, s_pt = blur(p * p) - mu_p ** 2, blur(t * t) - mu_t ** 2, blur(p * t) - mu_p * mu_t
+    m = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p ** 2 + mu_t ** 2 + c1) * (s_pp + s_tt + c2))
+    return m[5:-5, 5:-5].mean()
+
+
+def test_ssim_follows_the_torchmetrics_recipe():
+    g = torch.Generator().manual_seed(4)
+    gt = torch.rand(40, 52, 3, generator=g)
+    gt = torch.nn.functional.avg_pool2d(gt.permute(2, 0, 1)[None], 5, 1, 2)[0].permute(1, 2, 0)   # some structure
+    pred = torch.clamp(gt + 0.05 * torch.randn(gt.shape, generator=g), 0, 1)
+    assert abs(M.ssim(gt, gt) - 1.0) < 1e-6
+    v = M.ssim(pred, gt)
+    assert 0.0 < v < 1.0 and abs(v - _ssim_scipy(pred, gt)) < 2e-5
+    assert abs(M.ssim(pred.permute(2, 0, 1)[None], gt.permute(2, 0, 1)[None]) - v) < 1e-7     # [1,C,H,W] form
+    assert M.ssim(torch.clamp(gt + 0.2 * torch.randn(gt.shape, generator=g), 0, 1), gt) < v   # more noise, lower score
+
+
+def test_splat_ground_truth_composition():
+    """eval_uncertainty.py:321-322: RGBA ground truth is blended over the render's background colour"""
+    from uncertainty_nerf_gs_amd import models as Mo
+    m = Mo.ActiveSplatfactoModel(Mo.ActiveSplatfactoModelConfig(), num_points=4)
+    rgba = torch.zeros(2, 3, 4, dtype=torch.uint8)
+    rgba[..., 0] = 255
+    rgba[0, :, 3] = 255          # first row opaque red, second row transparent
+    bg = torch.tensor([0.0, 0.0, 1.0])
+    out = m.composite_gt(rgba, bg)
+    assert out.shape == (2, 3, 3) and out.dtype == torch.float32
+    assert torch.equal(out[0], torch.tensor([1.0, 0.0, 0.0]).expand(3, 3)) and torch.equal(out[1], bg.expand(3, 3))
+    rgb = torch.rand(2, 3, 3)
+    assert torch.equal(m.composite_gt(rgb, bg), rgb)      # no alpha channel: unchanged
+    items = [({"rgb": torch.rand(16, 16, 3), "rgb_std": torch.rand(16, 16, 1) + 0.01, "background": bg},
+              torch.cat([torch.rand(16, 16, 3), torch.ones(16, 16, 1)], -1))]
+    md, _ = E.image_metrics_unc(items[0][0], items[0][1], composite_gt=m.composite_gt)
+    assert np.isfinite(md["psnr"]) and np.isfinite(md["ssim"])

@@ -39,7 +39,9 @@ def image_metrics_unc(outputs: Dict[str, torch.Tensor], gt_image: torch.Tensor, 
     image = gt_image.to(rgb.device)
     if "background" in outputs and composite_gt is not None:  # splatfacto: blend GT alpha with the background
         image = composite_gt(image, outputs["background"])
-    md: Dict[str, float] = {"psnr": M.psnr(rgb, image)}
+    # psnr / ssim as at eval_uncertainty.py:683-688; lpips needs the pretrained AlexNet weights (not available
+    # offline) and is left out of the dict rather than faked
+    md: Dict[str, float] = {"psnr": M.psnr(rgb, image), "ssim": M.ssim(rgb, image[..., :3])}
     curves: Dict[str, np.ndarray] = {}
     if eval_rgb_unc:
         rgb_std = outputs["rgb_std"]
@@ -248,6 +250,8 @@ def run_eval(eval_config: EvalConfigs, model, eval_set, experiment_name: str = "
     """main() of scripts/eval_uncertainty.py:1082-1169 without nerfstudio's pipeline loading: pick the method's
     callable, average the per-image metrics, write the metrics.json envelope to eval_config.output_path."""
     fn = outputs_fn_for(eval_config, model, **fn_kw)
+    if composite_gt is None and hasattr(model, "composite_gt"):   # splat models: GT alpha over the background
+        composite_gt = model.composite_gt
     if eval_config.eval_depth and depth_gt_fn is None and eval_config.dataset_path is not None:
         depth_gt_fn = lambda i: load_depth_gt(str(eval_config.dataset_path), i)
     metrics, _curves = get_average_uncertainty_metrics(

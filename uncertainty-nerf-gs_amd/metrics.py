@@ -109,6 +109,36 @@ def psnr(pred: torch.Tensor, gt: torch.Tensor) -> float:
     return 10.0 * math.log10(1.0 / mse)
 
 
+def ssim(pred: torch.Tensor, gt: torch.Tensor, data_range=None) -> float:
+    """torchmetrics.functional.structural_similarity_index_measure with its defaults, as reached through
+    model.ssim (scripts/eval_uncertainty.py:684) on [1,3,H,W] images.  [UPSTREAM-RECALL, torchmetrics is absent
+    here]: 11x11 gaussian window, sigma 1.5, k1 0.01, k2 0.03; inputs reflect-padded by 5, depthwise filtered
+    (no further padding), the padded border cropped again, mean over everything; data_range=None means
+    max(pred.max() - pred.min(), gt.max() - gt.min()).  Runs on the images' device."""
+    p, t = pred.to(torch.float32), gt.to(torch.float32)
+    if p.dim() == 3:  # [H,W,C] -> [1,C,H,W]
+        p, t = p.permute(2, 0, 1)[None], t.permute(2, 0, 1)[None]
+    if data_range is None:
+        data_range = max(float(p.max() - p.min()), float(t.max() - t.min()))
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    ks, sigma, pad = 11, 1.5, 5
+    d = torch.arange((1 - ks) / 2, (1 + ks) / 2, 1, dtype=p.dtype, device=p.device)
+    g = torch.exp(-((d / sigma) ** 2) / 2)
+    g = (g / g.sum())[None]
+    C = p.shape[1]
+    kernel = (g.t() @ g).expand(C, 1, ks, ks)
+    p = torch.nn.functional.pad(p, (pad, pad, pad, pad), mode="reflect")
+    t = torch.nn.functional.pad(t, (pad, pad, pad, pad), mode="reflect")
+    stack = torch.cat((p, t, p * p, t * t, p * t))
+    out = torch.nn.functional.conv2d(stack, kernel, groups=C)
+    B = pred.shape[0] if pred.dim() == 4 else 1
+    mu_p, mu_t, e_pp, e_tt, e_pt = out.split(B)
+    s_pp, s_tt, s_pt = e_pp - mu_p ** 2, e_tt - mu_t ** 2, e_pt - mu_p * mu_t
+    upper, lower = 2 * s_pt + c2, s_pp + s_tt + c2
+    idx = ((2 * mu_p * mu_t + c1) * upper) / ((mu_p ** 2 + mu_t ** 2 + c1) * lower)
+    return float(idx[..., pad:-pad, pad:-pad].mean().item())
+
+
 def negative_gaussian_loglikelihood(preds: torch.Tensor, targets: torch.Tensor, stds: torch.Tensor,
                                     eps: float = 1e-6) -> torch.Tensor:
     """scripts/eval_uncertainty.py:404-412"""

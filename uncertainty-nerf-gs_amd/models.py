@@ -385,3 +385,23 @@ class ActiveSplatfactoModel(nn.Module):
                                                rasterize_mode=self.config.rasterize_mode, **cam)
 
     get_outputs_for_camera = get_outputs
+
+    # -- the two helpers the eval script calls on splat models (scripts/eval_uncertainty.py:321-322, 676-677) --
+    def get_gt_img(self, image: torch.Tensor) -> torch.Tensor:
+        """[UPSTREAM SplatfactoModel.get_gt_img] uint8 -> float / 255, then the training-resolution downscale,
+        which is 1 at eval (step is pinned to 30000 on load, past the resolution schedule)."""
+        if image.dtype == torch.uint8:
+            image = image.float() / 255.0
+        return image.to(self.gauss_params["means"].device)
+
+    @staticmethod
+    def composite_with_background(image: torch.Tensor, background: torch.Tensor) -> torch.Tensor:
+        """[UPSTREAM SplatfactoModel.composite_with_background] RGBA ground truth over the render's background."""
+        if image.shape[2] == 4:
+            alpha = image[..., -1].unsqueeze(-1).repeat((1, 1, 3))
+            return alpha * image[..., :3] + (1 - alpha) * background.to(image.device)
+        return image
+
+    def composite_gt(self, image: torch.Tensor, background: torch.Tensor) -> torch.Tensor:
+        """the composition the eval script applies: composite_with_background(get_gt_img(image), background)"""
+        return self.composite_with_background(self.get_gt_img(image), background)
