@@ -29,6 +29,29 @@ def _member(g, tag, i):
     return {k[len(f"{tag}_in{i}_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_in{i}_")}
 
 
+class _FakeMember:
+    def __init__(self, outputs):
+        self.outputs = outputs
+
+    def get_outputs_for_camera(self, camera):
+        assert camera == "camera"
+        return self.outputs
+
+
+def test_ensemble_pipeline_single_process_equals_aggregate():
+    from uncertainty_nerf_gs_amd import ensemble
+    g = golden("ensemble.npz")
+    members = [_member(g, "alea", i) for i in range(4)]
+    pipe = ensemble.EnsemblePipeline([_FakeMember(m) for m in members], moments_fn=_torch_moments)
+    assert pipe.model is pipe.models[0]
+    out = pipe.get_ensemble_outputs_for_camera_ray_bundle("camera")
+    ref = ensemble.aggregate(members, moments_fn=_torch_moments)
+    assert list(out) == list(ref) and all(torch.equal(out[k], ref[k]) for k in ref)
+    with pytest.raises(AssertionError, match="at least two"):
+        ensemble.EnsemblePipeline([_FakeMember(members[0])], moments_fn=_torch_moments) \
+            .get_ensemble_outputs_for_camera_ray_bundle("camera")
+
+
 def _worker(rank, world, port, tag, ret, per_rank=1):
     import torch.distributed as dist
     from uncertainty_nerf_gs_amd import ensemble
@@ -40,7 +63,11 @@ def _worker(rank, world, port, tag, ret, per_rank=1):
         member = _member(g, tag, rank)
     else:  # rank-major member order: rank r holds members r*per_rank .. r*per_rank+per_rank-1
         member = [_member(g, tag, rank * per_rank + i) for i in range(per_rank)]
-    out = ensemble.aggregate_distributed(member, moments_fn=_torch_moments)
+    if per_rank == 1:
+        out = ensemble.aggregate_distributed(member, moments_fn=_torch_moments)
+    else:  # the same through the EnsemblePipeline surface (fake members that return the golden images)
+        pipe = ensemble.EnsemblePipeline([_FakeMember(m) for m in member], moments_fn=_torch_moments)
+        out = pipe.get_ensemble_outputs_for_camera_ray_bundle("camera")
     ret[rank] = {k: v.numpy() for k, v in out.items()}
     dist.destroy_process_group()
 

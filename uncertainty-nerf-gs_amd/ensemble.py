@@ -112,6 +112,36 @@ def aggregate_distributed(outputs, group=None, moments_fn: Optional[MomentsFn] =
     return _finish(keys, mean, var, alea)
 
 
+class EnsemblePipeline:
+    """The render-side surface of models/ensemble/ensemble_pipeline.py: `models` (the members this process holds)
+    and `get_ensemble_outputs_for_camera_ray_bundle(camera, obb_box)` (:144-191), which is what
+    scripts/eval_uncertainty.py:1127 calls.  The reference keeps all M members in one process and renders them
+    in sequence; here a process holds M / world_size of them (all M without torch.distributed, one per GPU under
+    `torchrun`), and the per-pixel moments go through aggregate / aggregate_distributed.  Loading the members'
+    checkpoints (ensemble_pipeline.py:62-108) is nerfstudio's pipeline code and stays there: pass built Models."""
+
+    def __init__(self, models: Sequence, group=None, moments_fn: Optional[MomentsFn] = None):
+        self.models = torch.nn.ModuleList(models) if all(isinstance(m, torch.nn.Module) for m in models) else list(models)
+        self.group, self.moments_fn = group, moments_fn
+
+    @property
+    def model(self):  # VanillaPipeline.model = the first member (ensemble_pipeline.py:51)
+        return self.models[0]
+
+    def _distributed(self) -> bool:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    @torch.no_grad()
+    def get_ensemble_outputs_for_camera_ray_bundle(self, camera, obb_box=None) -> Dict[str, torch.Tensor]:
+        kw = {} if obb_box is None else {"obb_box": obb_box}
+        outs = [m.get_outputs_for_camera(camera, **kw) for m in self.models]
+        if self._distributed():
+            return aggregate_distributed(outs, group=self.group, moments_fn=self.moments_fn)
+        assert len(outs) > 1, "Ensemble requires at least two models."
+        return aggregate(outs, moments_fn=self.moments_fn)
+
+
 def views_for_rank(num_views: int, rank: int, world: int) -> List[int]:
     """View-batch data parallelism for splats / single models: replicas of the scene,
     disjoint cameras per rank, no data-path collective."""

@@ -217,9 +217,9 @@ def outputs_fn_for(eval_config: EvalConfigs, model, ggn_batches=None, pipeline=N
     import torch
     if isinstance(eval_config, EnsembleConfig):
         from . import ensemble
-        members = list(model)
-        assert len(members) > 1, "Ensemble requires at least two models."
-        return lambda camera: ensemble.aggregate([m.get_outputs_for_camera(camera) for m in members])
+        if hasattr(model, "get_ensemble_outputs_for_camera_ray_bundle"):   # an EnsemblePipeline (eval_uncertainty.py:1127)
+            return model.get_ensemble_outputs_for_camera_ray_bundle
+        return ensemble.EnsemblePipeline(list(model)).get_ensemble_outputs_for_camera_ray_bundle
     if isinstance(eval_config, MCDropoutConfig):
         model.config.mc_samples = eval_config.mc_samples if eval_config.mc_samples is not None else model.config.mc_samples
         model.invalidate()
