@@ -202,7 +202,9 @@ typedef struct {
  *   density [B,R,S]; rgb [B,R,S,3];
  *   aux     ACTIVE: beta [R,S] | LAPLACE: density_var [R,S] | else NULL
  *   aux2    LAPLACE: rgb_var [R,S] (relu, channel mean) | else NULL
- * sbins [R,S+1] spacing-domain bins of the final samples; ray_offset keys the dropout RNG. */
+ * sbins [R,S+1] spacing-domain bins of the final samples; ray_offset keys the dropout RNG.
+ * near_plane < 0: sbins holds EUCLIDEAN bin edges instead (the starts / last end of a RaySamples made by the
+ * caller's own sampler -- Field.forward(ray_samples)); far_plane is ignored then.  Not with `features`. */
 int unerf_field_fwd(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
                     float near_plane, float far_plane, int64_t ray_offset,
                     const unerf_field_params* p /* host struct */,

@@ -693,6 +693,12 @@ struct FieldArgs {
     TileMap tm;
 };
 
+// Bin edge -> Euclidean distance.  unerf_field_fwd(near_plane < 0) sets s_near = -1: sbins then already holds
+// Euclidean edges (RaySamples.frustums.starts / ends of a caller-made sampler) and passes through untouched.
+__device__ __forceinline__ float field_bin_edge(const FieldArgs& a, float b) {
+    return a.s_near < 0.f ? b : unerf_s2e(b, a.s_near, a.s_far);
+}
+
 // ray of column j of ray-block rb (a tile is (rb, sample index)); invalid columns are clamped by the caller
 __device__ __forceinline__ void tile_ray(const FieldArgs& a, uint32_t rb, int j, int64_t& r, bool& valid) {
     if (a.tm.img_w == 0) {  // uniform
@@ -724,7 +730,7 @@ __device__ __forceinline__ TileSample tile_sample(const FieldArgs& a, uint32_t t
     if (!t.valid) r = a.R - 1;
     t.n = r * a.S + s;
     const float* sb = a.sbins + r * (a.S + 1);
-    const float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+    const float e0 = field_bin_edge(a, sb[s]), e1 = field_bin_edge(a, sb[s + 1]);
     const float t01 = e0 + e1;
     t.dx = a.dirs[r * 3 + 0];
     t.dy = a.dirs[r * 3 + 1];
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
     const int s = (int)(n - r * a.S);
 
     const float* sb = a.sbins + r * (a.S + 1);
-    float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+    float e0 = field_bin_edge(a, sb[s]), e1 = field_bin_edge(a, sb[s + 1]);
     float t = e0 + e1;
     float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
     float px = a.origins[r * 3 + 0] + dxr * t / 2.f;
@@ -1935,12 +1941,14 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     UNERF_REQUIRE(p->tcnn_levels || (p->log2T >= 1 && p->log2T <= 24), "field_fwd: bad log2T=%d", p->log2T);
     UNERF_REQUIRE(!(p->tcnn_levels && features), "field_fwd: pre-gathered feature planes are built for the torch-layout grid only");
     UNERF_REQUIRE(R >= 0 && S >= 1, "field_fwd: bad R/S");
+    UNERF_REQUIRE(!(near_plane < 0.f && features), "field_fwd: Euclidean bins (near_plane < 0) cannot be combined with pre-gathered features");
     UNERF_REQUIRE((uint64_t)(ray_offset + R) * (uint64_t)S < (1ull << 32),
                   "field_fwd: sample index exceeds 32 bits (RNG counter)");
     if (R == 0) return UNERF_OK;
     FieldArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
-    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = ray_offset;
+    a.s_near = near_plane < 0.f ? -1.f : unerf_spacing_fn(near_plane);   // < 0: sbins are Euclidean edges
+    a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = ray_offset;
     a.p = *p; a.density = density; a.rgb = rgb; a.aux = aux; a.aux2 = aux2;
     a.features = features;
     a.keep_thr = (uint32_t)lrint((1.0 - (double)p->p_drop) * 65536.0);

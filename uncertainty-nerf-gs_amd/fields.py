@@ -4,7 +4,10 @@ load with `load_state_dict`) and lowering themselves to the device parameter pac
 kernels consume (`to_device`).
 
 These classes do not compute anything in Python: `get_density` / `get_outputs` of the reference
-are replaced by the fused `unerf_field_fwd` kernel, reached through `models.py` / `render.py`.
+are replaced by the fused `unerf_field_fwd` kernel, reached through `models.py` / `render.py`
+(whole-frame path) or through the Field-level calls nerfstudio makes on a RaySamples --
+`field.forward(ray_samples)` / `field(ray_samples)` and `density_field.density_fn(positions)` /
+`get_density(ray_samples)` -- which run the same kernels on the caller's own samples.
 nerfstudio is not required; when it is installed, `plugin.py` registers thin subclasses with its
 plugin registry.
 
@@ -16,7 +19,9 @@ Reference:
 """
 from __future__ import annotations
 
-from typing import List, Optional
+import enum
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import nn
@@ -25,6 +30,50 @@ from . import lib as _l
 from . import ops
 from .synthetic import hash_scalings
 from .utils import create_mlp
+
+
+class FieldHeadNames(enum.Enum):
+    """[UPSTREAM nerfstudio.field_components.field_heads.FieldHeadNames] the members this path emits"""
+    RGB = "rgb"
+    DENSITY = "density"
+    UNCERTAINTY = "uncertainty"
+
+
+@dataclass
+class Frustums:
+    """[UPSTREAM nerfstudio.cameras.rays.Frustums] the four tensors the field kernels read"""
+    origins: torch.Tensor      # [R,S,3]
+    directions: torch.Tensor   # [R,S,3]
+    starts: torch.Tensor       # [R,S,1] Euclidean
+    ends: torch.Tensor         # [R,S,1]
+
+
+@dataclass
+class RaySamples:
+    """[UPSTREAM nerfstudio.cameras.rays.RaySamples] stand-in for use without nerfstudio; nerfstudio's own object is
+    accepted wherever this one is (only `.frustums.{origins,directions,starts,ends}` is read)."""
+    frustums: Frustums
+    camera_indices: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def from_bins(origins: torch.Tensor, directions: torch.Tensor, euclid_bins: torch.Tensor) -> "RaySamples":
+        """rays [R,3] + bin edges [R,S+1] -> the per-sample layout nerfstudio's samplers produce"""
+        S = euclid_bins.shape[-1] - 1
+        return RaySamples(Frustums(origins[:, None, :].expand(-1, S, -1), directions[:, None, :].expand(-1, S, -1),
+                                   euclid_bins[:, :-1, None], euclid_bins[:, 1:, None]))
+
+
+def ray_samples_to_bins(ray_samples) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> origins [R,3], directions [R,3], Euclidean bin edges [R,S+1].  The kernels take contiguous bins (sample i
+    ends where sample i+1 starts), which is what every nerfstudio sampler emits."""
+    fr = ray_samples.frustums
+    starts, ends = fr.starts[..., 0], fr.ends[..., 0]
+    if starts.dim() != 2:
+        raise _l.UnerfError("ray samples must be [num_rays, num_samples, ...]")
+    if starts.shape[1] > 1 and not torch.equal(starts[:, 1:], ends[:, :-1]):
+        raise _l.UnerfError("ray samples are not contiguous bins (ends[i] != starts[i+1])")
+    f = lambda t: t.to(torch.float32).contiguous()
+    return f(fr.origins[:, 0]), f(fr.directions[:, 0]), f(torch.cat([starts, ends[:, -1:]], dim=-1))
 
 
 class _TcnnParams(nn.Module):
@@ -141,6 +190,40 @@ class HashMLPDensityField(nn.Module):
         return ops.DensityNetDev.from_torch(self.encoding.table, self.encoding.scalings, self.encoding.log2_hashmap_size,
                                             w0, b0, w1, b1, device, tcnn_levels=self.encoding.tcnn_levels)
 
+    # -- Field-level calls (nerfstudio HashMLPDensityField.get_density / Field.density_fn) on the proposal kernel --
+    _dev: Optional[ops.DensityNetDev] = None
+
+    def invalidate(self):
+        """drop the device copy of the parameters (call after changing them)"""
+        self._dev = None
+
+    def _net(self, device) -> ops.DensityNetDev:
+        if self._dev is None or self._dev.table.device != torch.device(device):
+            self._dev = self.to_device(device)
+        return self._dev
+
+    @torch.no_grad()
+    def density_fn(self, positions: torch.Tensor, times=None) -> torch.Tensor:
+        """[UPSTREAM Field.density_fn] world positions [..., 3] -> density [..., 1].  The kernel evaluates
+        origin + direction * t: a zero direction makes every position its own ray origin."""
+        _l.require_gpu()
+        shp = positions.shape[:-1]
+        o = positions.reshape(-1, 3).to(torch.float32).contiguous()
+        sb = torch.tensor([0.25, 0.75], device=o.device)   # any two spacing bins: the direction is 0
+        d = ops.proposal_density(o, torch.zeros_like(o), sb, self._net(o.device), 0.05, 1000.0, self.average_init_density)
+        return d.view(*shp, 1)
+
+    @torch.no_grad()
+    def get_density(self, ray_samples) -> Tuple[torch.Tensor, None]:
+        """[UPSTREAM HashMLPDensityField.get_density] -> (density [R,S,1], None)"""
+        fr = ray_samples.frustums
+        pos = fr.origins + fr.directions * (fr.starts + fr.ends) / 2
+        return self.density_fn(pos), None
+
+    def forward(self, ray_samples, compute_normals: bool = False):
+        density, _ = self.get_density(ray_samples)
+        return {FieldHeadNames.DENSITY: density}
+
 
 class _NerfactoFieldBase(nn.Module):
     """Pieces shared with nerfstudio NerfactoField: colour head input = SH16 + geo15 + appearance32."""
@@ -166,6 +249,40 @@ class _NerfactoFieldBase(nn.Module):
         if self.use_average_appearance_embedding:
             return self.embedding_appearance.mean(dim=0).detach()
         return torch.zeros(self.appearance_embedding_dim)
+
+    # -- Field-level call on a RaySamples (eval): one fused unerf_field_fwd launch on the caller's samples --------
+    _dev: Optional[ops.FieldDev] = None
+    _dev_kw: Optional[dict] = None
+
+    def invalidate(self):
+        """drop the device copy of the parameters (call after changing them)"""
+        self._dev = None
+
+    def _field_dev(self, device, **kw) -> ops.FieldDev:
+        if self._dev is None or self._dev.table.device != torch.device(device) or self._dev_kw != kw:
+            self._dev, self._dev_kw = self.to_device(device, **kw), dict(kw)
+        return self._dev
+
+    def _run(self, ray_samples, ray_offset: int = 0, **dev_kw):
+        _l.require_gpu()
+        o, d, eb = ray_samples_to_bins(ray_samples)
+        f = self._field_dev(o.device, **dev_kw)
+        return f, ops.field_fwd(o, d, eb, f, 0.0, 0.0, ray_offset, euclidean_bins=True)
+
+    @torch.no_grad()
+    def forward(self, ray_samples, compute_normals: bool = False) -> Dict:
+        """Field.forward at eval (deterministic pass): {DENSITY [R,S,1], RGB [R,S,3]} + the method's extra keys."""
+        assert not compute_normals, "normals need autograd; not on the render path"
+        f, (density, rgb, aux, aux2) = self._run(ray_samples, **self._forward_kw())
+        out = {FieldHeadNames.DENSITY: density[0].unsqueeze(-1), FieldHeadNames.RGB: rgb[0]}
+        self._extra_outputs(out, aux, aux2)
+        return out
+
+    def _forward_kw(self) -> dict:
+        return {}
+
+    def _extra_outputs(self, out: Dict, aux, aux2) -> None:
+        pass
 
 
 class ActiveNerfactoField(_NerfactoFieldBase):
@@ -196,6 +313,9 @@ class ActiveNerfactoField(_NerfactoFieldBase):
             _l.FIELD_ACTIVE, g.table, g.scalings, g.log2_hashmap_size, w0, b0, w1, b1,
             [w for w, _ in h], [b for _, b in h], self.eval_appearance(), device,
             average_init_density=self.average_init_density, beta_min=self.beta_min, **self._grid_kw(g), **kw)
+
+    def _extra_outputs(self, out, aux, aux2):
+        out["rgb_var"] = aux.unsqueeze(-1)   # beta under the key "rgb_var" (activenerfacto_field.py:209)
 
 
 class NerfactoMCDropoutField(_NerfactoFieldBase):
@@ -229,6 +349,16 @@ class NerfactoMCDropoutField(_NerfactoFieldBase):
             [h[0].weight, h[2].weight, h[5].weight], [h[0].bias, h[2].bias, h[5].bias], self.eval_appearance(), device,
             average_init_density=self.average_init_density, K=mc_samples, seed=seed, p_drop=self.dropout_rate,
             **self._grid_kw(self.mlp_base_grid), **kw)
+
+    def _forward_kw(self):
+        return {"mc_samples": 0}   # eval-mode Dropout is the identity; the K stochastic passes are the Model's job
+
+    @torch.no_grad()
+    def forward_passes(self, ray_samples, mc_samples: int, seed: int = 0, ray_offset: int = 0) -> Dict:
+        """The K dropout passes of mcdropout_models.py:116-119 on one RaySamples, fused (grid lookup and the first
+        layer shared): {DENSITY [K,R,S,1], RGB [K,R,S,3]}; masks keyed by (seed, pass, ray_offset*S + sample)."""
+        f, (density, rgb, _, _) = self._run(ray_samples, ray_offset, mc_samples=mc_samples, seed=seed)
+        return {FieldHeadNames.DENSITY: density.unsqueeze(-1), FieldHeadNames.RGB: rgb}
 
 
 class NerfactoLaplaceField(_NerfactoFieldBase):
@@ -281,6 +411,37 @@ class NerfactoLaplaceField(_NerfactoFieldBase):
             noise = torch.randn(n, mu.numel(), generator=generator, device=mu.device)
             out.append(mu.view(1, -1) + noise * std.view(1, -1))
         return out[0], out[1]
+
+    @torch.no_grad()
+    def forward_unc(self, ray_samples, compute_normals: bool = False, is_inference: bool = False,
+                    use_deterministic_density: bool = False, prior_prec: float = 1.0, n_samples: int = 100,
+                    eps: float = 1e-9, generator=None) -> Dict:
+        """laplace_field.py:487-525 with is_inference=True on one RaySamples: {DENSITY mu_d [R,S,1], "density_var"
+        [R,S,1] | None, RGB mu_rgb [R,S,3], "rgb_var" [R,S,1]}; the last-layer samples are drawn as sample_laplace
+        does (sample_last_layers), the 2 x n_samples head evaluations run inside the kernel."""
+        if not is_inference:
+            raise NotImplementedError("is_inference=False is the training forward")
+        assert not compute_normals
+        ws_d, ws_r = self.sample_last_layers(n_samples=n_samples, prior_prec=prior_prec, eps=eps, generator=generator,
+                                             deterministic_density=use_deterministic_density)
+        self.invalidate()   # fresh weight samples every call, like the reference
+        _l.require_gpu()
+        o, d, eb = ray_samples_to_bins(ray_samples)
+        f = self.to_device(o.device, ws_density=ws_d, ws_rgb=ws_r, lap_mask_density=int(use_deterministic_density))
+        density, rgb, dvar, rvar = ops.field_fwd(o, d, eb, f, 0.0, 0.0, 0, euclidean_bins=True)
+        return {FieldHeadNames.DENSITY: density[0].unsqueeze(-1),
+                "density_var": None if use_deterministic_density else dvar.unsqueeze(-1),
+                FieldHeadNames.RGB: rgb[0], "rgb_var": rvar.unsqueeze(-1)}
+
+    def forward(self, ray_samples, compute_normals: bool = False) -> Dict:
+        """the deterministic field (is_inference=False branch at eval): mean heads, selector-masked density"""
+        mu_d = torch.nn.utils.parameters_to_vector(self.mlp_density.parameters()).detach().view(1, -1)
+        mu_r = torch.nn.utils.parameters_to_vector(self.mlp_rgb_ll.parameters()).detach().view(1, -1)
+        _l.require_gpu()
+        o, d, eb = ray_samples_to_bins(ray_samples)
+        f = self.to_device(o.device, ws_density=mu_d, ws_rgb=mu_r, lap_mask_density=1)
+        density, rgb, _, _ = ops.field_fwd(o, d, eb, f, 0.0, 0.0, 0, euclidean_bins=True)
+        return {FieldHeadNames.DENSITY: density[0].unsqueeze(-1), FieldHeadNames.RGB: rgb[0]}
 
     def to_device(self, device, ws_density=None, ws_rgb=None, **kw) -> ops.FieldDev:
         h = self.mlp_head

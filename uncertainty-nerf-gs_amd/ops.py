@@ -554,9 +554,12 @@ def field_gather(origins, directions, sbins, field: FieldDev, near: float, far: 
 
 
 def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0,
-              features: Optional[torch.Tensor] = None, image_width: int = 0):
+              features: Optional[torch.Tensor] = None, image_width: int = 0, euclidean_bins: bool = False):
     """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h).  image_width > 0 tells the kernel that
-    rays [ray_offset, ray_offset+R) are consecutive pixels of a row-major image (8x4-pixel tiles: same results)."""
+    rays [ray_offset, ray_offset+R) are consecutive pixels of a row-major image (8x4-pixel tiles: same results).
+    euclidean_bins: `sbins` holds Euclidean bin edges (a caller-made RaySamples) instead of spacing-domain bins."""
+    if euclidean_bins:
+        near = -1.0
     lib = _l.load()
     R, S = sbins.shape[0], sbins.shape[1] - 1
     B = max(field.K, 1) if field.mode == _l.FIELD_MCDROPOUT else 1
