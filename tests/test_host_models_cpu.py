@@ -110,3 +110,17 @@ def test_laplace_deterministic_density_draws_only_the_colour_head():
     torch.testing.assert_close(ws_r, mu_r.view(1, -1) + noise / torch.sqrt(f.mlp_rgb_ggn + 1.0 + 1e-9))
     _, ws_r2 = f.sample_last_layers(n_samples=100, generator=torch.Generator().manual_seed(3))
     assert not torch.equal(ws_r, ws_r2)   # with density sampling the colour head sees a later generator state
+
+
+def test_models_expose_the_eval_scripts_image_metrics():
+    """scripts/eval_uncertainty.py:683-684 calls model.psnr / model.ssim on [1,3,H,W] tensors"""
+    from uncertainty_nerf_gs_amd import metrics
+    m = M.ActiveSplatfactoModel(M.ActiveSplatfactoModelConfig(), num_points=4)
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, 24, 32, generator=g)
+    rgb = torch.clamp(img + 0.05 * torch.randn(img.shape, generator=g), 0, 1)
+    assert abs(float(m.psnr(img, rgb).item()) - metrics.psnr(rgb, img)) < 1e-12
+    assert abs(float(m.ssim(img, rgb)) - metrics.ssim(rgb[0].permute(1, 2, 0), img[0].permute(1, 2, 0))) < 1e-6
+    assert M.ActiveNerfactoModel.psnr is M.ActiveSplatfactoModel.psnr
+    with pytest.raises(NotImplementedError):
+        m.lpips(img, rgb)

@@ -114,7 +114,28 @@ class ActiveSplatfactoModelConfig:
 
 # ------------------------------------------------------------------ NeRF models --------------
 
-class _NerfactoBase(nn.Module):
+
+class _ImageMetrics:
+    """`model.psnr(image, rgb)` / `model.ssim(image, rgb)` on [1,3,H,W] images, as the eval script calls them
+    (scripts/eval_uncertainty.py:683-684; nerfstudio sets them to torchmetrics' PSNR(data_range=1.0) and SSIM).
+    `lpips` needs the pretrained AlexNet weights and raises."""
+
+    @staticmethod
+    def psnr(image: torch.Tensor, rgb: torch.Tensor) -> torch.Tensor:
+        from . import metrics
+        return torch.tensor(metrics.psnr(rgb, image), dtype=torch.float64)
+
+    @staticmethod
+    def ssim(image: torch.Tensor, rgb: torch.Tensor) -> torch.Tensor:
+        from . import metrics
+        return torch.tensor(metrics.ssim(rgb, image), dtype=torch.float64)
+
+    @staticmethod
+    def lpips(image: torch.Tensor, rgb: torch.Tensor):
+        raise NotImplementedError("LPIPS needs pretrained network weights, which this offline build does not ship")
+
+
+class _NerfactoBase(nn.Module, _ImageMetrics):
     config: NerfactoModelConfig
 
     def __init__(self, config, scene_box=None, num_train_data: int = 1, **_kw):
@@ -339,7 +360,7 @@ class NerfactoLaplaceModel(_NerfactoBase):
 
 # ------------------------------------------------------------------ splats --------------------
 
-class ActiveSplatfactoModel(nn.Module):
+class ActiveSplatfactoModel(nn.Module, _ImageMetrics):
     config: ActiveSplatfactoModelConfig
     GAUSS = ("means", "scales", "quats", "features_dc", "features_rest", "opacities", "log_uncertainties")
 
