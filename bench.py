@@ -217,7 +217,7 @@ def main():
         roof["path_frac_of_hbm_peak"] = path_bytes * (H * W * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
             cpu = cpu_baseline(t, args, poses[0], cam, K)
 
         line = {
