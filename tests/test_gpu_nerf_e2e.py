@@ -187,6 +187,35 @@ def test_non_default_sampler_counts(dev, kind, num_prop, num_nerf):
     _img_close(out["depth"], ref["depth"], 0, 1e-3, "depth", max_bad_frac=2e-2)
 
 
+def test_blender_lego_200x200_mcdropout_plumbing_config(dev):
+    """BASELINE.json configs[0]: Blender-lego-shaped 200x200 single view, nerfacto-mcdropout with the torch-layout
+    field, reference chunking (32768 + 7232 rays).  The oracle needs ~80 s of host time for this frame, so its
+    outputs are a stored fixture (tests/golden/lego200_mcdropout.npz, made by tests/golden/make_oracle_fixtures.py)."""
+    import importlib.util, os
+    from conftest import golden
+    from uncertainty_nerf_gs_amd import render, synthetic
+    spec = importlib.util.spec_from_file_location(
+        "make_oracle_fixtures", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_oracle_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    c = mod.LEGO
+    t = synthetic.make_scene_tensors(seed=c["seed"], kind="mcdropout", log2T=c["log2T"], prop_log2T=c["prop_log2T"])
+    sd = synthetic.scene_to_device(t, dev, K=c["K"], seed=c["mc_seed"], p_drop=c["p_drop"])
+    assert sd.chunk_rays == 32768
+    cam = dict(synthetic.CAMERA_LEGO200)
+    c2w = synthetic.orbit_c2w(c["theta"], radius=c["radius"], height=c["height"])
+    out = render.render_camera(sd, c2w, **cam)
+    g = golden("lego200_mcdropout.npz")
+    ref = {k: torch.from_numpy(g[k]) for k in g.files}
+    assert set(ref) == set(out) and out["rgb"].shape == (200, 200, 3)
+    _gates("lego200-mcdropout", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _img_close(out["rgb"], ref["rgb"], 1e-4, 0, "rgb (mean over K)")
+    _img_close(out["rgb_std"], ref["rgb_std"], 2e-5, 5e-3, "rgb_std", max_bad_frac=2e-3)
+    _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=5e-3)
+    _img_close(out["depth"], ref["depth"], 0, 1e-3, "depth", max_bad_frac=2e-2)
+
+
 def test_full_1080p_frame_properties(dev):
     """BASELINE size (full nerfacto tables, 1920x1080): size-independent properties instead of an
     oracle comparison -- finite outputs, accumulation in [0,1], sorted sample bins, chunk-independent
