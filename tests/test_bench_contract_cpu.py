@@ -1,0 +1,45 @@
+"""bench.py's output contract, checked on the committed line of the latest profiled run (profiles/*_default_bench.json
+is the stdout line of `python bench.py` on MI355X) and on the script's command line -- no GPU needed."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _latest_line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_default_bench.json")))
+    assert files, "no committed default bench line under profiles/"
+    return json.load(open(files[-1])), files[-1]
+
+
+def test_committed_bench_line_has_every_contract_field():
+    d, path = _latest_line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, (path, k)
+    assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["n_gpus"] == 1
+    assert d["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    assert d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["peak"] == (8000.0 if r["bound"] == "hbm" else r["peak"])
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"]
+
+
+def test_bench_refuses_multi_gpu_without_a_launcher():
+    """--gpus N > 1 must come through torch.distributed.run (one process per GPU); a bare call says so"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert p.returncode == 2 and "torch.distributed.run" in p.stderr
