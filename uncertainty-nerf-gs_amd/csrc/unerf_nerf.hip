@@ -2240,14 +2240,20 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
         steps[e] = (eu[e] + eu[e + 1]) / 2.f;
         dens[e] = (!RAGGED || k0 + e < S) ? a.density[g * S + k0 + e] : 0.f;
     }
+    // colours requested with the densities, one 12-byte load per sample (the three channels as separate dword
+    // loads tripled the texture-unit work of this kernel), and consumed after the scan
+    struct Rgb { float r, g, b; };
+    Rgb col[SPL];
+#pragma unroll
+    for (int e = 0; e < SPL; ++e)
+        col[e] = (!RAGGED || k0 + e < S) ? reinterpret_cast<const Rgb*>(a.rgb)[g * S + k0 + e] : Rgb{0.f, 0.f, 0.f};
     group_weights<SPL>(dens, delta, l16, w);
 
     float cr = 0.f, cg = 0.f, cb = 0.f, accw = 0.f, uvar = 0.f, lr = 0.f, lg = 0.f, lb = 0.f;
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
         if (RAGGED && k0 + e >= S) continue;
-        const float* c = a.rgb + (g * S + k0 + e) * 3;
-        float r0 = unerf_nan_to_num(c[0]), g0 = unerf_nan_to_num(c[1]), b0 = unerf_nan_to_num(c[2]);
+        float r0 = unerf_nan_to_num(col[e].r), g0 = unerf_nan_to_num(col[e].g), b0 = unerf_nan_to_num(col[e].b);
         cr += w[e] * r0;
         cg += w[e] * g0;
         cb += w[e] * b0;
