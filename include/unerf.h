@@ -280,10 +280,18 @@ int unerf_splat_project(const float* means3d, const float* scales, float glob_sc
                         float* conics, float* compensation, int32_t* num_tiles_hit, float* cov3d, void* stream);
 
 /* :245-246 spherical_harmonics(degree, viewdirs, coeffs[N,16,3]) then clamp(+0.5, min 0);
- * and :286 softplus(log_unc)+beta_min.  cam_pos_host: 3 floats.  colors_out [N,3], beta_out [N]. */
+ * and :286 softplus(log_unc)+beta_min.  cam_pos_host: 3 floats.  colors_out [N,3], beta_out [N]. 
+ * sh_coeffs must be 16-byte aligned (rows of 48 floats are read as 16-byte loads). */
 int unerf_splat_sh_colors(int degree, const float* means3d, const float* cam_pos_host, const float* sh_coeffs,
                           const float* log_unc, float beta_min, int64_t N, float* colors_out, float* beta_out,
                           void* stream);
+
+/* The same with the coefficients as the model stores them -- gauss_params.features_dc [N,3] and
+ * gauss_params.features_rest [N,15,3] -- i.e. without the torch.cat of activesplatfacto_model.py:242-243
+ * (192 B per splat written and read back every frame).  features_rest may be NULL for degree 0. */
+int unerf_splat_sh_colors_split(int degree, const float* means3d, const float* cam_pos_host, const float* features_dc,
+                                const float* features_rest, const float* log_unc, float beta_min, int64_t N,
+                                float* colors_out, float* beta_out, void* stream);
 
 /* bin-and-sort done ONCE per frame (the reference repeats it inside each of its four
  * rasterize_gaussians calls :260,:289,:306,:343).  cum_tiles_hit [N] i32 (inclusive scan,

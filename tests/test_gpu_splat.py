@@ -70,6 +70,11 @@ def test_sh_colors_and_beta(dev, degree):
     np.testing.assert_allclose(col.cpu().numpy(), ref, rtol=0, atol=2e-6)
     np.testing.assert_allclose(beta.cpu().numpy(), SO.softplus(gp["log_uncertainties"].numpy()).reshape(-1) + np.float32(0.01),
                                rtol=2e-6, atol=0)
+    # the in-place form (features_dc / features_rest as the model stores them, no concatenation): the same bits
+    col2, beta2 = ops.splat_sh_colors_split(degree, gp["means"].to(dev), c2w[:3, 3], gp["features_dc"].to(dev),
+                                            gp["features_rest"].contiguous().to(dev),
+                                            gp["log_uncertainties"].reshape(-1).to(dev), 0.01)
+    assert torch.equal(col2, col) and torch.equal(beta2, beta)
 
 
 @pytest.mark.parametrize("N,H,W", [(6000, 48, 64), (2000, 100, 37)])

@@ -169,8 +169,13 @@ extern "C" int unerf_splat_project(const float* means3d, const float* scales, fl
 // ======================================================================================
 // SH colours (+0.5, clamp>=0) and beta = softplus(log_unc) + beta_min
 // ======================================================================================
+// SPLIT: the coefficients arrive as the model stores them -- features_dc [N,3] and features_rest [N,15,3]
+// (`coeffs` = dc, `rest` = the 45-float rows) -- which saves the per-frame torch.cat of 192 B per splat that the
+// reference performs (activesplatfacto_model.py:242-243) and this kernel would only read back once.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float* __restrict__ means, float cxp,
                                                         float cyp, float czp, const float* __restrict__ coeffs,
+                                                        const float* __restrict__ rest,
                                                         const float* __restrict__ log_unc, float beta_min, int64_t N,
                                                         float* __restrict__ colors, float* __restrict__ beta) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -180,7 +185,32 @@ __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float*
                          0.5462742152960396f};
     const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                          -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
-    const float* k = coeffs + i * 48;
+    // the splat's coefficient row (192 B, 16-byte aligned) as 16-byte loads: a thread-per-splat kernel reads with a
+    // 192-B stride, so every load instruction touches 64 cache lines -- 12 of them instead of 46 dword loads
+    float k[48];
+    if (SPLIT) {
+        const float* dc = coeffs + i * 3;
+        k[0] = dc[0]; k[1] = dc[1]; k[2] = dc[2];
+        // 180-byte rows are only 4-byte aligned: 11 x 16-byte + 1 x 4-byte unaligned-capable global loads
+        struct __attribute__((packed, aligned(4))) Q { float x, y, z, w; };
+        const Q* r4 = reinterpret_cast<const Q*>(rest + i * 45);
+        const int nq = degree <= 0 ? 0 : degree == 1 ? 3 : degree == 2 ? 6 : 11;       // 9 / 24 / 45 floats used
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            Q v = {0.f, 0.f, 0.f, 0.f};
+            if (q < nq) v = r4[q];
+            k[3 + 4 * q] = v.x; k[4 + 4 * q] = v.y; k[5 + 4 * q] = v.z; k[6 + 4 * q] = v.w;
+        }
+        k[47] = (degree >= 3) ? rest[i * 45 + 44] : 0.f;
+    } else {
+        const float4* k4 = reinterpret_cast<const float4*>(coeffs + i * 48);
+        const int nq = degree == 0 ? 1 : degree == 1 ? 3 : degree == 2 ? 7 : 12;   // 3 / 12 / 27 / 48 floats used
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const float4 v = (q < nq) ? k4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            k[4 * q] = v.x; k[4 * q + 1] = v.y; k[4 * q + 2] = v.z; k[4 * q + 3] = v.w;
+        }
+    }
     float col[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) col[c] = C0 * k[c];
@@ -217,10 +247,26 @@ extern "C" int unerf_splat_sh_colors(int degree, const float* means3d, const flo
     UNERF_REQUIRE(means3d && cam_pos && sh_coeffs && colors_out, "splat_sh_colors: null pointer");
     UNERF_REQUIRE(degree >= 0 && degree <= 3, "splat_sh_colors: degree %d outside [0,3]", degree);
     UNERF_REQUIRE(!beta_out || log_unc, "splat_sh_colors: beta_out without log_unc");
+    UNERF_REQUIRE(((uintptr_t)sh_coeffs & 15u) == 0, "splat_sh_colors: sh_coeffs must be 16-byte aligned");
     if (N <= 0) return UNERF_OK;
-    hipLaunchKernelGGL(sh_colors_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree, means3d,
-                       cam_pos[0], cam_pos[1], cam_pos[2], sh_coeffs, log_unc, beta_min, N, colors_out, beta_out);
+    hipLaunchKernelGGL(sh_colors_kernel<false>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
+                       means3d, cam_pos[0], cam_pos[1], cam_pos[2], sh_coeffs, nullptr, log_unc, beta_min, N, colors_out,
+                       beta_out);
     return unerf_check_launch("splat_sh_colors");
+}
+
+extern "C" int unerf_splat_sh_colors_split(int degree, const float* means3d, const float* cam_pos, const float* features_dc,
+                                           const float* features_rest, const float* log_unc, float beta_min, int64_t N,
+                                           float* colors_out, float* beta_out, void* stream) {
+    UNERF_REQUIRE(means3d && cam_pos && features_dc && colors_out, "splat_sh_colors_split: null pointer");
+    UNERF_REQUIRE(degree >= 0 && degree <= 3, "splat_sh_colors_split: degree %d outside [0,3]", degree);
+    UNERF_REQUIRE(degree == 0 || features_rest, "splat_sh_colors_split: degree %d needs features_rest", degree);
+    UNERF_REQUIRE(!beta_out || log_unc, "splat_sh_colors_split: beta_out without log_unc");
+    if (N <= 0) return UNERF_OK;
+    hipLaunchKernelGGL(sh_colors_kernel<true>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
+                       means3d, cam_pos[0], cam_pos[1], cam_pos[2], features_dc, features_rest, log_unc, beta_min, N,
+                       colors_out, beta_out);
+    return unerf_check_launch("splat_sh_colors_split");
 }
 
 // ======================================================================================

@@ -132,6 +132,7 @@ SIGNATURES = {
     "unerf_splat_project": (_i, [_vp, _vp, _f, _vp, _fp, _f, _f, _f, _f, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp]),
     "unerf_splat_sh_colors": (_i, [_i, _vp, _fp, _vp, _vp, _f, _i64, _vp, _vp, _vp]),
+    "unerf_splat_sh_colors_split": (_i, [_i, _vp, _fp, _vp, _vp, _vp, _f, _i64, _vp, _vp, _vp]),
     "unerf_splat_sort_workspace_bytes": (_i64, [_i64, _i64]),
     "unerf_splat_count_intersects": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "unerf_splat_bin_sort": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -683,6 +683,21 @@ def splat_sh_colors(degree: int, means3d, cam_pos: torch.Tensor, sh_coeffs, log_
     return colors, beta
 
 
+def splat_sh_colors_split(degree: int, means3d, cam_pos: torch.Tensor, features_dc, features_rest, log_unc=None,
+                          beta_min: float = 0.01):
+    """splat_sh_colors on gauss_params.features_dc [N,3] / features_rest [N,15,3] as stored (no concatenation)."""
+    lib = _l.load()
+    N, dev = means3d.shape[0], means3d.device
+    colors = torch.empty(N, 3, device=dev)
+    beta = torch.empty(N, device=dev) if log_unc is not None else None
+    cp = (C.c_float * 3)(*[float(v) for v in cam_pos.detach().cpu().reshape(-1)[:3]])
+    with _ctx(dev):
+        _run("splat_sh_colors", lambda: lib.unerf_splat_sh_colors_split(
+            degree, _p(means3d), cp, _p(features_dc), _p(features_rest), _p(log_unc), beta_min, N, _p(colors), _p(beta),
+            _stream()))
+    return colors, beta
+
+
 def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_width: int = 16,
                    want_isect_ids: bool = True):
     """-> (num_intersects, cum_tiles_hit, isect_ids_sorted | None, gaussian_ids_sorted, tile_bins [tiles,2])

@@ -41,9 +41,10 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     quats = gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True)
     xys, depths, radii, conics, comp, tiles, _cov = ops.splat_project(
         means, torch.exp(gp["scales"]), 1.0, quats.contiguous(), V[:3], fx, fy, cx, cy, H, W, block_width)
-    coeffs = torch.cat((gp["features_dc"][:, None, :], gp["features_rest"]), dim=1).contiguous()
-    rgbs, beta = ops.splat_sh_colors(sh_degree, means, c2w[:3, 3], coeffs, gp["log_uncertainties"].reshape(-1).contiguous(),
-                                     beta_min)
+    # the reference concatenates features_dc and features_rest first (:242-243); the kernel reads them in place
+    rgbs, beta = ops.splat_sh_colors_split(sh_degree, means, c2w[:3, 3], gp["features_dc"].contiguous(),
+                                           gp["features_rest"].contiguous(),
+                                           gp["log_uncertainties"].reshape(-1).contiguous(), beta_min)
     opac = torch.sigmoid(gp["opacities"]).reshape(-1)
     if rasterize_mode == "antialiased":
         opac = opac * comp
