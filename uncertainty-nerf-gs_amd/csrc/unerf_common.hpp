@@ -219,25 +219,36 @@ __device__ __forceinline__ float2 unerf_dense_level(const float4* __restrict__ c
     int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
     int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
     float ox = sx - (float)fx, oy = sy - (float)fy, oz = sz - (float)fz;
-    // 32-bit byte offsets off a uniform base (dim <= 129: the whole level is < 2^32 bytes)
+    // 32-bit byte offsets off a uniform base.  dim <= 255 (checked by the caller): every product below stays under
+    // 2^24, so the index arithmetic runs on the full-rate 24-bit multiply-add (v_mad_u32_u24) instead of six
+    // quarter-rate v_mul_lo_u32 per level.
     const char* base = reinterpret_cast<const char*>(cells);
     const uint32_t udim = (uint32_t)dim;
-    const uint32_t rowc = (uint32_t)cz * udim, rowf = (uint32_t)fz * udim;
-    const uint32_t x16 = (uint32_t)fx << 4, d16 = udim << 4;
-    const float4 pcc = *reinterpret_cast<const float4*>(base + ((rowc + (uint32_t)cy) * d16 + x16));
-    const float4 pfc = *reinterpret_cast<const float4*>(base + ((rowc + (uint32_t)fy) * d16 + x16));
-    const float4 pcf = *reinterpret_cast<const float4*>(base + ((rowf + (uint32_t)cy) * d16 + x16));
-    const float4 pff = *reinterpret_cast<const float4*>(base + ((rowf + (uint32_t)fy) * d16 + x16));
-    const bool step = cx != fx;  // false only when the scaled x is an exact integer (ceil == floor)
+    const uint32_t rcc = __umul24((uint32_t)cz, udim) + (uint32_t)cy, rfc = __umul24((uint32_t)cz, udim) + (uint32_t)fy;
+    const uint32_t rcf = __umul24((uint32_t)fz, udim) + (uint32_t)cy, rff = __umul24((uint32_t)fz, udim) + (uint32_t)fy;
+    const uint32_t ufx = (uint32_t)fx;
+    const float4 pcc = *reinterpret_cast<const float4*>(base + ((__umul24(rcc, udim) + ufx) << 4));
+    const float4 pfc = *reinterpret_cast<const float4*>(base + ((__umul24(rfc, udim) + ufx) << 4));
+    const float4 pcf = *reinterpret_cast<const float4*>(base + ((__umul24(rcf, udim) + ufx) << 4));
+    const float4 pff = *reinterpret_cast<const float4*>(base + ((__umul24(rff, udim) + ufx) << 4));
     float2 f[8];
     f[3] = make_float2(pcc.x, pcc.y);
-    f[0] = step ? make_float2(pcc.z, pcc.w) : f[3];
+    f[0] = make_float2(pcc.z, pcc.w);
     f[2] = make_float2(pfc.x, pfc.y);
-    f[1] = step ? make_float2(pfc.z, pfc.w) : f[2];
+    f[1] = make_float2(pfc.z, pfc.w);
     f[7] = make_float2(pcf.x, pcf.y);
-    f[4] = step ? make_float2(pcf.z, pcf.w) : f[7];
+    f[4] = make_float2(pcf.z, pcf.w);
     f[6] = make_float2(pff.x, pff.y);
-    f[5] = step ? make_float2(pff.z, pff.w) : f[6];
+    f[5] = make_float2(pff.z, pff.w);
+    // scaled x an exact integer (ceil == floor: masked samples sit at 0): the ceil-x corner IS the floor-x corner.
+    // Rare, so the eight selects are skipped unless some lane of the wave needs them.
+    if (__any(cx == fx)) {
+        const bool step = cx != fx;
+        f[0] = step ? f[0] : f[3];
+        f[1] = step ? f[1] : f[2];
+        f[4] = step ? f[4] : f[7];
+        f[5] = step ? f[5] : f[6];
+    }
     return unerf_blend8(f, ox, oy, oz);
 }
 
