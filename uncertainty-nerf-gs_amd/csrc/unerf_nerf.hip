@@ -396,8 +396,8 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
 // pixel patch x 4 consecutive sample indices, so its four waves need the same 64 origins / directions and five
 // consecutive bin edges of the same 64 rays, and produce 4 adjacent densities per ray.  Ray-indexed accesses cost
 // the texture path one cache line per LANE (64 rays = 64 rows of sbins / density_out): loading them once per
-// workgroup (and converting each edge to Euclidean once instead of twice) and storing one 16-byte vector per ray
-// removes 40 % of the cache-line accesses of the 96-sample pass and 25 % of the 256-sample pass.  Same arithmetic on
+// workgroup and storing one 16-byte vector per ray removes about half of the cache-line accesses of the 96-sample
+// pass (own sbins row per ray) and a quarter of the 256-sample pass (shared sbins).  Same arithmetic on
 // the same values: bit-identical to prop_density_kernel.
 template <int L, int HID>
 __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
@@ -413,15 +413,23 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
     const bool ray_ok = x < a.img_w && r >= 0 && r < a.R;
     if (!ray_ok) r = 0;
     const int i_base = (int)(sg * 4u);
-    {   // stage: thread (wv, lane) converts edge i_base + wv of ray `lane`; wave 0 also takes edge i_base + 4 and o, d
-        const float* sb = a.sbins + r * a.sstride;
-        s_e[wv][lane] = unerf_s2e(sb[min(i_base + (int)wv, a.n)], a.s_near, a.s_far);
+    {   // stage: wave 0 the ray, wave 1 its five raw bin edges (one 16-byte + one 4-byte load when the row allows)
         if (wv == 0) {
-            s_e[4][lane] = unerf_s2e(sb[min(i_base + 4, a.n)], a.s_near, a.s_far);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 s_od[c][lane] = a.origins[r * 3 + c];
                 s_od[3 + c][lane] = a.dirs[r * 3 + c];
+            }
+        } else if (wv == 1) {
+            const float* sb = a.sbins + r * a.sstride + i_base;
+            if (i_base + 4 <= a.n) {  // uniform
+                struct __attribute__((packed, aligned(4))) Q { float x, y, z, w; };
+                const Q q = *reinterpret_cast<const Q*>(sb);
+                s_e[0][lane] = q.x; s_e[1][lane] = q.y; s_e[2][lane] = q.z; s_e[3][lane] = q.w;
+                s_e[4][lane] = sb[4];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 5; ++e) s_e[e][lane] = sb[min(e, a.n - i_base)];
             }
         }
     }
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
     const int i = i_base + (int)wv;
     float dens = 0.f;
     if (ray_ok && i < a.n) {
-        const float t = s_e[wv][lane] + s_e[wv + 1][lane];
+        const float t = unerf_s2e(s_e[wv][lane], a.s_near, a.s_far) + unerf_s2e(s_e[wv + 1][lane], a.s_near, a.s_far);
         float px = s_od[0][lane] + s_od[3][lane] * t / 2.f;
         float py = s_od[1][lane] + s_od[4][lane] * t / 2.f;
         float pz = s_od[2][lane] + s_od[5][lane] * t / 2.f;
