@@ -466,3 +466,23 @@ def test_proposal_pixel_patch_schedule_changes_nothing(dev, level, W, R, offset)
     a = ops.proposal_density(*args)
     b = ops.proposal_density(*args, ray_offset=offset, image_width=W)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,shared", [(50, True), (7, False), (3, False), (97, False), (130, True), (1, False)])
+def test_proposal_patch_kernel_ragged_sample_counts(dev, n, shared):
+    """sample counts that are not a multiple of 4 (scalar-store path, clamped edge staging of the LDS-staged patch
+    kernel) and an output that is not 16-byte aligned: same bits as the one-thread-per-sample kernel"""
+    from uncertainty_nerf_gs_amd import ops
+    t, sc, sd = _scene("active", dev)
+    W, R, offset = 24, 24 * 11 + 3, 24 * 2 + 5
+    g = torch.Generator().manual_seed(n)
+    o = torch.randn(R, 3, generator=g) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    sb = O.initial_spacing_bins(n) if shared else torch.sort(torch.rand(R, n + 1, generator=g), dim=-1).values
+    args = (o.to(dev), d.to(dev), sb.contiguous().to(dev), sd.props[0], NEAR, FAR, 0.01)
+    a = ops.proposal_density(*args)
+    b = ops.proposal_density(*args, ray_offset=offset, image_width=W)
+    assert a.shape == (R, n) and torch.equal(a, b)
+    ref = O.density_field(O.sample_positions(o, d, O.spacing_to_euclidean(sb.expand(R, -1) if shared else sb, NEAR, FAR)),
+                          sc.prop_nets[0], 0.01)
+    _close(b, ref, 2e-5, 1e-7, "density")
