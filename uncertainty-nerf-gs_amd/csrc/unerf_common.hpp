@@ -283,18 +283,53 @@ __device__ __forceinline__ void unerf_tcnn_corners(const unerf_tcnn_level& lv, f
         }
     }
 }
+// weight of corner k = (wx_k * wy_k) * wz_k (the product order of tcnn's loop over dims, starting from 1), the
+// sum accumulated corner by corner with one fma per feature: four xy products shared by the two z layers, both
+// features of a row on one packed fma.
 __device__ __forceinline__ float2 unerf_tcnn_blend(const float2 (&f)[8], float wx, float wy, float wz) {
-    float2 r = make_float2(0.f, 0.f);
+    const float mx = 1.f - wx, my = 1.f - wy, mz = 1.f - wz;
+    const float wxy[4] = {mx * my, wx * my, mx * wy, wx * wy};
+    unerf_v2f r = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float w = 1.f;
-        w *= (k & 1) ? wx : 1.f - wx;
-        w *= (k & 2) ? wy : 1.f - wy;
-        w *= (k & 4) ? wz : 1.f - wz;
-        r.x = fmaf(w, f[k].x, r.x);
-        r.y = fmaf(w, f[k].y, r.y);
+        const float w = wxy[k & 3] * ((k & 4) ? wz : mz);
+        r = __builtin_elementwise_fma(unerf_v2f{w, w}, unerf_v2f{f[k].x, f[k].y}, r);
     }
-    return r;
+    return make_float2(r.x, r.y);
+}
+// Corner BYTE offsets (8-byte rows, level offset included) off the table base for the persistent field kernels:
+// a uniform (SGPR) base + 32-bit lane offset per load instead of 64-bit address arithmetic per corner; the level
+// record arrives as five scalars (staged in LDS by the caller).  Same rows as unerf_tcnn_corners.  Needs the
+// table below 2^32 bytes and, on dense levels, res^2 * (res + 1) < 2^24.
+__device__ __forceinline__ void unerf_tcnn_offsets(float scale, uint32_t res, uint32_t off8, uint32_t size,
+                                                   uint32_t dense, float px, float py, float pz, uint32_t (&off)[8],
+                                                   float& wx, float& wy, float& wz) {
+    const float fx = fmaf(scale, px, 0.5f), fy = fmaf(scale, py, 0.5f), fz = fmaf(scale, pz, 0.5f);
+    const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+    wx = fx - gx;
+    wy = fy - gy;
+    wz = fz - gz;
+    const uint32_t x0 = (uint32_t)(int)gx, y0 = (uint32_t)(int)gy, z0 = (uint32_t)(int)gz;
+    if (dense) {
+        const uint32_t r2 = __umul24(res, res);
+        const uint32_t b00 = x0 + __umul24(y0, res) + __umul24(z0, r2);
+        const uint32_t b[4] = {b00, b00 + res, b00 + r2, b00 + res + r2};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t i = b[k >> 1] + (uint32_t)(k & 1);
+            i = min(i, i - size);   // i >= size ? i - size : i  (the difference wraps to a huge value when i < size)
+            off[k] = off8 + (i << 3);
+        }
+    } else {
+        const uint32_t m8 = (size - 1u) << 3, P1 = 2654435761u << 3, P2 = 805459861u << 3;
+        const uint32_t hx0 = x0 << 3, hx1 = hx0 + 8u;
+        const uint32_t hy0 = y0 * P1, hz0 = z0 * P2, hy1 = hy0 + P1, hz1 = hz0 + P2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t hx = (k & 1) ? hx1 : hx0, hy = (k & 2) ? hy1 : hy0, hz = (k & 4) ? hz1 : hz0;
+            off[k] = off8 + ((hx ^ hy ^ hz) & m8);
+        }
+    }
 }
 __device__ __forceinline__ float2 unerf_tcnn_level_feat(const float2* __restrict__ params, const unerf_tcnn_level& lv,
                                                         float px, float py, float pz) {

@@ -447,7 +447,9 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             float2 f;
-            if (l < a.net.n_dense) {  // wave-uniform: coarse level with a dense, x-paired copy
+            if (a.net.tcnn_levels) {  // uniform: tcnn-layout grid
+                f = unerf_tcnn_level_feat(reinterpret_cast<const float2*>(a.net.table), a.net.tcnn_levels[l], px, py, pz);
+            } else if (l < a.net.n_dense) {  // wave-uniform: coarse level with a dense, x-paired copy
                 f = unerf_dense_level(reinterpret_cast<const float4*>(a.net.dense) + a.net.dense_off[l], a.net.dense_dim[l],
                                       px, py, pz, a.net.scalings[l]);
             } else {
@@ -525,8 +527,8 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    // image-ordered rays of a torch-layout grid: the LDS-staged patch kernel; anything else: one thread per sample
-    const bool patch = a.img_w != 0 && !net->tcnn_levels && !getenv("UNERF_NO_PATCH_KERNEL");
+    // image-ordered rays: the LDS-staged patch kernel; anything else: one thread per sample
+    const bool patch = a.img_w != 0 && !getenv("UNERF_NO_PATCH_KERNEL");
 #define UNERF_PROP_LAUNCH(LL, HH)                                                                          \
     if (patch) hipLaunchKernelGGL((prop_patch_kernel<LL, HH>), grid, block, 0, st, a);                    \
     else hipLaunchKernelGGL((prop_density_kernel<LL, HH>), grid, block, 0, st, a)
@@ -1137,22 +1139,39 @@ __device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], 
 // PACKED picks the fp32x2 blend (fewer VALU issues, ~18 more VGPRs): right for the K-pass and Laplace
 // kernels, which sit at 2 waves/SIMD anyway; the ACTIVE kernel keeps the scalar blend and its third wave
 // (packed + 168-VGPR cap: 20 B of scratch, 22.2 vs 21.8 ms/frame).
+// The 16 level records of a tcnn-layout grid, staged once per workgroup as five 16-entry LDS rows (scale, res,
+// byte offset, size, dense): read per lane from the device array they were 40 vector loads per tile (the level
+// index differs between the wave's halves, and loads after stores in the tile loop cannot be scalar).
+#define MF_TL_WORDS 80
+__device__ __forceinline__ void mf_stage_tcnn_levels(const FieldArgs& a, uint32_t* tl) {
+    if (threadIdx.x < 16) {
+        const unerf_tcnn_level lv = a.p.tcnn_levels[threadIdx.x];
+        tl[threadIdx.x] = __float_as_uint(lv.scale);
+        tl[16 + threadIdx.x] = lv.res;
+        tl[32 + threadIdx.x] = lv.offset << 3;
+        tl[48 + threadIdx.x] = lv.size;
+        tl[64 + threadIdx.x] = lv.dense;
+    }
+}
+
 template <bool PACKED, bool TCNN>
-__device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, float py, float pz, int h, uint32_t mask) {
+__device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, float py, float pz, int h, uint32_t mask,
+                                                  const uint32_t* tl = nullptr) {
     f32x16 feat;
     if (TCNN) {  // tcnn-layout grid: same batching (4 levels = 32 corner rows in flight), tcnn indexing + blend
-        const float2* params = reinterpret_cast<const float2*>(a.p.table);
+        const char* tbase = reinterpret_cast<const char*>(a.p.table);
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             float2 cd[32];
             float wf[12];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const unerf_tcnn_level lv = a.p.tcnn_levels[8 * h + 4 * hb + q];
-                uint32_t rows[8];
-                unerf_tcnn_corners(lv, px, py, pz, rows, wf[3 * q], wf[3 * q + 1], wf[3 * q + 2]);
+                const int lev = 8 * h + 4 * hb + q;
+                uint32_t off[8];
+                unerf_tcnn_offsets(__uint_as_float(tl[lev]), tl[16 + lev], tl[32 + lev], tl[48 + lev], tl[64 + lev], px, py, pz,
+                                   off, wf[3 * q], wf[3 * q + 1], wf[3 * q + 2]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) cd[8 * q + k] = params[rows[k]];
+                for (int k = 0; k < 8; ++k) cd[8 * q + k] = *reinterpret_cast<const float2*>(tbase + off[k]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1212,6 +1231,8 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         float4* dst = reinterpret_cast<float4*>(lds);
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
+    __shared__ uint32_t s_tl[TCNN ? MF_TL_WORDS : 1];
+    if (TCNN) mf_stage_tcnn_levels(a, s_tl);
     __syncthreads();
     // wave index as a scalar: the tile walk and its divisions then run on the scalar unit
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1251,7 +1272,7 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 feat[2 * l + 1] = f.y;
             }
         } else {
-            feat = mf_gather_feats<(MODE != UNERF_FIELD_ACTIVE), TCNN>(a, px, py, pz, h, mask);
+            feat = mf_gather_feats<(MODE != UNERF_FIELD_ACTIVE), TCNN>(a, px, py, pz, h, mask, s_tl);
         }
         // Colour layer 0 sees [geo(15) | SH(16)]; the SH half does not depend on the MC pass, so its
         // 16 MFMAs (+ bias) are done once per tile and every pass starts from that partial sum.
@@ -1454,6 +1475,8 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         float4* dst = reinterpret_cast<float4*>(lds);
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
+    __shared__ uint32_t s_tl[TCNN ? MF_TL_WORDS : 1];
+    if (TCNN) mf_stage_tcnn_levels(a, s_tl);
     __syncthreads();
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane_c & 31, h = lane_c >> 5;
@@ -1472,7 +1495,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         float px = ts.px, py = ts.py, pz = ts.pz;
         const float sel = unerf_normalize_position(px, py, pz);
         // packed fp32x2 blend: this kernel has the registers for it (123 VGPRs without) in every mode
-        const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask);
+        const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
 
         // colour layer 0, SH half (pass-invariant): components 8h..8h+7 of this lane half, one k-step
         f32x16 csh0 = mf_bias(lds, 3, h), csh1 = mf_bias(lds, 4, h);
@@ -1669,6 +1692,8 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         float4* dst = reinterpret_cast<float4*>(lds);
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
+    __shared__ uint32_t s_tl[TCNN ? MF_TL_WORDS : 1];
+    if (TCNN) mf_stage_tcnn_levels(a, s_tl);
     __syncthreads();
     // wave index as a scalar: the tile walk and its divisions then run on the scalar unit
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1693,7 +1718,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         float px = ts.px, py = ts.py, pz = ts.pz;
         // inference: the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
         const float sel = unerf_normalize_position(px, py, pz);
-        f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask);
+        f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
 
         // base_mlp is a bare Linear: no ReLU (utils.py:22-23)
         f32x16 hb0 = mf_slab(lds, 0, lane, feat, mf_bias(lds, 0, h));
@@ -2067,10 +2092,14 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     switch (p->mode) {
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
-            if (p->mfma16_blob && !features && !p->tcnn_levels) {  // tcnn-layout grids stay on the exact kernels
+            if (p->mfma16_blob && !features) {
                 int64_t tiles = make_tiles(a, p->image_width);
-                hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), tiles)), dim3(256),
-                                   UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                if (p->tcnn_levels)
+                    hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_ACTIVE, true>), tiles)), dim3(256),
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                else
+                    hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), tiles)), dim3(256),
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else if (p->mfma_blob) {
                 int64_t tiles = make_tiles(a, p->image_width);
                 if (features)
@@ -2090,11 +2119,16 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_MCDROPOUT:
             UNERF_REQUIRE(p->out1 == 16, "field_fwd MCDROPOUT: out1 must be 16");
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
-            if (p->mfma16_blob && !features && !p->tcnn_levels) {
+            if (p->mfma16_blob && !features) {
                 int64_t tiles = make_tiles(a, p->image_width);
-                hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), tiles)),
-                                   dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
-                                   make_fastdiv((uint32_t)S));
+                if (p->tcnn_levels)
+                    hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>), tiles)),
+                                       dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
+                                       make_fastdiv((uint32_t)S));
+                else
+                    hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), tiles)),
+                                       dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
+                                       make_fastdiv((uint32_t)S));
             } else if (p->mfma_blob) {
                 int64_t tiles = make_tiles(a, p->image_width);
                 if (features)
