@@ -263,12 +263,16 @@ __device__ __forceinline__ void unerf_tcnn_corners(const unerf_tcnn_level& lv, f
     wz = fz - gz;
     const uint32_t x0 = (uint32_t)(int)gx, y0 = (uint32_t)(int)gy, z0 = (uint32_t)(int)gz;
     if (lv.dense) {
-        // (x + y res + z res^2) mod size; the index stays below 2 size (size >= res^3, coordinates <= res)
-        const uint32_t r = lv.res, r2 = lv.res * lv.res;
+        // (x + y res + z res^2) mod size; the index stays below 2 size (size >= res^3, coordinates <= res).
+        // One base index and the +res / +res^2 steps (24-bit multiplies: res < 4096) instead of two
+        // quarter-rate 32-bit multiplies per corner; i - size wraps to a huge value when i < size.
+        const uint32_t r = lv.res, r2 = __umul24(lv.res, lv.res);
+        const uint32_t b00 = x0 + __umul24(y0, r) + __umul24(z0, r2);
+        const uint32_t b[4] = {b00, b00 + r, b00 + r2, b00 + r + r2};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            uint32_t i = (x0 + (k & 1)) + (y0 + ((k >> 1) & 1)) * r + (z0 + ((k >> 2) & 1)) * r2;
-            i = i >= lv.size ? i - lv.size : i;
+            uint32_t i = b[k >> 1] + (uint32_t)(k & 1);
+            i = min(i, i - lv.size);
             rows[k] = lv.offset + i;
         }
     } else {
@@ -313,12 +317,19 @@ __device__ __forceinline__ void unerf_tcnn_offsets(float scale, uint32_t res, ui
     if (dense) {
         const uint32_t r2 = __umul24(res, res);
         const uint32_t b00 = x0 + __umul24(y0, res) + __umul24(z0, r2);
-        const uint32_t b[4] = {b00, b00 + res, b00 + r2, b00 + res + r2};
+        if (__any(b00 + res + r2 + 1u >= size)) {  // some lane's cell straddles the wrap at `size` (grid boundary only)
+            const uint32_t b[4] = {b00, b00 + res, b00 + r2, b00 + res + r2};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t i = b[k >> 1] + (uint32_t)(k & 1);
-            i = min(i, i - size);   // i >= size ? i - size : i  (the difference wraps to a huge value when i < size)
-            off[k] = off8 + (i << 3);
+            for (int k = 0; k < 8; ++k) {
+                uint32_t i = b[k >> 1] + (uint32_t)(k & 1);
+                i = min(i, i - size);   // i >= size ? i - size : i  (the difference wraps to a huge value when i < size)
+                off[k] = off8 + (i << 3);
+            }
+        } else {  // one base offset + uniform steps (+8 rides in the load's immediate offset)
+            const uint32_t o00 = off8 + (b00 << 3), r8 = res << 3, r28 = r2 << 3;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                off[k] = o00 + ((k & 1) ? 8u : 0u) + ((k & 2) ? r8 : 0u) + ((k & 4) ? r28 : 0u);
         }
     } else {
         const uint32_t m8 = (size - 1u) << 3, P1 = 2654435761u << 3, P2 = 805459861u << 3;
@@ -333,12 +344,34 @@ __device__ __forceinline__ void unerf_tcnn_offsets(float scale, uint32_t res, ui
 }
 __device__ __forceinline__ float2 unerf_tcnn_level_feat(const float2* __restrict__ params, const unerf_tcnn_level& lv,
                                                         float px, float py, float pz) {
-    uint32_t rows[8];
-    float wx, wy, wz;
-    unerf_tcnn_corners(lv, px, py, pz, rows, wx, wy, wz);
+    // uniform base + 32-bit byte offsets (the table is below 2^32 bytes): no 64-bit address arithmetic per corner
+    const char* base = reinterpret_cast<const char*>(params);
     float2 f[8];
+    float wx, wy, wz;
+    if (lv.dense) {  // uniform here (every lane evaluates the same level)
+        const float fx = fmaf(lv.scale, px, 0.5f), fy = fmaf(lv.scale, py, 0.5f), fz = fmaf(lv.scale, pz, 0.5f);
+        const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+        const uint32_t x0 = (uint32_t)(int)gx, y0 = (uint32_t)(int)gy, z0 = (uint32_t)(int)gz;
+        const uint32_t r2 = __umul24(lv.res, lv.res);
+        const uint32_t b00 = x0 + __umul24(y0, lv.res) + __umul24(z0, r2);
+        if (!__any(b00 + lv.res + r2 + 1u >= lv.size)) {
+            // a dense tcnn level keeps x-neighbours in adjacent rows: the (x0, x0+1) corners of a (y, z) edge are 16
+            // contiguous bytes (8-byte aligned) -- four loads per level instead of eight
+            struct __attribute__((packed, aligned(8))) Pair { float a, b, c, d; };
+            const uint32_t o00 = (lv.offset + b00) << 3, r8 = lv.res << 3, r28 = r2 << 3;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = params[rows[k]];
+            for (int e = 0; e < 4; ++e) {
+                const Pair v = *reinterpret_cast<const Pair*>(base + (o00 + ((e & 1) ? r8 : 0u) + ((e & 2) ? r28 : 0u)));
+                f[2 * e] = make_float2(v.a, v.b);
+                f[2 * e + 1] = make_float2(v.c, v.d);
+            }
+            return unerf_tcnn_blend(f, fx - gx, fy - gy, fz - gz);
+        }
+    }
+    uint32_t off[8];
+    unerf_tcnn_offsets(lv.scale, lv.res, lv.offset << 3, lv.size, lv.dense, px, py, pz, off, wx, wy, wz);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = *reinterpret_cast<const float2*>(base + off[k]);
     return unerf_tcnn_blend(f, wx, wy, wz);
 }
 
