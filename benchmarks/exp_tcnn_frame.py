@@ -10,6 +10,9 @@ for kind in kinds:
     kw = dict(K=8, seed=1, p_drop=0.2) if kind == "mcdropout" else {}
     for grid in ("tcnn", "torch"):
         t = synthetic.make_scene_tensors(seed=0, kind=kind, grid=grid)
+        if kind == "laplace":
+            wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+            kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
         sd = synthetic.scene_to_device(t, dev, **kw)
         cam = dict(synthetic.CAMERA_1080P)
         for i in range(2): render.render_camera(sd, synthetic.orbit_c2w(0.3 * i), **cam)

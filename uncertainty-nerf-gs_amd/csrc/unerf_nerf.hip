@@ -1870,6 +1870,7 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
     sum2 += __shfl_xor(sum2, 32, 64);
 }
 
+template <bool TCNN>
 __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
@@ -1877,6 +1878,8 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         float4* dst = reinterpret_cast<float4*>(lds);
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
+    __shared__ uint32_t s_tl[TCNN ? MF_TL_WORDS : 1];
+    if (TCNN) mf_stage_tcnn_levels(a, s_tl);
     __syncthreads();
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane_c & 31, h = lane_c >> 5;
@@ -1895,7 +1898,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         float px = ts.px, py = ts.py, pz = ts.pz;
         // inference: the returned mu_d is NOT selector-masked (laplace_field.py:356-362) unless lap_mask_density
         const float sel = unerf_normalize_position(px, py, pz);
-        const f32x16 feat = mf_gather_feats<true, false>(a, px, py, pz, h, mask);
+        const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
 
         // base_mlp: bare Linear 32 -> 64 (no ReLU, utils.py:22-23)
         f32x16 hb0 = mf_bias(lds, 0, h), hb1 = mf_bias(lds, 1, h);
@@ -2148,10 +2151,14 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_LAPLACE:
             UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
-            if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS && !p->tcnn_levels) {
+            if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS) {
                 int64_t tiles = make_tiles(a, p->image_width);
-                hipLaunchKernelGGL(field_kernel_mfma16_laplace, dim3(mfma_grid_for(field_kernel_mfma16_laplace, tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
-                                   st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                if (p->tcnn_levels)
+                    hipLaunchKernelGGL(field_kernel_mfma16_laplace<true>, dim3(mfma_grid_for(field_kernel_mfma16_laplace<true>, tiles)), dim3(256),
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                else
+                    hipLaunchKernelGGL(field_kernel_mfma16_laplace<false>, dim3(mfma_grid_for(field_kernel_mfma16_laplace<false>, tiles)), dim3(256),
+                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
             } else if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
                 int64_t tiles = make_tiles(a, p->image_width);
                 if (p->tcnn_levels)
