@@ -428,11 +428,13 @@ def mc_base(seed: int, pass_idx: int, sample_idx: np.ndarray) -> np.ndarray:
         return _hash32(_hash32(sample_idx.astype(np.uint32)) + key)
 
 
-def _xorshift32(x: np.ndarray) -> np.ndarray:
+def _mask_step(x: np.ndarray) -> np.ndarray:
+    """twin of unerf_mask_step: x *= 8193; x ^= x >> 17; x *= 33 (mod 2^32)"""
     x = x.astype(np.uint32)
-    x = x ^ (x << np.uint32(13))
-    x = x ^ (x >> np.uint32(17))
-    x = x ^ (x << np.uint32(5))
+    with np.errstate(over="ignore"):
+        x = x + (x << np.uint32(13))
+        x = x ^ (x >> np.uint32(17))
+        x = x + (x << np.uint32(5))
     return x
 
 
@@ -440,9 +442,9 @@ def mc_keep_mask(seed: int, pass_idx: int, sample_idx: np.ndarray, stream: int, 
                  p_drop: float) -> np.ndarray:
     """[N, n_units] bool keep-mask.  stream 0 = density trunk, 1 = colour head.
     Mask word of unit pair j: pass 0 = hash32(base0 + (32*stream + j + 1)*GOLDEN) with
-    base0 = mc_base(seed, 0, sample) (0 -> GOLDEN); pass k = xorshift32 of pass k-1.
+    base0 = mc_base(seed, 0, sample) (0 -> GOLDEN); pass k = _mask_step of pass k-1.
     Low 16 bits -> unit 2j, high 16 bits -> unit 2j+1; keep iff u16 < round((1-p)*65536).
-    (twin of unerf_mask_word0 / unerf_xorshift32 in csrc/unerf_common.hpp)"""
+    (twin of unerf_mask_word0 / unerf_mask_step in csrc/unerf_common.hpp)"""
     assert n_units % 2 == 0 and n_units <= 64
     thr = np.uint32(int(round((1.0 - p_drop) * 65536.0)))
     base = mc_base(seed, 0, sample_idx)[:, None]
@@ -451,7 +453,7 @@ def mc_keep_mask(seed: int, pass_idx: int, sample_idx: np.ndarray, stream: int, 
         r = _hash32(base + (np.uint32(stream * 32) + j + np.uint32(1)) * GOLDEN)
     r = np.where(r == 0, GOLDEN, r).astype(np.uint32)
     for _ in range(pass_idx):
-        r = _xorshift32(r)
+        r = _mask_step(r)
     lo = (r & np.uint32(0xFFFF)) < thr
     hi = (r >> np.uint32(16)) < thr
     return np.stack([lo, hi], axis=-1).reshape(base.shape[0], n_units)

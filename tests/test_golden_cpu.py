@@ -137,3 +137,34 @@ def test_auce_torch_equals_the_reference_pinned_loop():
         for k in ("auc_abs_error_values", "auc_neg_error_values"):
             assert abs(got[k] - ref[k]) < 1e-12
         assert abs(got["auc_length_values"] - ref["auc_length_values"]) < 1e-6 * ref["auc_length_values"]
+
+
+def test_dropout_mask_generator_statistics():
+    """The MC-dropout masks (oracle.mc_keep_mask = twin of the kernel's unerf_mask_word0 / unerf_mask_step): keep
+    rate 1 - p in both 16-bit halves at every pass, no correlation between consecutive passes, between the halves
+    of a word or between neighbouring units, and the number of keeps of one unit over K = 8 passes is
+    Binomial(8, 0.8) -- on 2 M words, tolerances at ~5 sigma of the sampling noise."""
+    from math import comb
+    from oracle import nerf_oracle as O
+    n, K, p = 62500, 8, 0.2
+    sidx = np.arange(n, dtype=np.int64) * 7 + 11
+    keeps = np.stack([O.mc_keep_mask(1234, k, sidx, 0, 64, p) for k in range(K)])      # [K, n, 64]
+    N = n * 64
+    tol = 5.0 / np.sqrt(N)
+    assert np.abs(keeps.reshape(K, -1).mean(axis=1) - (1 - p)).max() < tol * 0.5        # std of a rate = 0.4 / sqrt(N)
+    assert abs(keeps[:, :, 0::2].mean() - 0.8) < tol and abs(keeps[:, :, 1::2].mean() - 0.8) < tol
+
+    def corr(a, b):
+        return abs(np.corrcoef(a.reshape(-1).astype(np.float64), b.reshape(-1).astype(np.float64))[0, 1])
+    for k in range(K - 1):
+        assert corr(keeps[k], keeps[k + 1]) < tol, k                                    # same unit, consecutive passes
+        assert corr(keeps[k][:, 0::2], keeps[k + 1][:, 1::2]) < tol * 1.5, k            # low half -> high half of the next word
+    assert corr(keeps[:, :, 0::2], keeps[:, :, 1::2]) < tol                             # the two halves of a word
+    assert corr(keeps[:, :, :-2], keeps[:, :, 2:]) < tol                                # neighbouring words
+    cnt = keeps.sum(axis=0).reshape(-1)
+    hist = np.bincount(cnt, minlength=K + 1) / N
+    binom = np.array([comb(K, i) * 0.8 ** i * 0.2 ** (K - i) for i in range(K + 1)])
+    assert np.abs(hist - binom).max() < tol
+    s0 = O.mc_keep_mask(1234, 3, sidx[:100], 0, 64, p)
+    assert not np.array_equal(s0, O.mc_keep_mask(1234, 3, sidx[:100], 1, 64, p))        # trunk and head streams differ
+    assert not np.array_equal(s0, O.mc_keep_mask(1235, 3, sidx[:100], 0, 64, p))        # and so do seeds

@@ -41,18 +41,23 @@ __host__ __device__ __forceinline__ uint32_t unerf_mc_base(uint32_t key, uint32_
 }
 // MC-dropout mask words.  Unit pair j of stream s (0 = density trunk, 1 = colour head) of one sample:
 //   pass 0 : w = hash32(base0 + (32 s + j + 1) * GOLDEN), base0 = mc_base(mc_key(seed, 0), sample)  (0 -> GOLDEN)
-//   pass k : w = xorshift32(w of pass k-1)
+//   pass k : w = mask_step(w of pass k-1)
 // low 16 bits gate unit 2j, high 16 bits unit 2j+1 (keep iff < round((1-p) 65536)).  The full hash
-// (two quarter-rate integer multiplies) is paid once per sample; every further pass costs three
-// shift-xor pairs per word -- the K-pass kernel is VALU-issue-bound (twin: oracle mc_keep_mask).
+// (two quarter-rate integer multiplies) is paid once per sample; every further pass costs four instructions
+// per word -- the K-pass kernel is VALU-issue-bound (twin: oracle mc_keep_mask).
 __host__ __device__ __forceinline__ uint32_t unerf_mask_word0(uint32_t base0, uint32_t stream_id, uint32_t j) {
     uint32_t w = unerf_hash32(base0 + (stream_id * 32u + j + 1u) * UNERF_GOLDEN);
     return w ? w : UNERF_GOLDEN;
 }
-__host__ __device__ __forceinline__ uint32_t unerf_xorshift32(uint32_t x) {
-    x ^= x << 13;
+// One step of a mask word: x *= 8193, x ^= x >> 17, x *= 33 -- each stage a bijection of the 32-bit words (0 is
+// the only fixed point, and mask_word0 never returns it), four instructions (v_lshl_add_u32, shift, xor,
+// v_lshl_add_u32) against six for the xorshift32 used before.  Only <= K - 1 steps are ever taken from a hashed
+// start; tests/test_golden_cpu.py checks keep rate, pass-to-pass / half-to-half independence and the
+// Binomial(K, 1 - p) count of keeps over 4 M words.
+__host__ __device__ __forceinline__ uint32_t unerf_mask_step(uint32_t x) {
+    x += x << 13;
     x ^= x >> 17;
-    x ^= x << 5;
+    x += x << 5;
     return x;
 }
 

@@ -883,7 +883,7 @@ __device__ __forceinline__ void dense_lds(const float* __restrict__ Wt, const fl
     }
 }
 
-// same, with an inverted-dropout mask on the 64 inputs (mask words: unerf_mask_word0 / unerf_xorshift32)
+// same, with an inverted-dropout mask on the 64 inputs (mask words: unerf_mask_word0 / unerf_mask_step)
 template <int OUT>
 __device__ __forceinline__ void dense_lds_dropout(const float* __restrict__ Wt, const float* __restrict__ b,
                                                   const float* act, int lane, uint32_t base0, int pass,
@@ -892,7 +892,7 @@ __device__ __forceinline__ void dense_lds_dropout(const float* __restrict__ Wt, 
     for (int o = 0; o < OUT; ++o) acc[o] = b[o];
     for (int j = 0; j < 32; ++j) {
         uint32_t rnd = unerf_mask_word0(base0, stream_id, (uint32_t)j);
-        for (int q = 0; q < pass; ++q) rnd = unerf_xorshift32(rnd);
+        for (int q = 0; q < pass; ++q) rnd = unerf_mask_step(rnd);
         float x0 = act[(2 * j) * 64 + lane];
         float x1 = act[(2 * j + 1) * 64 + lane];
         x0 = ((rnd & 0xFFFFu) < thr) ? x0 * scale : 0.f;
@@ -1121,7 +1121,7 @@ __device__ __forceinline__ void mf_mask_init(uint32_t (&st)[8], int blk, int h, 
 }
 __device__ __forceinline__ void mf_mask_step(uint32_t (&st)[8]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) st[q] = unerf_xorshift32(st[q]);
+    for (int q = 0; q < 8; ++q) st[q] = unerf_mask_step(st[q]);
 }
 __device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], uint32_t thr, float scale) {
 #pragma unroll
