@@ -93,9 +93,11 @@ def test_active_nerfacto_camera_parity(dev):
     _img_close(out["density"], ref["density"], 1e-6, 1e-2, "density", max_bad_frac=1e-3)
 
 
-def test_mcdropout_camera_parity(dev):
+@pytest.mark.parametrize("K", [4, 8, 17])
+def test_mcdropout_camera_parity(dev, K):
+    """K = 8: the BASELINE config; K = 17: beyond the fused 16-pass composite (composite_var + moments fallback)."""
     from uncertainty_nerf_gs_amd import render, synthetic
-    K, seed, p = 4, 1234, 0.2
+    seed, p = 1234, 0.2
     t = synthetic.make_scene_tensors(seed=1, kind="mcdropout", log2T=14, prop_log2T=12)
     sc = O.scene_from_tensors(t)
     sd = synthetic.scene_to_device(t, dev, K=K, seed=seed, p_drop=p)
@@ -106,7 +108,7 @@ def test_mcdropout_camera_parity(dev):
     o, d = _oracle_rays(c2w, cam)
     ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, K, seed, p, ray_offset=off), o, d, chunk=512)
     assert set(ref) == set(out), set(ref) ^ set(out)
-    _gates("mcdropout", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _gates(f"mcdropout-K{K}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
     _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb (mean over K)")
     _img_close(out["rgb_std"], ref["rgb_std"], 1e-5, 5e-3, "rgb_std")
     _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")

@@ -213,8 +213,10 @@ def test_field_level_major_gather_equals_fused_lookup(dev, kind, kw):
 
 
 @pytest.mark.parametrize("use_mfma,precision", _KERNELS, ids=_KERNEL_IDS)
-@pytest.mark.parametrize("K", [0, 3])
+@pytest.mark.parametrize("K", [0, 3, 8, 10])
 def test_field_mcdropout_matches_oracle(dev, K, use_mfma, precision):
+    """K = 8 is the BASELINE config, K = 10 the reference default (mcdropout_models.py:45): pass k's masks are k
+    chained mask steps, so every pass up to the largest K in use is compared with the oracle."""
     from uncertainty_nerf_gs_amd import ops
     seed, p = 1234, 0.2
     t, sc, sd = _scene("mcdropout", dev, K=K, seed=seed, p_drop=p)

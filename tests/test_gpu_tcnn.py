@@ -47,10 +47,10 @@ def test_tcnn_layout_camera_parity(dev, kind):
         out = render.render_camera(sd, c2w, rays_per_launch=1024, keep_density=True, **cam)
         ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=512)
     elif kind == "mcdropout":
-        sd = synthetic.scene_to_device(t, dev, K=3, seed=9, p_drop=0.2)
+        sd = synthetic.scene_to_device(t, dev, K=8, seed=9, p_drop=0.2)   # K = 8: the BASELINE config
         sd.chunk_rays = 512
         out = render.render_camera(sd, c2w, rays_per_launch=1024, **cam)
-        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 3, 9, 0.2, ray_offset=off), o, d, chunk=512)
+        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 9, 0.2, ray_offset=off), o, d, chunk=512)
     else:
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
         sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
