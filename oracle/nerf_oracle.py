@@ -429,12 +429,11 @@ def mc_base(seed: int, pass_idx: int, sample_idx: np.ndarray) -> np.ndarray:
 
 
 def _mask_step(x: np.ndarray) -> np.ndarray:
-    """twin of unerf_mask_step: x *= 8193; x ^= x >> 17; x *= 33 (mod 2^32)"""
+    """twin of unerf_mask_step: x = rotr(x, 22) * 65 (mod 2^32)"""
     x = x.astype(np.uint32)
     with np.errstate(over="ignore"):
-        x = x + (x << np.uint32(13))
-        x = x ^ (x >> np.uint32(17))
-        x = x + (x << np.uint32(5))
+        y = (x >> np.uint32(22)) | (x << np.uint32(10))
+        x = y + (y << np.uint32(6))
     return x
 
 
@@ -443,8 +442,9 @@ def mc_keep_mask(seed: int, pass_idx: int, sample_idx: np.ndarray, stream: int, 
     """[N, n_units] bool keep-mask.  stream 0 = density trunk, 1 = colour head.
     Mask word of unit pair j: pass 0 = hash32(base0 + (32*stream + j + 1)*GOLDEN) with
     base0 = mc_base(seed, 0, sample) (0 -> GOLDEN); pass k = _mask_step of pass k-1.
-    Low 16 bits -> unit 2j, high 16 bits -> unit 2j+1; keep iff u16 < round((1-p)*65536).
-    (twin of unerf_mask_word0 / unerf_mask_step in csrc/unerf_common.hpp)"""
+    Low 16 bits -> unit 2j, high 16 bits -> unit 2j+1; keep iff the half read as a signed 16-bit number is below
+    round((1-p)*65536) - 32768, i.e. iff (u16 ^ 0x8000) < round((1-p)*65536); p = 0 keeps every unit.
+    (twin of unerf_mask_word0 / unerf_mask_step / unerf_keep_lo / unerf_keep_hi in csrc/unerf_common.hpp)"""
     assert n_units % 2 == 0 and n_units <= 64
     thr = np.uint32(int(round((1.0 - p_drop) * 65536.0)))
     base = mc_base(seed, 0, sample_idx)[:, None]
@@ -454,8 +454,8 @@ def mc_keep_mask(seed: int, pass_idx: int, sample_idx: np.ndarray, stream: int, 
     r = np.where(r == 0, GOLDEN, r).astype(np.uint32)
     for _ in range(pass_idx):
         r = _mask_step(r)
-    lo = (r & np.uint32(0xFFFF)) < thr
-    hi = (r >> np.uint32(16)) < thr
+    lo = ((r & np.uint32(0xFFFF)) ^ np.uint32(0x8000)) < thr
+    hi = ((r >> np.uint32(16)) ^ np.uint32(0x8000)) < thr
     return np.stack([lo, hi], axis=-1).reshape(base.shape[0], n_units)
 
 

@@ -7,7 +7,7 @@ reference-generated files of make_golden.py.  Needs neither /root/reference nor 
 
 lego200_mcdropout.npz -- BASELINE.json configs[0]: Blender-lego-shaped 200x200 single view (fx = fy = 277.78,
 camera on a radius-4.03 orbit in scene units scaled by 0.33), nerfacto-mcdropout with the torch-layout field,
-K = 2 dropout passes (seed 7, p = 0.2; one pass has no std), reference chunking 32768 rays.
+K = 8 dropout passes (the BASELINE K; seed 7, p = 0.2), reference chunking 32768 rays.
 """
 import os
 import sys
@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-LEGO = dict(seed=1, log2T=15, prop_log2T=13, theta=0.9, radius=4.03 * 0.33, height=0.4, K=2, mc_seed=7, p_drop=0.2)
+LEGO = dict(seed=1, log2T=15, prop_log2T=13, theta=0.9, radius=4.03 * 0.33, height=0.4, K=8, mc_seed=7, p_drop=0.2)
 
 
 def lego200():

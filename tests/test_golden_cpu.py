@@ -141,12 +141,13 @@ def test_auce_torch_equals_the_reference_pinned_loop():
 
 def test_dropout_mask_generator_statistics():
     """The MC-dropout masks (oracle.mc_keep_mask = twin of the kernel's unerf_mask_word0 / unerf_mask_step): keep
-    rate 1 - p in both 16-bit halves at every pass, no correlation between consecutive passes, between the halves
-    of a word or between neighbouring units, and the number of keeps of one unit over K = 8 passes is
-    Binomial(8, 0.8) -- on 2 M words, tolerances at ~5 sigma of the sampling noise."""
+    rate 1 - p in both 16-bit halves at every pass, no correlation between ANY two of K = 10 passes (same unit, and
+    low half against high half of the stepped word), between the halves of a word or between neighbouring words,
+    and the number of keeps of one unit over 8 passes is Binomial(8, 0.8) -- on 4 M units per pass, tolerances at
+    ~5 sigma of the sampling noise."""
     from math import comb
     from oracle import nerf_oracle as O
-    n, K, p = 62500, 8, 0.2
+    n, K, p = 62500, 10, 0.2
     sidx = np.arange(n, dtype=np.int64) * 7 + 11
     keeps = np.stack([O.mc_keep_mask(1234, k, sidx, 0, 64, p) for k in range(K)])      # [K, n, 64]
     N = n * 64
@@ -155,16 +156,24 @@ def test_dropout_mask_generator_statistics():
     assert abs(keeps[:, :, 0::2].mean() - 0.8) < tol and abs(keeps[:, :, 1::2].mean() - 0.8) < tol
 
     def corr(a, b):
-        return abs(np.corrcoef(a.reshape(-1).astype(np.float64), b.reshape(-1).astype(np.float64))[0, 1])
-    for k in range(K - 1):
-        assert corr(keeps[k], keeps[k + 1]) < tol, k                                    # same unit, consecutive passes
-        assert corr(keeps[k][:, 0::2], keeps[k + 1][:, 1::2]) < tol * 1.5, k            # low half -> high half of the next word
+        a = a.reshape(-1).astype(np.float32)
+        b = b.reshape(-1).astype(np.float32)
+        a -= a.mean()
+        b -= b.mean()
+        return abs(float(np.dot(a, b)) / float(np.sqrt(np.dot(a, a) * np.dot(b, b))))
+    for k in range(K):
+        for m in range(k + 1, K):
+            assert corr(keeps[k], keeps[m]) < tol, (k, m)                               # same unit, any two passes
+            assert corr(keeps[k][:, 0::2], keeps[m][:, 1::2]) < tol * 1.5, (k, m)       # low half -> high half of a later word
+            assert corr(keeps[k][:, 1::2], keeps[m][:, 0::2]) < tol * 1.5, (k, m)
     assert corr(keeps[:, :, 0::2], keeps[:, :, 1::2]) < tol                             # the two halves of a word
     assert corr(keeps[:, :, :-2], keeps[:, :, 2:]) < tol                                # neighbouring words
-    cnt = keeps.sum(axis=0).reshape(-1)
-    hist = np.bincount(cnt, minlength=K + 1) / N
-    binom = np.array([comb(K, i) * 0.8 ** i * 0.2 ** (K - i) for i in range(K + 1)])
+    cnt = keeps[:8].sum(axis=0).reshape(-1)
+    hist = np.bincount(cnt, minlength=9) / N
+    binom = np.array([comb(8, i) * 0.8 ** i * 0.2 ** (8 - i) for i in range(9)])
     assert np.abs(hist - binom).max() < tol
+    # p = 0 keeps every unit; the signed-half test is the unsigned test on (half ^ 0x8000)
+    assert O.mc_keep_mask(1234, 5, sidx[:1000], 1, 64, 0.0).all()
     s0 = O.mc_keep_mask(1234, 3, sidx[:100], 0, 64, p)
     assert not np.array_equal(s0, O.mc_keep_mask(1234, 3, sidx[:100], 1, 64, p))        # trunk and head streams differ
     assert not np.array_equal(s0, O.mc_keep_mask(1235, 3, sidx[:100], 0, 64, p))        # and so do seeds

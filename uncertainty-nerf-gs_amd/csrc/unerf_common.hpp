@@ -42,23 +42,40 @@ __host__ __device__ __forceinline__ uint32_t unerf_mc_base(uint32_t key, uint32_
 // MC-dropout mask words.  Unit pair j of stream s (0 = density trunk, 1 = colour head) of one sample:
 //   pass 0 : w = hash32(base0 + (32 s + j + 1) * GOLDEN), base0 = mc_base(mc_key(seed, 0), sample)  (0 -> GOLDEN)
 //   pass k : w = mask_step(w of pass k-1)
-// low 16 bits gate unit 2j, high 16 bits unit 2j+1 (keep iff < round((1-p) 65536)).  The full hash
-// (two quarter-rate integer multiplies) is paid once per sample; every further pass costs four instructions
-// per word -- the K-pass kernel is VALU-issue-bound (twin: oracle mc_keep_mask).
+// low 16 bits gate unit 2j, high 16 bits unit 2j+1: a unit is kept iff its half, read as a SIGNED 16-bit number,
+// is below thr_s = round((1-p) 65536) - 32768 (the same event as "unsigned half ^ 0x8000 < round((1-p) 65536)",
+// i.e. a relabelling of uniform bits).  The signed form lets the split-f16 kernels build the AND mask of a
+// packed f16 pair in two packed instructions (saturating v_pk_sub_i16, v_pk_ashrrev_i16 15).  The full hash (two
+// quarter-rate integer multiplies) is paid once per sample; every further pass costs two instructions per word --
+// the K-pass kernel is VALU-issue-bound (twin: oracle mc_keep_mask).
 __host__ __device__ __forceinline__ uint32_t unerf_mask_word0(uint32_t base0, uint32_t stream_id, uint32_t j) {
     uint32_t w = unerf_hash32(base0 + (stream_id * 32u + j + 1u) * UNERF_GOLDEN);
     return w ? w : UNERF_GOLDEN;
 }
-// One step of a mask word: x *= 8193, x ^= x >> 17, x *= 33 -- each stage a bijection of the 32-bit words (0 is
-// the only fixed point, and mask_word0 never returns it), four instructions (v_lshl_add_u32, shift, xor,
-// v_lshl_add_u32) against six for the xorshift32 used before.  Only <= K - 1 steps are ever taken from a hashed
-// start; tests/test_golden_cpu.py checks keep rate, pass-to-pass / half-to-half independence and the
-// Binomial(K, 1 - p) count of keeps over 4 M words.
+// One step of a mask word: x = rotr(x, 22) * 65 -- a bijection of the 32-bit words (rotation, odd multiplier; 0 is
+// a fixed point and mask_word0 never returns it), two instructions (v_alignbit_b32, v_lshl_add_u32) against four
+// for the x*8193 / x ^= x>>17 / x*33 step used in round 1 and six for xorshift32.  The rotation feeds the high
+// bits back into the low half, the multiply carries the low bits up.  Only <= K - 1 steps are ever taken from a
+// hashed start; tests/test_golden_cpu.py checks keep rate, independence between ALL pairs of passes (same unit,
+// either half), between the halves and between neighbouring words, and the Binomial(K, 1 - p) count of keeps
+// over 4 M words ((rotation, shift) = (22, 6) came out of a search over all 2-instruction rotate-multiply steps,
+// /benchmarks/mask_step_search.py).
 __host__ __device__ __forceinline__ uint32_t unerf_mask_step(uint32_t x) {
-    x += x << 13;
-    x ^= x >> 17;
-    x += x << 5;
-    return x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t y = __builtin_amdgcn_alignbit(x, x, 22);
+#else
+    const uint32_t y = (x >> 22) | (x << 10);
+#endif
+    return y + (y << 6);
+}
+// keep tests for one word on a scalar path: thr_hi = thr_s << 16 (a signed 32-bit number with zero low half).
+// Written as 16-bit signed compares so that the compiler can select v_cmp_lt_i16 (low half) and its SDWA form
+// reading WORD_1 (high half): one compare per unit, no shift / mask in front of it.
+__host__ __device__ __forceinline__ bool unerf_keep_lo(uint32_t w, int32_t thr_hi) {
+    return (int16_t)(uint16_t)w < (int16_t)(thr_hi >> 16);
+}
+__host__ __device__ __forceinline__ bool unerf_keep_hi(uint32_t w, int32_t thr_hi) {
+    return (int16_t)(uint16_t)(w >> 16) < (int16_t)(thr_hi >> 16);
 }
 
 // ---- spacing (UniformLinDispPiecewiseSampler) ---------------------------------------

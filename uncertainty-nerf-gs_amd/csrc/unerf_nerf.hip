@@ -798,7 +798,9 @@ struct FieldArgs {
     float* rgb;
     float* aux;
     float* aux2;
-    uint32_t keep_thr;
+    int32_t keep_hi;     // MC-dropout keep threshold thr_s << 16 (unerf_keep_lo / unerf_keep_hi)
+    uint32_t keep_pk;    // thr_s in both 16-bit halves (packed-f16 masks of the split-f16 kernels)
+    int drop_on;         // K > 0 and p_drop > 0: masks are generated (p_drop == 0 keeps every unit)
     float drop_scale;
     const float* features;  // optional [16][N][2] level-major planes from unerf_field_gather (MFMA kernel)
     TileMap tm;
@@ -887,7 +889,7 @@ __device__ __forceinline__ void dense_lds(const float* __restrict__ Wt, const fl
 template <int OUT>
 __device__ __forceinline__ void dense_lds_dropout(const float* __restrict__ Wt, const float* __restrict__ b,
                                                   const float* act, int lane, uint32_t base0, int pass,
-                                                  uint32_t stream_id, uint32_t thr, float scale, float (&acc)[OUT]) {
+                                                  uint32_t stream_id, int32_t thr_hi, float scale, float (&acc)[OUT]) {
 #pragma unroll
     for (int o = 0; o < OUT; ++o) acc[o] = b[o];
     for (int j = 0; j < 32; ++j) {
@@ -895,8 +897,8 @@ __device__ __forceinline__ void dense_lds_dropout(const float* __restrict__ Wt, 
         for (int q = 0; q < pass; ++q) rnd = unerf_mask_step(rnd);
         float x0 = act[(2 * j) * 64 + lane];
         float x1 = act[(2 * j + 1) * 64 + lane];
-        x0 = ((rnd & 0xFFFFu) < thr) ? x0 * scale : 0.f;
-        x1 = ((rnd >> 16) < thr) ? x1 * scale : 0.f;
+        x0 = unerf_keep_lo(rnd, thr_hi) ? x0 * scale : 0.f;
+        x1 = unerf_keep_hi(rnd, thr_hi) ? x1 * scale : 0.f;
 #pragma unroll
         for (int o = 0; o < OUT; ++o) acc[o] = fmaf(x0, Wt[(2 * j) * OUT + o], acc[o]);
 #pragma unroll
@@ -990,7 +992,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
         for (int k = 0; k < passes; ++k) {
             const uint32_t base = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
             float o1[16];
-            if (a.p.K > 0) dense_lds_dropout<16>(a.p.w1t, a.p.b1, A, lane, base, k, 0u, a.keep_thr, a.drop_scale, o1);
+            if (a.drop_on) dense_lds_dropout<16>(a.p.w1t, a.p.b1, A, lane, base, k, 0u, a.keep_hi, a.drop_scale, o1);
             else dense_lds<64, 16>(a.p.w1t, a.p.b1, A, lane, o1);
             float density = a.p.average_init_density * expf(o1[0]) * sel;
             store_act<16>(Bf, lane, sh, 0, false);
@@ -1001,7 +1003,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
             dense_lds<64, 64>(a.p.h1t, a.p.hb1, Bf, lane, acc);
             store_act<64>(Bf, lane, acc, 0, true);
             float c[3];
-            if (a.p.K > 0) dense_lds_dropout<3>(a.p.h2t, a.p.hb2, Bf, lane, base, k, 1u, a.keep_thr, a.drop_scale, c);
+            if (a.drop_on) dense_lds_dropout<3>(a.p.h2t, a.p.hb2, Bf, lane, base, k, 1u, a.keep_hi, a.drop_scale, c);
             else dense_lds<64, 3>(a.p.h2t, a.p.hb2, Bf, lane, c);
             if (valid) {
                 int64_t q = (int64_t)k * N + n;
@@ -1123,11 +1125,11 @@ __device__ __forceinline__ void mf_mask_step(uint32_t (&st)[8]) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) st[q] = unerf_mask_step(st[q]);
 }
-__device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], uint32_t thr, float scale) {
+__device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], int32_t thr_hi, float scale) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        v[2 * q] = ((st[q] & 0xFFFFu) < thr) ? v[2 * q] * scale : 0.f;
-        v[2 * q + 1] = ((st[q] >> 16) < thr) ? v[2 * q + 1] * scale : 0.f;
+        v[2 * q] = unerf_keep_lo(st[q], thr_hi) ? v[2 * q] * scale : 0.f;
+        v[2 * q + 1] = unerf_keep_hi(st[q], thr_hi) ? v[2 * q + 1] * scale : 0.f;
     }
     return v;
 }
@@ -1302,7 +1304,7 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         f32x16 hid1 = mf_relu(mf_slab(lds, 16, lane, feat, mf_bias(lds, 1, h)));
 
         const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
-        const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.p.K > 0;
+        const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.drop_on;
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         uint32_t mk0[8], mk1[8], mk2[8], mk3[8];  // this lane's mask words: trunk blk 0/1, head blk 0/1
         if (drop) {
@@ -1322,8 +1324,8 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                     mf_mask_step(mk2);
                     mf_mask_step(mk3);
                 }
-                m0 = mf_dropout(hid0, mk0, a.keep_thr, a.drop_scale);
-                m1 = mf_dropout(hid1, mk1, a.keep_thr, a.drop_scale);
+                m0 = mf_dropout(hid0, mk0, a.keep_hi, a.drop_scale);
+                m1 = mf_dropout(hid1, mk1, a.keep_hi, a.drop_scale);
             }
             // trunk out: 64 -> out1 (rows >= out1 are zero-padded): row 0 density, 1..15 geo, 16 beta
             f32x16 t = mf_bias(lds, 2, h);
@@ -1347,8 +1349,8 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
             if (drop) {
-                d0 = mf_dropout(d0, mk2, a.keep_thr, a.drop_scale);
-                d1 = mf_dropout(d1, mk3, a.keep_thr, a.drop_scale);
+                d0 = mf_dropout(d0, mk2, a.keep_hi, a.drop_scale);
+                d1 = mf_dropout(d1, mk3, a.keep_hi, a.drop_scale);
             }
             // colour 2: 64 -> 3 on the VALU: each half sums its 32 units, halves meet by one shuffle
             float rgbv[3];
@@ -1394,15 +1396,26 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 // ops.pack_field_mfma16 packs the A slabs in.  LDS blob: 20 slabs x (hi|lo) x 64 lanes x 16 B = 40 KiB, then
 // the same bias rows / rgb layer as the fp32 blob (same offsets, same total size).
 // --------------------------------------------------------------------------------------
-// dropout mask only: the inverted-dropout scale 1/(1-p) is folded into the weights of the layer that follows
-// (ops.pack_field_mfma16(drop_scale=...)), which saves one multiply per hidden unit and pass
-__device__ __forceinline__ f32x16 mf_dropout_mask(f32x16 v, const uint32_t (&st)[8], uint32_t thr) {
+// MC-dropout on PACKED f16 operands.  The inverted-dropout scale 1/(1-p) is folded into the weights of the layer
+// that follows (ops.pack_field_mfma16(drop_scale=...)), so a dropped unit is just a zeroed operand, and an operand
+// pair (units 2j, 2j+1 = the two halves of one register of the hi and of the lo quad) is zeroed by ONE and with a
+// mask whose halves are 0xFFFF / 0.  That mask costs two packed instructions per RNG word: the saturating signed
+// difference half - thr_s is negative exactly when the unit is kept (v_pk_sub_i16 clamp), and an arithmetic shift
+// by 15 spreads the sign over the half (v_pk_ashrrev_i16).  Per unit: 1 (mask) + 1 (two ands) instructions, against
+// compare + select on the fp32 accumulator (2) in round 1 -- and the trunk layer's input is pass-invariant, so its
+// operand split (1.5 per unit) moves out of the K loop altogether.
+__device__ __forceinline__ f32x16 mf_dropout_keep(f32x16 v, const uint32_t (&st)[8], int32_t thr_hi) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        v[2 * q] = ((st[q] & 0xFFFFu) < thr) ? v[2 * q] : 0.f;
-        v[2 * q + 1] = ((st[q] >> 16) < thr) ? v[2 * q + 1] : 0.f;
+        v[2 * q] = unerf_keep_lo(st[q], thr_hi) ? v[2 * q] : 0.f;
+        v[2 * q + 1] = unerf_keep_hi(st[q], thr_hi) ? v[2 * q + 1] : 0.f;
     }
     return v;
+}
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mf16_keep_mask(uint32_t word, uint32_t thr_pk) {
+    const i16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(i16x2, word), __builtin_bit_cast(i16x2, thr_pk));
+    return __builtin_bit_cast(uint32_t, d >> (short)15);
 }
 // sigmoid on the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1e-7 relative each) instead of the ~25-instruction
 // exact expf + IEEE division
@@ -1466,6 +1479,19 @@ __device__ __forceinline__ void mf16_layer64(const float* lds, int slab0, int la
     }
 }
 
+// split-f16 blob (ops.pack_field_mfma16): 20 operand slabs, then the bias rows and the fp32 rgb layer at the
+// offsets of the fp32 blob (same total size)
+#define mf16_bias mf_bias
+// and both operand quads of k-step `st` (accumulator registers 8 st .. 8 st + 7 = mask words 4 st .. 4 st + 3 of
+// the block's eight) with their keep masks
+__device__ __forceinline__ void mf16_apply_masks(f16x8& hi, f16x8& lo, const uint32_t (&words)[8], int st, uint32_t thr_pk) {
+    u32x4 m;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) m[p] = mf16_keep_mask(words[4 * st + p], thr_pk);
+    hi = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, hi) & m);
+    lo = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, lo) & m);
+}
+
 template <int MODE, bool TCNN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && !TCNN) ? 3 : 2)))
 void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
@@ -1498,7 +1524,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
 
         // colour layer 0, SH half (pass-invariant): components 8h..8h+7 of this lane half, one k-step
-        f32x16 csh0 = mf_bias(lds, 3, h), csh1 = mf_bias(lds, 4, h);
+        f32x16 csh0 = mf16_bias(lds, 3, h), csh1 = mf16_bias(lds, 4, h);
         {
             float sh[16];
             float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
@@ -1519,20 +1545,26 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             csh1 = mf16_mac(lds, 11, lane, bhi, blo, csh1);
         }
 
-        // layer 0: 32 -> 64 (this half's 16 features = two k-steps), ReLU
-        f32x16 hid0 = mf_bias(lds, 0, h), hid1 = mf_bias(lds, 1, h);
+        // layer 0: 32 -> 64 (this half's 16 features = two k-steps), ReLU; the 64 hidden units are the trunk
+        // layer's four k-steps and do not depend on the MC pass: they are split into f16 operand quads ONCE
+        f16x8 hhi[4], hlo[4];
+        {
+            f32x16 hid0 = mf16_bias(lds, 0, h), hid1 = mf16_bias(lds, 1, h);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            f16x8 bhi, blo;
-            mf16_split(feat, st, bhi, blo);
-            hid0 = mf16_mac(lds, 2 * st, lane, bhi, blo, hid0);
-            hid1 = mf16_mac(lds, 2 * st + 1, lane, bhi, blo, hid1);
+            for (int st = 0; st < 2; ++st) {
+                f16x8 bhi, blo;
+                mf16_split(feat, st, bhi, blo);
+                hid0 = mf16_mac(lds, 2 * st, lane, bhi, blo, hid0);
+                hid1 = mf16_mac(lds, 2 * st + 1, lane, bhi, blo, hid1);
+            }
+            hid0 = mf_relu(hid0);
+            hid1 = mf_relu(hid1);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) mf16_split(st < 2 ? hid0 : hid1, st & 1, hhi[st], hlo[st]);
         }
-        hid0 = mf_relu(hid0);
-        hid1 = mf_relu(hid1);
 
         const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
-        const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.p.K > 0;
+        const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.drop_on;
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         uint32_t mk0[8], mk1[8], mk2[8], mk3[8];
         if (drop) {
@@ -1544,20 +1576,20 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         }
         for (int k = 0; k < passes; ++k) {
             asm volatile("" : "+v"(lane));
-            f32x16 m0 = hid0, m1 = hid1;
-            if (drop) {
-                if (k > 0) {
-                    mf_mask_step(mk0);
-                    mf_mask_step(mk1);
-                    mf_mask_step(mk2);
-                    mf_mask_step(mk3);
-                }
-                m0 = mf_dropout_mask(hid0, mk0, a.keep_thr);
-                m1 = mf_dropout_mask(hid1, mk1, a.keep_thr);
+            if (drop && k > 0) {
+                mf_mask_step(mk0);
+                mf_mask_step(mk1);
+                mf_mask_step(mk2);
+                mf_mask_step(mk3);
             }
-            // trunk out: 64 -> out1 rows (row 0 density, 1..15 geo, 16 beta)
-            f32x16 t = mf_bias(lds, 2, h), unused = t;
-            mf16_layer64<1>(lds, 4, lane, m0, m1, t, unused);
+            // trunk out: 64 -> out1 rows (row 0 density, 1..15 geo, 16 beta) from the (masked) hidden operands
+            f32x16 t = mf16_bias(lds, 2, h);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                f16x8 bhi = hhi[st], blo = hlo[st];
+                if (drop) mf16_apply_masks(bhi, blo, st < 2 ? mk0 : mk1, st & 1, a.keep_pk);
+                t = mf16_mac(lds, 4 + st, lane, bhi, blo, t);
+            }
             // colour 0: geo rows of t (registers 0..7 = one k-step) on top of the SH partial sum, ReLU
             f32x16 c0 = csh0, c1 = csh1;
             {
@@ -1569,34 +1601,47 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             c0 = mf_relu(c0);
             c1 = mf_relu(c1);
             // colour 1: 64 -> 64, ReLU
-            f32x16 d0 = mf_bias(lds, 5, h), d1 = mf_bias(lds, 6, h);
+            f32x16 d0 = mf16_bias(lds, 5, h), d1 = mf16_bias(lds, 6, h);
             mf16_layer64<2>(lds, 12, lane, c0, c1, d0, d1);
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
-            if (drop) {
-                d0 = mf_dropout_mask(d0, mk2, a.keep_thr);
-                d1 = mf_dropout_mask(d1, mk3, a.keep_thr);
+            if (drop) {   // masks on the fp32 accumulators: one half-word compare + one select per unit
+                d0 = mf_dropout_keep(d0, mk2, a.keep_hi);
+                d1 = mf_dropout_keep(d1, mk3, a.keep_hi);
             }
-            // colour 2: 64 -> 3 on the VALU in fp32 (weights pre-scaled by the dropout scale when masks are on)
-            float rgbv[3];
+            // colour 2: 64 -> 3 on the VALU in fp32 (weights pre-scaled by the dropout scale when masks are on).
+            // MFMA and VALU instructions share one issue pipe on gfx950 and never overlap
+            // (benchmarks/mfma_valu_overlap_probe.hip: 32 cycles per f16 MFMA + 4 per VALU instruction, additive at
+            // every occupancy and instruction order), so a layer belongs where it costs fewer of those cycles: as four
+            // more k-steps on the matrix pipe this one took 12 MFMAs + 48 split instructions (576 cycles, 29 of 32
+            // output rows wasted), as packed fp32 FMAs it takes 48 + the half-to-half exchange (~240 cycles).
+            float o[3];
+            {
+                const float4* wq = reinterpret_cast<const float4*>(lds + MF_H2_OFF + h * 48);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float* w0p = lds + MF_H2_OFF + ((0 * 2 + h) * 3 + c) * 16;
-                const float* w1p = lds + MF_H2_OFF + ((1 * 2 + h) * 3 + c) * 16;
-                float acc = 0.f;
+                for (int c = 0; c < 3; ++c) {
+                    unerf_v2f acc2 = {0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc = fmaf(d0[q], w0p[q], acc);
+                    for (int blk = 0; blk < 2; ++blk) {
+                        const f32x16& dv = blk ? d1 : d0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc = fmaf(d1[q], w1p[q], acc);
-                acc += __shfl_xor(acc, 32, 64);
-                rgbv[c] = mf_sigmoid_fast(acc + lds[MF_H2_OFF + 192 + c]);
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const float4 w = wq[blk * 24 + c * 4 + q4];
+                            acc2 = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4], dv[4 * q4 + 1]}, unerf_v2f{w.x, w.y}, acc2);
+                            acc2 = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4 + 2], dv[4 * q4 + 3]}, unerf_v2f{w.z, w.w}, acc2);
+                        }
+                    }
+                    const float half_sum = acc2.x + acc2.y;
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(half_sum), __float_as_uint(half_sum), false, false);
+                    o[c] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + lds[MF_H2_OFF + 192 + c];
+                }
             }
             if (valid && h == 0) {
                 int64_t q = (int64_t)k * N + n;
-                a.density[q] = a.p.average_init_density * expf(t[0]) * sel;
-                a.rgb[q * 3 + 0] = rgbv[0];
-                a.rgb[q * 3 + 1] = rgbv[1];
-                a.rgb[q * 3 + 2] = rgbv[2];
+                a.density[q] = a.p.average_init_density * __expf(t[0]) * sel;
+                a.rgb[q * 3 + 0] = mf_sigmoid_fast(o[0]);
+                a.rgb[q * 3 + 1] = mf_sigmoid_fast(o[1]);
+                a.rgb[q * 3 + 2] = mf_sigmoid_fast(o[2]);
                 if (MODE == UNERF_FIELD_ACTIVE) a.aux[n] = unerf_softplus(t[8]) + a.p.beta_min;
             }
         }
@@ -1901,7 +1946,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
 
         // base_mlp: bare Linear 32 -> 64 (no ReLU, utils.py:22-23)
-        f32x16 hb0 = mf_bias(lds, 0, h), hb1 = mf_bias(lds, 1, h);
+        f32x16 hb0 = mf16_bias(lds, 0, h), hb1 = mf16_bias(lds, 1, h);
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             f16x8 bhi, blo;
@@ -1913,7 +1958,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         f16x8 xhi[4], xlo[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) mf16_split(st < 2 ? hb0 : hb1, st & 1, xhi[st], xlo[st]);
-        f32x16 t = mf_bias(lds, 2, h);
+        f32x16 t = mf16_bias(lds, 2, h);
 #pragma unroll
         for (int st = 0; st < 4; ++st) t = mf16_mac(lds, 4 + st, lane, xhi[st], xlo[st], t);
         float d1, d2;
@@ -1925,7 +1970,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         }
 
         // colour trunk: [geo15 | SH16] -> 64 -> 64
-        f32x16 c0 = mf_bias(lds, 3, h), c1 = mf_bias(lds, 4, h);
+        f32x16 c0 = mf16_bias(lds, 3, h), c1 = mf16_bias(lds, 4, h);
         {
             f16x8 bhi, blo;
             mf16_split(t, 0, bhi, blo);
@@ -1950,7 +1995,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         }
         c0 = mf_relu(c0);
         c1 = mf_relu(c1);
-        f32x16 x0 = mf_bias(lds, 5, h), x1 = mf_bias(lds, 6, h);
+        f32x16 x0 = mf16_bias(lds, 5, h), x1 = mf16_bias(lds, 6, h);
         mf16_layer64<2>(lds, 12, lane, c0, c1, x0, x1);
         x0 = mf_relu(x0);
         x1 = mf_relu(x1);
@@ -2038,7 +2083,7 @@ extern "C" int unerf_field_gather(const float* origins, const float* directions,
 // multiple of the 8 XCDs).  The ACTIVE kernels fit 3 per CU (42.6 KB LDS, <= 168 VGPRs), the K-pass and Laplace
 // kernels 2; launching 3 per CU for those left a third of the tiles to a half-empty second round.
 template <typename Kern>
-static int mfma_grid_for(Kern kernel, int64_t num_tiles) {
+static int mfma_grid_for(Kern kernel, int64_t num_tiles, size_t lds_bytes) {
     static std::mutex mu;
     static std::unordered_map<const void*, int> cache;
     int cap = 0;
@@ -2049,8 +2094,7 @@ static int mfma_grid_for(Kern kernel, int64_t num_tiles) {
     }
     if (cap == 0) {
         int per_cu = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, UNERF_MFMA_BLOB_FLOATS * 4) != hipSuccess ||
-            per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu < 1)
             per_cu = 2;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         (void)hipGetLastError();
@@ -2062,6 +2106,15 @@ static int mfma_grid_for(Kern kernel, int64_t num_tiles) {
     int64_t blocks = (num_tiles + 3) / 4;
     if (blocks > cap) blocks = cap;
     return (int)((blocks + 7) / 8 * 8);
+}
+// one persistent matrix-kernel launch: tile map from the image_width hint, LDS = the operand blob
+#define MF_LDS_FP32 ((size_t)UNERF_MFMA_BLOB_FLOATS * 4)
+#define MF_LDS_F16 MF_LDS_FP32
+template <typename Kern>
+static void launch_matrix_kernel(Kern kernel, size_t lds_bytes, FieldArgs& a, hipStream_t st) {
+    const int64_t tiles = make_tiles(a, a.p.image_width);
+    hipLaunchKernelGGL(kernel, dim3(mfma_grid_for(kernel, tiles, lds_bytes)), dim3(256), lds_bytes, st, a, (uint32_t)tiles,
+                       make_fastdiv((uint32_t)a.S));
 }
 
 extern "C" int unerf_field_fwd(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
@@ -2088,33 +2141,27 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = ray_offset;
     a.p = *p; a.density = density; a.rgb = rgb; a.aux = aux; a.aux2 = aux2;
     a.features = features;
-    a.keep_thr = (uint32_t)lrint((1.0 - (double)p->p_drop) * 65536.0);
+    {   // keep iff (signed 16-bit half) < thr_s = round((1-p) 65536) - 32768; p = 0 keeps everything (no masks)
+        const long thr = lrint((1.0 - (double)p->p_drop) * 65536.0);
+        a.drop_on = (p->mode == UNERF_FIELD_MCDROPOUT && p->K > 0 && thr < 65536) ? 1 : 0;
+        const int32_t thr_s = (int32_t)(thr < 65536 ? thr : 65535) - 32768;
+        a.keep_hi = (int32_t)((uint32_t)thr_s << 16);
+        a.keep_pk = ((uint32_t)thr_s & 0xFFFFu) * 0x10001u;
+    }
     a.drop_scale = 1.f / (1.f - p->p_drop);
     dim3 grid(blocks_for(R * (int64_t)S, 64)), block(64);
     hipStream_t st = (hipStream_t)stream;
+    const bool tc = p->tcnn_levels != nullptr;
     switch (p->mode) {
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
             if (p->mfma16_blob && !features) {
-                int64_t tiles = make_tiles(a, p->image_width);
-                if (p->tcnn_levels)
-                    hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_ACTIVE, true>), tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
-                else
-                    hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>), tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, true>, MF_LDS_F16, a, st);
+                else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob) {
-                int64_t tiles = make_tiles(a, p->image_width);
-                if (features)
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_ACTIVE, true>), tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
-                else if (p->tcnn_levels)
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_ACTIVE, false, true>), tiles)),
-                                       dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
-                                       make_fastdiv((uint32_t)S));
-                else
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_ACTIVE, false>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_ACTIVE, false>), tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                if (features) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_ACTIVE, true>, MF_LDS_FP32, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_ACTIVE, false, true>, MF_LDS_FP32, a, st);
+                else launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_ACTIVE, false>, MF_LDS_FP32, a, st);
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_ACTIVE>), grid, block, 64 * 64 * 4, st, a);
             }
@@ -2123,27 +2170,12 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->out1 == 16, "field_fwd MCDROPOUT: out1 must be 16");
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
             if (p->mfma16_blob && !features) {
-                int64_t tiles = make_tiles(a, p->image_width);
-                if (p->tcnn_levels)
-                    hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>), tiles)),
-                                       dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
-                                       make_fastdiv((uint32_t)S));
-                else
-                    hipLaunchKernelGGL((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid_for((field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>), tiles)),
-                                       dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
-                                       make_fastdiv((uint32_t)S));
+                if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>, MF_LDS_F16, a, st);
+                else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob) {
-                int64_t tiles = make_tiles(a, p->image_width);
-                if (features)
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>), tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
-                else if (p->tcnn_levels)
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, true>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, true>), tiles)),
-                                       dim3(256), UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles,
-                                       make_fastdiv((uint32_t)S));
-                else
-                    hipLaunchKernelGGL((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>), dim3(mfma_grid_for((field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>), tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                if (features) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>, MF_LDS_FP32, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, true>, MF_LDS_FP32, a, st);
+                else launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>, MF_LDS_FP32, a, st);
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
             }
@@ -2152,21 +2184,11 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
             if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS) {
-                int64_t tiles = make_tiles(a, p->image_width);
-                if (p->tcnn_levels)
-                    hipLaunchKernelGGL(field_kernel_mfma16_laplace<true>, dim3(mfma_grid_for(field_kernel_mfma16_laplace<true>, tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
-                else
-                    hipLaunchKernelGGL(field_kernel_mfma16_laplace<false>, dim3(mfma_grid_for(field_kernel_mfma16_laplace<false>, tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                if (tc) launch_matrix_kernel(field_kernel_mfma16_laplace<true>, MF_LDS_F16, a, st);
+                else launch_matrix_kernel(field_kernel_mfma16_laplace<false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
-                int64_t tiles = make_tiles(a, p->image_width);
-                if (p->tcnn_levels)
-                    hipLaunchKernelGGL((field_kernel_mfma_laplace<false, true>), dim3(mfma_grid_for((field_kernel_mfma_laplace<false, true>), tiles)), dim3(256),
-                                       UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
-                else
-                    hipLaunchKernelGGL((field_kernel_mfma_laplace<false>), dim3(mfma_grid_for((field_kernel_mfma_laplace<false>), tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
-                                   st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+                if (tc) launch_matrix_kernel(field_kernel_mfma_laplace<false, true>, MF_LDS_FP32, a, st);
+                else launch_matrix_kernel(field_kernel_mfma_laplace<false>, MF_LDS_FP32, a, st);
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_LAPLACE>), grid, block, 64 * 64 * 4, st, a);
             }
@@ -2319,14 +2341,10 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = 0;
     a.p = *p; a.density = sigma; a.rgb = col; a.aux = X; a.aux2 = Hc; a.features = nullptr;
-    a.keep_thr = 0; a.drop_scale = 1.f;
-    const int64_t tiles = make_tiles(a, 0);
-    if (p->tcnn_levels)
-        hipLaunchKernelGGL((field_kernel_mfma_laplace<true, true>), dim3(mfma_grid_for((field_kernel_mfma_laplace<true, true>), tiles)), dim3(256),
-                           UNERF_MFMA_BLOB_FLOATS * 4, st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
-    else
-        hipLaunchKernelGGL((field_kernel_mfma_laplace<true>), dim3(mfma_grid_for((field_kernel_mfma_laplace<true>), tiles)), dim3(256), UNERF_MFMA_BLOB_FLOATS * 4,
-                       st, a, (uint32_t)tiles, make_fastdiv((uint32_t)S));
+    a.keep_hi = 0; a.keep_pk = 0; a.drop_on = 0; a.drop_scale = 1.f;
+    a.p.image_width = 0;   // 1-D tiles
+    if (p->tcnn_levels) launch_matrix_kernel(field_kernel_mfma_laplace<true, true>, MF_LDS_FP32, a, st);
+    else launch_matrix_kernel(field_kernel_mfma_laplace<true>, MF_LDS_FP32, a, st);
     GgnArgs g;
     g.sbins = sbins; g.R = R; g.S = S; g.s_near = a.s_near; g.s_far = a.s_far;
     g.sigma = sigma; g.rgb = col; g.X = X; g.Hc = Hc; g.partials = partials;

@@ -250,6 +250,7 @@ class FieldDev:
     mfma16_blob: Optional[torch.Tensor] = None   # split-f16 operands of the dense layers (pack_field_mfma16)
     lap16_blob: Optional[torch.Tensor] = None
     precision: str = "f16x2"                     # "f16x2": split-f16 matrix kernels (fp32-equivalent); "fp32": exact
+    packed_drop_scale: float = 1.0               # the inverted-dropout scale folded into mfma16_blob at pack time
 
     @classmethod
     def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device,
@@ -265,10 +266,9 @@ class FieldDev:
         lap = mode == _l.FIELD_LAPLACE
         blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
                                  geo_first_unit=0 if lap else 1))
-        masks_on = mode == _l.FIELD_MCDROPOUT and int(kw.get("K", 0)) > 0
+        kw["packed_drop_scale"] = cls._drop_scale(mode, int(kw.get("K", 0)), float(kw.get("p_drop", 0.2)))
         blob16 = pack_field_mfma16(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
-                                   geo_first_unit=0 if lap else 1,
-                                   drop_scale=1.0 / (1.0 - float(kw.get("p_drop", 0.2))) if masks_on else 1.0)
+                                   geo_first_unit=0 if lap else 1, drop_scale=kw["packed_drop_scale"])
         kw["mfma16_blob"] = None if blob16 is None else f(blob16)   # None (weights beyond the f16 range): exact kernels
         lap_blob = None
         if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
@@ -279,7 +279,19 @@ class FieldDev:
                    f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
                    mfma_blob=blob, lap_blob=lap_blob, **kw)
 
+    @staticmethod
+    def _drop_scale(mode: int, K: int, p_drop: float) -> float:
+        """1/(1-p) when the kernels generate dropout masks (MCDROPOUT, K > 0), else 1"""
+        return 1.0 / (1.0 - p_drop) if (mode == _l.FIELD_MCDROPOUT and K > 0) else 1.0
+
     def cstruct(self) -> _l.FieldParams:
+        use16 = self.use_mfma and self.precision == "f16x2" and self.mfma16_blob is not None
+        if use16 and abs(self._drop_scale(self.mode, self.K, self.p_drop) - self.packed_drop_scale) > 1e-7:
+            # the split-f16 operands carry 1/(1-p) inside two weight matrices: K (0 <-> > 0) or p_drop changed since
+            # from_torch().  The exact kernels apply the scale at run time, so the two paths would silently disagree.
+            raise _l.UnerfError(
+                f"FieldDev: K={self.K}, p_drop={self.p_drop} do not match the dropout scale {self.packed_drop_scale:.6g} "
+                "packed into mfma16_blob; rebuild the FieldDev (from_torch) after changing K or p_drop")
         return _l.FieldParams(
             self.mode, _p(self.table), _p(self.scalings), self.scalings.numel(), self.log2T,
             _p(self.w0t), _p(self.b0), _p(self.w1t), _p(self.b1), self.b1.numel(),
