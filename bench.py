@@ -8,7 +8,10 @@ MLPs with the method's uncertainty head) -> front-to-back composite with varianc
 [-> per-pixel mean/std over the K MC passes].  Inputs (weights, tables, camera) are resident in
 HBM before the timed region; synthetic seeded data, random-init weights of the nerfacto shape.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--method active|mcdropout|laplace] [--mc-samples 8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--method active|mcdropout|laplace|splat|ensemble] [--mc-samples 8]
+
+Without --method the headline is the north-star target config (BASELINE.json configs[2]): nerfacto-mcdropout with
+K = 8 fused passes; active-nerfacto, nerfacto-laplace and active-splatfacto follow as `sub_records` of the same line.
 
 N>1 is launched by torch.distributed.run (one rank per GPU).  Rays are independent, so ranks
 render different cameras of the orbit with replicated weights and no data-path collective
@@ -55,12 +58,177 @@ def _alg(kind, K):
     }
 
 
+ISSUE_PEAK_GCYC = 1024 * 2.4   # 256 CUs x 4 SIMDs x 2.4 GHz peak engine clock: issue cycles per nanosecond x 1e9
+
+
+def _issue_profile(method, K):
+    """Instruction-issue cycles of the field kernel per launch, from the committed rocprofv3 --pmc pass of this
+    command (profiles/issue_<method>.json, written by benchmarks/summarize_pmc.py): on gfx950 MFMA and VALU
+    instructions share one issue pipe per SIMD and never overlap (benchmarks/mfma_valu_overlap_probe.hip), so
+    busy cycles = 4 x SQ_ACTIVE_INST_VALU (counted in quad-cycles) + SQ_VALU_MFMA_BUSY_CYCLES is the work the
+    instruction stream needs, a property of the code (not of the clock it ran at)."""
+    f = os.path.join(ROOT, "profiles", f"issue_{method}.json")
+    if not os.path.exists(f):
+        return None
+    j = json.load(open(f))
+    return j if j.get("K", 0) == K else None
+
+
+def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check=True, want_cpu=True):
+    """One NeRF method through the whole frame path; returns the record (headline fields + roofline + cpu_baseline)."""
+    from uncertainty_nerf_gs_amd import ops, render, synthetic
+    t = synthetic.make_scene_tensors(seed=0, kind=method)   # full nerfacto shape: 16x2^19x2 + 2 x 5x2^17x2
+    kw = {}
+    if method == "mcdropout":
+        kw = dict(K=K, seed=1234, p_drop=0.2)
+    if method == "laplace":
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+        kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+    scene = synthetic.scene_to_device(t, dev, **kw)
+    scene.field.precision = "fp32" if (args.exact_fp32 or args.split_gather) else "f16x2"
+    scene.split_gather = args.split_gather
+    H, W = args.height, args.width
+    cam = dict(synthetic.CAMERA_1080P)
+    cam.update(H=H, W=W, cx=W / 2, cy=H / 2)
+    n_views = 24
+    poses = [synthetic.orbit_c2w(2 * math.pi * i / n_views) for i in range(n_views)]
+    # the reference's active-nerfacto output dict carries the raw density [H,W,48] too (activenerfacto_model.py:115,122)
+    shade_kw = dict(keep_density=True) if method == "active" else {}
+
+    def frame(i):
+        c2w = poses[(rank + i * world) % n_views]   # view-batch partition across ranks
+        return render.render_camera(scene, c2w, rays_per_launch=args.rays_per_launch, overlap=args.overlap,
+                                    depth_seed=7, **cam, **shade_kw)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        out = frame(i)
+    sync_all()
+    ops.TIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = frame(warmup + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    timer = ops.TIMER
+    ops.TIMER = None
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out["rgb"]).all()
+    mrays = H * W * steps * world / elapsed / 1e6
+
+    # Reported next to the headline, outside its timed region: the same frames with the dense layers on the
+    # exact fp32-input MFMA kernels, and how far the split-f16 image is from that exact-fp32 image.
+    exact = None
+    if scene.field.precision == "f16x2" and exact_check:
+        scene.field.precision = "fp32"
+        n_alt = max(1, min(steps, 3))
+        ref = frame(warmup + steps - 1)          # also warms the exact kernels up
+        sync_all()
+        t1 = time.perf_counter()
+        for i in range(n_alt):
+            frame(warmup + i)
+        sync_all()
+        alt = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([alt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            alt = float(tt.item())
+        scene.field.precision = "f16x2"
+        exact = {"value": H * W * n_alt * world / alt / 1e6, "unit": "Mrays/s", "ms_per_step": alt / n_alt * 1e3,
+                 "steps": n_alt, "max_abs_rgb_diff_vs_split_f16": float((ref["rgb"] - out["rgb"]).abs().max()),
+                 "max_abs_rgb_std_diff_vs_split_f16": float((ref["rgb_std"] - out["rgb_std"]).abs().max())}
+
+    rec = {"value": mrays, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "exact_fp32_kernels": exact}
+    split = scene.field.precision == "f16x2"
+    rec["workload"] = (f"{method}-nerfacto {W}x{H} render with variance" + (f", K={K} MC-dropout passes" if K else "")
+                       + (", 100 last-layer Laplace samples" if method == "laplace" else "")
+                       + (", density [H,W,48] kept" if method == "active" else ""))
+    rec["dense_layers"] = ("fp32 operands split into two f16 halves, 3 products on v_mfma_f32_32x32x16_f16, "
+                           "fp32 accumulate (fp32-equivalent, DESIGN.md 4.2)" if split else "exact fp32 (v_mfma_f32_32x32x2_f32)")
+    if rank != 0:
+        return rec
+    ksum = timer.summary()
+    alg = _alg(method, K)
+    dom = max(ksum, key=lambda k: ksum[k]["total_ms"])
+    rays_per_launch = H * W * steps / ksum[dom]["launches"]
+    avg_s = ksum[dom]["avg_ms"] * 1e-3
+    a = alg.get(dom, {"bytes": 0, "flops": 0})
+    # Side figures for the dominant kernel: algorithmic gather rate and matrix-pipe rate.  Neither binds: the tables
+    # are cache resident (the gather rate can exceed the DRAM peak) and the f16 matrix pipe is a third busy.
+    gather_gbs = a["bytes"] * rays_per_launch / avg_s / 1e9
+    mfma_ach = a["flops"] * rays_per_launch / avg_s / 1e12
+    mfma_peak = F16_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
+    mfma_issued = 3.0 * mfma_ach if split else mfma_ach
+    roof = {"kernel": dom, "avg_launch_ms": ksum[dom]["avg_ms"], "launches": ksum[dom]["launches"],
+            "rays_per_launch": rays_per_launch}
+    prof = _issue_profile(method, K) if dom == "field_fwd" and split else None
+    if prof is not None:
+        # the roof that binds: instruction issue (VALU + MFMA share one pipe per SIMD).  achieved = issue cycles the
+        # launch's instruction stream needs (PMC, per launch of prof["rays_per_launch"] rays) / live launch duration;
+        # peak = every SIMD issuing every cycle at the peak engine clock.
+        cyc = prof["issue_cycles_per_launch"] * rays_per_launch / prof["rays_per_launch"]
+        ach = cyc / avg_s / 1e9
+        roof.update({"bound": "valu-issue", "achieved": ach, "peak": ISSUE_PEAK_GCYC, "unit": "Gcycle/s",
+                     "frac": ach / ISSUE_PEAK_GCYC,
+                     "note": "VALU and MFMA instructions share one issue pipe per SIMD on gfx950 and do not overlap "
+                             "(benchmarks/mfma_valu_overlap_probe.hip); achieved = (4 x VALU-active quad-cycles + MFMA-busy "
+                             "cycles) of one launch, from the committed PMC pass, over the live launch time; peak = 1024 SIMDs x "
+                             "2.4 GHz.  The engine clock under this load is ~2.07 GHz, so 0.86 is the practical ceiling",
+                     "issue_source": prof["source"], "valu_insts_per_ray": prof["valu_insts_per_launch"] / prof["rays_per_launch"],
+                     "mfma_insts_per_ray": prof["mfma_insts_per_launch"] / prof["rays_per_launch"],
+                     "simd_busy_frac_under_profiler": prof.get("busy_frac")})
+    else:
+        frac_m, frac_h = mfma_issued / mfma_peak, gather_gbs / HBM_PEAK_GBS
+        if frac_m > frac_h or frac_h > 1.0:
+            roof.update({"bound": "mfma", "achieved": mfma_issued, "peak": mfma_peak, "unit": "TFLOP/s", "frac": frac_m,
+                         "note": "no PMC issue profile committed for this kernel: matrix-pipe rate (issued flops)"})
+        else:
+            roof.update({"bound": "hbm", "achieved": gather_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_h,
+                         "note": "algorithmic bytes of the dominant kernel"})
+    roof["other_roofs"] = {"algorithmic_gather_GBps": gather_gbs,
+                           "algorithmic_gather_note": "8 B per hash-grid corner; tables are L2 / Infinity-Cache resident, so "
+                                                      "this is a cache-gather rate and may exceed the DRAM peak",
+                           "algorithmic_TFLOPs": mfma_ach, "matrix_pipe": "f16 (3 products per MAC)" if split else "fp32",
+                           "issued_matrix_TFLOPs": mfma_issued, "matrix_frac": mfma_issued / mfma_peak}
+    roof["algorithmic_bytes_per_ray"] = a["bytes"]
+    roof["algorithmic_flops_per_ray"] = a["flops"]
+    roof["traffic"] = None
+    tfile = os.path.join(ROOT, "profiles", f"traffic_{method}.json")
+    if os.path.exists(tfile):  # HBM-side bytes from committed rocprofv3 --pmc passes of this command
+        tj = json.load(open(tfile))
+        tk = tj.get("kernels", {}).get(dom)
+        if tk and K == tj.get("K", 0):
+            scale = rays_per_launch / tj["rays_per_launch"]
+            roof["traffic"] = (tk["fetch_bytes"] + tk["write_bytes"]) * scale
+            roof["traffic_source"] = tj["source"]
+            roof["other_roofs"]["hbm_traffic_GBps"] = roof["traffic"] / avg_s / 1e9
+            roof["other_roofs"]["hbm_frac"] = roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS
+    roof["per_kernel_ms_per_frame"] = {k: round(v["total_ms"] / steps, 3) for k, v in sorted(ksum.items())}
+    path_bytes = sum(alg[k]["bytes"] for k in ksum if k in alg)
+    roof["path_bytes_per_ray"] = path_bytes
+    rec["roofline"] = roof
+    rec["cpu_baseline"] = None
+    if want_cpu and not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
+        rec["cpu_baseline"] = cpu_baseline(t, args, method, poses[0], cam, K)
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--method", default="active", choices=["active", "mcdropout", "laplace", "splat", "ensemble"])
+    ap.add_argument("--method", default=None, choices=["active", "mcdropout", "laplace", "splat", "ensemble"],
+                    help="default: nerfacto-mcdropout K=8 (the north-star target config) as the headline, with active / "
+                         "laplace / splat sub-records in the same line")
     ap.add_argument("--members", type=int, default=8, help="ensemble size M (members are sharded over the ranks)")
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--mc-samples", type=int, default=8)
@@ -73,6 +241,7 @@ def main():
                     help="dense layers on the exact fp32-input MFMA kernels instead of the split-f16 ones")
     ap.add_argument("--no-exact-check", action="store_true",
                     help="skip the extra exact-fp32 frames rendered after the timed region")
+    ap.add_argument("--no-sub-records", action="store_true", help="headline only (default run: skip active / laplace / splat)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -85,7 +254,7 @@ def main():
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
             sys.exit(2)
 
-    from uncertainty_nerf_gs_amd import lib, ops, render, synthetic
+    from uncertainty_nerf_gs_amd import lib
     lib.build_library()
     lib.require_gpu()
     torch.cuda.set_device(local_rank)
@@ -96,145 +265,49 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    if args.method == "splat":
-        return bench_splat(args, rank, world, dev, dist)
-    if args.method == "ensemble":
-        return bench_ensemble(args, rank, world, dev, dist)
-    K = args.mc_samples if args.method == "mcdropout" else 0
-    t = synthetic.make_scene_tensors(seed=0, kind=args.method)   # full nerfacto shape: 16x2^19x2 + 2 x 5x2^17x2
-    kw = {}
-    if args.method == "mcdropout":
-        kw = dict(K=K, seed=1234, p_drop=0.2)
-    if args.method == "laplace":
-        wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
-        kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
-    scene = synthetic.scene_to_device(t, dev, **kw)
-    scene.field.precision = "fp32" if (args.exact_fp32 or args.split_gather) else "f16x2"
-    scene.split_gather = args.split_gather
-    H, W = args.height, args.width
-    cam = dict(synthetic.CAMERA_1080P)
-    cam.update(H=H, W=W, cx=W / 2, cy=H / 2)
-    n_views = 24
-    poses = [synthetic.orbit_c2w(2 * math.pi * i / n_views) for i in range(n_views)]
-
-    def frame(i):
-        c2w = poses[(rank + i * world) % n_views]   # view-batch partition across ranks
-        return render.render_camera(scene, c2w, rays_per_launch=args.rays_per_launch, overlap=args.overlap,
-                                    depth_seed=7, **cam)
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        out = frame(i)
-    sync_all()
-    ops.TIMER = ops.KernelTimer()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = frame(args.warmup + i)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    timer = ops.TIMER
-    ops.TIMER = None
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(out["rgb"]).all()
-
-    rays = H * W * args.steps * world
-    mrays = rays / elapsed / 1e6
-
-    # Reported next to the headline, outside its timed region: the same frames with the dense layers on the
-    # exact fp32-input MFMA kernels, and how far the split-f16 image is from that exact-fp32 image.
-    exact = None
-    if scene.field.precision == "f16x2" and not args.no_exact_check:
-        scene.field.precision = "fp32"
-        n_alt = max(1, min(args.steps, 3))
-        ref = frame(args.warmup + args.steps - 1)          # also warms the exact kernels up
-        sync_all()
-        t1 = time.perf_counter()
-        for i in range(n_alt):
-            frame(args.warmup + i)
-        sync_all()
-        alt = time.perf_counter() - t1
-        if dist is not None:
-            tt = torch.tensor([alt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            alt = float(tt.item())
-        scene.field.precision = "f16x2"
-        exact = {"value": H * W * n_alt * world / alt / 1e6, "unit": "Mrays/s", "ms_per_step": alt / n_alt * 1e3,
-                 "steps": n_alt, "max_abs_rgb_diff_vs_split_f16": float((ref["rgb"] - out["rgb"]).abs().max()),
-                 "max_abs_rgb_std_diff_vs_split_f16": float((ref["rgb_std"] - out["rgb_std"]).abs().max())}
-
-    if rank == 0:
-        ksum = timer.summary()
-        alg = _alg(args.method, K)
-        dom = max(ksum, key=lambda k: ksum[k]["total_ms"])
-        rays_per_launch = H * W * args.steps / ksum[dom]["launches"]
-        avg_s = ksum[dom]["avg_ms"] * 1e-3
-        a = alg.get(dom, {"bytes": 0, "flops": 0})
-        # both roofs for the dominant kernel; the binding one (larger fraction) is reported as `bound`.
-        # Matrix roof: the exact kernels run fp32-input MFMAs (peak = the fp32 vector peak); the split-f16 kernels
-        # issue three f16 products per algorithmic MAC on the f16 matrix pipe (peak 2.5 PFLOP/s dense).
-        split = scene.field.precision == "f16x2"
-        hbm_ach = a["bytes"] * rays_per_launch / avg_s / 1e9
-        mfma_ach = a["flops"] * rays_per_launch / avg_s / 1e12
-        mfma_peak = F16_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
-        mfma_issued = 3.0 * mfma_ach if split else mfma_ach
-        if mfma_issued / mfma_peak > hbm_ach / HBM_PEAK_GBS:
-            roof = {"kernel": dom, "bound": "mfma", "achieved": mfma_ach, "peak": mfma_peak, "unit": "TFLOP/s",
-                    "note": ("algorithmic flops; the kernel issues 3x as many on the f16 matrix pipe" if split else
-                             "fp32 arithmetic: fp32-input MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)")}
-        else:
-            roof = {"kernel": dom, "bound": "hbm", "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "note": "algorithmic gather bytes (8 B per hash-grid corner); the tables are L2 / Infinity-Cache "
-                            "resident, so this rate can exceed the DRAM peak -- `traffic` is what reached the fabric"}
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["other_roof"] = {"hbm_GBps": hbm_ach, "hbm_frac": hbm_ach / HBM_PEAK_GBS,
-                              "algorithmic_TFLOPs": mfma_ach, "matrix_pipe": "f16 (3 products per MAC)" if split else "fp32",
-                              "issued_matrix_TFLOPs": mfma_issued, "matrix_frac": mfma_issued / mfma_peak}
-        roof["algorithmic_bytes_per_ray"] = a["bytes"]
-        roof["algorithmic_flops_per_ray"] = a["flops"]
-        roof["traffic"] = None
-        tfile = os.path.join(ROOT, "profiles", f"traffic_{args.method}.json")
-        if os.path.exists(tfile):  # HBM-side bytes from committed rocprofv3 --pmc passes of this command
-            tj = json.load(open(tfile))
-            tk = tj.get("kernels", {}).get(dom)
-            if tk and K == tj.get("K", 0):
-                scale = rays_per_launch / tj["rays_per_launch"]
-                roof["traffic"] = (tk["fetch_bytes"] + tk["write_bytes"]) * scale
-                roof["traffic_source"] = tj["source"]
-        roof["avg_launch_ms"] = ksum[dom]["avg_ms"]
-        roof["launches"] = ksum[dom]["launches"]
-        roof["per_kernel_ms_per_frame"] = {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(ksum.items())}
-        # whole-path algorithmic bytes per ray against the HBM roof
-        path_bytes = sum(alg[k]["bytes"] for k in ksum if k in alg)
-        roof["path_bytes_per_ray"] = path_bytes
-        roof["path_frac_of_hbm_peak"] = path_bytes * (H * W * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS
-
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
-            cpu = cpu_baseline(t, args, poses[0], cam, K)
-
-        line = {
-            "metric": "Mrays/s (+var), Mip-NeRF360-garden-shaped 1080p", "value": mrays, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.method}-nerfacto {W}x{H} render with variance"
-                                   + (f", K={K} MC-dropout passes" if K else "")
-                                   + (", 100 last-layer Laplace samples" if args.method == "laplace" else ""),
-                       "rays_per_step": H * W, "samples_per_ray": [256, 96, 48], "hash_grid": "16x2^19x2 fp32",
-                       "dense_layers": ("fp32 operands split into two f16 halves, 3 products on v_mfma_f32_32x32x16_f16, "
-                                        "fp32 accumulate (fp32-equivalent, DESIGN.md 4.2)" if split else
-                                        "exact fp32 (v_mfma_f32_32x32x2_f32)"),
-                       "parallelism": f"views x{world}" if world > 1 else "single"},
-            "roofline": roof, "cpu_baseline": cpu, "exact_fp32_kernels": exact,
-        }
-        print(json.dumps(line))
+    default_run = args.method is None
+    method = args.method or "mcdropout"
+    if method == "splat":
+        line = bench_splat(args, rank, world, dev, dist, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps(line))
+    elif method == "ensemble":
+        bench_ensemble(args, rank, world, dev, dist)
+        return
+    else:
+        K = args.mc_samples if method == "mcdropout" else 0
+        rec = run_nerf(args, method, K, args.steps, args.warmup, rank, world, dev, dist, exact_check=not args.no_exact_check)
+        subs = None
+        if default_run and not args.no_sub_records and world == 1:
+            # the other single-GPU configs of BASELINE.json, each with its own per-kernel times (fewer steps: the
+            # default run must stay within minutes); the headline above is the north-star target config
+            subs = {}
+            for m in ("active", "laplace"):
+                r = run_nerf(args, m, 0, 3, 1, rank, world, dev, dist, exact_check=False, want_cpu=False)
+                subs[m] = {"value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
+                           "workload": r["workload"], "per_kernel_ms_per_frame": r["roofline"]["per_kernel_ms_per_frame"],
+                           "roofline": {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                                          "avg_launch_ms", "traffic")}}
+            sp = bench_splat(args, rank, world, dev, dist, 5, 2)
+            subs["splat"] = {"value": sp["value"], "unit": sp["unit"], "ms_per_step": sp["ms_per_step"], "steps": 5, "warmup": 2,
+                             "workload": sp["config"]["workload"],
+                             "per_kernel_ms_per_frame": sp["roofline"]["per_kernel_ms_per_frame"],
+                             "roofline": {k: sp["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                                             "avg_launch_ms", "traffic")}}
+        if rank == 0:
+            H, W = args.height, args.width
+            line = {
+                "metric": "Mrays/s (+var), Mip-NeRF360-garden-shaped 1080p", "value": rec["value"], "unit": "Mrays/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": rec["workload"], "rays_per_step": H * W, "samples_per_ray": [256, 96, 48],
+                           "hash_grid": "16x2^19x2 fp32", "dense_layers": rec["dense_layers"],
+                           "parallelism": f"views x{world}" if world > 1 else "single"},
+                "roofline": rec["roofline"], "cpu_baseline": rec["cpu_baseline"], "exact_fp32_kernels": rec["exact_fp32_kernels"],
+            }
+            if subs is not None:
+                line["sub_records"] = subs
+            print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -297,7 +370,7 @@ def bench_ensemble(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
-def bench_splat(args, rank, world, dev, dist):
+def bench_splat(args, rank, world, dev, dist, steps, warmup):
     """config 5: active-splatfacto, N splats (SURVEY.md 8d synthetic set), 1080p, per-splat variance.
     A step = one frame: project + SH/beta + ONE bin-and-sort + 5-channel raster + depth-variance raster.
     Ranks render different views of the orbit with replicated splats (view-batch DP, no collective)."""
@@ -318,13 +391,13 @@ def bench_splat(args, rank, world, dev, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         out = frame(i)
     sync_all()
     ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = frame(args.warmup + i)
+    for i in range(steps):
+        out = frame(warmup + i)
     sync_all()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
@@ -350,9 +423,9 @@ def bench_splat(args, rank, world, dev, dist):
         kbytes = {"splat_bin_sort": sort_bytes, "splat_rasterize": n_isect * 36 + H * W * 4 * 4}
         ach = kbytes.get(dom, 0) / (ksum[dom]["avg_ms"] * 1e-3) / 1e9 if dom in kbytes else None
         line = {
-            "metric": "Mrays/s (+var) [pixels of an active-splatfacto frame], 1080p", "value": H * W * args.steps * world / elapsed / 1e6,
-            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "Mrays/s (+var) [pixels of an active-splatfacto frame], 1080p", "value": H * W * steps * world / elapsed / 1e6,
+            "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"active-splatfacto {W}x{H}, N={args.splats} splats, rgb+beta+depth+depth_var",
                        "parallelism": f"views x{world}" if world > 1 else "single"},
@@ -360,16 +433,15 @@ def bench_splat(args, rank, world, dev, dist):
                          "frac": None if ach is None else ach / HBM_PEAK_GBS,
                          "traffic": None, "avg_launch_ms": ksum[dom]["avg_ms"], "num_intersects": n_isect,
                          "frame_algorithmic_bytes": frame_bytes,
-                         "frame_frac_of_hbm_peak": frame_bytes * args.steps * world / elapsed / 1e9 / HBM_PEAK_GBS,
-                         "per_kernel_ms_per_frame": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(ksum.items())}},
+                         "frame_frac_of_hbm_peak": frame_bytes * steps * world / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "per_kernel_ms_per_frame": {k: round(v["total_ms"] / steps, 3) for k, v in sorted(ksum.items())}},
             "cpu_baseline": None,
         }
-        print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+        return line
+    return None
 
 
-def cpu_baseline(t, args, c2w, cam, K):
+def cpu_baseline(t, args, method, c2w, cam, K):
     """The CPU oracle (a port: the reference's own stack is not installable here) on a bounded,
     strided sample of the same frame's rays, all host cores."""
     from oracle import nerf_oracle as O
@@ -384,14 +456,14 @@ def cpu_baseline(t, args, c2w, cam, K):
     stride = max(1, o.shape[0] // 64 // chunk) * chunk
     done, t0, i = 0, time.perf_counter(), 0
     wsd = wsr = None
-    if args.method == "laplace":
+    if method == "laplace":
         from uncertainty_nerf_gs_amd import synthetic
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
     while time.perf_counter() - t0 < args.cpu_seconds and i * stride + chunk <= o.shape[0]:
         oo, dd = o[i * stride:i * stride + chunk], d[i * stride:i * stride + chunk]
-        if args.method == "active":
+        if method == "active":
             O.active_outputs(sc, oo, dd)
-        elif args.method == "mcdropout":
+        elif method == "mcdropout":
             O.mcdropout_outputs(sc, oo, dd, K, 1234, 0.2, ray_offset=i * stride)
         else:
             O.laplace_outputs(sc, oo, dd, wsd, wsr, torch.randn(100, chunk, 48))

@@ -38,8 +38,12 @@ for m in active mcdropout; do
     pmc $m fetch FETCH_SIZE
     pmc $m write WRITE_SIZE
 done
-pmc active sq SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
+for m in active mcdropout; do
+    pmc $m sq SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
+done
 pmc active ta TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
 pmc active tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
 python3 "$ROOT/benchmarks/summarize_pmc.py" summary "$DST" "$TAG"
+# the default line (what the driver runs), outside the profiler
+cd "$ROOT" && python3 bench.py > "$DST/${TAG}_default_bench.json" 2> "$OUT/default_bench.err"
 ls -la "$DST"

@@ -72,6 +72,22 @@ def summary(d, tag):
                                    "coalesced streams for which MI355X_MICROARCH.md prescribes x2; writes read exact"}}}
             with open(os.path.join(d, f"traffic_{method}.json"), "w") as f:
                 json.dump(t, f, indent=1)
+        need = ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")
+        if fk and all(c in kernels[fk] for c in need):
+            kk = kernels[fk]
+            # SQ_ACTIVE_INST_VALU counts quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (32 per v_mfma_f32_32x32x16_f16);
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs -> elapsed cycles of one XCD x 1024 SIMDs = available cycles
+            issue = 4.0 * kk["SQ_ACTIVE_INST_VALU"] + kk["SQ_VALU_MFMA_BUSY_CYCLES"]
+            simd_cycles = kk["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+            j = {"method": method, "K": 8 if method == "mcdropout" else 0, "rays_per_launch": 262144, "kernel_name": fk,
+                 "source": f"profiles/{tag}_{method}_pmc_sq.csv (rocprofv3 --pmc, own pass)",
+                 "issue_cycles_per_launch": issue,
+                 "valu_active_quad_cycles": kk["SQ_ACTIVE_INST_VALU"], "mfma_busy_cycles": kk["SQ_VALU_MFMA_BUSY_CYCLES"],
+                 "valu_insts_per_launch": kk["SQ_INSTS_VALU"] - kk["SQ_INSTS_MFMA"], "mfma_insts_per_launch": kk["SQ_INSTS_MFMA"],
+                 "simd_cycles_per_launch": simd_cycles, "busy_frac": issue / simd_cycles,
+                 "engine_clock_GHz_under_profiler": kk["GRBM_GUI_ACTIVE"] / 8.0 / (kk["avg_dur_us"] * 1e3)}
+            with open(os.path.join(d, f"issue_{method}.json"), "w") as f:
+                json.dump(j, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -280,7 +280,8 @@ int unerf_splat_project(const float* means3d, const float* scales, float glob_sc
                         float* conics, float* compensation, int32_t* num_tiles_hit, float* cov3d, void* stream);
 
 /* :245-246 spherical_harmonics(degree, viewdirs, coeffs[N,16,3]) then clamp(+0.5, min 0);
- * and :286 softplus(log_unc)+beta_min.  cam_pos_host: 3 floats.  colors_out [N,3], beta_out [N]. 
+ * and :286 softplus(log_unc)+beta_min.  cam_pos_host: 3 floats.  colors_out [N,3], beta_out [N].
+ * degree = -1: the config.sh_degree == 0 branch (:247-248), colors = sigmoid(DC coefficients), no SH, no +0.5.
  * sh_coeffs must be 16-byte aligned (rows of 48 floats are read as 16-byte loads). */
 int unerf_splat_sh_colors(int degree, const float* means3d, const float* cam_pos_host, const float* sh_coeffs,
                           const float* log_unc, float beta_min, int64_t N, float* colors_out, float* beta_out,

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float*
         k[47] = (degree >= 3) ? rest[i * 45 + 44] : 0.f;
     } else {
         const float4* k4 = reinterpret_cast<const float4*>(coeffs + i * 48);
-        const int nq = degree == 0 ? 1 : degree == 1 ? 3 : degree == 2 ? 7 : 12;   // 3 / 12 / 27 / 48 floats used
+        const int nq = degree <= 0 ? 1 : degree == 1 ? 3 : degree == 2 ? 7 : 12;   // 3 / 12 / 27 / 48 floats used
 #pragma unroll
         for (int q = 0; q < 12; ++q) {
             const float4 v = (q < nq) ? k4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -236,8 +236,13 @@ __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float*
             }
         }
     }
+    if (degree < 0) {  // config.sh_degree == 0: rgbs = sigmoid(features_dc) (activesplatfacto_model.py:247-248)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) colors[i * 3 + c] = fmaxf(col[c] + 0.5f, 0.f);
+        for (int c = 0; c < 3; ++c) colors[i * 3 + c] = unerf_sigmoid(k[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) colors[i * 3 + c] = fmaxf(col[c] + 0.5f, 0.f);
+    }
     if (beta) beta[i] = unerf_softplus(log_unc[i]) + beta_min;
 }
 
@@ -245,7 +250,7 @@ extern "C" int unerf_splat_sh_colors(int degree, const float* means3d, const flo
                                      const float* log_unc, float beta_min, int64_t N, float* colors_out,
                                      float* beta_out, void* stream) {
     UNERF_REQUIRE(means3d && cam_pos && sh_coeffs && colors_out, "splat_sh_colors: null pointer");
-    UNERF_REQUIRE(degree >= 0 && degree <= 3, "splat_sh_colors: degree %d outside [0,3]", degree);
+    UNERF_REQUIRE(degree >= -1 && degree <= 3, "splat_sh_colors: degree %d outside [-1,3]", degree);
     UNERF_REQUIRE(!beta_out || log_unc, "splat_sh_colors: beta_out without log_unc");
     UNERF_REQUIRE(((uintptr_t)sh_coeffs & 15u) == 0, "splat_sh_colors: sh_coeffs must be 16-byte aligned");
     if (N <= 0) return UNERF_OK;
@@ -259,8 +264,8 @@ extern "C" int unerf_splat_sh_colors_split(int degree, const float* means3d, con
                                            const float* features_rest, const float* log_unc, float beta_min, int64_t N,
                                            float* colors_out, float* beta_out, void* stream) {
     UNERF_REQUIRE(means3d && cam_pos && features_dc && colors_out, "splat_sh_colors_split: null pointer");
-    UNERF_REQUIRE(degree >= 0 && degree <= 3, "splat_sh_colors_split: degree %d outside [0,3]", degree);
-    UNERF_REQUIRE(degree == 0 || features_rest, "splat_sh_colors_split: degree %d needs features_rest", degree);
+    UNERF_REQUIRE(degree >= -1 && degree <= 3, "splat_sh_colors_split: degree %d outside [-1,3]", degree);
+    UNERF_REQUIRE(degree <= 0 || features_rest, "splat_sh_colors_split: degree %d needs features_rest", degree);
     UNERF_REQUIRE(!beta_out || log_unc, "splat_sh_colors_split: beta_out without log_unc");
     if (N <= 0) return UNERF_OK;
     hipLaunchKernelGGL(sh_colors_kernel<true>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,

@@ -217,9 +217,18 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
                                     **cam, **self._render_kwargs())
 
     @torch.no_grad()
-    def get_outputs_for_camera_ray_bundle(self, origins: torch.Tensor, directions: torch.Tensor):
-        """origins / directions [H,W,3] on the device (a nerfstudio RayBundle's fields)."""
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle, directions: Optional[torch.Tensor] = None):
+        """Model.get_outputs_for_camera_ray_bundle(camera_ray_bundle: RayBundle) (mcdropout_models.py:94-96): any object
+        with `.origins` / `.directions` [H,W,3] -- a nerfstudio RayBundle from `camera.generate_rays(keep_shape=True)` --
+        or, for callers without nerfstudio, the two tensors (origins, directions)."""
+        if directions is None:
+            origins, directions = camera_ray_bundle.origins, camera_ray_bundle.directions
+        else:
+            origins = camera_ray_bundle
         H, W = origins.shape[:2]
+        scene0 = self.device_scene(origins.device if origins.is_cuda else None)
+        origins = origins.to(device=scene0.device, dtype=torch.float32)
+        directions = directions.to(device=scene0.device, dtype=torch.float32)
         scene = self.device_scene(origins.device)
         o, d = origins.reshape(-1, 3).contiguous(), directions.reshape(-1, 3).contiguous()
         rpl = max(scene.chunk_rays, (self.rays_per_launch // scene.chunk_rays) * scene.chunk_rays)
@@ -291,10 +300,29 @@ class NerfactoLaplaceModel(_NerfactoBase):
     def _make_field(self):
         return F.NerfactoLaplaceField(density_activation=self.config.density_activation, **self._field_kwargs())
 
+    _ws = None                       # sampled last layers of the current *_unc call; None: the mean heads
+    _deterministic_density = False
+
     def _field_to_device(self, device):
+        if self._ws is None:
+            # get_outputs_for_camera / get_outputs / forward without a preceding *_unc call: the deterministic render
+            # of NerfactoLaplaceField.forward (laplace_field.py:317-345, 462-465) -- the mean last layers as the single
+            # "sample", selector-masked density
+            from torch.nn.utils import parameters_to_vector
+            ws_d = parameters_to_vector(self.field.mlp_density.parameters()).detach().reshape(1, -1)
+            ws_r = parameters_to_vector(self.field.mlp_rgb_ll.parameters()).detach().reshape(1, -1)
+            return self.field.to_device(device, ws_density=ws_d, ws_rgb=ws_r, lap_mask_density=1)
         ws_d, ws_r = self._ws
         return self.field.to_device(device, ws_density=ws_d, ws_rgb=ws_r,
-                                    lap_mask_density=int(getattr(self, "_deterministic_density", False)))
+                                    lap_mask_density=int(self._deterministic_density))
+
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera, obb_box=None):
+        """the plain (deterministic, mean-head) render unless called through get_outputs_for_camera_unc"""
+        if not getattr(self, "_in_unc_call", False) and self._ws is not None:
+            self._ws, self._deterministic_density = None, False     # leave the previous camera's sampled heads behind
+            self.invalidate()
+        return super().get_outputs_for_camera(camera, obb_box)
 
     @torch.no_grad()
     def get_outputs_for_camera_unc(self, camera, obb_box=None, is_inference: bool = True,
@@ -310,7 +338,11 @@ class NerfactoLaplaceModel(_NerfactoBase):
                                                  deterministic_density=use_deterministic_density)
         self._deterministic_density = bool(use_deterministic_density)
         self.invalidate()
-        return self.get_outputs_for_camera(camera, obb_box)
+        self._in_unc_call = True
+        try:
+            return self.get_outputs_for_camera(camera, obb_box)
+        finally:
+            self._in_unc_call = False
 
     def _render_kwargs(self):
         return {"depth_draws": 100, "depth_seed": self.depth_seed}  # num_samples = 100 (laplace_model.py:487)
@@ -380,7 +412,11 @@ class ActiveSplatfactoModel(nn.Module, _ImageMetrics):
             # optimised in log space, initialised U(0,1) (activesplatfacto_model.py:58-61)
             "log_uncertainties": nn.Parameter(torch.rand(num_points, 1)),
         })
-        self.register_buffer("background_color", torch.zeros(3), persistent=False)
+        # [UPSTREAM SplatfactoModel.populate_modules] the eval background is a stored colour, not part of the
+        # checkpoint: "random" -> the Viser grey (0.1490, 0.1647, 0.2157), otherwise the named colour.  It is blended
+        # into rgb wherever alpha < 1 and returned as outputs["background"] (activesplatfacto_model.py:159-173, :363).
+        self.register_buffer("background_color", splat.background_for(self.config.background_color), persistent=False)
+        self.crop_box = None
 
     def load_state_dict(self, dict, **kwargs):  # type: ignore[override]
         """activesplatfacto_model.py:87-100: resize every gaussian parameter to the checkpoint's point
@@ -396,16 +432,33 @@ class ActiveSplatfactoModel(nn.Module, _ImageMetrics):
         own = self.state_dict()
         return super().load_state_dict({k: v for k, v in dict.items() if k in own}, strict=False)
 
+    def set_crop(self, crop_box) -> None:
+        """[UPSTREAM SplatfactoModel.set_crop] crop_box: None or an object with `.within(points [N,3]) -> bool [N(,1)]`
+        (a nerfstudio OrientedBox)"""
+        self.crop_box = crop_box
+
+    def set_background(self, background_color: torch.Tensor) -> None:
+        assert background_color.shape == (3,)
+        self.background_color = background_color.to(self.background_color.device, torch.float32)
+
     @torch.no_grad()
     def get_outputs(self, camera) -> Dict[str, Optional[torch.Tensor]]:
         c2w, cam = _camera_args(camera)
         n = min(self.step // self.config.sh_degree_interval, self.config.sh_degree) if self.config.sh_degree > 0 else 0
         gp = {k: v.detach() for k, v in self.gauss_params.items()}
+        crop_ids = None
+        if self.crop_box is not None and not self.training:                     # :174-180
+            crop_ids = self.crop_box.within(gp["means"]).squeeze()
         return splat.active_splatfacto_outputs(gp, c2w, background=self.background_color.to(gp["means"].device),
                                                beta_min=self.config.beta_min, sh_degree=n,
-                                               rasterize_mode=self.config.rasterize_mode, **cam)
+                                               rasterize_mode=self.config.rasterize_mode, crop_ids=crop_ids,
+                                               config_sh_degree=self.config.sh_degree, **cam)
 
-    get_outputs_for_camera = get_outputs
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Optional[torch.Tensor]]:
+        """[UPSTREAM SplatfactoModel.get_outputs_for_camera] set_crop(obb_box), then get_outputs(camera)"""
+        self.set_crop(obb_box)
+        return self.get_outputs(camera)
 
     # -- the two helpers the eval script calls on splat models (scripts/eval_uncertainty.py:321-322, 676-677) --
     def get_gt_img(self, image: torch.Tensor) -> torch.Tensor:

@@ -28,19 +28,60 @@ def viewmat_from_c2w(c2w: torch.Tensor) -> torch.Tensor:
     return V
 
 
+# [UPSTREAM nerfstudio 1.1.0 SplatfactoModel.populate_modules] the stored eval background: config "random" ->
+# the Viser grey, otherwise the named colour (nerfstudio.utils.colors.get_color)
+BACKGROUND_RANDOM = (0.1490, 0.1647, 0.2157)
+NAMED_COLORS = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0), "red": (1.0, 0.0, 0.0), "green": (0.0, 1.0, 0.0),
+                "blue": (0.0, 0.0, 1.0)}
+
+
+def background_for(config_background_color: str) -> torch.Tensor:
+    if config_background_color == "random":
+        return torch.tensor(BACKGROUND_RANDOM, dtype=torch.float32)
+    if config_background_color not in NAMED_COLORS:
+        raise ValueError(f"unknown background_color {config_background_color!r}; known: random, {', '.join(NAMED_COLORS)}")
+    return torch.tensor(NAMED_COLORS[config_background_color], dtype=torch.float32)
+
+
+def empty_outputs(W: int, H: int, background: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """[UPSTREAM SplatfactoModel.get_empty_outputs] what the reference returns when the crop box holds no splat or
+    every projected radius is zero (activesplatfacto_model.py:176-177, 239-240): background image, depth 10, zero
+    accumulation -- and none of the uncertainty keys."""
+    rgb = background.repeat(H, W, 1)
+    return {"rgb": rgb, "depth": background.new_ones(H, W, 1) * 10, "accumulation": background.new_zeros(H, W, 1),
+            "background": background}
+
+
 def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx: float, fy: float, cx: float,
                               cy: float, H: int, W: int, background: torch.Tensor, beta_min: float = 0.01,
                               sh_degree: int = 3, rasterize_mode: str = "classic",
-                              block_width: int = 16) -> Dict[str, Optional[torch.Tensor]]:
+                              block_width: int = 16, crop_ids: Optional[torch.Tensor] = None,
+                              config_sh_degree: Optional[int] = None) -> Dict[str, Optional[torch.Tensor]]:
     """gp: gauss_params on the device (means, scales, quats, features_dc, features_rest, opacities,
-    log_uncertainties).  Returns the reference's output dict (:359-367) as [H,W,C] tensors."""
+    log_uncertainties).  Returns the reference's output dict (:359-367) as [H,W,C] tensors.
+    crop_ids: bool [N] from `crop_box.within(means)` (:174-180, 202-217) -- only those splats are rendered.
+    sh_degree: the active degree n = min(step // interval, config.sh_degree) (:244);
+    config_sh_degree == 0 selects the sigmoid(features_dc) colours of :247-248."""
     _l.require_gpu()
-    means = gp["means"]
+    background = background.to(gp["means"].device, torch.float32)
+    if crop_ids is not None:
+        crop_ids = crop_ids.reshape(-1).to(gp["means"].device)
+        if int(crop_ids.sum().item()) == 0:
+            return empty_outputs(W, H, background)
+        gp = {k: v[crop_ids].contiguous() for k, v in gp.items()}
+    means = gp["means"].contiguous()
     dev = means.device
     V = viewmat_from_c2w(c2w)
     quats = gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True)
     xys, depths, radii, conics, comp, tiles, _cov = ops.splat_project(
         means, torch.exp(gp["scales"]), 1.0, quats.contiguous(), V[:3], fx, fy, cx, cy, H, W, block_width)
+    # (self.radii).sum() == 0 -> get_empty_outputs (:239-240).  A splat has a non-zero radius exactly when it hits at
+    # least one tile, so "no intersections" is the same test and rides on the one host read-back of the frame
+    I, _cum, _keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, block_width, want_isect_ids=False)
+    if I == 0:
+        return empty_outputs(W, H, background)
+    if config_sh_degree is not None and config_sh_degree <= 0:
+        sh_degree = -1                                     # kernel: colours = sigmoid(features_dc)
     # the reference concatenates features_dc and features_rest first (:242-243); the kernel reads them in place
     rgbs, beta = ops.splat_sh_colors_split(sh_degree, means, c2w[:3, 3], gp["features_dc"].contiguous(),
                                            gp["features_rest"].contiguous(),
@@ -51,7 +92,6 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     elif rasterize_mode != "classic":
         raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
     opac = opac.contiguous()
-    I, _cum, _keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, block_width, want_isect_ids=False)
     cols = torch.cat([rgbs, beta[:, None], depths[:, None]], dim=1).contiguous()
     bg5 = torch.cat([background.to(dev, torch.float32), torch.zeros(2, device=dev)])
     img, fT, _ = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg5, block_width)
