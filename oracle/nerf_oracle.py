@@ -675,10 +675,10 @@ def _prop_depths(scene, wl, bl):
     return out
 
 
-def active_outputs(scene: NerfScene, origins, directions) -> Dict[str, torch.Tensor]:
-    """[REF activenerfacto_model.py:83-152] one chunk of rays [R,3]."""
-    eb, wl, bl = _sample(scene, origins, directions)
-    density, rgb, beta = active_field(origins, directions, eb, scene.field)
+def active_compose(eb, density, rgb, beta) -> Dict[str, torch.Tensor]:
+    """[REF activenerfacto_model.py:94-127] everything get_outputs does after the field call: eb [R,S+1] Euclidean
+    bin edges, density / beta [R,S], rgb [R,S,3].  Pinned to the reference's own code by
+    tests/golden/nerf_model_glue.npz (fake-self run of ActiveNerfactoModel.get_outputs)."""
     deltas = eb[..., 1:] - eb[..., :-1]
     steps = (eb[..., :-1] + eb[..., 1:]) / 2
     w = get_weights(density, deltas)
@@ -694,6 +694,14 @@ def active_outputs(scene: NerfScene, origins, directions) -> Dict[str, torch.Ten
     out["rgb_std"] = out["rgb_var"].sqrt()
     out["depth_var"] = torch.sum(w * (steps - out["depth"]) ** 2, dim=-1, keepdim=True) + 1e-5
     out["depth_std"] = out["depth_var"].sqrt()
+    return out
+
+
+def active_outputs(scene: NerfScene, origins, directions) -> Dict[str, torch.Tensor]:
+    """[REF activenerfacto_model.py:83-152] one chunk of rays [R,3]."""
+    eb, wl, bl = _sample(scene, origins, directions)
+    density, rgb, beta = active_field(origins, directions, eb, scene.field)
+    out = active_compose(eb, density, rgb, beta)
     out.update(_prop_depths(scene, wl, bl))
     return out
 
@@ -737,17 +745,12 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
     return res
 
 
-def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
-                    depth_noise: Optional[torch.Tensor], use_deterministic_density: bool = False) -> Dict[str, torch.Tensor]:
-    """[REF laplace_model.py:456-556] is_inference=True.
-    use_deterministic_density=False: density = sampled-head mean (NOT selector-masked), depth from the mean of the
-    weights of D Normal(mu_d, sigma_d) density draws; depth_noise [D,R,S] = the standard-normal draw behind them.
-    use_deterministic_density=True (laplace_field.py:501-506): density = the plain mean head, selector-masked
-    (is_inference=False branch of get_density), colour still sampled, depth from the ordinary weights."""
-    eb, wl, bl = _sample(scene, origins, directions)
-    mu_d, var_d, mu_rgb, var_rgb = laplace_field(origins, directions, eb, scene.field, ws_density, ws_rgb)
-    if use_deterministic_density:
-        mu_d, _ = laplace_field_deterministic(origins, directions, eb, scene.field)
+def laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise: Optional[torch.Tensor],
+                    use_deterministic_density: bool = False) -> Dict[str, torch.Tensor]:
+    """[REF laplace_model.py:471-530] everything get_outputs_unc does after the field call: weights from mu_d,
+    rgb / rgb_var from those weights, then (unless use_deterministic_density) D density draws
+    relu(mu_d + max(sqrt(var_d), 1e-10) * noise), their mean weights, and depth / expected depth / accumulation
+    from THOSE.  Pinned to the reference's own code by tests/golden/nerf_model_glue.npz."""
     deltas = eb[..., 1:] - eb[..., :-1]
     steps = (eb[..., :-1] + eb[..., 1:]) / 2
     w = get_weights(mu_d, deltas)
@@ -763,10 +766,24 @@ def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
         wm = sw.mean(dim=0)
     depth = render_depth_median(wm, steps)
     depth_var = torch.sum(wm * (steps - depth) ** 2, dim=-1, keepdim=True) + 1e-5
-    out = {
+    return {
         "rgb": rgb, "rgb_std": rgb_var.sqrt(), "accumulation": render_accumulation(wm), "depth": depth,
         "depth_std": depth_var.sqrt(), "expected_depth": render_depth_expected(wm, steps),
     }
+
+
+def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
+                    depth_noise: Optional[torch.Tensor], use_deterministic_density: bool = False) -> Dict[str, torch.Tensor]:
+    """[REF laplace_model.py:456-556] is_inference=True.
+    use_deterministic_density=False: density = sampled-head mean (NOT selector-masked), depth from the mean of the
+    weights of D Normal(mu_d, sigma_d) density draws; depth_noise [D,R,S] = the standard-normal draw behind them.
+    use_deterministic_density=True (laplace_field.py:501-506): density = the plain mean head, selector-masked
+    (is_inference=False branch of get_density), colour still sampled, depth from the ordinary weights."""
+    eb, wl, bl = _sample(scene, origins, directions)
+    mu_d, var_d, mu_rgb, var_rgb = laplace_field(origins, directions, eb, scene.field, ws_density, ws_rgb)
+    if use_deterministic_density:
+        mu_d, _ = laplace_field_deterministic(origins, directions, eb, scene.field)
+    out = laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise, use_deterministic_density)
     out.update(_prop_depths(scene, wl, bl))
     return out
 

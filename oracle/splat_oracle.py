@@ -227,21 +227,47 @@ def viewmat_from_c2w(c2w):
     return V
 
 
+def empty_outputs(W, H, background) -> Dict[str, np.ndarray]:
+    """[UPSTREAM SplatfactoModel.get_empty_outputs] (activesplatfacto_model.py:176-177, 239-240)"""
+    bg = _f(background)
+    return {"rgb": np.broadcast_to(bg, (H, W, 3)).copy(), "depth": np.full((H, W, 1), 10, f32),
+            "accumulation": np.zeros((H, W, 1), f32), "background": bg}
+
+
 def active_splatfacto_outputs(gp: Dict[str, np.ndarray], c2w, fx, fy, cx, cy, H, W, background, beta_min=0.01,
-                              sh_degree=3) -> Dict[str, np.ndarray]:
-    """[REF activesplatfacto_model.py:142-367] eval branch, rasterize_mode='classic', no crop box.
+                              sh_degree=3, rasterize_mode="classic", config_sh_degree=None,
+                              crop_ids=None) -> Dict[str, np.ndarray]:
+    """[REF activesplatfacto_model.py:142-367] eval branch.  sh_degree = the active degree n (:244);
+    config_sh_degree == 0 -> sigmoid(features_dc) colours (:247-248); crop_ids: bool [N] of `crop_box.within`.
     The four rasterize_gaussians calls share their blending weights, so they are evaluated as one
-    5-channel pass (rgb, beta, depth) plus the depth-variance pass."""
+    5-channel pass (rgb, beta, depth) plus the depth-variance pass -- pinned to the reference's own four-pass code by
+    tests/golden/splat_get_outputs.npz (fake-self run of ActiveSplatfactoModel.get_outputs)."""
+    if crop_ids is not None:
+        crop_ids = np.asarray(crop_ids).reshape(-1).astype(bool)
+        if crop_ids.sum() == 0:
+            return empty_outputs(W, H, background)
+        gp = {k: np.asarray(v)[crop_ids] for k, v in gp.items()}
+    import torch   # the elementwise activations are torch's in the reference (torch.exp / sigmoid / Softplus / norm)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(_f(a)))
     means = _f(gp["means"])
     V = viewmat_from_c2w(c2w)
-    quats = _f(gp["quats"])
-    quats = quats / np.linalg.norm(quats, axis=-1, keepdims=True)
-    pr = project_gaussians(means, np.exp(_f(gp["scales"])), 1.0, quats, V[:3], fx, fy, cx, cy, H, W, 16)
+    quats = tt(gp["quats"])
+    quats = (quats / quats.norm(dim=-1, keepdim=True)).numpy()
+    pr = project_gaussians(means, torch.exp(tt(gp["scales"])).numpy(), 1.0, quats, V[:3], fx, fy, cx, cy, H, W, 16)
     coeffs = np.concatenate([_f(gp["features_dc"])[:, None, :], _f(gp["features_rest"])], axis=1)
     viewdirs = means - _f(c2w)[:3, 3]
-    rgbs = np.maximum(spherical_harmonics(sh_degree, viewdirs, coeffs) + f32(0.5), f32(0))
-    opac = (f32(1) / (f32(1) + np.exp(-_f(gp["opacities"])))).reshape(-1)
-    beta = softplus(gp["log_uncertainties"]).reshape(-1) + f32(beta_min)
+    if pr["radii"].sum() == 0:
+        return empty_outputs(W, H, background)
+    if config_sh_degree is not None and config_sh_degree <= 0:
+        rgbs = torch.sigmoid(tt(coeffs)[:, 0, :]).numpy()   # the same strided view the reference takes (:248)
+    else:
+        rgbs = np.maximum(spherical_harmonics(sh_degree, viewdirs, coeffs) + f32(0.5), f32(0))
+    opac = torch.sigmoid(tt(gp["opacities"])).numpy().reshape(-1)
+    if rasterize_mode == "antialiased":
+        opac = opac * pr["compensation"]
+    elif rasterize_mode != "classic":
+        raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
+    beta = (torch.nn.functional.softplus(tt(gp["log_uncertainties"])) + beta_min).numpy().reshape(-1)
     I, cum, keys, gids, bins = bin_and_sort(pr["xys"], pr["depths"], pr["radii"], pr["num_tiles_hit"], H, W)
     cols = np.concatenate([rgbs, beta[:, None], pr["depths"][:, None]], axis=1)
     bg5 = np.concatenate([_f(background), np.zeros(2, f32)])
@@ -260,5 +286,5 @@ def active_splatfacto_outputs(gp: Dict[str, np.ndarray], c2w, fx, fy, cx, cy, H,
     with np.errstate(all="ignore"):
         depth_var = np.where(alpha > 0, dv_img / alpha, dv_img.max())
     return {"rgb": rgb, "depth": depth, "accumulation": alpha, "background": _f(background), "uncertainty": unc,
-            "rgb_var": unc ** 2, "rgb_std": unc, "depth_var": depth_var, "depth_std": np.sqrt(depth_var),
+            "rgb_var": unc ** 2, "rgb_std": unc, "depth_var": depth_var, "depth_std": torch.sqrt(tt(depth_var)).numpy(),
             "_proj": pr, "_sort": (I, cum, keys, gids, bins), "_sqdiff": diff ** 2}

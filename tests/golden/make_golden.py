@@ -59,6 +59,9 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 def install_stubs():
     sys.meta_path.insert(0, _StubFinder())
     sys.path.insert(0, REF)
+    # the two enum members the reference's model code indexes field outputs with
+    import nerfstudio.field_components.field_heads as fh
+    fh.FieldHeadNames.DENSITY, fh.FieldHeadNames.RGB = "density", "rgb"
 
 
 def golden_create_mlp():
@@ -208,6 +211,193 @@ def golden_mc_aggregate():
     np.savez_compressed(os.path.join(OUT, "mc_aggregate.npz"), **res)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# [REF] model glue driven with a fake `self` (the reference's own get_outputs code runs; the upstream primitives it
+# calls -- gsplat kernels, nerfstudio samplers / renderers -- are bound to the ORACLE's restatements).  These fixtures
+# pin the oracle's model-level functions (active_splatfacto_outputs, laplace_outputs, active_outputs: composition,
+# key names, the four-raster-pass structure, the depth-draw averaging, ...) to the reference's text; the primitives
+# themselves stay upstream-recall.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _np(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def golden_splat_get_outputs():
+    """ActiveSplatfactoModel.get_outputs (activesplatfacto_model.py:142-367), eval branch, on a seeded 400-splat set:
+    default config, a named background, sh_degree 0, an early SH degree (step < 3000), antialiased mode."""
+    import nerfuncertainty.models.activesplatfacto.activesplatfacto_model as M
+    from nerfstudio.cameras.cameras import Cameras
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import splat_oracle as SO
+
+    def project_gaussians(means, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, bw, clip_thresh=0.01):
+        pr = SO.project_gaussians(_np(means), _np(scales), glob_scale, _np(quats), _np(viewmat), fx, fy, cx, cy, H, W, bw,
+                                  clip_thresh)
+        return tuple(torch.from_numpy(pr[k]) for k in ("xys", "depths", "radii", "conics", "compensation",
+                                                       "num_tiles_hit", "cov3d"))
+
+    def spherical_harmonics(n, viewdirs, coeffs):
+        return torch.from_numpy(SO.spherical_harmonics(n, _np(viewdirs), _np(coeffs)))
+
+    def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, bw, background=None,
+                            return_alpha=False):
+        I, cum, keys, gids, bins = SO.bin_and_sort(_np(xys), _np(depths), _np(radii), _np(num_tiles_hit), H, W, bw)
+        out, fT, _ = SO.rasterize(gids, bins, _np(xys), _np(conics), _np(colors), _np(opacity), H, W,
+                                  None if background is None else _np(background), bw)
+        out = torch.from_numpy(out)
+        return (out, torch.from_numpy(1.0 - fT)) if return_alpha else out
+
+    M.project_gaussians, M.spherical_harmonics, M.rasterize_gaussians = project_gaussians, spherical_harmonics, rasterize_gaussians
+    M.renderers.BACKGROUND_COLOR_OVERRIDE = None
+
+    g = torch.Generator().manual_seed(31)
+    N, H, W = 400, 40, 56
+    q = torch.randn(N, 4, generator=g)
+    gp = {"means": (torch.rand(N, 3, generator=g) * 2 - 1) * 0.8, "scales": torch.randn(N, 3, generator=g) * 0.4 - 2.6,
+          "quats": q, "features_dc": torch.randn(N, 3, generator=g) * 0.5,
+          "features_rest": torch.randn(N, 15, 3, generator=g) * 0.05, "opacities": torch.randn(N, 1, generator=g) * 2,
+          "log_uncertainties": torch.rand(N, 1, generator=g)}
+    c2w = torch.tensor([[0.8, -0.2, 0.5657, 1.4], [0.6, 0.2667, -0.7542, -1.9], [0.0, 0.9428, 0.3333, 0.8]])
+    c2w[:, :3] = torch.linalg.qr(c2w[:, :3])[0]
+    fx = fy = 50.0
+    res = {"c2w": c2w.numpy(), "intr": np.array([fx, fy, W / 2, H / 2, H, W], dtype=np.float64)}
+    for k, v in gp.items():
+        res["gp_" + k] = v.numpy()
+
+    def run(tag, background, sh_degree=3, step=30000, rasterize_mode="classic"):
+        cam = object.__new__(Cameras)
+        cam.shape = (1,)
+        cam.width, cam.height = torch.tensor([[W]]), torch.tensor([[H]])
+        cam.fx, cam.fy = torch.tensor([[fx]]), torch.tensor([[fy]])
+        cam.cx, cam.cy = torch.tensor([[W / 2.0]]), torch.tensor([[H / 2.0]])
+        cam.rescale_output_resolution = lambda f: None
+        obj = object.__new__(M.ActiveSplatfactoModel)
+        obj.training = False
+        obj.device = torch.device("cpu")
+        obj.step = step
+        obj.config = SimpleNamespace(background_color="random", sh_degree=sh_degree, sh_degree_interval=1000,
+                                     rasterize_mode=rasterize_mode, beta_min=0.01, output_depth_during_training=False)
+        obj.gauss_params = gp
+        for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
+            setattr(obj, k, gp[k])
+        obj.background_color = background
+        obj.crop_box = None
+        obj.camera_optimizer = SimpleNamespace(apply_to_camera=lambda c: c2w[None])
+        obj._get_downscale_factor = lambda: 1
+        obj.activation_uncertainty = torch.nn.Softplus()
+        out = obj.get_outputs(cam)
+        res[f"{tag}_cfg"] = np.array([sh_degree, step, 1 if rasterize_mode == "antialiased" else 0], dtype=np.int64)
+        for k, v in out.items():
+            res[f"{tag}_out_{k}"] = _np(v).astype(np.float32)
+
+    run("default", torch.tensor([0.1490, 0.1647, 0.2157]))
+    run("white", torch.ones(3))
+    run("sh0", torch.zeros(3), sh_degree=0)
+    run("early", torch.tensor([0.1490, 0.1647, 0.2157]), step=1500)
+    run("aa", torch.tensor([0.1490, 0.1647, 0.2157]), rasterize_mode="antialiased")
+    np.savez_compressed(os.path.join(OUT, "splat_get_outputs.npz"), **res)
+
+
+class _FakeRaySamples:
+    """what the reference's model code touches on a nerfstudio RaySamples: frustums.starts / ends and get_weights"""
+
+    def __init__(self, eb):
+        self.frustums = SimpleNamespace(starts=eb[:, :-1, None], ends=eb[:, 1:, None])
+        self.deltas = eb[:, 1:, None] - eb[:, :-1, None]
+        self._get_weights = None
+
+    def get_weights(self, densities):
+        from nerfuncertainty.models.laplace.laplace_model import ComputeWeightsModule
+        return ComputeWeightsModule()(densities, self.deltas)          # the reference's own copy of get_weights
+
+
+def _oracle_renderers(O):
+    def steps_of(rs):
+        return ((rs.frustums.starts + rs.frustums.ends) / 2)[..., 0]
+    return dict(
+        renderer_rgb=lambda rgb, weights: O.render_rgb(rgb, weights[..., 0]),
+        renderer_accumulation=lambda weights: O.render_accumulation(weights[..., 0]),
+        renderer_depth=lambda weights, ray_samples: O.render_depth_median(weights[..., 0], steps_of(ray_samples)),
+        renderer_expected_depth=lambda weights, ray_samples: O.render_depth_expected(weights[..., 0], steps_of(ray_samples)),
+        renderer_uncertainty=lambda betas, weights: O.render_uncertainty(betas[..., 0], weights[..., 0]),
+    )
+
+
+def golden_nerf_model_glue():
+    """NerfactoLaplaceModel.get_outputs_unc (laplace_model.py:456-556, both density modes) and
+    ActiveNerfactoModel.get_outputs (activenerfacto_model.py:83-152) with a fake `self`: the proposal sampler returns
+    seeded bins, the field returns seeded outputs, the renderers are the oracle's; everything in between is the
+    reference's code."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import nerf_oracle as O
+    from nerfstudio.field_components.field_heads import FieldHeadNames
+    import nerfuncertainty.models.laplace.laplace_model as LM
+    import nerfuncertainty.models.activenerfacto.activenerfacto_model as AM
+    g = torch.Generator().manual_seed(41)
+    R, S = 96, 48
+    res = {}
+
+    def bins(n):
+        sb = torch.sort(torch.rand(R, n + 1, generator=g), dim=-1).values
+        return O.spacing_to_euclidean(sb, 0.05, 1000.0)
+
+    eb0, eb1, eb = bins(256), bins(96), bins(S)
+    w0 = torch.rand(R, 256, 1, generator=g) / 100
+    w1 = torch.rand(R, 96, 1, generator=g) / 40
+    density = torch.exp(torch.randn(R, S, 1, generator=g) * 2.0)
+    density[0] = 0.0
+    rgb = torch.rand(R, S, 3, generator=g)
+    res.update(eb0=eb0.numpy(), eb1=eb1.numpy(), eb=eb.numpy(), w0=w0.numpy(), w1=w1.numpy(), density=density.numpy(),
+               rgb=rgb.numpy())
+    rend = _oracle_renderers(O)
+
+    def sampler(ray_bundle, density_fns=None):
+        return _FakeRaySamples(eb), [w0.clone(), w1.clone()], [_FakeRaySamples(eb0), _FakeRaySamples(eb1)]
+
+    # ---- laplace ----
+    density_var = torch.rand(R, S, 1, generator=g) * density ** 2 * 0.05
+    rgb_var = torch.rand(R, S, 1, generator=g) * 0.01
+    res.update(lap_density_var=density_var.numpy(), lap_rgb_var=rgb_var.numpy())
+    for tag, det in (("lap", False), ("lapdet", True)):
+        obj = object.__new__(LM.NerfactoLaplaceModel)
+        obj.training = False
+        obj.config = SimpleNamespace(predict_normals=False, use_gradient_scaling=False, num_proposal_iterations=2)
+        obj.proposal_sampler = sampler
+        obj.density_fns = None
+        obj.field = SimpleNamespace(forward_unc=lambda rs, **kw: {FieldHeadNames.DENSITY: density, FieldHeadNames.RGB: rgb,
+                                                                  "density_var": density_var, "rgb_var": rgb_var})
+        obj.renderer_rgb, obj.renderer_accumulation = rend["renderer_rgb"], rend["renderer_accumulation"]
+        obj.renderer_depth, obj.renderer_expected_depth = rend["renderer_depth"], rend["renderer_expected_depth"]
+        obj.uncertainty_renderer = rend["renderer_uncertainty"]
+        seed = 77
+        torch.manual_seed(seed)
+        out = obj.get_outputs_unc(None, is_inference=True, use_deterministic_density=det)
+        # the draw Normal(loc, scale).sample((100,)) made: same generator state -> loc + scale * randn(100, R, S, 1)
+        torch.manual_seed(seed)
+        res[f"{tag}_noise"] = torch.randn(100, R, S, 1).numpy()[..., 0]
+        for k, v in out.items():
+            res[f"{tag}_out_{k}"] = _np(v).astype(np.float32)
+
+    # ---- active-nerfacto ----
+    beta = torch.rand(R, S, 1, generator=g) + 0.01
+    res["act_beta"] = beta.numpy()
+    obj = object.__new__(AM.ActiveNerfactoModel)
+    obj.training = False
+    obj.config = SimpleNamespace(predict_normals=False, use_gradient_scaling=False, num_proposal_iterations=2)
+    obj.proposal_sampler = sampler
+    obj.density_fns = None
+    obj.field = SimpleNamespace(forward=lambda rs, compute_normals=False: {FieldHeadNames.DENSITY: density,
+                                                                           FieldHeadNames.RGB: rgb, "rgb_var": beta})
+    obj.renderer_rgb, obj.renderer_accumulation = rend["renderer_rgb"], rend["renderer_accumulation"]
+    obj.renderer_depth, obj.renderer_expected_depth = rend["renderer_depth"], rend["renderer_expected_depth"]
+    obj.renderer_uncertainty = rend["renderer_uncertainty"]
+    out = obj.get_outputs(None)
+    for k, v in out.items():
+        res[f"act_out_{k}"] = _np(v).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "nerf_model_glue.npz"), **res)
+
+
 def golden_eval_configs():
     """field names and defaults of the eval script's configuration dataclasses (scripts/eval_configs.py)"""
     import dataclasses
@@ -228,6 +418,6 @@ if __name__ == "__main__":
         raise SystemExit("/root/reference is not mounted: golden vectors can only be regenerated in the build container")
     install_stubs()
     for fn in (golden_create_mlp, golden_metrics, golden_sample_laplace, golden_get_weights, golden_ensemble,
-               golden_mc_aggregate, golden_eval_configs):
+               golden_mc_aggregate, golden_eval_configs, golden_splat_get_outputs, golden_nerf_model_glue):
         fn()
         print("wrote", fn.__name__)

@@ -90,6 +90,51 @@ def test_one_member_per_rank_matches_single_process(tag):
                 assert np.array_equal(ret[r][k], v.numpy()), (r, k)
 
 
+def _splat_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from uncertainty_nerf_gs_amd import ensemble
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = ensemble.aggregate_distributed(_splat_members()[rank], moments_fn=_torch_moments)
+    ret[rank] = {k: v.numpy() for k, v in out.items()}
+    dist.destroy_process_group()
+
+
+def _splat_members(M=3, H=5, W=7):
+    """active-splatfacto member dicts (activesplatfacto_model.py:359-367): images plus the [3] `background`"""
+    g = torch.Generator().manual_seed(4)
+    out = []
+    for _ in range(M):
+        unc = torch.rand(H, W, 1, generator=g)
+        dv = torch.rand(H, W, 1, generator=g)
+        out.append({"rgb": torch.rand(H, W, 3, generator=g), "depth": torch.rand(H, W, 1, generator=g) * 4,
+                    "accumulation": torch.rand(H, W, 1, generator=g), "background": torch.tensor([0.1490, 0.1647, 0.2157]),
+                    "uncertainty": unc, "rgb_var": unc ** 2, "rgb_std": unc, "depth_var": dv, "depth_std": dv.sqrt()})
+    return out
+
+
+def test_splat_member_ensemble_with_a_non_image_key():
+    """EnsemblePipelineSplatfacto (ensemble_pipeline.py:210-300) inherits the aggregation: every key is stacked and
+    averaged, `background` [3] included; 3 ranks x 35 pixels also exercises unequal pixel slices (12 / 12 / 11)."""
+    from uncertainty_nerf_gs_amd import ensemble
+    from oracle import nerf_oracle as O
+    members = _splat_members()
+    single = ensemble.aggregate(members, moments_fn=_torch_moments)
+    ref = O.ensemble_aggregate(members)                 # the reference-pinned restatement of :159-189
+    assert set(single) == set(ref)
+    for k in ref:
+        torch.testing.assert_close(single[k], ref[k], rtol=1e-6, atol=1e-7, msg=k)
+    assert torch.allclose(single["background"], members[0]["background"])
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_splat_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
+        for r in range(3):
+            assert set(ret[r]) == set(single)
+            for k, v in single.items():
+                assert np.array_equal(ret[r][k], v.numpy()), (r, k)
+
+
 def test_two_members_per_rank_matches_single_process():
     """M = 4 members over 2 ranks (the M > N case of bench.py --method ensemble)."""
     from uncertainty_nerf_gs_amd import ensemble

@@ -177,3 +177,63 @@ def test_dropout_mask_generator_statistics():
     s0 = O.mc_keep_mask(1234, 3, sidx[:100], 0, 64, p)
     assert not np.array_equal(s0, O.mc_keep_mask(1234, 3, sidx[:100], 1, 64, p))        # trunk and head streams differ
     assert not np.array_equal(s0, O.mc_keep_mask(1235, 3, sidx[:100], 0, 64, p))        # and so do seeds
+
+
+# ---- [REF] model glue run with a fake `self` (tests/golden/make_golden.py: golden_splat_get_outputs / golden_nerf_model_glue)
+
+@pytest.mark.parametrize("tag", ["default", "white", "sh0", "early", "aa"])
+def test_oracle_splat_outputs_match_the_references_four_pass_get_outputs(tag):
+    """ActiveSplatfactoModel.get_outputs itself (activesplatfacto_model.py:142-367) ran on these splats with gsplat's
+    three entry points bound to the oracle's restatements: the oracle's one-sort / 5-channel restructuring, the
+    background handling, sh_degree 0, the SH-degree schedule and the antialiased opacity must reproduce its dict."""
+    from oracle import splat_oracle as SO
+    g = golden("splat_get_outputs.npz")
+    gp = {k[3:]: g[k] for k in g.files if k.startswith("gp_")}
+    fx, fy, cx, cy, H, W = g["intr"]
+    sh_degree, step, aa = (int(v) for v in g[f"{tag}_cfg"])
+    n = min(step // 1000, sh_degree) if sh_degree > 0 else 0
+    out = SO.active_splatfacto_outputs(gp, g["c2w"], fx, fy, cx, cy, int(H), int(W), g[f"{tag}_out_background"],
+                                       beta_min=0.01, sh_degree=n, rasterize_mode="antialiased" if aa else "classic",
+                                       config_sh_degree=sh_degree)
+    keys = [k[len(tag) + 5:] for k in g.files if k.startswith(f"{tag}_out_")]
+    assert set(keys) == {"rgb", "depth", "accumulation", "background", "uncertainty", "rgb_var", "rgb_std", "depth_var", "depth_std"}
+    assert set(keys) == {k for k in out if not k.startswith("_")}
+    for k in keys:
+        ref = g[f"{tag}_out_{k}"]
+        # same primitives, same order of operations: the 5-channel pass blends each channel exactly like the
+        # reference's separate 3-channel passes, so the images agree to the last bit
+        np.testing.assert_array_equal(np.asarray(out[k], dtype=np.float32).reshape(ref.shape), ref, err_msg=f"{tag}:{k}")
+    assert float(g[f"{tag}_out_accumulation"].max()) > 0.5 and float(g[f"{tag}_out_accumulation"].min()) < 0.5
+
+
+@pytest.mark.parametrize("tag,det", [("lap", False), ("lapdet", True)])
+def test_oracle_laplace_compose_matches_the_references_get_outputs_unc(tag, det):
+    """NerfactoLaplaceModel.get_outputs_unc (laplace_model.py:456-556) ran on these field outputs (renderers = the
+    oracle's, get_weights = the reference's own ComputeWeightsModule, the 100 density draws = torch's Normal with a
+    recorded seed): the oracle's laplace_compose must reproduce every key."""
+    from oracle import nerf_oracle as O
+    g = golden("nerf_model_glue.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    out = O.laplace_compose(t("eb"), t("density")[..., 0], t("lap_density_var")[..., 0], t("rgb"), t("lap_rgb_var")[..., 0],
+                            t(f"{tag}_noise"), use_deterministic_density=det)
+    for i, (w, eb) in enumerate(((t("w0"), t("eb0")), (t("w1"), t("eb1")))):
+        out[f"prop_depth_{i}"] = O.render_depth_median(w[..., 0], (eb[..., :-1] + eb[..., 1:]) / 2)
+    keys = [k[len(tag) + 5:] for k in g.files if k.startswith(f"{tag}_out_")]
+    assert set(keys) == set(out), set(keys) ^ set(out)
+    for k in keys:
+        torch.testing.assert_close(out[k].reshape(g[f"{tag}_out_{k}"].shape), t(f"{tag}_out_{k}"), rtol=2e-6, atol=1e-7, msg=f"{tag}:{k}")
+
+
+def test_oracle_active_compose_matches_the_references_get_outputs():
+    """ActiveNerfactoModel.get_outputs (activenerfacto_model.py:83-152) with a fake self: key set, rgb_var = sum w^2 beta,
+    depth_var around the median depth + 1e-5, the raw density output, the prop depths."""
+    from oracle import nerf_oracle as O
+    g = golden("nerf_model_glue.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    out = O.active_compose(t("eb"), t("density")[..., 0], t("rgb"), t("act_beta")[..., 0])
+    for i, (w, eb) in enumerate(((t("w0"), t("eb0")), (t("w1"), t("eb1")))):
+        out[f"prop_depth_{i}"] = O.render_depth_median(w[..., 0], (eb[..., :-1] + eb[..., 1:]) / 2)
+    keys = [k[len("act_out_"):] for k in g.files if k.startswith("act_out_")]
+    assert set(keys) == set(out), set(keys) ^ set(out)
+    for k in keys:
+        torch.testing.assert_close(out[k].reshape(g[f"act_out_{k}"].shape), t(f"act_out_{k}"), rtol=2e-6, atol=1e-7, msg=k)

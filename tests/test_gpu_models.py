@@ -239,8 +239,47 @@ def test_splat_model_get_outputs(dev):
     cam = models.Camera(synthetic.orbit_c2w(0.9, radius=2.5, height=0.5), 60.0, 60.0, W / 2, H / 2, H, W)
     out = m.get_outputs(cam)
     ref = splat.active_splatfacto_outputs({k: v.to(dev) for k, v in gp.items()}, cam.camera_to_worlds, 60.0, 60.0, W / 2,
-                                          H / 2, H, W, torch.zeros(3, device=dev))
+                                          H / 2, H, W, splat.background_for("random").to(dev))   # config default
+    assert torch.allclose(out["background"].cpu(), torch.tensor([0.1490, 0.1647, 0.2157]))
     assert set(out) == {"rgb", "depth", "accumulation", "background", "uncertainty", "rgb_var", "rgb_std", "depth_var",
                         "depth_std"}
     for k in ("rgb", "depth", "accumulation", "uncertainty", "depth_var"):
         assert torch.equal(out[k], ref[k]), k
+
+
+def test_nerfstudio_plugin_model_renders_like_the_mirror(dev):
+    """The nerfstudio-facing Model subclass of plugin.py (real nerfstudio when installed, else tests/stubs): built from
+    the registered MethodSpecification, loaded from a reference-style pipeline checkpoint, called with a RayBundle --
+    get_outputs_for_camera_ray_bundle(bundle) equals get_outputs_for_camera(camera) of the mirror bit for bit."""
+    import os
+    import sys
+    from conftest import ROOT
+    try:
+        import nerfstudio  # noqa: F401
+    except ImportError:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "stubs"))
+    from nerfstudio.cameras.rays import RayBundle
+    from uncertainty_nerf_gs_amd import models, ops, plugin, synthetic
+    cfg = plugin.method_specifications()["active-nerfacto"].config.pipeline.model
+    cfg.log2_hashmap_size = 12
+    cfg.proposal_net_args_list = [dict(a, log2_hashmap_size=10) for a in cfg.proposal_net_args_list]
+    torch.manual_seed(3)
+    model = cfg.setup(scene_box=None, num_train_data=2)
+    ref_model = plugin.build_model("active-nerfacto")        # the plain mirror with the same config values
+    ref_model.config.log2_hashmap_size, ref_model.config.proposal_net_args_list = 12, cfg.proposal_net_args_list
+    ref_model = type(ref_model)(ref_model.config, num_train_data=2)
+    # a pipeline checkpoint as the reference writes it: `_model.` prefix (ensemble_pipeline.py:77-91)
+    sd = {"_model." + k: torch.randn_like(v) * (0.05 if "hash_table" not in k else 0.3) for k, v in ref_model.state_dict().items()}
+    model.load_state_dict(sd)
+    ref_model.load_state_dict(sd)
+    H, W = 24, 40
+    c2w = synthetic.orbit_c2w(0.4)
+    cam = models.Camera(c2w, 40.0, 40.0, W / 2, H / 2, H, W)
+    want = ref_model.to(dev).get_outputs_for_camera(cam)
+    o, d, _ = ops.generate_rays(c2w, 40.0, 40.0, W / 2, H / 2, H, W, dev)
+    got = model.to(dev).get_outputs_for_camera_ray_bundle(RayBundle(origins=o.view(H, W, 3), directions=d.view(H, W, 3)))
+    assert set(got) == set(want) and "density" in got and got["density"].shape == (H, W, 48)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    one = model.get_outputs(RayBundle(origins=o[:100], directions=d[:100]))
+    assert one["rgb"].shape == (100, 3) and torch.isfinite(one["rgb_var"]).all()

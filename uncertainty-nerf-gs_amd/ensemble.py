@@ -8,10 +8,11 @@ The reference renders its M members sequentially on one device and then does
   * `aggregate_distributed(outputs)` -- ONE MEMBER PER RANK (one process per GPU, RCCL over xGMI):
     every rank renders the same camera with its own member, then the per-pixel moments are formed
     with the exact two-pass formula on a pixel slice per rank:
-        all_gather(member images)  ->  rank g reduces pixel rows [g*P/W, (g+1)*P/W)  ->  all_gather(slices)
+        all_to_all(pixel slices of the member images)  ->  rank g reduces its rows  ->  all_gather(reduced slices)
     This is SURVEY.md 8(e) option A (exact parity with torch.stack(...).var(0); no E[x^2]-E[x]^2
-    cancellation).  Payload per GPU at 1080p, M=8: 8 x 2.07 M px x <=8 floats = <=530 MB received,
-    spread over 7 point-to-point xGMI links -- a few ms, negligible next to a render.
+    cancellation).  Payload per GPU at 1080p, 6 floats per pixel: 7/8 x 50 MB sent and received in the exchange,
+    every xGMI link carrying 1/8 of an image at once (point-to-point, not ring-bound), then 7/8 x 100 MB of
+    reduced slices gathered -- well under a millisecond each at ~150 GB/s per link, next to a ~110 ms member render.
 
 The moment math is injected (`moments_fn`) so that the collective plumbing can be tested with
 world_size=2 on the gloo backend without a GPU; the default is the HIP kernel.
@@ -61,7 +62,7 @@ def aggregate(outputs_list: List[Dict[str, torch.Tensor]], moments_fn: Optional[
     for k in keys:
         x = torch.stack([o[k] for o in outputs_list], dim=0)
         shp = x.shape[1:]
-        m, v = moments_fn(x.reshape(x.shape[0], -1, shp[-1]))
+        m, v = moments_fn(x.reshape(x.shape[0], -1, shp[-1]).contiguous())   # also [M,1,3] for a splat `background`
         mean[k], var[k] = m.view(shp), v.view(shp)
     alea = {k: mean[k + "_var"] for k in ("rgb", "depth") if k + "_var" in mean}
     return _finish(keys, mean, var, alea)
@@ -75,41 +76,76 @@ def pixel_slice(num_pixels: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def _image_keys(member: Dict[str, torch.Tensor]) -> Tuple[List[str], List[str]]:
+    """tensor keys split into per-pixel images [H,W,C] and everything else (active-splatfacto's `background` [3],
+    activesplatfacto_model.py:363): the reference stacks and averages every key alike (ensemble_pipeline.py:159-162),
+    only the images need the pixel-sliced exchange"""
+    keys = [k for k, v in member.items() if torch.is_tensor(v)]
+    H, W = next(v.shape[:2] for v in (member[k] for k in keys) if v.dim() == 3)
+    img = [k for k in keys if member[k].dim() == 3 and tuple(member[k].shape[:2]) == (H, W)]
+    return img, [k for k in keys if k not in img]
+
+
 def aggregate_distributed(outputs, group=None, moments_fn: Optional[MomentsFn] = None):
     """This rank's member outputs -> the ensemble outputs, identical on every rank.
     `outputs` is one member's dict ([H,W,C] per key) or a list of such dicts when a rank holds several
-    members (M members over N < M GPUs; every rank must hold the same number)."""
+    members (M members over N < M GPUs; every rank must hold the same number).
+
+    Exchange (SURVEY.md 8e option A): ONE all_to_all of pixel slices -- rank g receives rows
+    [a_g, b_g) of every member's packed image, (N-1)/N of one packed image sent and received per rank, all xGMI links
+    busy at once -- then the exact two-pass moments on the slice (what torch.stack(...).mean(0) / .var(0) compute),
+    then ONE all_gather of the reduced slices.  1080p, 6 floats per pixel: 44 MB out, 44 MB in per rank for the
+    exchange (the two all_gathers of whole member images this replaces moved 8x that)."""
     import torch.distributed as dist
     moments_fn = moments_fn or _hip_moments
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     members = outputs if isinstance(outputs, (list, tuple)) else [outputs]
-    keys = [k for k, v in members[0].items() if torch.is_tensor(v)]  # member key order (it matters, see _finish)
+    all_keys = [k for k, v in members[0].items() if torch.is_tensor(v)]   # member key order (it matters, see _finish)
+    keys, small_keys = _image_keys(members[0])
     widths = [members[0][k].shape[-1] for k in keys]
     H, W = members[0][keys[0]].shape[:2]
     P = H * W
+    ml = len(members)
     # one packed [m_local, P, sum(C)] block per rank -> a single collective instead of one per key
     packed = torch.stack([torch.cat([m[k].reshape(P, -1) for k in keys], dim=-1) for m in members], dim=0).contiguous()
     Ctot = packed.shape[-1]
-    gathered = [torch.empty_like(packed) for _ in range(world)]
-    dist.all_gather(gathered, packed, group=group)
-    a, b = pixel_slice(P, rank, world)
-    stack = torch.cat([g[:, a:b] for g in gathered], dim=0)         # [M, b-a, Ctot], member order = rank-major
-    m, v = moments_fn(stack.contiguous())
+    edges = [pixel_slice(P, r, world) for r in range(world)]
+    a, b = edges[rank]
+    # send block for destination r: this rank's members restricted to r's pixel rows, [m_local * (b_r - a_r), Ctot]
+    send = torch.cat([packed[:, ar:br].reshape(-1, Ctot) for ar, br in edges], dim=0).contiguous()
+    recv = torch.empty(world * ml * (b - a), Ctot, dtype=packed.dtype, device=packed.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[ml * (b - a)] * world,
+                           input_split_sizes=[ml * (br - ar) for ar, br in edges], group=group)
+    stack = recv.view(world * ml, b - a, Ctot)                      # [M, b-a, Ctot], member order = rank-major
+    if b > a:
+        m, v = moments_fn(stack.contiguous())
+    else:
+        m = v = torch.zeros(0, Ctot, dtype=packed.dtype, device=packed.device)
     part = torch.cat([m, v], dim=-1).contiguous()                   # [b-a, 2*Ctot]
     # slices differ by at most one row: pad to the largest so all_gather sees equal shapes
-    rows = max(pixel_slice(P, r, world)[1] - pixel_slice(P, r, world)[0] for r in range(world))
+    rows = max(br - ar for ar, br in edges)
     padded = torch.zeros(rows, 2 * Ctot, dtype=part.dtype, device=part.device)
     padded[: b - a] = part
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
-    full = torch.cat([parts[r][: pixel_slice(P, r, world)[1] - pixel_slice(P, r, world)[0]] for r in range(world)], dim=0)
+    full = torch.cat([parts[r][: edges[r][1] - edges[r][0]] for r in range(world)], dim=0)
     mean, var, off = {}, {}, 0
     for k, c in zip(keys, widths):
         mean[k] = full[:, off:off + c].reshape(H, W, c)
         var[k] = full[:, Ctot + off:Ctot + off + c].reshape(H, W, c)
         off += c
+    if small_keys:   # a few floats per member: gathered whole, reduced on every rank
+        flat = torch.stack([torch.cat([m[k].reshape(-1) for k in small_keys]) for m in members], dim=0).contiguous()
+        allf = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(allf, flat, group=group)
+        sm, sv = moments_fn(torch.cat(allf, dim=0)[:, None, :].contiguous())       # [M, 1, n] -> [1, n]
+        off = 0
+        for k in small_keys:
+            n = members[0][k].numel()
+            mean[k], var[k] = sm[0, off:off + n].reshape(members[0][k].shape), sv[0, off:off + n].reshape(members[0][k].shape)
+            off += n
     alea = {k: mean[k + "_var"] for k in ("rgb", "depth") if k + "_var" in mean}
-    return _finish(keys, mean, var, alea)
+    return _finish(all_keys, mean, var, alea)
 
 
 class EnsemblePipeline:

@@ -8,8 +8,9 @@ are replaced by the fused `unerf_field_fwd` kernel, reached through `models.py` 
 (whole-frame path) or through the Field-level calls nerfstudio makes on a RaySamples --
 `field.forward(ray_samples)` / `field(ray_samples)` and `density_field.density_fn(positions)` /
 `get_density(ray_samples)` -- which run the same kernels on the caller's own samples.
-nerfstudio is not required; when it is installed, `plugin.py` registers thin subclasses with its
-plugin registry.
+nerfstudio is not required; when it is installed, `plugin.py` wraps the Model mirrors of `models.py` (which own
+these fields under the reference's attribute names) in `nerfstudio.models.base_model.Model` subclasses and registers
+them through the `nerfstudio.method_configs` entry points of `pyproject.toml`.
 
 Reference:
   ActiveNerfactoField      models/activenerfacto/activenerfacto_field.py:33-215
