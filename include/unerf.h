@@ -194,6 +194,11 @@ typedef struct {
        consecutive pixels) as the 32 columns of a tile: fewer distinct cache lines per gather instruction.
        Results are identical with and without the hint. */
     int image_width;
+    /* Output layout of the ACTIVE / MCDROPOUT matrix kernels.  0: density [B,R,S], rgb [B,R,S,3], aux [R,S] (the
+       RaySamples layout).  1: sample-major planes density [B,S,R], rgb [B,S,3,R], aux [S,R]: a kernel tile is 32 rays
+       at one sample slot, so its stores then fill whole 32-byte sectors instead of 4 bytes per cache line; consumed
+       by unerf_composite_var_planes / unerf_composite_moments_planes. */
+    int sample_major;
 } unerf_field_params;
 #define UNERF_MFMA_BLOB_FLOATS 10660
 #define UNERF_LAP_BLOB_FLOATS 33280
@@ -260,6 +265,18 @@ int unerf_composite_var(const float* density, const float* rgb, const float* bet
 int unerf_composite_moments(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
                             float near_plane, float far_plane, const float* clip_minmax, int64_t ray_offset,
                             int64_t chunk_rays, float* mean_out, float* var_out, void* stream);
+
+/* The same two reductions over the sample-major planes unerf_field_fwd writes with sample_major = 1
+ * (density [B,S,R], rgb [B,S,3,R], beta [S,R] or NULL): one lane per ray walks the samples front to back, so
+ * get_weights is the sequential recurrence of activenerfacto_model.py:94 / RaySamples.get_weights, and the K passes
+ * of mcdropout_models.py:116-126 are reduced to mean / unbiased variance in the same thread.
+ * out [B,R,8]; mean_out / var_out [R,8] (B >= 2); channel order as unerf_composite_var. */
+int unerf_composite_var_planes(const float* density, const float* rgb, const float* beta, const float* sbins, int B,
+                               int64_t R, int S, float near_plane, float far_plane, const float* clip_minmax,
+                               int64_t ray_offset, int64_t chunk_rays, float* out, void* stream);
+int unerf_composite_moments_planes(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
+                                   float near_plane, float far_plane, const float* clip_minmax, int64_t ray_offset,
+                                   int64_t chunk_rays, float* mean_out, float* var_out, void* stream);
 
 /* ------------------------------------------------------ moments over K --
  * Replaces torch.stack(...).mean(0) / .std(0) / .var(0) over MC passes

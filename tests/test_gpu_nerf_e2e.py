@@ -117,6 +117,35 @@ def test_mcdropout_camera_parity(dev, K):
     _img_close(out["depth"], ref["depth"], 0, 1e-3, "depth", max_bad_frac=2e-2)
 
 
+@pytest.mark.parametrize("kind", ["active", "mcdropout"])
+def test_sample_major_plane_path_meets_the_same_gates(dev, kind):
+    """scene.sample_major = True (plane stores + lane-per-ray composite, the measured alternative of DESIGN.md 4.5):
+    same parity gates as the default path"""
+    from uncertainty_nerf_gs_amd import render, synthetic
+    t = synthetic.make_scene_tensors(seed=4, kind=kind, log2T=14, prop_log2T=12)
+    sc = O.scene_from_tensors(t)
+    H, W = 36, 48
+    cam, c2w = _cam(H, W), synthetic.orbit_c2w(1.9)
+    o, d = _oracle_rays(c2w, cam)
+    if kind == "active":
+        sd = synthetic.scene_to_device(t, dev)
+        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=512)
+    else:
+        sd = synthetic.scene_to_device(t, dev, K=8, seed=3, p_drop=0.2)
+        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 3, 0.2, ray_offset=off), o, d, chunk=512)
+    sd.chunk_rays, sd.sample_major = 512, True
+    out = render.render_camera(sd, c2w, rays_per_launch=1024, keep_density=(kind == "active"), **cam)
+    assert set(ref) <= set(out)
+    _gates(f"planes-{kind}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb")
+    _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=5e-3)
+    _img_close(out["depth"], ref["depth"], 0, 1e-3, "median depth", max_bad_frac=2e-2)
+    if kind == "active":
+        _img_close(out["density"], ref["density"], 1e-6, 1e-2, "density", max_bad_frac=1e-3)
+        _img_close(out["depth_var"], ref["depth_var"], 0, 5e-3, "depth_var", max_bad_frac=2e-2)
+
+
 def test_laplace_camera_parity(dev):
     from uncertainty_nerf_gs_amd import render, synthetic
     t = synthetic.make_scene_tensors(seed=2, kind="laplace", log2T=14, prop_log2T=12)

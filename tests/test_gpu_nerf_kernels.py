@@ -302,6 +302,84 @@ def test_composite_var_matches_oracle(dev, B, S):
         _close(out[b, :, 7:8][same], dv_ref[same], 5e-5, 1e-7, "depth_var")
 
 
+@pytest.mark.parametrize("B,S", [(1, 48), (3, 48), (2, 17), (1, 2), (5, 96), (9, 40)])
+def test_composite_planes_match_oracle_and_the_group_kernels(dev, B, S):
+    """sample-major planes + one lane per ray (unerf_composite_var_planes / _moments_planes): against the oracle's
+    renderers, and against the 16-lanes-per-ray kernels on the transposed data"""
+    from uncertainty_nerf_gs_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    R = 333
+    dens = torch.exp(torch.randn(B, R, S, generator=g) * 2.0)
+    dens[:, 0] = 0.0
+    dens[:, 1, S // 3:] = 1e5
+    dens[:, 4, min(2, S - 1)] = float("inf")
+    rgb = torch.rand(B, R, S, 3, generator=g)
+    rgb[0, 2, min(3, S - 1), 1] = float("nan")
+    beta = torch.rand(R, S, generator=g) + 0.01
+    sb = torch.sort(torch.rand(R, S + 1, generator=g), dim=-1).values
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    deltas, steps = eb[:, 1:] - eb[:, :-1], (eb[:, :-1] + eb[:, 1:]) / 2
+    chunk = 100
+    clip = torch.empty((R + chunk - 1) // chunk, 2)
+    for c in range(clip.shape[0]):
+        clip[c, 0], clip[c, 1] = steps[c * chunk:(c + 1) * chunk].min(), steps[c * chunk:(c + 1) * chunk].max()
+    dp = dens.permute(0, 2, 1).contiguous().to(dev)               # [B,S,R]
+    cp = rgb.permute(0, 2, 3, 1).contiguous().to(dev)             # [B,S,3,R]
+    bp = beta.t().contiguous().to(dev)                            # [S,R]
+    kw = dict(clip_minmax=clip.to(dev), ray_offset=0, chunk_rays=chunk)
+    out = ops.composite_var_planes(dp, cp, sb.to(dev), NEAR, FAR, beta=bp, **kw).cpu()
+    for b in range(B):
+        w = O.get_weights(dens[b], deltas)
+        _close(out[b, :, 0:3], O.render_rgb(rgb[b], w), 0, 3e-6, "rgb")
+        _close(out[b, :, 3:4], O.render_accumulation(w), 2e-6, 1e-7, "accumulation")
+        depth_ref = O.render_depth_median(w, steps)
+        _close(out[b, :, 4:5], depth_ref, 1e-6, 0, "median depth", max_bad_frac=0.02)
+        ed = torch.cat([O.render_depth_expected(w[c * chunk:(c + 1) * chunk], steps[c * chunk:(c + 1) * chunk])
+                        for c in range(clip.shape[0])])
+        _close(out[b, :, 5:6], ed, 2e-5, 1e-6, "expected depth")
+        _close(out[b, :, 6:7], O.render_uncertainty(beta, w ** 2), 2e-5, 1e-8, "rgb_var")
+        same = (out[b, :, 4:5] - depth_ref).abs() <= 1e-6 * depth_ref.abs()
+        dv_ref = torch.sum(w.double() * (steps.double() - depth_ref.double()) ** 2, dim=-1, keepdim=True) + 1e-5
+        _close(out[b, :, 7:8][same], dv_ref[same].float(), 5e-5, 1e-7, "depth_var")
+    old = ops.composite_var(dens.to(dev), rgb.to(dev), sb.to(dev), NEAR, FAR, beta=beta.to(dev), **kw).cpu()
+    fin = torch.isfinite(old) & torch.isfinite(out)
+    assert fin.float().mean() > 0.98
+    same_depth = (old[..., 4] - out[..., 4]).abs() <= 1e-6 * old[..., 4].abs()
+    assert same_depth.float().mean() >= 0.98                     # a cumsum grazing 0.5 may pick the neighbouring sample
+    for c, (rt, at) in enumerate([(0, 3e-6)] * 3 + [(2e-6, 1e-7), (1e-6, 0), (2e-5, 1e-6), (2e-5, 1e-8), (1e-4, 1e-7)]):
+        m = same_depth & fin[..., c]
+        _close(out[..., c][m], old[..., c][m], rt, at, f"planes vs groups, channel {c}", max_bad_frac=2e-3 if c == 5 else 0.0)
+    if B >= 2:
+        mean, var = ops.composite_moments_planes(dp, cp, sb.to(dev), NEAR, FAR, **kw)
+        ref_out = ops.composite_var_planes(dp, cp, sb.to(dev), NEAR, FAR, **kw).cpu().double()     # beta = None here
+        ok = torch.isfinite(ref_out).all(dim=0)
+        m_ref, v_ref = ref_out.mean(dim=0), ref_out.var(dim=0)
+        _close(mean.cpu()[ok], m_ref[ok].float(), 2e-6, 1e-7, "mean over passes")
+        _close(var.cpu()[ok], v_ref[ok].float(), 1e-4, 1e-9 + 1e-6 * float(v_ref[ok].max()), "unbiased variance over passes")
+
+
+@pytest.mark.parametrize("kind,kw,image_width", [("active", {}, 0), ("active", {}, 24), ("mcdropout", dict(K=3, seed=5, p_drop=0.2), 24)])
+@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
+def test_field_sample_major_planes_equal_the_ray_major_outputs(dev, kind, kw, image_width, precision):
+    """unerf_field_params.sample_major only changes WHERE a value is stored: planes == transposed ray-major, bit for bit"""
+    from uncertainty_nerf_gs_amd import ops
+    t, sc, sd = _scene(kind, dev, **kw)
+    sd.field.precision = precision
+    o, d = _rays(20, 24)
+    sb = _final_bins(sc, o, d)
+    od, dd, sbd = o.to(dev), d.to(dev), sb.to(dev)
+    a = ops.field_fwd(od, dd, sbd, sd.field, NEAR, FAR, ray_offset=480, image_width=image_width)
+    b = ops.field_fwd(od, dd, sbd, sd.field, NEAR, FAR, ray_offset=480, image_width=image_width, sample_major=True)
+    assert b[0].shape == a[0].permute(0, 2, 1).shape and torch.equal(b[0], a[0].permute(0, 2, 1))
+    assert torch.equal(b[1], a[1].permute(0, 2, 3, 1))
+    if kind == "active":
+        assert torch.equal(b[2], a[2].t())
+    # planes are refused where no kernel writes them
+    sd.field.use_mfma = False
+    with pytest.raises(Exception, match="sample_major"):
+        ops.field_fwd(od, dd, sbd, sd.field, NEAR, FAR, sample_major=True)
+
+
 @pytest.mark.parametrize("S", [48, 50, 21])
 def test_composite_var_weights_alt(dev, S):
     """laplace: rgb / rgb_var from get_weights(mu_d), depth-side outputs from the mean sampled weights"""

@@ -830,6 +830,8 @@ __device__ __forceinline__ void tile_ray(const FieldArgs& a, uint32_t rb, int j,
 // spacing bin, euclidean, before contraction).  Shared by the four field_kernel_mfma* kernels.
 struct TileSample {
     int64_t n;        // r * S + s
+    int64_t r;        // ray (clamped to a valid one when !valid)
+    int s;            // sample slot
     bool valid;       // column maps to a ray of this launch (else clamped to the last ray, results dropped)
     float dx, dy, dz;
     float px, py, pz;
@@ -842,6 +844,8 @@ __device__ __forceinline__ TileSample tile_sample(const FieldArgs& a, uint32_t t
     tile_ray(a, rb, j, r, t.valid);
     if (!t.valid) r = a.R - 1;
     t.n = r * a.S + s;
+    t.r = r;
+    t.s = s;
     const float* sb = a.sbins + r * (a.S + 1);
     const float e0 = field_bin_edge(a, sb[s]), e1 = field_bin_edge(a, sb[s + 1]);
     const float t01 = e0 + e1;
@@ -852,6 +856,32 @@ __device__ __forceinline__ TileSample tile_sample(const FieldArgs& a, uint32_t t
     t.py = a.origins[r * 3 + 1] + t.dy * t01 / 2.f;
     t.pz = a.origins[r * 3 + 2] + t.dz * t01 / 2.f;
     return t;
+}
+
+// Where one (pass k, ray r, sample s) lands in the outputs.  Default (sample_major = 0): density [B,R,S], rgb [B,R,S,3],
+// aux [R,S] -- the RaySamples layout the Field-level API returns.  sample_major = 1: planes density [B,S,R],
+// rgb [B,S,3,R], aux [S,R].  A tile's 32 columns are 32 rays at ONE sample slot, so in the ray-major layout each of
+// its stores is a lone 4-byte write into its own cache line (2.9 x the algorithmic bytes reached the fabric,
+// profiles/r1_11_active_pmc_summary.json); in the plane layout the same store covers whole 32-byte sectors (8
+// consecutive rays of a pixel patch, 32 of a 1-D tile), and the composite kernel reads the planes with a lane per ray.
+struct OutIndex {
+    int64_t dens, rgb, rgb_stride, aux;
+};
+__device__ __forceinline__ OutIndex out_index(const FieldArgs& a, int k, const TileSample& ts) {
+    OutIndex o;
+    if (a.p.sample_major) {  // uniform
+        const int64_t plane = (int64_t)k * a.S + ts.s;
+        o.dens = plane * a.R + ts.r;
+        o.rgb = plane * 3 * a.R + ts.r;
+        o.rgb_stride = a.R;
+        o.aux = (int64_t)ts.s * a.R + ts.r;
+    } else {
+        o.dens = (int64_t)k * (a.R * (int64_t)a.S) + ts.n;
+        o.rgb = o.dens * 3;
+        o.rgb_stride = 1;
+        o.aux = ts.n;
+    }
+    return o;
 }
 
 // host side: fills a.tm and returns the number of tiles
@@ -1367,12 +1397,12 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 rgbv[c] = unerf_sigmoid(acc + lds[MF_H2_OFF + 192 + c]);
             }
             if (valid && h == 0) {
-                int64_t q = (int64_t)k * N + n;
-                a.density[q] = a.p.average_init_density * expf(t[0]) * sel;
-                a.rgb[q * 3 + 0] = rgbv[0];
-                a.rgb[q * 3 + 1] = rgbv[1];
-                a.rgb[q * 3 + 2] = rgbv[2];
-                if (MODE == UNERF_FIELD_ACTIVE) a.aux[n] = unerf_softplus(t[8]) + a.p.beta_min;
+                const OutIndex q = out_index(a, k, ts);
+                a.density[q.dens] = a.p.average_init_density * expf(t[0]) * sel;
+                a.rgb[q.rgb] = rgbv[0];
+                a.rgb[q.rgb + q.rgb_stride] = rgbv[1];
+                a.rgb[q.rgb + 2 * q.rgb_stride] = rgbv[2];
+                if (MODE == UNERF_FIELD_ACTIVE) a.aux[q.aux] = unerf_softplus(t[8]) + a.p.beta_min;
             }
         }
     }
@@ -1637,12 +1667,12 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 }
             }
             if (valid && h == 0) {
-                int64_t q = (int64_t)k * N + n;
-                a.density[q] = a.p.average_init_density * __expf(t[0]) * sel;
-                a.rgb[q * 3 + 0] = mf_sigmoid_fast(o[0]);
-                a.rgb[q * 3 + 1] = mf_sigmoid_fast(o[1]);
-                a.rgb[q * 3 + 2] = mf_sigmoid_fast(o[2]);
-                if (MODE == UNERF_FIELD_ACTIVE) a.aux[n] = unerf_softplus(t[8]) + a.p.beta_min;
+                const OutIndex q = out_index(a, k, ts);
+                a.density[q.dens] = a.p.average_init_density * __expf(t[0]) * sel;
+                a.rgb[q.rgb] = mf_sigmoid_fast(o[0]);
+                a.rgb[q.rgb + q.rgb_stride] = mf_sigmoid_fast(o[1]);
+                a.rgb[q.rgb + 2 * q.rgb_stride] = mf_sigmoid_fast(o[2]);
+                if (MODE == UNERF_FIELD_ACTIVE) a.aux[q.aux] = unerf_softplus(t[8]) + a.p.beta_min;
             }
         }
     }
@@ -2134,6 +2164,8 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     UNERF_REQUIRE(!(near_plane < 0.f && features), "field_fwd: Euclidean bins (near_plane < 0) cannot be combined with pre-gathered features");
     UNERF_REQUIRE((uint64_t)(ray_offset + R) * (uint64_t)S < (1ull << 32),
                   "field_fwd: sample index exceeds 32 bits (RNG counter)");
+    UNERF_REQUIRE(!p->sample_major || (p->mode != UNERF_FIELD_LAPLACE && (p->mfma16_blob || p->mfma_blob)),
+                  "field_fwd: sample_major planes are written by the ACTIVE / MCDROPOUT matrix kernels only");
     if (R == 0) return UNERF_OK;
     FieldArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
@@ -2608,6 +2640,192 @@ extern "C" int unerf_composite_moments(const float* density, const float* rgb, c
     hipStream_t st = (hipStream_t)stream;
     UNERF_DISPATCH_SPL(S, composite_moments_kernel, grid, block, 0, st, a, mean_out, var_out);
     return unerf_check_launch("composite_moments");
+}
+
+// ---- composite over sample-major planes: one lane per ray, front to back --------------------------------------
+// Input = the planes unerf_field_fwd writes with sample_major = 1: density [B,S,R], rgb [B,S,3,R], beta [S,R].  A lane
+// walks its ray's samples in order (every load is a coalesced row of 64 consecutive rays), so get_weights is the
+// plain sequential recurrence -- no cross-lane scan -- and the K passes of a ray are reduced to mean / unbiased
+// variance in the same thread (MOMENTS).  Passes are walked four at a time so that the bin edges (one IEEE
+// division each) are converted once per group, not once per pass.
+//   depth_var = sum_i w_i (t_i - d_median)^2 needs d_median, which is only known after the walk; instead of a second
+//   walk (two more exp per sample) the three moments sum w, sum w t, sum w t^2 are kept in fp64 (products of fp32
+//   numbers are exact there) and combined at the end: sum w t^2 - 2 d sum w t + d^2 sum w.
+//   mean / variance over the passes: sums of (x - x_0) and (x - x_0)^2 around the first pass's value x_0 -- the
+//   two-pass result of torch.stack(...).var(0) up to fp32 rounding, without keeping the B per-pass values.
+struct CompSmArgs {
+    const float* density;
+    const float* rgb;
+    const float* beta;
+    const float* sbins;
+    int B;
+    int64_t R;
+    int S;
+    float s_near, s_far;
+    const float* clip;
+    int64_t ray_offset, chunk_rays;
+    float* out;       // [B,R,8] (MOMENTS = false)
+    float* mean_out;  // [R,8]
+    float* var_out;   // [R,8]
+};
+
+#define CSM_G 4   // passes per walk
+
+template <bool MOMENTS>
+__global__ __launch_bounds__(256) void composite_sm_kernel(CompSmArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.R) return;
+    const int S = a.S;
+    const int64_t R = a.R;
+    const float* sb = a.sbins + r * (S + 1);
+    float clip_lo = 0.f, clip_hi = 0.f;
+    if (a.clip) {
+        const int64_t chunk = (a.ray_offset + r) / a.chunk_rays;
+        clip_lo = a.clip[chunk * 2 + 0];
+        clip_hi = a.clip[chunk * 2 + 1];
+    }
+    float x0[8], sd[8], sd2[8];   // moments over the passes, around pass 0
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x0[c] = sd[c] = sd2[c] = 0.f;
+    for (int b0 = 0; b0 < a.B; b0 += CSM_G) {
+        const int nb = min(CSM_G, a.B - b0);
+        float cum[CSM_G], cr[CSM_G], cg[CSM_G], cb[CSM_G], accw[CSM_G], wt[CSM_G], uvar[CSM_G], depth[CSM_G];
+        float lr[CSM_G], lg[CSM_G], lb[CSM_G];
+        double m0[CSM_G], m1[CSM_G], m2[CSM_G];
+        bool found[CSM_G];
+#pragma unroll
+        for (int j = 0; j < CSM_G; ++j) {
+            cum[j] = cr[j] = cg[j] = cb[j] = accw[j] = wt[j] = uvar[j] = depth[j] = 0.f;
+            lr[j] = lg[j] = lb[j] = 0.f;
+            m0[j] = m1[j] = m2[j] = 0.0;
+            found[j] = false;
+        }
+        float e0 = unerf_s2e(sb[0], a.s_near, a.s_far);
+        float step = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+            const float delta = e1 - e0;
+            step = (e0 + e1) / 2.f;
+            e0 = e1;
+            const double t64 = (double)step, t264 = t64 * t64;
+            const float bt = a.beta ? a.beta[(int64_t)s * R + r] : 0.f;
+#pragma unroll
+            for (int j = 0; j < CSM_G; ++j) {
+                if (j < nb) {  // uniform
+                    const int64_t plane = (int64_t)(b0 + j) * S + s;
+                    const float dens = a.density[plane * R + r];
+                    const float* cp = a.rgb + plane * 3 * R + r;
+                    const float r0 = unerf_nan_to_num(cp[0]), g0 = unerf_nan_to_num(cp[R]), bl0 = unerf_nan_to_num(cp[2 * R]);
+                    const float dd = delta * dens;
+                    const float alpha = 1.f - expf(-dd);
+                    const float T = expf(-cum[j]);
+                    cum[j] += dd;
+                    const float w = unerf_nan_to_num(alpha * T);
+                    cr[j] += w * r0;
+                    cg[j] += w * g0;
+                    cb[j] += w * bl0;
+                    accw[j] += w;
+                    wt[j] += w * step;
+                    uvar[j] += (w * w) * bt;
+                    if (!found[j] && !(accw[j] < 0.5f)) {   // first index whose inclusive cumsum reaches 0.5
+                        found[j] = true;
+                        depth[j] = step;
+                    }
+                    const double w64 = (double)w;
+                    m0[j] += w64;
+                    m1[j] = fma(w64, t64, m1[j]);
+                    m2[j] = fma(w64, t264, m2[j]);
+                    lr[j] = r0; lg[j] = g0; lb[j] = bl0;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CSM_G; ++j) {
+            if (j < nb) {
+                if (!found[j]) depth[j] = step;   // clamp(searchsorted, 0, S-1): the last sample's mid-point
+                float o8[8];
+                o8[0] = fminf(fmaxf(cr[j] + lr[j] * (1.f - accw[j]), 0.f), 1.f);   // background_color = "last_sample"
+                o8[1] = fminf(fmaxf(cg[j] + lg[j] * (1.f - accw[j]), 0.f), 1.f);
+                o8[2] = fminf(fmaxf(cb[j] + lb[j] * (1.f - accw[j]), 0.f), 1.f);
+                o8[3] = accw[j];
+                o8[4] = depth[j];
+                float ed = wt[j] / (accw[j] + 1e-10f);
+                if (a.clip) ed = fminf(fmaxf(ed, clip_lo), clip_hi);
+                o8[5] = ed;
+                o8[6] = uvar[j];
+                const double d64 = (double)depth[j];
+                o8[7] = (float)(m2[j] - 2.0 * d64 * m1[j] + d64 * d64 * m0[j]) + 1e-5f;
+                if (!MOMENTS) {
+                    float4* o = reinterpret_cast<float4*>(a.out + ((int64_t)(b0 + j) * R + r) * 8);
+                    o[0] = make_float4(o8[0], o8[1], o8[2], o8[3]);
+                    o[1] = make_float4(o8[4], o8[5], o8[6], o8[7]);
+                } else if (b0 + j == 0) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) x0[c] = o8[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float d = o8[c] - x0[c];
+                        sd[c] += d;
+                        sd2[c] += d * d;
+                    }
+                }
+            }
+        }
+    }
+    if (MOMENTS) {
+        const float invB = 1.f / (float)a.B, invB1 = 1.f / (float)(a.B - 1);
+        float m8[8], v8[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            m8[c] = x0[c] + sd[c] * invB;
+            v8[c] = fmaxf(sd2[c] - sd[c] * sd[c] * invB, 0.f) * invB1;
+        }
+        float4* mo = reinterpret_cast<float4*>(a.mean_out + r * 8);
+        float4* vo = reinterpret_cast<float4*>(a.var_out + r * 8);
+        mo[0] = make_float4(m8[0], m8[1], m8[2], m8[3]);
+        mo[1] = make_float4(m8[4], m8[5], m8[6], m8[7]);
+        vo[0] = make_float4(v8[0], v8[1], v8[2], v8[3]);
+        vo[1] = make_float4(v8[4], v8[5], v8[6], v8[7]);
+    }
+}
+
+static int composite_planes_launch(const float* density, const float* rgb, const float* beta, const float* sbins, int B,
+                                   int64_t R, int S, float near_plane, float far_plane, const float* clip_minmax,
+                                   int64_t ray_offset, int64_t chunk_rays, float* out, float* mean_out, float* var_out,
+                                   void* stream, const char* what) {
+    UNERF_REQUIRE(density && rgb && sbins, "%s: null pointer", what);
+    UNERF_REQUIRE(B >= 1 && R >= 0 && S >= 1, "%s: bad B/R/S", what);
+    UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "%s: chunk_rays must be > 0 with clip_minmax", what);
+    if (R == 0) return UNERF_OK;
+    CompSmArgs a;
+    a.density = density; a.rgb = rgb; a.beta = beta; a.sbins = sbins; a.B = B; a.R = R; a.S = S;
+    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays;
+    a.out = out; a.mean_out = mean_out; a.var_out = var_out;
+    dim3 grid(blocks_for(R, 256)), block(256);
+    if (out) hipLaunchKernelGGL(composite_sm_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(composite_sm_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+    return unerf_check_launch(what);
+}
+
+extern "C" int unerf_composite_var_planes(const float* density, const float* rgb, const float* beta, const float* sbins,
+                                          int B, int64_t R, int S, float near_plane, float far_plane,
+                                          const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, float* out,
+                                          void* stream) {
+    UNERF_REQUIRE(out, "composite_var_planes: null pointer");
+    return composite_planes_launch(density, rgb, beta, sbins, B, R, S, near_plane, far_plane, clip_minmax, ray_offset,
+                                   chunk_rays, out, nullptr, nullptr, stream, "composite_var_planes");
+}
+
+extern "C" int unerf_composite_moments_planes(const float* density, const float* rgb, const float* sbins, int B,
+                                              int64_t R, int S, float near_plane, float far_plane,
+                                              const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays,
+                                              float* mean_out, float* var_out, void* stream) {
+    UNERF_REQUIRE(mean_out && var_out, "composite_moments_planes: null pointer");
+    UNERF_REQUIRE(B >= 2, "composite_moments_planes: B=%d (the unbiased variance needs at least two passes)", B);
+    return composite_planes_launch(density, rgb, nullptr, sbins, B, R, S, near_plane, far_plane, clip_minmax, ray_offset,
+                                   chunk_rays, nullptr, mean_out, var_out, stream, "composite_moments_planes");
 }
 
 // ---- laplace depth draws --------------------------------------------------------------

@@ -99,7 +99,7 @@ class FieldParams(C.Structure):
         ("mfma_blob", C.c_void_p), ("lap_blob", C.c_void_p),
         ("tcnn_levels", C.c_void_p),
         ("mfma16_blob", C.c_void_p), ("lap16_blob", C.c_void_p),
-        ("image_width", C.c_int),
+        ("image_width", C.c_int), ("sample_major", C.c_int),
     ]
 
 
@@ -128,6 +128,8 @@ SIGNATURES = {
                                     _vp]),
     "unerf_composite_var": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp]),
     "unerf_composite_moments": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "unerf_composite_var_planes": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp]),
+    "unerf_composite_moments_planes": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp, _vp]),
     "unerf_moments": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "unerf_splat_project": (_i, [_vp, _vp, _f, _vp, _fp, _f, _f, _f, _f, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp]),

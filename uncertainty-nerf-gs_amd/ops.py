@@ -565,23 +565,36 @@ def field_gather(origins, directions, sbins, field: FieldDev, near: float, far: 
     return out
 
 
+def supports_planes(field: FieldDev) -> bool:
+    """the sample-major plane layout is written by the ACTIVE / MCDROPOUT matrix kernels"""
+    return field.mode != _l.FIELD_LAPLACE and field.use_mfma and (field.mfma_blob is not None or field.mfma16_blob is not None)
+
+
 def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0,
-              features: Optional[torch.Tensor] = None, image_width: int = 0, euclidean_bins: bool = False):
+              features: Optional[torch.Tensor] = None, image_width: int = 0, euclidean_bins: bool = False,
+              sample_major: bool = False):
     """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h).  image_width > 0 tells the kernel that
     rays [ray_offset, ray_offset+R) are consecutive pixels of a row-major image (8x4-pixel tiles: same results).
-    euclidean_bins: `sbins` holds Euclidean bin edges (a caller-made RaySamples) instead of spacing-domain bins."""
+    euclidean_bins: `sbins` holds Euclidean bin edges (a caller-made RaySamples) instead of spacing-domain bins.
+    sample_major: the outputs are planes density [B,S,R], rgb [B,S,3,R], aux [S,R] (composite_*_planes read them)."""
     if euclidean_bins:
         near = -1.0
     lib = _l.load()
     R, S = sbins.shape[0], sbins.shape[1] - 1
     B = max(field.K, 1) if field.mode == _l.FIELD_MCDROPOUT else 1
     dev = origins.device
-    density = torch.empty(B, R, S, device=dev, dtype=torch.float32)
-    rgb = torch.empty(B, R, S, 3, device=dev, dtype=torch.float32)
-    aux = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
+    if sample_major:
+        density = torch.empty(B, S, R, device=dev, dtype=torch.float32)
+        rgb = torch.empty(B, S, 3, R, device=dev, dtype=torch.float32)
+        aux = torch.empty(S, R, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
+    else:
+        density = torch.empty(B, R, S, device=dev, dtype=torch.float32)
+        rgb = torch.empty(B, R, S, 3, device=dev, dtype=torch.float32)
+        aux = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
     aux2 = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode == _l.FIELD_LAPLACE else None
     cs = field.cstruct()
     cs.image_width = int(image_width)
+    cs.sample_major = 1 if sample_major else 0
     with _ctx(dev):
         _run("field_fwd", lambda: lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, ray_offset,
                                      C.byref(cs), _p(features), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()))
@@ -647,6 +660,32 @@ def composite_moments(density, rgb, sbins, near: float, far: float, clip_minmax=
         _run("composite_moments", lambda: lib.unerf_composite_moments(_p(density), _p(rgb), _p(sbins), B, R, S, near, far,
                                                                       _p(clip_minmax), ray_offset, chunk_rays, _p(mean),
                                                                       _p(var), _stream()))
+    return mean, var
+
+
+def composite_var_planes(density, rgb, sbins, near: float, far: float, beta=None, clip_minmax=None,
+                         ray_offset: int = 0, chunk_rays: int = 1 << 15) -> torch.Tensor:
+    """planes density [B,S,R], rgb [B,S,3,R], beta [S,R] -> out [B,R,8] (channels as composite_var)"""
+    lib = _l.load()
+    B, S, R = density.shape
+    out = torch.empty(B, R, 8, device=density.device, dtype=torch.float32)
+    with _ctx(out.device):
+        _run("composite_var", lambda: lib.unerf_composite_var_planes(_p(density), _p(rgb), _p(beta), _p(sbins), B, R, S, near, far,
+                                                                    _p(clip_minmax), ray_offset, chunk_rays, _p(out), _stream()))
+    return out
+
+
+def composite_moments_planes(density, rgb, sbins, near: float, far: float, clip_minmax=None, ray_offset: int = 0,
+                             chunk_rays: int = 1 << 15):
+    """planes density [B>=2,S,R], rgb [B,S,3,R] -> (mean [R,8], var [R,8]) over the B passes"""
+    lib = _l.load()
+    B, S, R = density.shape
+    mean = torch.empty(R, 8, device=density.device, dtype=torch.float32)
+    var = torch.empty(R, 8, device=density.device, dtype=torch.float32)
+    with _ctx(mean.device):
+        _run("composite_moments", lambda: lib.unerf_composite_moments_planes(_p(density), _p(rgb), _p(sbins), B, R, S, near, far,
+                                                                             _p(clip_minmax), ray_offset, chunk_rays,
+                                                                             _p(mean), _p(var), _stream()))
     return mean, var
 
 

@@ -21,6 +21,7 @@ shapes: the stages contend for the same CUs' issue slots and register file.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -53,6 +54,10 @@ class NerfSceneDev:
     prop_average_init_density: float = 0.01
     chunk_rays: int = 1 << 15
     split_gather: bool = False  # True: level-major gather kernel + feature planes instead of the fused lookup
+    # field outputs as sample-major planes + lane-per-ray composite (ACTIVE / MCDROPOUT).  Measured alternative, off by
+    # default: the plane stores cut the field kernel's write traffic to the algorithmic bytes, but the lane-per-ray
+    # composite is latency-bound and costs more than the stores gain; UNERF_SAMPLE_MAJOR=1 turns it on
+    sample_major: bool = field(default_factory=lambda: os.environ.get("UNERF_SAMPLE_MAJOR", "0") == "1")
     _const: Dict[str, torch.Tensor] = field(default_factory=dict)
 
     @property
@@ -110,19 +115,30 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
                   depth_noise: Optional[torch.Tensor] = None, depth_draws: int = 100, depth_seed: int = 0,
                   keep_density: bool = False, image_width: int = 0) -> Dict[str, torch.Tensor]:
     f = scene.field
+    # ACTIVE / MCDROPOUT: the field kernel writes sample-major planes (whole 32-byte sectors per store) and the
+    # composite walks them with a lane per ray; LAPLACE keeps the ray-major layout its depth-draw kernel reads
+    planes = scene.sample_major and feats is None and ops.supports_planes(f)
     density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset, features=feats,
-                                            image_width=image_width)
+                                            image_width=image_width, sample_major=planes)
     kw = dict(clip_minmax=clip, ray_offset=ray_offset, chunk_rays=scene.chunk_rays)
     res: Dict[str, torch.Tensor] = {}
     if f.mode == _l.FIELD_ACTIVE:
-        out = ops.composite_var(density, rgb, sb, scene.near, scene.far, beta=aux, **kw)[0]
+        if planes:
+            out = ops.composite_var_planes(density, rgb, sb, scene.near, scene.far, beta=aux, **kw)[0]
+        else:
+            out = ops.composite_var(density, rgb, sb, scene.near, scene.far, beta=aux, **kw)[0]
         res = _unpack(out)
         res["rgb_std"] = res["rgb_var"].sqrt()
         res["depth_std"] = res["depth_var"].sqrt()
-        if keep_density:
-            res["density"] = density[0]
+        if keep_density:   # the reference returns density [R,48,1] (activenerfacto_model.py:115,122)
+            res["density"] = density[0].t().contiguous() if planes else density[0]
     elif f.mode == _l.FIELD_MCDROPOUT:
-        if 0 < f.K <= 16:
+        if planes and f.K >= 2:
+            mean, var = ops.composite_moments_planes(density, rgb, sb, scene.near, scene.far, **kw)
+        elif planes and f.K == 1:
+            mean = ops.composite_var_planes(density, rgb, sb, scene.near, scene.far, **kw)[0]
+            var = torch.full_like(mean, float("nan"))       # torch.std of one pass (unbiased) is NaN
+        elif 0 < f.K <= 16:
             mean, var = ops.composite_moments(density, rgb, sb, scene.near, scene.far, **kw)
         elif f.K > 16:
             out = ops.composite_var(density, rgb, sb, scene.near, scene.far, **kw)  # [B,R,8]
@@ -135,7 +151,8 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
             res["depth_std"] = std[:, 4:5].mean(dim=-1)[..., None]
             res["expected_depth_std"] = std[:, 5:6].mean(dim=-1)[..., None]
         else:
-            u = _unpack(ops.composite_var(density, rgb, sb, scene.near, scene.far, **kw)[0])
+            comp = ops.composite_var_planes if planes else ops.composite_var
+            u = _unpack(comp(density, rgb, sb, scene.near, scene.far, **kw)[0])
             res = {k: u[k] for k in ("rgb", "accumulation", "depth", "expected_depth")}
     else:
         # use_deterministic_density (laplace_model.py:486-507 is skipped): depth from the ordinary weights
