@@ -237,3 +237,70 @@ def test_oracle_active_compose_matches_the_references_get_outputs():
     assert set(keys) == set(out), set(keys) ^ set(out)
     for k in keys:
         torch.testing.assert_close(out[k].reshape(g[f"act_out_{k}"].shape), t(f"act_out_{k}"), rtol=2e-6, atol=1e-7, msg=k)
+
+
+# ---- [REF] Field methods run with a fake `self` (tests/golden/make_golden.py: golden_field_glue) -----------------------
+
+def _field_from_fixture(g, prefix, kind):
+    from oracle import nerf_oracle as O
+    t = lambda k: torch.from_numpy(g[prefix + k])
+    from uncertainty_nerf_gs_amd import synthetic
+    table = t("table")
+    log2T = int(np.log2(table.shape[0] // 16))
+    grid = O.GridMLP(table=table, scalings=t("scalings"), log2_T=log2T, weights=[t("w0"), t("w1")], biases=[t("b0"), t("b1")])
+    kw = {}
+    if kind == "laplace":
+        kw = dict(hidden_w=t("w1"), hidden_b=t("b1"), density_w=t("density_w"), density_b=t("density_b"))
+    if prefix == "mc_":
+        return O.FieldParams(grid=grid, head_w=[], head_b=[], appearance=torch.zeros(32), average_init_density=0.01)
+    return O.FieldParams(grid=grid, head_w=[t(f"head_w{i}") for i in range(3)], head_b=[t(f"head_b{i}") for i in range(3)],
+                         appearance=t("appearance"), **kw)
+
+
+def test_oracle_laplace_field_matches_the_references_forward_unc():
+    """NerfactoLaplaceField.forward_unc -> get_density -> sample_laplace, get_outputs -> sample_laplace
+    (laplace_field.py:279-568) ran on a seeded field: bare-Linear base_mlp, mu_d NOT selector-masked, relu + channel
+    mean of the colour variance, and (use_deterministic_density) the masked plain density with a still-sampled colour."""
+    g = golden("field_glue.npz")
+    fp = _field_from_fixture(g, "lap_", "laplace")
+    t = lambda k: torch.from_numpy(g[k])
+    o, d, eb = t("o"), t("d"), t("eb")
+    mu_q_d = torch.cat([fp.density_w.reshape(-1), fp.density_b.reshape(-1)])
+    mu_q_r = torch.cat([fp.head_w[2].reshape(-1), fp.head_b[2].reshape(-1)])
+    ws_d = O.laplace_weight_samples(mu_q_d, t("lap_ggn_density"), 1.0, 1e-9, t("lapf_noise_density"))
+    ws_r = O.laplace_weight_samples(mu_q_r, t("lap_ggn_rgb"), 1.0, 1e-9, t("lapf_noise_rgb"))
+    mu_d, var_d, mu_rgb, var_rgb = O.laplace_field(o, d, eb, fp, ws_d, ws_r)
+    torch.testing.assert_close(mu_d, t("lapf_density")[..., 0], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(var_d, t("lapf_density_var")[..., 0], rtol=1e-4, atol=1e-6 * float(t("lapf_density")[..., 0].max()) ** 2)
+    torch.testing.assert_close(mu_rgb, t("lapf_rgb"), rtol=0, atol=2e-6)
+    torch.testing.assert_close(var_rgb, t("lapf_rgb_var")[..., 0], rtol=0, atol=2e-7)
+    # use_deterministic_density: density = plain masked head (no draw), colour head sampled with the first draw of the seed
+    ws_r2 = O.laplace_weight_samples(mu_q_r, t("lap_ggn_rgb"), 1.0, 1e-9, t("lapf_det_noise_rgb"))
+    dens_det, _ = O.laplace_field_deterministic(o, d, eb, fp)
+    _, _, mu_rgb2, var_rgb2 = O.laplace_field(o, d, eb, fp, ws_d, ws_r2)
+    torch.testing.assert_close(dens_det, t("lapf_det_density")[..., 0], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(mu_rgb2, t("lapf_det_rgb"), rtol=0, atol=2e-6)
+    torch.testing.assert_close(var_rgb2, t("lapf_det_rgb_var")[..., 0], rtol=0, atol=2e-7)
+    assert "lapf_det_density_var" not in g.files                       # density_var is None on that path (:503)
+    # the is_inference=False forward (what compute_hessian_naive differentiates)
+    dens_p, rgb_p = O.laplace_field_deterministic(o, d, eb, fp)
+    torch.testing.assert_close(dens_p, t("lapf_plain_density")[..., 0], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(rgb_p, t("lapf_plain_rgb"), rtol=0, atol=2e-6)
+    # some samples lie outside the unit box after contraction-normalisation: the selector is exercised
+    assert (t("lapf_plain_density") == 0).any() and (t("lapf_density") > 0).all()
+
+
+def test_oracle_active_and_mcdropout_fields_match_the_references_get_density():
+    g = golden("field_glue.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    o, d, eb = t("o"), t("d"), t("eb")
+    fpa = _field_from_fixture(g, "act_", "active")
+    dens, rgb, beta = O.active_field(o, d, eb, fpa)                          # activenerfacto_field.py:162-215
+    torch.testing.assert_close(dens, t("actf_density")[..., 0], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(beta, t("actf_rgb_var")[..., 0], rtol=2e-6, atol=1e-7)   # stored under "rgb_var" (:209)
+    torch.testing.assert_close(rgb, t("actf_rgb"), rtol=0, atol=2e-6)
+    fpm = _field_from_fixture(g, "mc_", "mcdropout")
+    fpm.head_w = [torch.zeros(64, 63), torch.zeros(64, 64), torch.zeros(3, 64)]
+    fpm.head_b = [torch.zeros(64), torch.zeros(64), torch.zeros(3)]
+    dens_m, _ = O.mcdropout_field(o, d, eb, fpm, None, None, 0.2)           # mcdropout_fields.py:146-174, dropout off
+    torch.testing.assert_close(dens_m, t("mcf_density")[..., 0], rtol=2e-6, atol=1e-9)
