@@ -101,6 +101,11 @@ typedef struct {
     /* NULL: nerfstudio torch HashEncoding (above).  Else DEVICE array [L] of level records: `table` is a
        tcnn-layout parameter vector (`scalings`, `log2T`, `dense*` are ignored). */
     const unerf_tcnn_level* tcnn_levels;
+    /* use_aabb = 1: spatial_distortion = None (disable_scene_contraction, mcdropout_models.py:60-63): positions are
+       normalised with SceneBox.get_normalized_positions, (x - aabb[0..2]) / (aabb[3..5] - aabb[0..2]), instead of
+       SceneContraction(inf) followed by (x + 2) / 4.  aabb = {min xyz, max xyz}. */
+    int use_aabb;
+    float aabb[6];
 } unerf_density_net;
 
 /* -------------------------------------------------- proposal density --
@@ -199,7 +204,23 @@ typedef struct {
        at one sample slot, so its stores then fill whole 32-byte sectors instead of 4 bytes per cache line; consumed
        by unerf_composite_var_planes / unerf_composite_moments_planes. */
     int sample_major;
+    /* MCDROPOUT: where the Dropout modules sit (mcdropout_fields.py:112-144 via create_mlp, utils.py:6-43).  0 = the
+       reference default UNERF_DROP_TRUNK | UNERF_DROP_HEAD1 (density_dropout_layers=True, rgb_dropout_layers=[-1]).
+       UNERF_DROP_TRUNK: after the trunk's hidden ReLU (density_dropout_layers); UNERF_DROP_HEAD0: in front of the
+       colour head's Linear 1 (rgb_dropout_layers contains 1); UNERF_DROP_HEAD1: in front of its last Linear (contains
+       2 or -1).  Mask streams 0 / 2 / 1 of the counter RNG.  With mfma16_blob the scale 1/(1-p) is expected folded
+       into the layer behind each active site (ops.pack_field_mfma16). */
+    int drop_sites;
+    /* LAPLACE: 1 = density_activation "softplus" (laplace_model.py:151, laplace_field.py:323) instead of trunc_exp on
+       the (sampled) density head; unerf_laplace_ggn_diag supports trunc_exp only. */
+    int lap_softplus;
+    /* as unerf_density_net: 1 = normalise positions with the scene box instead of the contraction */
+    int use_aabb;
+    float aabb[6];
 } unerf_field_params;
+#define UNERF_DROP_TRUNK 1
+#define UNERF_DROP_HEAD0 2
+#define UNERF_DROP_HEAD1 4
 #define UNERF_MFMA_BLOB_FLOATS 10660
 #define UNERF_LAP_BLOB_FLOATS 33280
 

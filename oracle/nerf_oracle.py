@@ -211,10 +211,15 @@ def contract_inf(x: torch.Tensor) -> torch.Tensor:
     return torch.where(mag < 1, x, (2 - (1 / mag)) * (x / mag))
 
 
-def normalized_positions(positions: torch.Tensor):
-    """[REF activenerfacto_field.py:164-172] contraction -> (x+2)/4 -> selector mask."""
-    p = contract_inf(positions)
-    p = (p + 2.0) / 4.0
+def normalized_positions(positions: torch.Tensor, aabb: Optional[torch.Tensor] = None):
+    """[REF activenerfacto_field.py:164-172] contraction -> (x+2)/4 -> selector mask; with `aabb` [2,3] the
+    spatial_distortion-is-None branch (:168, disable_scene_contraction): [UPSTREAM SceneBox.get_normalized_positions]
+    (x - aabb[0]) / (aabb[1] - aabb[0])."""
+    if aabb is not None:
+        p = (positions - aabb[0]) / (aabb[1] - aabb[0])
+    else:
+        p = contract_inf(positions)
+        p = (p + 2.0) / 4.0
     selector = ((p > 0.0) & (p < 1.0)).all(dim=-1)
     p = p * selector[..., None]
     return p, selector
@@ -323,6 +328,7 @@ class GridMLP:
     weights: List[torch.Tensor]
     biases: List[torch.Tensor]
     tcnn_levels: Optional[list] = None   # set: `table` is a tcnn-layout parameter vector (tcnn_grid_levels)
+    aabb: Optional[torch.Tensor] = None  # [2,3]: scene-box normalisation instead of the contraction
 
 
 def grid_encode(x: torch.Tensor, g: "GridMLP") -> torch.Tensor:
@@ -340,7 +346,7 @@ def sample_positions(origins, directions, euclid_bins):
 def density_field(positions: torch.Tensor, net: GridMLP, average_init_density: float) -> torch.Tensor:
     """HashMLPDensityField.get_density on explicit positions [R,n,3] -> [R,n]."""
     shp = positions.shape[:-1]
-    p, sel = normalized_positions(positions)
+    p, sel = normalized_positions(positions, net.aabb)
     h = grid_encode(p.reshape(-1, 3), net)
     out = mlp_forward(h, net.weights, net.biases).view(*shp)
     return average_init_density * torch.exp(out) * sel
@@ -495,6 +501,7 @@ class FieldParams:
     beta_min: float = 0.01
     geo_feat_dim: int = 15
     sh_remap: bool = False             # tcnn SphericalHarmonics maps its [0,1] input back to [-1,1]
+    density_activation: str = "exp"    # laplace only: "exp" (trunc_exp) | "softplus" (laplace_model.py:151)
 
 
 def _color_inputs(directions: torch.Tensor, S: int, geo: torch.Tensor, appearance: torch.Tensor,
@@ -514,7 +521,7 @@ def active_field(origins, directions, euclid_bins, fp: FieldParams):
     """[REF activenerfacto_field.py:162-215]  -> density [R,S], rgb [R,S,3], beta [R,S]"""
     R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
     pos = sample_positions(origins, directions, euclid_bins)
-    p, sel = normalized_positions(pos)
+    p, sel = normalized_positions(pos, fp.grid.aabb)
     feat = grid_encode(p.reshape(-1, 3), fp.grid)
     h = mlp_forward(feat, fp.grid.weights, fp.grid.biases).view(R, S, -1)
     g = fp.geo_feat_dim
@@ -526,14 +533,16 @@ def active_field(origins, directions, euclid_bins, fp: FieldParams):
 
 
 def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trunk: Optional[torch.Tensor],
-                    keep_head: Optional[torch.Tensor], p_drop: float):
+                    keep_head: Optional[torch.Tensor], p_drop: float, keep_head0: Optional[torch.Tensor] = None):
     """[REF mcdropout_fields.py:110-174 + utils.py:6-43]
-    trunk = Linear(32,64),ReLU,Dropout,Linear(64,16); head = Linear(63,64),ReLU,Linear(64,64),ReLU,
-    Dropout,Linear(64,3),Sigmoid.  keep_* are bool masks [R*S,64] (None = dropout off)."""
+    trunk = Linear(32,64),ReLU,Dropout,Linear(64,16); head = Linear(63,64),ReLU,[Dropout,]Linear(64,64),ReLU,
+    Dropout,Linear(64,3),Sigmoid.  keep_* are bool masks [R*S,64] (None = no Dropout module at that site):
+    keep_trunk -- density_dropout_layers; keep_head0 -- rgb_dropout_layers contains 1 (in front of Linear 1);
+    keep_head -- rgb_dropout_layers contains -1 / 2 (in front of the last Linear)."""
     R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
     scale = 1.0 / (1.0 - p_drop)
     pos = sample_positions(origins, directions, euclid_bins)
-    p, sel = normalized_positions(pos)
+    p, sel = normalized_positions(pos, fp.grid.aabb)
     feat = grid_encode(p.reshape(-1, 3), fp.grid)
     h = F.relu(F.linear(feat, fp.grid.weights[0], fp.grid.biases[0]))
     if keep_trunk is not None:
@@ -544,6 +553,8 @@ def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trun
     geo = out[..., 1:1 + g]
     x = _color_inputs(directions, S, geo, fp.appearance, fp.sh_remap)
     x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
+    if keep_head0 is not None:
+        x = x * keep_head0.to(x.dtype) * scale
     x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
     if keep_head is not None:
         x = x * keep_head.to(x.dtype) * scale
@@ -563,7 +574,7 @@ def sample_laplace(weight_samples: torch.Tensor, activation: str, x: torch.Tenso
         w = weight_samples[s, : out_dim * in_dim].view(out_dim, in_dim)
         b = weight_samples[s, out_dim * in_dim:]
         pred = F.linear(x, w, b)
-        pred = torch.exp(pred) if activation == "exp" else torch.sigmoid(pred)
+        pred = {"exp": torch.exp, "softplus": F.softplus, "sigmoid": torch.sigmoid}[activation](pred)
         mu = mu + pred
         mu2 = mu2 + pred ** 2
     mu = mu / n
@@ -586,11 +597,11 @@ def laplace_field(origins, directions, euclid_bins, fp: FieldParams, ws_density:
     -> mu_d [R,S], var_d [R,S], mu_rgb [R,S,3], var_rgb [R,S] (relu, channel-mean)"""
     R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
     pos = sample_positions(origins, directions, euclid_bins)
-    p, _sel = normalized_positions(pos)
+    p, _sel = normalized_positions(pos, fp.grid.aabb)
     feat = grid_encode(p.reshape(-1, 3), fp.grid)
     hb = F.linear(feat, fp.grid.weights[0], fp.grid.biases[0])
     geo = F.linear(hb, fp.hidden_w, fp.hidden_b).view(R, S, -1)
-    mu_d, var_d = sample_laplace(ws_density, "exp", hb, 1)
+    mu_d, var_d = sample_laplace(ws_density, fp.density_activation, hb, 1)
     x = _color_inputs(directions, S, geo, fp.appearance, fp.sh_remap)
     x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
     x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
@@ -603,11 +614,12 @@ def laplace_field_deterministic(origins, directions, euclid_bins, fp: FieldParam
     """[REF laplace_field.py:317-345, 462-465] is_inference=False path (plain forward)."""
     R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
     pos = sample_positions(origins, directions, euclid_bins)
-    p, sel = normalized_positions(pos)
+    p, sel = normalized_positions(pos, fp.grid.aabb)
     feat = grid_encode(p.reshape(-1, 3), fp.grid)
     hb = F.linear(feat, fp.grid.weights[0], fp.grid.biases[0])
     geo = F.linear(hb, fp.hidden_w, fp.hidden_b).view(R, S, -1)
-    density = torch.exp(F.linear(hb, fp.density_w, fp.density_b)).view(R, S) * sel
+    act = F.softplus if fp.density_activation == "softplus" else torch.exp
+    density = act(F.linear(hb, fp.density_w, fp.density_b)).view(R, S) * sel
     x = _color_inputs(directions, S, geo, fp.appearance, fp.sh_remap)
     x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
     x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
@@ -722,7 +734,7 @@ def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, den
 
 
 def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, p_drop: float,
-                      ray_offset: int = 0) -> Dict[str, torch.Tensor]:
+                      ray_offset: int = 0, drop_sites: int = 5) -> Dict[str, torch.Tensor]:
     """[REF mcdropout_models.py:94-131] K stochastic passes of one chunk + mean / unbiased std.
     Masks come from the shared counter RNG keyed by the global sample index
     (ray_offset+r)*S+s, so chunking does not change them."""
@@ -732,9 +744,11 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
     sidx = ((np.arange(R, dtype=np.int64)[:, None] + ray_offset) * S + np.arange(S)[None, :]).reshape(-1)
     outs = []
     for k in range(K):
-        kt = torch.from_numpy(mc_keep_mask(seed, k, sidx, 0, 64, p_drop))
-        kh = torch.from_numpy(mc_keep_mask(seed, k, sidx, 1, 64, p_drop))
-        density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop)
+        # drop_sites bits: 1 trunk (mask stream 0), 2 head hidden-0 (stream 2), 4 head hidden-1 (stream 1)
+        kt = torch.from_numpy(mc_keep_mask(seed, k, sidx, 0, 64, p_drop)) if drop_sites & 1 else None
+        kh0 = torch.from_numpy(mc_keep_mask(seed, k, sidx, 2, 64, p_drop)) if drop_sites & 2 else None
+        kh = torch.from_numpy(mc_keep_mask(seed, k, sidx, 1, 64, p_drop)) if drop_sites & 4 else None
+        density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop, keep_head0=kh0)
         outs.append(nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb))
     res = {}
     for key in outs[0].keys():
@@ -833,7 +847,8 @@ def scene_from_tensors(t: dict) -> NerfScene:
         if "w1" in d and d.get("w1") is not None and not d.get("_laplace", False):
             ws.append(d["w1"])
             bs.append(d["b1"])
-        return GridMLP(d["table"], d["scalings"], int(d["log2T"]), ws, bs, tcnn_levels=d.get("tcnn_levels"))
+        return GridMLP(d["table"], d["scalings"], int(d["log2T"]), ws, bs, tcnn_levels=d.get("tcnn_levels"),
+                       aabb=t.get("aabb"))   # scene box [2,3]: disable_scene_contraction
 
     f = t["field"]
     lap = t["kind"] == "laplace"

@@ -146,6 +146,47 @@ def test_sample_major_plane_path_meets_the_same_gates(dev, kind):
         _img_close(out["depth_var"], ref["depth_var"], 0, 5e-3, "depth_var", max_bad_frac=2e-2)
 
 
+@pytest.mark.parametrize("kind", ["active", "mcdropout", "laplace"])
+def test_disable_scene_contraction_uses_the_scene_box(dev, kind):
+    """disable_scene_contraction (mcdropout_models.py:60-63): spatial_distortion = None, positions normalised with the
+    scene box in the main field AND both proposal networks; samples outside the box get selector 0"""
+    from uncertainty_nerf_gs_amd import ops, render, synthetic
+    t = synthetic.make_scene_tensors(seed=8, kind=kind, log2T=14, prop_log2T=12)
+    t["aabb"] = torch.tensor([[-1.0, -1.2, -0.8], [1.0, 0.9, 1.1]])
+    sc = O.scene_from_tensors(t)
+    assert sc.field.grid.aabb is not None and sc.prop_nets[0].aabb is not None
+    H, W = 30, 40
+    cam, c2w = _cam(H, W), synthetic.orbit_c2w(0.6)
+    o, d = _oracle_rays(c2w, cam)
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    if kind == "active":
+        sd = synthetic.scene_to_device(t, dev)
+        ref = O.active_outputs(sc, o, d)
+        out = render.render_rays(sd, o.to(dev), d.to(dev), keep_density=True)
+    elif kind == "mcdropout":
+        sd = synthetic.scene_to_device(t, dev, K=8, seed=2, p_drop=0.2)
+        ref = O.mcdropout_outputs(sc, o, d, 8, 2, 0.2)
+        out = render.render_rays(sd, o.to(dev), d.to(dev))
+    else:
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=5, n_samples=30)
+        sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+        noise = torch.randn(20, H * W, 48, generator=torch.Generator().manual_seed(8))
+        ref = O.laplace_outputs(sc, o, d, wsd, wsr, noise)
+        out = render.render_rays(sd, o.to(dev), d.to(dev), depth_noise=noise.to(dev), depth_draws=20)
+    assert sd.field.aabb is not None and sd.props[1].aabb is not None
+    v = lambda x: x.view(H, W, -1)
+    _gates(f"aabb-{kind}", v(out["rgb"].cpu()), v(out["rgb_std"].cpu()), v(ref["rgb"]), v(ref["rgb_std"]))
+    _img_close(v(out["rgb"]), v(ref["rgb"]), 5e-5, 0, "rgb")
+    _img_close(v(out["accumulation"]), v(ref["accumulation"]), 2e-4, 0, "accumulation")
+    _img_close(v(out["expected_depth"]), v(ref["expected_depth"]), 0, 1e-3, "expected_depth", max_bad_frac=1e-2)
+    # the contraction path gives a different image: far samples are outside the box here and contribute nothing
+    t2 = dict(t)
+    t2.pop("aabb")
+    alt = O.active_outputs(O.scene_from_tensors(t2), o, d) if kind == "active" else None
+    if alt is not None:
+        assert (alt["rgb"] - ref["rgb"]).abs().max() > 1e-3
+
+
 def test_laplace_camera_parity(dev):
     from uncertainty_nerf_gs_amd import render, synthetic
     t = synthetic.make_scene_tensors(seed=2, kind="laplace", log2T=14, prop_log2T=12)

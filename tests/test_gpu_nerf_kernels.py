@@ -242,6 +242,37 @@ def test_field_mcdropout_matches_oracle(dev, K, use_mfma, precision):
         assert not torch.equal(dens[0], dens[1]), "passes must use different masks"
 
 
+@pytest.mark.parametrize("use_mfma,precision", _KERNELS, ids=_KERNEL_IDS)
+@pytest.mark.parametrize("sites", [1, 4, 2, 6, 7])
+def test_field_mcdropout_dropout_sites_match_oracle(dev, sites, use_mfma, precision):
+    """Non-default placements of the Dropout modules (mcdropout_fields.py:112-144 through create_mlp):
+    density_dropout_layers=False (no trunk mask), rgb_dropout_layers containing 1 (masks in front of the head's
+    Linear 1, RNG stream 2) and / or -1 (in front of the last Linear) -- unerf_field_params.drop_sites"""
+    from uncertainty_nerf_gs_amd import ops
+    K, seed, p = 3, 77, 0.25
+    t, sc, sd = _scene("mcdropout", dev, K=K, seed=seed, p_drop=p, drop_sites=sites)
+    sd.field.use_mfma, sd.field.precision = use_mfma, precision
+    o, d = _rays(12, 20)
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    dens, rgb, _, _ = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR, ray_offset=64)
+    R, S = sb.shape[0], sb.shape[1] - 1
+    sidx = ((np.arange(R)[:, None] + 64) * S + np.arange(S)[None]).reshape(-1)
+    for k in range(K):
+        m = lambda stream, bit: torch.from_numpy(O.mc_keep_mask(seed, k, sidx, stream, 64, p)) if sites & bit else None
+        dr, cr = O.mcdropout_field(o, d, eb, sc.field, m(0, 1), m(1, 4), p, keep_head0=m(2, 2))
+        _close(dens[k], dr, 2e-4, 1e-7, f"density pass {k}")
+        _close(rgb[k], cr, 0, 2e-5, f"rgb pass {k}")
+    if not sites & 1:
+        assert torch.equal(dens[0], dens[1]), "no trunk dropout: the density is the same in every pass"
+    assert not torch.equal(rgb[0], rgb[1])
+    # changing the sites after the operands were packed (the scale lives in other layers) is refused on the f16 path
+    if precision == "f16x2" and use_mfma:
+        sd.field.drop_sites = 5 if sites != 5 else 1
+        with pytest.raises(Exception, match="rebuild the FieldDev"):
+            ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
+
+
 @pytest.mark.parametrize("use_mfma,precision,n_samples",
                          [(True, "f16x2", 100), (True, "fp32", 100), (False, "fp32", 100), (True, "f16x2", 37),
                           (True, "fp32", 37), (True, "f16x2", 128), (True, "f16x2", 4)],
@@ -263,6 +294,33 @@ def test_field_laplace_matches_oracle(dev, use_mfma, precision, n_samples):
     # variances are E[x^2]-E[x]^2 in fp32: compare against the scale of E[x^2]
     _close(dvar, var_d, 0, 2e-5 * float((mu_d ** 2).max()), "var_d")
     _close(rvar, var_rgb, 0, 2e-6, "var_rgb")
+
+
+@pytest.mark.parametrize("use_mfma,precision", _KERNELS, ids=_KERNEL_IDS)
+def test_field_laplace_softplus_density_activation(dev, use_mfma, precision):
+    """density_activation = "softplus" (laplace_model.py:151): the sampled density head goes through softplus instead
+    of trunc_exp, in the sampling path and in the use_deterministic_density path"""
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    import copy
+    t, sc, _ = _scene("laplace", dev)
+    wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=50)
+    sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev), lap_softplus=1)
+    sd.field.use_mfma, sd.field.precision = use_mfma, precision
+    o, d = _rays(10, 16)
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    fp = copy.copy(sc.field)
+    fp.density_activation = "softplus"
+    mu_d, var_d, mu_rgb, var_rgb = O.laplace_field(o, d, eb, fp, wsd, wsr)
+    dens, rgb, dvar, rvar = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
+    _close(dens[0], mu_d, 2e-4, 1e-6, "mu_d (softplus)")
+    _close(dvar, var_d, 0, 2e-5 * float((mu_d ** 2).max()), "var_d")
+    _close(rgb[0], mu_rgb, 0, 2e-5, "mu_rgb")
+    exp_fp = copy.copy(sc.field)
+    assert not torch.allclose(O.laplace_field(o, d, eb, exp_fp, wsd, wsr)[0], mu_d)      # the activation matters
+    with pytest.raises(NotImplementedError):
+        ops.laplace_ggn_diag(o.to(dev), d.to(dev), sb.to(dev), sd.field, wsd[0], wsr[0], NEAR, FAR,
+                             torch.zeros(65, device=dev), torch.zeros(195, device=dev))
 
 
 @pytest.mark.parametrize("B,S", [(1, 48), (3, 48), (1, 96), (2, 16), (1, 256),

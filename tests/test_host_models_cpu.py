@@ -124,3 +124,23 @@ def test_models_expose_the_eval_scripts_image_metrics():
     assert M.ActiveNerfactoModel.psnr is M.ActiveSplatfactoModel.psnr
     with pytest.raises(NotImplementedError):
         m.lpips(img, rgb)
+
+
+def test_mcdropout_field_dropout_layer_options():
+    """density_dropout_layers / rgb_dropout_layers (mcdropout_fields.py:80-81, 112-144): module layout follows
+    create_mlp, the kernel's site bits follow the layout, index 0 (dropout on the head's input) is refused"""
+    from torch import nn
+    from uncertainty_nerf_gs_amd import fields as F
+    from uncertainty_nerf_gs_amd import lib as L
+    kw = dict(num_images=2, log2_hashmap_size=6, max_res=64)
+    f = F.NerfactoMCDropoutField(**kw)
+    assert f.drop_sites == (L.DROP_TRUNK | L.DROP_HEAD1) and isinstance(f.mlp_base[2], nn.Dropout) and isinstance(f.mlp_head[4], nn.Dropout)
+    f = F.NerfactoMCDropoutField(density_dropout_layers=False, rgb_dropout_layers=[1, -1], **kw)
+    assert f.drop_sites == (L.DROP_HEAD0 | L.DROP_HEAD1)
+    assert [type(m).__name__ for m in f.mlp_base] == ["Linear", "ReLU", "Linear"]
+    assert [type(m).__name__ for m in f.mlp_head] == ["Linear", "ReLU", "Dropout", "Linear", "ReLU", "Dropout", "Linear", "Sigmoid"]
+    f = F.NerfactoMCDropoutField(density_dropout_layers=False, rgb_dropout_layers=[], **kw)
+    assert f.drop_sites == 0 and not any(isinstance(m, nn.Dropout) for m in list(f.mlp_base) + list(f.mlp_head))
+    import pytest
+    with pytest.raises(NotImplementedError):
+        F.NerfactoMCDropoutField(rgb_dropout_layers=[0], **kw)

@@ -97,17 +97,30 @@ __device__ __forceinline__ float unerf_nan_to_num(float w) {
 }
 
 // ---- SceneContraction(inf) -> (x+2)/4 -> selector mask ------------------------------
-__device__ __forceinline__ float unerf_normalize_position(float& x, float& y, float& z) {
-    float mag = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
-    if (!(mag < 1.f)) {
-        float s = 2.f - (1.f / mag);
-        x = s * (x / mag);
-        y = s * (y / mag);
-        z = s * (z / mag);
+// `box` = NULL-like (use_aabb == 0): the contraction path above.  use_aabb: disable_scene_contraction
+// (mcdropout_models.py:60-63 -> spatial_distortion = None): SceneBox.get_normalized_positions,
+// (x - aabb_min) / (aabb_max - aabb_min), a division as upstream does it.
+struct unerf_norm_box {
+    int use_aabb;
+    float lo[3], len[3];
+};
+__device__ __forceinline__ float unerf_normalize_position(float& x, float& y, float& z, const unerf_norm_box& box) {
+    if (box.use_aabb) {  // uniform
+        x = (x - box.lo[0]) / box.len[0];
+        y = (y - box.lo[1]) / box.len[1];
+        z = (z - box.lo[2]) / box.len[2];
+    } else {
+        float mag = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
+        if (!(mag < 1.f)) {
+            float s = 2.f - (1.f / mag);
+            x = s * (x / mag);
+            y = s * (y / mag);
+            z = s * (z / mag);
+        }
+        x = (x + 2.f) / 4.f;
+        y = (y + 2.f) / 4.f;
+        z = (z + 2.f) / 4.f;
     }
-    x = (x + 2.f) / 4.f;
-    y = (y + 2.f) / 4.f;
-    z = (z + 2.f) / 4.f;
     float sel = (x > 0.f && x < 1.f && y > 0.f && y < 1.f && z > 0.f && z < 1.f) ? 1.f : 0.f;
     x *= sel;
     y *= sel;

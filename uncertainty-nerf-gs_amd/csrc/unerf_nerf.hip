@@ -46,6 +46,15 @@ struct TcnnLevels {
     unerf_tcnn_level v[32];
 };
 
+static inline unerf_norm_box make_norm_box(int use_aabb, const float* aabb) {
+    unerf_norm_box b;
+    b.use_aabb = use_aabb ? 1 : 0;
+    for (int c = 0; c < 3; ++c) {
+        b.lo[c] = use_aabb ? aabb[c] : 0.f;
+        b.len[c] = use_aabb ? aabb[3 + c] - aabb[c] : 1.f;
+    }
+    return b;
+}
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 // Division of an index < 2^31 by a launch-invariant divisor (samples per ray): one multiply-high and a
@@ -314,6 +323,7 @@ struct PropArgs {
     FastDiv div_nsg, div_pcols;
     int64_t g0, first_row;
     int vec4;   // prop_patch_kernel: n % 4 == 0 and density_out 16-byte aligned
+    unerf_norm_box box;
 };
 
 template <int L, int HID>
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
     float px = a.origins[r * 3 + 0] + a.dirs[r * 3 + 0] * t / 2.f;
     float py = a.origins[r * 3 + 1] + a.dirs[r * 3 + 1] * t / 2.f;
     float pz = a.origins[r * 3 + 2] + a.dirs[r * 3 + 2] * t / 2.f;
-    float sel = unerf_normalize_position(px, py, pz);
+    float sel = unerf_normalize_position(px, py, pz, a.box);
     const uint32_t mask = (1u << a.net.log2T) - 1u;
     float feat[2 * L];
 #pragma unroll
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
         float px = s_od[0][lane] + s_od[3][lane] * t / 2.f;
         float py = s_od[1][lane] + s_od[4][lane] * t / 2.f;
         float pz = s_od[2][lane] + s_od[5][lane] * t / 2.f;
-        const float sel = unerf_normalize_position(px, py, pz);
+        const float sel = unerf_normalize_position(px, py, pz, a.box);
         const uint32_t mask = (1u << a.net.log2T) - 1u;
         float feat[2 * L];
 #pragma unroll
@@ -511,6 +521,7 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.sstride = sbins_stride; a.R = R; a.n = n;
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
     a.net = *net; a.avg = average_init_density; a.out = density_out;
+    a.box = make_norm_box(net->use_aabb, net->aabb);
     a.fd = make_fastdiv((uint32_t)n); a.small = (R * (int64_t)n < (1ll << 31)) ? 1 : 0;
     a.img_w = 0; a.pcols = 0; a.nsg = 0; a.div_nsg = a.div_pcols = make_fastdiv(1); a.g0 = 0; a.first_row = 0;
     a.vec4 = (n % 4 == 0 && ((uintptr_t)density_out & 15u) == 0) ? 1 : 0;
@@ -801,9 +812,11 @@ struct FieldArgs {
     int32_t keep_hi;     // MC-dropout keep threshold thr_s << 16 (unerf_keep_lo / unerf_keep_hi)
     uint32_t keep_pk;    // thr_s in both 16-bit halves (packed-f16 masks of the split-f16 kernels)
     int drop_on;         // K > 0 and p_drop > 0: masks are generated (p_drop == 0 keeps every unit)
+    int drop_sites;      // UNERF_DROP_* bits actually in use (0 when !drop_on)
     float drop_scale;
     const float* features;  // optional [16][N][2] level-major planes from unerf_field_gather (MFMA kernel)
     TileMap tm;
+    unerf_norm_box box;
 };
 
 // Bin edge -> Euclidean distance.  unerf_field_fwd(near_plane < 0) sets s_near = -1: sbins then already holds
@@ -962,7 +975,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
     float px = a.origins[r * 3 + 0] + dxr * t / 2.f;
     float py = a.origins[r * 3 + 1] + dyr * t / 2.f;
     float pz = a.origins[r * 3 + 2] + dzr * t / 2.f;
-    const float sel = unerf_normalize_position(px, py, pz);
+    const float sel = unerf_normalize_position(px, py, pz, a.box);
 
     const uint32_t mask = (1u << a.p.log2T) - 1u;
 #pragma unroll 4
@@ -1022,7 +1035,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
         for (int k = 0; k < passes; ++k) {
             const uint32_t base = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
             float o1[16];
-            if (a.drop_on) dense_lds_dropout<16>(a.p.w1t, a.p.b1, A, lane, base, k, 0u, a.keep_hi, a.drop_scale, o1);
+            if (a.drop_sites & UNERF_DROP_TRUNK) dense_lds_dropout<16>(a.p.w1t, a.p.b1, A, lane, base, k, 0u, a.keep_hi, a.drop_scale, o1);
             else dense_lds<64, 16>(a.p.w1t, a.p.b1, A, lane, o1);
             float density = a.p.average_init_density * expf(o1[0]) * sel;
             store_act<16>(Bf, lane, sh, 0, false);
@@ -1030,10 +1043,16 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
             for (int g = 0; g < 15; ++g) Bf[(16 + g) * 64 + lane] = o1[1 + g];
             dense_lds<31, 64>(a.p.h0t, a.p.hb0, Bf, lane, acc);
             store_act<64>(Bf, lane, acc, 0, true);
-            dense_lds<64, 64>(a.p.h1t, a.p.hb1, Bf, lane, acc);
-            store_act<64>(Bf, lane, acc, 0, true);
+            if (a.drop_sites & UNERF_DROP_HEAD0) {
+                float acc2[64];
+                dense_lds_dropout<64>(a.p.h1t, a.p.hb1, Bf, lane, base, k, 2u, a.keep_hi, a.drop_scale, acc2);
+                store_act<64>(Bf, lane, acc2, 0, true);
+            } else {
+                dense_lds<64, 64>(a.p.h1t, a.p.hb1, Bf, lane, acc);
+                store_act<64>(Bf, lane, acc, 0, true);
+            }
             float c[3];
-            if (a.drop_on) dense_lds_dropout<3>(a.p.h2t, a.p.hb2, Bf, lane, base, k, 1u, a.keep_hi, a.drop_scale, c);
+            if (a.drop_sites & UNERF_DROP_HEAD1) dense_lds_dropout<3>(a.p.h2t, a.p.hb2, Bf, lane, base, k, 1u, a.keep_hi, a.drop_scale, c);
             else dense_lds<64, 3>(a.p.h2t, a.p.hb2, Bf, lane, c);
             if (valid) {
                 int64_t q = (int64_t)k * N + n;
@@ -1055,7 +1074,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
 #pragma unroll
             for (int i = 0; i < 64; ++i) pre = fmaf(acc[i], w[i], pre);
             pre += w[64];
-            float pred = expf(pre);
+            float pred = a.p.lap_softplus ? unerf_softplus(pre) : expf(pre);
             mu += pred;
             mu2 += pred * pred;
         }
@@ -1154,6 +1173,12 @@ __device__ __forceinline__ void mf_mask_init(uint32_t (&st)[8], int blk, int h, 
 __device__ __forceinline__ void mf_mask_step(uint32_t (&st)[8]) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) st[q] = unerf_mask_step(st[q]);
+}
+// the eight words of one block at pass k, recomputed from the sample's base hash (k chained steps): used only by the
+// non-default dropout site UNERF_DROP_HEAD0, which therefore costs the default configuration no registers
+__device__ __forceinline__ void mf_mask_words_at(uint32_t (&st)[8], int blk, int h, uint32_t base0, uint32_t stream_id, int k) {
+    mf_mask_init(st, blk, h, base0, stream_id);
+    for (int q = 0; q < k; ++q) mf_mask_step(st);
 }
 __device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], int32_t thr_hi, float scale) {
 #pragma unroll
@@ -1291,7 +1316,7 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         const int64_t n = ts.n;
         const float dxr = ts.dx, dyr = ts.dy, dzr = ts.dz;
         float px = ts.px, py = ts.py, pz = ts.pz;
-        const float sel = unerf_normalize_position(px, py, pz);
+        const float sel = unerf_normalize_position(px, py, pz, a.box);
 
         // hash grid: this half's 8 levels -> 16 features = the 16 k-steps of layer 0
         f32x16 feat;
@@ -1337,8 +1362,8 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.drop_on;
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         uint32_t mk0[8], mk1[8], mk2[8], mk3[8];  // this lane's mask words: trunk blk 0/1, head blk 0/1
+        const uint32_t base0 = drop ? unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx) : 0u;
         if (drop) {
-            const uint32_t base0 = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
             mf_mask_init(mk0, 0, h, base0, 0u);
             mf_mask_init(mk1, 1, h, base0, 0u);
             mf_mask_init(mk2, 0, h, base0, 1u);
@@ -1354,8 +1379,10 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                     mf_mask_step(mk2);
                     mf_mask_step(mk3);
                 }
-                m0 = mf_dropout(hid0, mk0, a.keep_hi, a.drop_scale);
-                m1 = mf_dropout(hid1, mk1, a.keep_hi, a.drop_scale);
+                if (a.drop_sites & UNERF_DROP_TRUNK) {
+                    m0 = mf_dropout(hid0, mk0, a.keep_hi, a.drop_scale);
+                    m1 = mf_dropout(hid1, mk1, a.keep_hi, a.drop_scale);
+                }
             }
             // trunk out: 64 -> out1 (rows >= out1 are zero-padded): row 0 density, 1..15 geo, 16 beta
             f32x16 t = mf_bias(lds, 2, h);
@@ -1370,6 +1397,13 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             }
             c0 = mf_relu(c0);
             c1 = mf_relu(c1);
+            if (drop && (a.drop_sites & UNERF_DROP_HEAD0)) {   // rgb_dropout_layers contains 1: Dropout in front of Linear 1
+                uint32_t mw[8];
+                mf_mask_words_at(mw, 0, h, base0, 2u, k);
+                c0 = mf_dropout(c0, mw, a.keep_hi, a.drop_scale);
+                mf_mask_words_at(mw, 1, h, base0, 2u, k);
+                c1 = mf_dropout(c1, mw, a.keep_hi, a.drop_scale);
+            }
             // colour 1: 64 -> 64, ReLU
             f32x16 d0 = mf_bias(lds, 5, h), d1 = mf_bias(lds, 6, h);
             d0 = mf_slab(lds, 96, lane, c0, d0);
@@ -1378,7 +1412,7 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             d1 = mf_slab(lds, 144, lane, c1, d1);
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
-            if (drop) {
+            if (drop && (a.drop_sites & UNERF_DROP_HEAD1)) {
                 d0 = mf_dropout(d0, mk2, a.keep_hi, a.drop_scale);
                 d1 = mf_dropout(d1, mk3, a.keep_hi, a.drop_scale);
             }
@@ -1450,6 +1484,13 @@ __device__ __forceinline__ uint32_t mf16_keep_mask(uint32_t word, uint32_t thr_p
 // sigmoid on the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1e-7 relative each) instead of the ~25-instruction
 // exact expf + IEEE division
 __device__ __forceinline__ float mf_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+// softplus on the hardware exp / log (density_activation = "softplus", laplace_model.py:151): log1p by its series
+// where 1 + e would round e away
+__device__ __forceinline__ float mf_softplus_fast(float x) {
+    const float e = __expf(x);
+    const float small = e * (1.f - e * (0.5f - e * (1.f / 3.f)));
+    return x > 20.f ? x : (e < 1e-3f ? small : __logf(1.f + e));
+}
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -1549,7 +1590,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         const int64_t n = ts.n;
         const float dxr = ts.dx, dyr = ts.dy, dzr = ts.dz;
         float px = ts.px, py = ts.py, pz = ts.pz;
-        const float sel = unerf_normalize_position(px, py, pz);
+        const float sel = unerf_normalize_position(px, py, pz, a.box);
         // packed fp32x2 blend: this kernel has the registers for it (123 VGPRs without) in every mode
         const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
 
@@ -1597,8 +1638,9 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.drop_on;
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         uint32_t mk0[8], mk1[8], mk2[8], mk3[8];
+        const uint32_t base0 = drop ? unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx) : 0u;
+        const bool drop_trunk = drop && (a.drop_sites & UNERF_DROP_TRUNK), drop_head1 = drop && (a.drop_sites & UNERF_DROP_HEAD1);
         if (drop) {
-            const uint32_t base0 = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
             mf_mask_init(mk0, 0, h, base0, 0u);
             mf_mask_init(mk1, 1, h, base0, 0u);
             mf_mask_init(mk2, 0, h, base0, 1u);
@@ -1617,7 +1659,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 f16x8 bhi = hhi[st], blo = hlo[st];
-                if (drop) mf16_apply_masks(bhi, blo, st < 2 ? mk0 : mk1, st & 1, a.keep_pk);
+                if (drop_trunk) mf16_apply_masks(bhi, blo, st < 2 ? mk0 : mk1, st & 1, a.keep_pk);
                 t = mf16_mac(lds, 4 + st, lane, bhi, blo, t);
             }
             // colour 0: geo rows of t (registers 0..7 = one k-step) on top of the SH partial sum, ReLU
@@ -1632,10 +1674,23 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             c1 = mf_relu(c1);
             // colour 1: 64 -> 64, ReLU
             f32x16 d0 = mf16_bias(lds, 5, h), d1 = mf16_bias(lds, 6, h);
-            mf16_layer64<2>(lds, 12, lane, c0, c1, d0, d1);
+            if (drop && (a.drop_sites & UNERF_DROP_HEAD0)) {   // rgb_dropout_layers contains 1 (non-default): masks on c
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    f16x8 bhi, blo;
+                    mf16_split(st < 2 ? c0 : c1, st & 1, bhi, blo);
+                    uint32_t mw[8];
+                    mf_mask_words_at(mw, st >> 1, h, base0, 2u, k);
+                    mf16_apply_masks(bhi, blo, mw, st & 1, a.keep_pk);
+                    d0 = mf16_mac(lds, 12 + 2 * st, lane, bhi, blo, d0);
+                    d1 = mf16_mac(lds, 12 + 2 * st + 1, lane, bhi, blo, d1);
+                }
+            } else {
+                mf16_layer64<2>(lds, 12, lane, c0, c1, d0, d1);
+            }
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
-            if (drop) {   // masks on the fp32 accumulators: one half-word compare + one select per unit
+            if (drop_head1) {   // masks on the fp32 accumulators: one half-word compare + one select per unit
                 d0 = mf_dropout_keep(d0, mk2, a.keep_hi);
                 d1 = mf_dropout_keep(d1, mk3, a.keep_hi);
             }
@@ -1696,7 +1751,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 // own load: 254 ms/frame instead of the ~70 ms the MFMA count predicts).
 template <bool SIGMOID>
 __device__ __forceinline__ void mf_lap_head(const float* __restrict__ lap, int q, int lane, int h, const f32x16& s0,
-                                            const f32x16& s1, float& sum1, float& sum2) {
+                                            const f32x16& s1, float& sum1, float& sum2, int softplus = 0) {
     sum1 = 0.f;
     sum2 = 0.f;
     float cur[32], nxt[32];
@@ -1725,7 +1780,7 @@ __device__ __forceinline__ void mf_lap_head(const float* __restrict__ lap, int q
             // hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1e-6 relative) instead of the ~25-instruction exact
             // expf / division: 16 activations follow every 32 MFMAs here and would otherwise take as long as
             // the matrix work.  The results only enter means / variances over the n_lap samples.
-            float p = SIGMOID ? __builtin_amdgcn_rcpf(1.f + __expf(-acc[r])) : __expf(acc[r]);
+            float p = SIGMOID ? __builtin_amdgcn_rcpf(1.f + __expf(-acc[r])) : (softplus ? mf_softplus_fast(acc[r]) : __expf(acc[r]));
             sum1 += p;
             sum2 += p * p;
         }
@@ -1792,7 +1847,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         const float dxr = ts.dx, dyr = ts.dy, dzr = ts.dz;
         float px = ts.px, py = ts.py, pz = ts.pz;
         // inference: the returned mu_d is NOT selector-masked (laplace_field.py:356-362)
-        const float sel = unerf_normalize_position(px, py, pz);
+        const float sel = unerf_normalize_position(px, py, pz, a.box);
         f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
 
         // base_mlp is a bare Linear: no ReLU (utils.py:22-23)
@@ -1812,7 +1867,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
             }
         } else {
             float d1, d2;
-            mf_lap_head<false>(a.p.lap_blob, 0, lane, h, hb0, hb1, d1, d2);
+            mf_lap_head<false>(a.p.lap_blob, 0, lane, h, hb0, hb1, d1, d2, a.p.lap_softplus);
             mu_d = d1 * inv_n;
             mu2_d = d2 * inv_n;
             if (a.p.lap_mask_density) {  // use_deterministic_density: selector-masked mean, no variance
@@ -1896,7 +1951,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
 template <bool SIGMOID>
 __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int q, int n_lap, int lane,
                                               const f16x8 (&bhi)[4], const f16x8 (&blo)[4], int h, float& sum1,
-                                              float& sum2) {
+                                              float& sum2, int softplus = 0) {
     sum1 = 0.f;
     sum2 = 0.f;
     f16x8 cur[8], nxt[8];
@@ -1929,7 +1984,7 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
             if (8 * qd < rows) {  // uniform
 #pragma unroll
                 for (int r = 4 * qd; r < 4 * qd + 4; ++r) {
-                    float p = SIGMOID ? __builtin_amdgcn_rcpf(1.f + __expf(-acc[r])) : __expf(acc[r]);
+                    float p = SIGMOID ? __builtin_amdgcn_rcpf(1.f + __expf(-acc[r])) : (softplus ? mf_softplus_fast(acc[r]) : __expf(acc[r]));
                     sum1 += p;
                     sum2 += p * p;
                 }
@@ -1972,7 +2027,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         const float dxr = ts.dx, dyr = ts.dy, dzr = ts.dz;
         float px = ts.px, py = ts.py, pz = ts.pz;
         // inference: the returned mu_d is NOT selector-masked (laplace_field.py:356-362) unless lap_mask_density
-        const float sel = unerf_normalize_position(px, py, pz);
+        const float sel = unerf_normalize_position(px, py, pz, a.box);
         const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
 
         // base_mlp: bare Linear 32 -> 64 (no ReLU, utils.py:22-23)
@@ -1992,7 +2047,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
 #pragma unroll
         for (int st = 0; st < 4; ++st) t = mf16_mac(lds, 4 + st, lane, xhi[st], xlo[st], t);
         float d1, d2;
-        mf16_lap_head<false>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
+        mf16_lap_head<false>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2, a.p.lap_softplus);
         float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
         if (a.p.lap_mask_density) {  // use_deterministic_density: selector-masked mean, no variance
             mu_d *= sel;
@@ -2071,6 +2126,7 @@ struct GatherArgs {
     const float* scalings;
     int L, log2T;
     float* planes;
+    unerf_norm_box box;   // contraction path only (unerf_field_gather has no aabb argument)
 };
 
 __global__ __launch_bounds__(256) void field_gather_kernel(GatherArgs a) {
@@ -2086,7 +2142,7 @@ __global__ __launch_bounds__(256) void field_gather_kernel(GatherArgs a) {
     float px = a.origins[r * 3 + 0] + a.dirs[r * 3 + 0] * t01 / 2.f;
     float py = a.origins[r * 3 + 1] + a.dirs[r * 3 + 1] * t01 / 2.f;
     float pz = a.origins[r * 3 + 2] + a.dirs[r * 3 + 2] * t01 / 2.f;
-    (void)unerf_normalize_position(px, py, pz);
+    (void)unerf_normalize_position(px, py, pz, a.box);
     const float2* lvl = reinterpret_cast<const float2*>(a.table) + ((size_t)lev << a.log2T);
     float2 f = unerf_hash_level(lvl, px, py, pz, a.scalings[lev], (1u << a.log2T) - 1u);
     reinterpret_cast<float2*>(a.planes)[(int64_t)lev * N + n] = f;
@@ -2102,6 +2158,7 @@ extern "C" int unerf_field_gather(const float* origins, const float* directions,
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
     a.table = table; a.scalings = scalings; a.L = L; a.log2T = log2T; a.planes = feature_planes;
+    a.box = make_norm_box(0, nullptr);
     // blockIdx.x runs fastest in dispatch order, so all workgroups of level l are issued before
     // level l+1: the chip works on (at most) two adjacent level tables at any time
     dim3 grid(blocks_for(R * (int64_t)S, 256), L), block(256);
@@ -2173,9 +2230,12 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = ray_offset;
     a.p = *p; a.density = density; a.rgb = rgb; a.aux = aux; a.aux2 = aux2;
     a.features = features;
+    a.box = make_norm_box(p->use_aabb, p->aabb);
+    UNERF_REQUIRE(!(features && p->use_aabb), "field_fwd: pre-gathered feature planes are built for the contraction path only");
     {   // keep iff (signed 16-bit half) < thr_s = round((1-p) 65536) - 32768; p = 0 keeps everything (no masks)
         const long thr = lrint((1.0 - (double)p->p_drop) * 65536.0);
         a.drop_on = (p->mode == UNERF_FIELD_MCDROPOUT && p->K > 0 && thr < 65536) ? 1 : 0;
+        a.drop_sites = a.drop_on ? (p->drop_sites ? p->drop_sites : (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1)) : 0;
         const int32_t thr_s = (int32_t)(thr < 65536 ? thr : 65535) - 32768;
         a.keep_hi = (int32_t)((uint32_t)thr_s << 16);
         a.keep_pk = ((uint32_t)thr_s & 0xFFFFu) * 0x10001u;
@@ -2201,6 +2261,8 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_MCDROPOUT:
             UNERF_REQUIRE(p->out1 == 16, "field_fwd MCDROPOUT: out1 must be 16");
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
+            UNERF_REQUIRE((p->drop_sites & ~(UNERF_DROP_TRUNK | UNERF_DROP_HEAD0 | UNERF_DROP_HEAD1)) == 0,
+                          "field_fwd MCDROPOUT: unknown bits in drop_sites=%d", p->drop_sites);
             if (p->mfma16_blob && !features) {
                 if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>, MF_LDS_F16, a, st);
@@ -2372,8 +2434,10 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     FieldArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = 0;
+    UNERF_REQUIRE(!p->lap_softplus, "laplace_ggn_diag: the closed-form Jacobian is built for the trunc_exp density activation only");
     a.p = *p; a.density = sigma; a.rgb = col; a.aux = X; a.aux2 = Hc; a.features = nullptr;
-    a.keep_hi = 0; a.keep_pk = 0; a.drop_on = 0; a.drop_scale = 1.f;
+    a.keep_hi = 0; a.keep_pk = 0; a.drop_on = 0; a.drop_sites = 0; a.drop_scale = 1.f;
+    a.box = make_norm_box(p->use_aabb, p->aabb);
     a.p.image_width = 0;   // 1-D tiles
     if (p->tcnn_levels) launch_matrix_kernel(field_kernel_mfma_laplace<true, true>, MF_LDS_FP32, a, st);
     else launch_matrix_kernel(field_kernel_mfma_laplace<true>, MF_LDS_FP32, a, st);

@@ -330,26 +330,41 @@ class NerfactoMCDropoutField(_NerfactoFieldBase):
         super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
                          implementation)
         assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
-        rgb_dropout_layers = [-1] if rgb_dropout_layers is None else rgb_dropout_layers
-        assert density_dropout_layers and list(rgb_dropout_layers) == [-1], \
-            "kernels implement the reference default: dropout before the last Linear of trunk and head"
+        rgb_dropout_layers = [-1] if rgb_dropout_layers is None else list(rgb_dropout_layers)
+        # create_mlp (utils.py:6-43) puts a Dropout in front of Linear i for every i in dropout_layers; -1 and
+        # num_layers - 1 both mean "in front of the last Linear".  Built: the trunk's hidden layer
+        # (density_dropout_layers) and the colour head's two hidden layers; index 0 would drop the head's INPUT
+        # (direction encoding / appearance embedding), which is folded into constants here.
+        bad = [i for i in rgb_dropout_layers if i not in (-1, 1, 2)]
+        if bad:
+            raise NotImplementedError(f"rgb_dropout_layers={rgb_dropout_layers}: dropout on the colour head's input (index 0) is not built")
+        self.density_dropout_layers = bool(density_dropout_layers)
+        self.rgb_dropout_layers = rgb_dropout_layers
+        self.drop_sites = ((_l.DROP_TRUNK if density_dropout_layers else 0) | (_l.DROP_HEAD0 if 1 in rgb_dropout_layers else 0)
+                           | (_l.DROP_HEAD1 if (-1 in rgb_dropout_layers or 2 in rgb_dropout_layers) else 0))
         self.dropout_rate = dropout_rate
         self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
                                           implementation=implementation)
+        # density_dropout_layers=False leaves the parent's trunk in place (mcdropout_fields.py:112, :162-166); it is the
+        # same Linear-ReLU-Linear without the Dropout module (state-dict indices 0, 2 instead of 0, 3)
         self.mlp_base = create_mlp(self.mlp_base_grid.get_out_dim(), num_layers, hidden_dim, 1 + geo_feat_dim,
-                                   activation=nn.ReLU, dropout_layers=[-1], dropout_rate=dropout_rate)
+                                   activation=nn.ReLU, dropout_layers=[-1] if density_dropout_layers else None,
+                                   dropout_rate=dropout_rate)
         self.mlp_head = create_mlp(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color, hidden_dim_color, 3,
                                    activation=nn.ReLU, out_activation=nn.Sigmoid, dropout_layers=rgb_dropout_layers,
                                    dropout_rate=dropout_rate)
 
     def to_device(self, device, mc_samples=10, seed=0, **kw) -> ops.FieldDev:
-        b, h = self.mlp_base, self.mlp_head
+        bl = [m for m in self.mlp_base if isinstance(m, nn.Linear)]
+        hl = [m for m in self.mlp_head if isinstance(m, nn.Linear)]
+        # no Dropout module anywhere: the K passes are identical -- p = 0 switches the mask generation off
+        p_drop = self.dropout_rate if self.drop_sites else 0.0
         return ops.FieldDev.from_torch(
             _l.FIELD_MCDROPOUT, self.mlp_base_grid.table, self.mlp_base_grid.scalings,
-            self.mlp_base_grid.log2_hashmap_size, b[0].weight, b[0].bias, b[3].weight, b[3].bias,
-            [h[0].weight, h[2].weight, h[5].weight], [h[0].bias, h[2].bias, h[5].bias], self.eval_appearance(), device,
-            average_init_density=self.average_init_density, K=mc_samples, seed=seed, p_drop=self.dropout_rate,
-            **self._grid_kw(self.mlp_base_grid), **kw)
+            self.mlp_base_grid.log2_hashmap_size, bl[0].weight, bl[0].bias, bl[1].weight, bl[1].bias,
+            [m.weight for m in hl], [m.bias for m in hl], self.eval_appearance(), device,
+            average_init_density=self.average_init_density, K=mc_samples, seed=seed, p_drop=p_drop,
+            drop_sites=self.drop_sites, **self._grid_kw(self.mlp_base_grid), **kw)
 
     def _forward_kw(self):
         return {"mc_samples": 0}   # eval-mode Dropout is the identity; the K stochastic passes are the Model's job
@@ -374,7 +389,9 @@ class NerfactoLaplaceField(_NerfactoFieldBase):
         super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
                          implementation)
         assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
-        assert density_activation == "trunc_exp", "softplus density activation is not built"
+        if density_activation not in ("trunc_exp", "softplus"):        # laplace_model.py:151
+            raise ValueError(f"density_activation={density_activation!r}: expected 'trunc_exp' or 'softplus'")
+        self.density_activation = density_activation
         self.register_buffer("aabb", torch.zeros(2, 3) if aabb is None else aabb)
         self.register_buffer("max_res", torch.tensor(max_res))
         self.register_buffer("num_levels", torch.tensor(num_levels))
@@ -452,4 +469,4 @@ class NerfactoLaplaceField(_NerfactoFieldBase):
             self.base_mlp[0].weight, self.base_mlp[0].bias, self.mlp_hidden.weight, self.mlp_hidden.bias,
             [h[0].weight, h[2].weight, self.mlp_rgb_ll.weight], [h[0].bias, h[2].bias, self.mlp_rgb_ll.bias],
             self.eval_appearance(), device, ws_density=f(ws_density), ws_rgb=f(ws_rgb),
-            **self._grid_kw(self.base_grid), **kw)
+            lap_softplus=int(self.density_activation == "softplus"), **self._grid_kw(self.base_grid), **kw)

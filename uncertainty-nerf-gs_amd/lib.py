@@ -82,7 +82,7 @@ class DensityNet(C.Structure):
         ("table", C.c_void_p), ("scalings", C.c_void_p), ("L", C.c_int), ("log2T", C.c_int),
         ("w0t", C.c_void_p), ("b0", C.c_void_p), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("hidden", C.c_int),
         ("dense", C.c_void_p), ("n_dense", C.c_int), ("dense_off", C.c_int * 8), ("dense_dim", C.c_int * 8),
-        ("tcnn_levels", C.c_void_p),
+        ("tcnn_levels", C.c_void_p), ("use_aabb", C.c_int), ("aabb", C.c_float * 6),
     ]
 
 
@@ -99,11 +99,13 @@ class FieldParams(C.Structure):
         ("mfma_blob", C.c_void_p), ("lap_blob", C.c_void_p),
         ("tcnn_levels", C.c_void_p),
         ("mfma16_blob", C.c_void_p), ("lap16_blob", C.c_void_p),
-        ("image_width", C.c_int), ("sample_major", C.c_int),
+        ("image_width", C.c_int), ("sample_major", C.c_int), ("drop_sites", C.c_int), ("lap_softplus", C.c_int), ("use_aabb", C.c_int),
+        ("aabb", C.c_float * 6),
     ]
 
 
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
+DROP_TRUNK, DROP_HEAD0, DROP_HEAD1 = 1, 2, 4     # include/unerf.h: UNERF_DROP_*
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 _fp = C.POINTER(C.c_float)

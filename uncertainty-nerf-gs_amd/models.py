@@ -150,8 +150,6 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
     # -- construction -------------------------------------------------------------------------
     def _field_kwargs(self):
         c = self.config
-        if c.disable_scene_contraction:
-            raise NotImplementedError("only SceneContraction(order=inf) is built (the reference default)")
         return dict(num_images=self.num_train_data, hidden_dim=c.hidden_dim, num_levels=c.num_levels, max_res=c.max_res,
                     base_res=c.base_res, features_per_level=c.features_per_level,
                     log2_hashmap_size=c.log2_hashmap_size, hidden_dim_color=c.hidden_dim_color,
@@ -193,8 +191,18 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self._dev_scene is None or self._dev_scene.device != device:
             c = self.config
+            fd, props = self._field_to_device(device), [p.to_device(device) for p in self.proposal_networks]
+            if c.disable_scene_contraction:
+                # mcdropout_models.py:60-63 / activenerfacto_model.py:57-60: spatial_distortion = None -> every network
+                # normalises positions with SceneBox.get_normalized_positions(positions, self.scene_box.aabb)
+                if self.scene_box is None or getattr(self.scene_box, "aabb", None) is None:
+                    raise ValueError("disable_scene_contraction needs scene_box.aabb ([2,3])")
+                box = tuple(float(v) for v in torch.as_tensor(self.scene_box.aabb).reshape(-1))
+                fd.aabb = box
+                for p in props:
+                    p.aabb = box
             self._dev_scene = NerfSceneDev(
-                field=self._field_to_device(device), props=[p.to_device(device) for p in self.proposal_networks],
+                field=fd, props=props,
                 near=c.near_plane, far=c.far_plane, num_prop=tuple(c.num_proposal_samples_per_ray),
                 num_nerf=c.num_nerf_samples_per_ray, prop_average_init_density=c.average_init_density,
                 chunk_rays=c.eval_num_rays_per_chunk)
@@ -291,6 +299,23 @@ class NerfactoMCDropoutModel(_NerfactoBase):
 
     def _field_to_device(self, device):
         return self.field.to_device(device, mc_samples=self.config.mc_samples, seed=self.seed)
+
+    def load_state_dict(self, state_dict, strict: bool = False, **kw):  # type: ignore[override]
+        """density_dropout_layers=False keeps the PARENT's trunk (mcdropout_fields.py:112, :162-166), whose checkpoint
+        names are nerfstudio's [UPSTREAM-RECALL NerfactoField.mlp_base = MLPWithHashEncoding, torch implementation:
+        `mlp_base.encoder.hash_table`, `mlp_base.mlp.layers.{0,1}.*`, mirrored under `mlp_base.model.{0,1}.*`]; they are
+        mapped onto this mirror's `mlp_base_grid.hash_table` / `mlp_base.{0,2}.*`."""
+        if not self.config.density_dropout_layers:
+            ren = {}
+            for k, v in state_dict.items():
+                k2 = k
+                for a, b in (("field.mlp_base.encoder.", "field.mlp_base_grid."), ("field.mlp_base.model.0.", "field.mlp_base_grid."),
+                             ("field.mlp_base.mlp.layers.0.", "field.mlp_base.0."), ("field.mlp_base.mlp.layers.1.", "field.mlp_base.2."),
+                             ("field.mlp_base.model.1.layers.0.", "field.mlp_base.0."), ("field.mlp_base.model.1.layers.1.", "field.mlp_base.2.")):
+                    k2 = k2.replace(a, b)
+                ren[k2] = v
+            state_dict = ren
+        return super().load_state_dict(state_dict, strict=strict, **kw)
 
 
 class NerfactoLaplaceModel(_NerfactoBase):

@@ -179,6 +179,12 @@ def build_dense_pairs(table: torch.Tensor, scalings: torch.Tensor, log2T: int, m
     return torch.cat(chunks, dim=0).contiguous(), offs, dims
 
 
+def _aabb6(aabb):
+    vals = [0.0] * 6 if aabb is None else [float(v) for v in aabb]
+    assert len(vals) == 6
+    return (C.c_float * 6)(*vals)
+
+
 @dataclass
 class DensityNetDev:
     """Device-resident proposal network (hash grid + Linear-ReLU-Linear), weights transposed."""
@@ -194,6 +200,7 @@ class DensityNetDev:
     dense_dim: Tuple[int, ...] = ()
     use_dense: bool = True
     tcnn_levels: Optional[torch.Tensor] = None   # device records: `table` is then a tcnn-layout parameter vector
+    aabb: Optional[Tuple[float, ...]] = None     # 6 floats: scene-box normalisation instead of the contraction
 
     @classmethod
     def from_torch(cls, table, scalings, log2T, w0, b0, w1, b1, device, tcnn_levels=None):
@@ -212,7 +219,8 @@ class DensityNetDev:
         dims = (C.c_int * 8)(*(list(self.dense_dim[:nd]) + [0] * (8 - nd)))
         return _l.DensityNet(_p(self.table), _p(self.scalings), self.scalings.numel(), self.log2T, _p(self.w0t),
                              _p(self.b0), _p(self.w1t), _p(self.b1), self.b0.numel(),
-                             _p(self.dense) if nd else None, nd, offs, dims, _p(self.tcnn_levels, torch.int32))
+                             _p(self.dense) if nd else None, nd, offs, dims, _p(self.tcnn_levels, torch.int32),
+                             0 if self.aabb is None else 1, _aabb6(self.aabb))
 
 
 @dataclass
@@ -251,6 +259,10 @@ class FieldDev:
     lap16_blob: Optional[torch.Tensor] = None
     precision: str = "f16x2"                     # "f16x2": split-f16 matrix kernels (fp32-equivalent); "fp32": exact
     packed_drop_scale: float = 1.0               # the inverted-dropout scale folded into mfma16_blob at pack time
+    drop_sites: int = 0                          # UNERF_DROP_* bits (0 = reference default: trunk + last head layer)
+    packed_drop_sites: int = 0                   # ... and the layers it was folded into
+    lap_softplus: int = 0                        # LAPLACE: density_activation "softplus" instead of trunc_exp
+    aabb: Optional[Tuple[float, ...]] = None     # 6 floats: scene-box normalisation instead of the contraction
 
     @classmethod
     def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device,
@@ -267,8 +279,10 @@ class FieldDev:
         blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
                                  geo_first_unit=0 if lap else 1))
         kw["packed_drop_scale"] = cls._drop_scale(mode, int(kw.get("K", 0)), float(kw.get("p_drop", 0.2)))
+        kw["packed_drop_sites"] = cls._sites(int(kw.get("drop_sites", 0)))
         blob16 = pack_field_mfma16(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
-                                   geo_first_unit=0 if lap else 1, drop_scale=kw["packed_drop_scale"])
+                                   geo_first_unit=0 if lap else 1, drop_scale=kw["packed_drop_scale"],
+                                   drop_sites=kw["packed_drop_sites"])
         kw["mfma16_blob"] = None if blob16 is None else f(blob16)   # None (weights beyond the f16 range): exact kernels
         lap_blob = None
         if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
@@ -284,9 +298,14 @@ class FieldDev:
         """1/(1-p) when the kernels generate dropout masks (MCDROPOUT, K > 0), else 1"""
         return 1.0 / (1.0 - p_drop) if (mode == _l.FIELD_MCDROPOUT and K > 0) else 1.0
 
+    @staticmethod
+    def _sites(drop_sites: int) -> int:
+        return drop_sites if drop_sites else (_l.DROP_TRUNK | _l.DROP_HEAD1)
+
     def cstruct(self) -> _l.FieldParams:
         use16 = self.use_mfma and self.precision == "f16x2" and self.mfma16_blob is not None
-        if use16 and abs(self._drop_scale(self.mode, self.K, self.p_drop) - self.packed_drop_scale) > 1e-7:
+        if use16 and (abs(self._drop_scale(self.mode, self.K, self.p_drop) - self.packed_drop_scale) > 1e-7
+                      or (self.packed_drop_scale != 1.0 and self._sites(self.drop_sites) != self.packed_drop_sites)):
             # the split-f16 operands carry 1/(1-p) inside two weight matrices: K (0 <-> > 0) or p_drop changed since
             # from_torch().  The exact kernels apply the scale at run time, so the two paths would silently disagree.
             raise _l.UnerfError(
@@ -302,7 +321,8 @@ class FieldDev:
             _p(self.mfma_blob) if self.use_mfma else None, _p(self.lap_blob) if self.use_mfma else None,
             _p(self.tcnn_levels, torch.int32),
             _p(self.mfma16_blob) if (self.use_mfma and self.precision == "f16x2") else None,
-            _p(self.lap16_blob) if (self.use_mfma and self.precision == "f16x2") else None, 0)
+            _p(self.lap16_blob) if (self.use_mfma and self.precision == "f16x2") else None, 0, 0, int(self.drop_sites), int(self.lap_softplus),
+            0 if self.aabb is None else 1, _aabb6(self.aabb))
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------
@@ -398,14 +418,18 @@ def _split_f16(w: torch.Tensor):
 
 
 def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit: int = 1,
-                      drop_scale: float = 1.0) -> torch.Tensor:
+                      drop_scale: float = 1.0, drop_sites: int = 5) -> torch.Tensor:
     """Same arguments and same blob size as pack_field_mfma; the first 10240 floats hold the 20 split-f16
     A-operand slabs [slab][hi|lo][lane][8 halves], the bias rows and the rgb layer follow (fp32).
     drop_scale = 1/(1-p) when MC-dropout masks are applied in front of the trunk-out and rgb layers: the
     inverted-dropout scale is folded into those two weight matrices (the kernel then only zeroes units)."""
     f = lambda t: t.detach().to("cpu", torch.float32)
     w0f, w1f, h0f, h1f = map(f, (w0, w1, h0, h1))
-    w1f = w1f * float(drop_scale)
+    # the scale sits in the layer BEHIND each active dropout site (include/unerf.h: UNERF_DROP_*)
+    if drop_sites & 1:
+        w1f = w1f * float(drop_scale)
+    if drop_sites & 2:
+        h1f = h1f * float(drop_scale)
     out1 = w1f.shape[0]
     assert w0f.shape == (64, 32) and w1f.shape[1] == 64 and out1 <= 32 and h0f.shape == (64, 31) and h1f.shape == (64, 64)
     if max(float(abs(w).max()) for w in (w0f, w1f, h0f, h1f)) >= F16_OPERAND_LIMIT:
@@ -433,7 +457,8 @@ def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit:
     frag = torch.stack([hi, lo], dim=1).contiguous()      # [slab][hi|lo][lane][8]
     head = frag.view(torch.int16).reshape(-1).view(torch.float32)
     assert head.numel() == MF16_SLABS * MF16_SLAB_FLOATS == MFMA_BIAS_OFF
-    tail = pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, f(h2) * float(drop_scale), hb2, geo_first_unit)[MFMA_BIAS_OFF:]
+    tail = pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, f(h2) * (float(drop_scale) if drop_sites & 4 else 1.0), hb2,
+                           geo_first_unit)[MFMA_BIAS_OFF:]
     return torch.cat([head, tail])
 
 
@@ -620,6 +645,8 @@ def laplace_ggn_diag(origins, directions, sbins, field: FieldDev, density_mean: 
     lib = _l.load()
     if field.mode != _l.FIELD_LAPLACE:
         raise _l.UnerfError("laplace_ggn_diag needs a LAPLACE field")
+    if field.lap_softplus:
+        raise NotImplementedError("GGN fitting is built for density_activation='trunc_exp' (the reference default) only")
     R, S = sbins.shape[0], sbins.shape[1] - 1
     dev = origins.device
     cs = field.cstruct()

@@ -108,6 +108,11 @@ def scene_to_device(t: Dict, device, **field_kw) -> NerfSceneDev:
                                  sh_remap=int(bool(f.get("sh_remap", False))), **field_kw)
     props = [ops.DensityNetDev.from_torch(p["table"], p["scalings"], p["log2T"], p["w0"], p["b0"], p["w1"], p["b1"],
                                           device, tcnn_levels=p.get("tcnn_levels")) for p in t["props"]]
+    if t.get("aabb") is not None:   # disable_scene_contraction: scene-box normalisation in every network
+        box = tuple(float(v) for v in t["aabb"].reshape(-1))
+        fd.aabb = box
+        for p in props:
+            p.aabb = box
     return NerfSceneDev(field=fd, props=props, near=float(t["near"]), far=float(t["far"]),
                         num_prop=tuple(t["num_prop"]), num_nerf=int(t["num_nerf"]),
                         prop_average_init_density=float(t["prop_average_init_density"]))
