@@ -36,8 +36,10 @@ def reduce(src, dst):
             w.writerow([k, c, n, f"{v / n:.6f}", f"{d / n:.3f}"])
 
 
-FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false>", "field_kernel_mfma<0, false, false>", "field_kernel_mfma<0, false>"),
-                 "mcdropout": ("field_kernel_mfma16<1, false>", "field_kernel_mfma<1, false, false>", "field_kernel_mfma<1, false>")}
+FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false, false>", "field_kernel_mfma16<0, false>", "field_kernel_mfma<0, false, false>",
+                            "field_kernel_mfma<0, false>"),
+                 "mcdropout": ("field_kernel_mfma16<1, false, false>", "field_kernel_mfma16<1, false>", "field_kernel_mfma<1, false, false>",
+                               "field_kernel_mfma<1, false>")}
 
 
 def summary(d, tag):

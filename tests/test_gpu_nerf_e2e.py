@@ -176,8 +176,12 @@ def test_disable_scene_contraction_uses_the_scene_box(dev, kind):
     assert sd.field.aabb is not None and sd.props[1].aabb is not None
     v = lambda x: x.view(H, W, -1)
     _gates(f"aabb-{kind}", v(out["rgb"].cpu()), v(out["rgb_std"].cpu()), v(ref["rgb"]), v(ref["rgb_std"]))
-    _img_close(v(out["rgb"]), v(ref["rgb"]), 5e-5, 0, "rgb")
-    _img_close(v(out["accumulation"]), v(ref["accumulation"]), 2e-4, 0, "accumulation")
+    # the box has a HARD edge: a sample within an ulp of a face can fall on different sides in the two pipelines (their
+    # sample positions differ by ~1e-6, see test_active_nerfacto_camera_parity) and take or lose its whole density
+    _img_close(v(out["rgb"]), v(ref["rgb"]), 5e-5, 0, "rgb", max_bad_frac=2e-2)
+    _img_close(v(out["rgb"]), v(ref["rgb"]), 2e-3, 0, "rgb (all pixels)")
+    _img_close(v(out["accumulation"]), v(ref["accumulation"]), 2e-4, 0, "accumulation", max_bad_frac=2e-2)
+    _img_close(v(out["accumulation"]), v(ref["accumulation"]), 2e-3, 0, "accumulation (all pixels)")
     _img_close(v(out["expected_depth"]), v(ref["expected_depth"]), 0, 1e-3, "expected_depth", max_bad_frac=1e-2)
     # the contraction path gives a different image: far samples are outside the box here and contribute nothing
     t2 = dict(t)

@@ -1563,7 +1563,11 @@ __device__ __forceinline__ void mf16_apply_masks(f16x8& hi, f16x8& lo, const uin
     lo = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, lo) & m);
 }
 
-template <int MODE, bool TCNN>
+// SITES = false: the reference's default Dropout placement (trunk + last head layer), every site test a compile-time
+// constant.  SITES = true: any other unerf_field_params.drop_sites (run-time site tests, and the words of the
+// UNERF_DROP_HEAD0 site recomputed per pass).  A separate instantiation: as run-time branches of the default kernel
+// they cost that kernel 50 VGPRs and 84 bytes of scratch (K = 8 field kernel 50 -> 55.6 ms).
+template <int MODE, bool TCNN, bool SITES = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && !TCNN) ? 3 : 2)))
 void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
@@ -1638,9 +1642,12 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.drop_on;
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         uint32_t mk0[8], mk1[8], mk2[8], mk3[8];
-        const uint32_t base0 = drop ? unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx) : 0u;
-        const bool drop_trunk = drop && (a.drop_sites & UNERF_DROP_TRUNK), drop_head1 = drop && (a.drop_sites & UNERF_DROP_HEAD1);
+        uint32_t base0_h0 = 0u;   // SITES only: the sample's base hash stays live across the passes
+        const bool drop_trunk = SITES ? (drop && (a.drop_sites & UNERF_DROP_TRUNK)) : drop;
+        const bool drop_head1 = SITES ? (drop && (a.drop_sites & UNERF_DROP_HEAD1)) : drop;
         if (drop) {
+            const uint32_t base0 = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
+            if (SITES) base0_h0 = base0;
             mf_mask_init(mk0, 0, h, base0, 0u);
             mf_mask_init(mk1, 1, h, base0, 0u);
             mf_mask_init(mk2, 0, h, base0, 1u);
@@ -1674,13 +1681,13 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             c1 = mf_relu(c1);
             // colour 1: 64 -> 64, ReLU
             f32x16 d0 = mf16_bias(lds, 5, h), d1 = mf16_bias(lds, 6, h);
-            if (drop && (a.drop_sites & UNERF_DROP_HEAD0)) {   // rgb_dropout_layers contains 1 (non-default): masks on c
+            if (SITES && drop && (a.drop_sites & UNERF_DROP_HEAD0)) {   // rgb_dropout_layers contains 1 (non-default): masks on c
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     f16x8 bhi, blo;
                     mf16_split(st < 2 ? c0 : c1, st & 1, bhi, blo);
                     uint32_t mw[8];
-                    mf_mask_words_at(mw, st >> 1, h, base0, 2u, k);
+                    mf_mask_words_at(mw, st >> 1, h, base0_h0, 2u, k);
                     mf16_apply_masks(bhi, blo, mw, st & 1, a.keep_pk);
                     d0 = mf16_mac(lds, 12 + 2 * st, lane, bhi, blo, d0);
                     d1 = mf16_mac(lds, 12 + 2 * st + 1, lane, bhi, blo, d1);
@@ -2264,7 +2271,10 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE((p->drop_sites & ~(UNERF_DROP_TRUNK | UNERF_DROP_HEAD0 | UNERF_DROP_HEAD1)) == 0,
                           "field_fwd MCDROPOUT: unknown bits in drop_sites=%d", p->drop_sites);
             if (p->mfma16_blob && !features) {
-                if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>, MF_LDS_F16, a, st);
+                const bool head0 = a.drop_on && a.drop_sites != (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1);   // non-default sites
+                if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, true>, MF_LDS_F16, a, st);
+                else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true>, MF_LDS_F16, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob) {
                 if (features) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>, MF_LDS_FP32, a, st);
