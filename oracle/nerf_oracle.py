@@ -532,8 +532,20 @@ def active_field(origins, directions, euclid_bins, fp: FieldParams):
     return density, rgb.view(R, S, 3), beta
 
 
+def _linear(x, w, b, autocast: Optional[torch.dtype] = None):
+    """nn.Linear, optionally the way torch.autocast runs it (mcdropout_models.py:86-92 forces autocast at eval: fp16 on
+    a GPU, bf16 on the CPU): operands rounded to the low-precision type, fp32 accumulation, result rounded to that type.
+    Used only to MEASURE how far the reference's autocast arithmetic is from its fp32 semantics (the semantics this
+    build matches, DESIGN.md section 1 "Precision")."""
+    if autocast is None:
+        return F.linear(x, w, b)
+    r = lambda t: t.to(autocast).to(torch.float32)
+    return r(F.linear(r(x), r(w), r(b)))
+
+
 def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trunk: Optional[torch.Tensor],
-                    keep_head: Optional[torch.Tensor], p_drop: float, keep_head0: Optional[torch.Tensor] = None):
+                    keep_head: Optional[torch.Tensor], p_drop: float, keep_head0: Optional[torch.Tensor] = None,
+                    autocast: Optional[torch.dtype] = None):
     """[REF mcdropout_fields.py:110-174 + utils.py:6-43]
     trunk = Linear(32,64),ReLU,Dropout,Linear(64,16); head = Linear(63,64),ReLU,[Dropout,]Linear(64,64),ReLU,
     Dropout,Linear(64,3),Sigmoid.  keep_* are bool masks [R*S,64] (None = no Dropout module at that site):
@@ -544,21 +556,21 @@ def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trun
     pos = sample_positions(origins, directions, euclid_bins)
     p, sel = normalized_positions(pos, fp.grid.aabb)
     feat = grid_encode(p.reshape(-1, 3), fp.grid)
-    h = F.relu(F.linear(feat, fp.grid.weights[0], fp.grid.biases[0]))
+    h = F.relu(_linear(feat, fp.grid.weights[0], fp.grid.biases[0], autocast))
     if keep_trunk is not None:
         h = h * keep_trunk.to(h.dtype) * scale
-    out = F.linear(h, fp.grid.weights[1], fp.grid.biases[1]).view(R, S, -1)
+    out = _linear(h, fp.grid.weights[1], fp.grid.biases[1], autocast).view(R, S, -1)
     g = fp.geo_feat_dim
     density = fp.average_init_density * torch.exp(out[..., 0]) * sel
     geo = out[..., 1:1 + g]
     x = _color_inputs(directions, S, geo, fp.appearance, fp.sh_remap)
-    x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
+    x = F.relu(_linear(x, fp.head_w[0], fp.head_b[0], autocast))
     if keep_head0 is not None:
         x = x * keep_head0.to(x.dtype) * scale
-    x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
+    x = F.relu(_linear(x, fp.head_w[1], fp.head_b[1], autocast))
     if keep_head is not None:
         x = x * keep_head.to(x.dtype) * scale
-    rgb = torch.sigmoid(F.linear(x, fp.head_w[2], fp.head_b[2]))
+    rgb = torch.sigmoid(_linear(x, fp.head_w[2], fp.head_b[2], autocast))
     return density, rgb.view(R, S, 3)
 
 
@@ -734,7 +746,7 @@ def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, den
 
 
 def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, p_drop: float,
-                      ray_offset: int = 0, drop_sites: int = 5) -> Dict[str, torch.Tensor]:
+                      ray_offset: int = 0, drop_sites: int = 5, autocast: Optional[torch.dtype] = None) -> Dict[str, torch.Tensor]:
     """[REF mcdropout_models.py:94-131] K stochastic passes of one chunk + mean / unbiased std.
     Masks come from the shared counter RNG keyed by the global sample index
     (ray_offset+r)*S+s, so chunking does not change them."""
@@ -748,7 +760,7 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
         kt = torch.from_numpy(mc_keep_mask(seed, k, sidx, 0, 64, p_drop)) if drop_sites & 1 else None
         kh0 = torch.from_numpy(mc_keep_mask(seed, k, sidx, 2, 64, p_drop)) if drop_sites & 2 else None
         kh = torch.from_numpy(mc_keep_mask(seed, k, sidx, 1, 64, p_drop)) if drop_sites & 4 else None
-        density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop, keep_head0=kh0)
+        density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop, keep_head0=kh0, autocast=autocast)
         outs.append(nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb))
     res = {}
     for key in outs[0].keys():

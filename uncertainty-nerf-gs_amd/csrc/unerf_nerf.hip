@@ -32,7 +32,7 @@ int unerf_check_launch(const char* what) {
     return UNERF_OK;
 }
 extern "C" const char* unerf_last_error(void) { return g_err; }
-extern "C" int unerf_version(void) { return 1000; }
+extern "C" int unerf_version(void) { return 1100; }   // 1100: round-2 ABI (drop_sites, sample_major planes, aabb, ...)
 extern "C" int unerf_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
