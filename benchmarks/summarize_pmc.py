@@ -38,7 +38,7 @@ def reduce(src, dst):
 
 FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false, false>", "field_kernel_mfma16<0, false>", "field_kernel_mfma<0, false, false>",
                             "field_kernel_mfma<0, false>"),
-                 "mcdropout": ("field_kernel_mfma16<1, false, false>", "field_kernel_mfma16<1, false>", "field_kernel_mfma<1, false, false>",
+                 "mcdropout": ("field_kernel_mfma16<1, false, false, true>", "field_kernel_mfma16<1, false, false>", "field_kernel_mfma16<1, false>", "field_kernel_mfma<1, false, false>",
                                "field_kernel_mfma<1, false>")}
 
 

@@ -61,3 +61,40 @@ def test_one_member_per_gpu_over_rccl_matches_the_reference_fixture(tag):
                 np.testing.assert_allclose(ret[r][k], v.numpy(), rtol=1e-6, atol=1e-7, err_msg=f"rank {r}: {k}")
             for k in single:
                 assert np.array_equal(ret[r][k], ret[0][k]), f"ranks disagree on {k}"
+
+
+def _solo_worker(rank, world, port, tag, ret):
+    """world_size 1 over NCCL: all members on the one GPU, but the same collectives (all_to_all_single, all_gather)
+    and the HIP moments kernel as in the multi-GPU run"""
+    import torch.distributed as dist
+    from uncertainty_nerf_gs_amd import ensemble, lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    lib.build_library()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    g = golden("ensemble.npz")
+    members = [{k: v.to(dev) for k, v in _member(g, tag, i).items()} for i in range(5)]
+    out = ensemble.aggregate_distributed(members)
+    torch.cuda.synchronize()
+    ret[0] = {k: v.cpu().numpy() for k, v in out.items()}
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag", ["plain", "alea"])
+def test_rccl_collectives_with_hip_moments_on_one_gpu_match_the_reference_fixture(tag):
+    """The 1-GPU box cannot run one member per GPU, but it can run the same code path: an NCCL (= RCCL) process group
+    of size 1, the all_to_all_single / all_gather calls of aggregate_distributed on device tensors, the HIP moments
+    kernel -- 5 members against the REFERENCE's EnsemblePipeline output recorded in tests/golden/ensemble.npz."""
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    g = golden("ensemble.npz")
+    expect = {k[len(f"{tag}_out_"):]: g[k] for k in g.files if k.startswith(f"{tag}_out_")}
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_solo_worker, args=(1, _free_port(), tag, ret), nprocs=1, join=True)
+        assert set(ret[0]) == set(expect)
+        for k, v in expect.items():
+            np.testing.assert_allclose(ret[0][k], v, rtol=1e-6, atol=1e-7, err_msg=k)

@@ -63,10 +63,15 @@ __host__ __device__ __forceinline__ uint32_t unerf_mask_word0(uint32_t base0, ui
 __host__ __device__ __forceinline__ uint32_t unerf_mask_step(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t y = __builtin_amdgcn_alignbit(x, x, 22);
+    uint32_t r = y + (y << 6);
+    // opaque to the optimiser: it otherwise recomputes the stepped word as y * 65 with a quarter-rate v_mul_lo_u32
+    // next to the v_lshl_add_u32 that updates the state (seen in the K-pass kernel: 16 multiplies per pass)
+    asm("" : "+v"(r));
+    return r;
 #else
     const uint32_t y = (x >> 22) | (x << 10);
-#endif
     return y + (y << 6);
+#endif
 }
 // keep tests for one word on a scalar path: thr_hi = thr_s << 16 (a signed 32-bit number with zero low half).
 // Written as 16-bit signed compares so that the compiler can select v_cmp_lt_i16 (low half) and its SDWA form

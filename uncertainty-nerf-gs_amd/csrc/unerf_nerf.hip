@@ -430,6 +430,13 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
                 s_od[c][lane] = a.origins[r * 3 + c];
                 s_od[3 + c][lane] = a.dirs[r * 3 + c];
             }
+        } else if (wv == 1 && a.sstride == 0) {
+            // one shared row of bin edges (the 256 initial bins): the Euclidean edges are the same for every ray, so
+            // five lanes convert them ONCE for the workgroup (one conversion stream instead of two per wave; a
+            // conversion is an IEEE division and the kernel is VALU-issue bound) and every lane reads them back
+            const float* sb = a.sbins + i_base;
+            const float e = unerf_s2e(sb[min((int)(lane < 5u ? lane : 4u), a.n - i_base)], a.s_near, a.s_far);
+            if (lane < 5u) s_e[lane][0] = e;
         } else if (wv == 1) {
             const float* sb = a.sbins + r * a.sstride + i_base;
             if (i_base + 4 <= a.n) {  // uniform
@@ -447,7 +454,8 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
     const int i = i_base + (int)wv;
     float dens = 0.f;
     if (ray_ok && i < a.n) {
-        const float t = unerf_s2e(s_e[wv][lane], a.s_near, a.s_far) + unerf_s2e(s_e[wv + 1][lane], a.s_near, a.s_far);
+        const float t = a.sstride == 0 ? s_e[wv][0] + s_e[wv + 1][0]   // uniform: already Euclidean (same bits)
+                                       : unerf_s2e(s_e[wv][lane], a.s_near, a.s_far) + unerf_s2e(s_e[wv + 1][lane], a.s_near, a.s_far);
         float px = s_od[0][lane] + s_od[3][lane] * t / 2.f;
         float py = s_od[1][lane] + s_od[4][lane] * t / 2.f;
         float pz = s_od[2][lane] + s_od[5][lane] * t / 2.f;
@@ -1567,7 +1575,9 @@ __device__ __forceinline__ void mf16_apply_masks(f16x8& hi, f16x8& lo, const uin
 // constant.  SITES = true: any other unerf_field_params.drop_sites (run-time site tests, and the words of the
 // UNERF_DROP_HEAD0 site recomputed per pass).  A separate instantiation: as run-time branches of the default kernel
 // they cost that kernel 50 VGPRs and 84 bytes of scratch (K = 8 field kernel 50 -> 55.6 ms).
-template <int MODE, bool TCNN, bool SITES = false>
+// DROP: masks are generated (MCDROPOUT with K > 0 and p > 0).  A compile-time flag: as a run-time (uniform) flag every
+// k-step of the masked layers carried a branch and the operand quads were copied to merge the two paths.
+template <int MODE, bool TCNN, bool SITES = false, bool DROP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && !TCNN) ? 3 : 2)))
 void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
@@ -1639,7 +1649,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         }
 
         const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
-        const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.drop_on;
+        constexpr bool drop = DROP;   // host: a.drop_on
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         uint32_t mk0[8], mk1[8], mk2[8], mk3[8];
         uint32_t base0_h0 = 0u;   // SITES only: the sample's base hash stays live across the passes
@@ -2272,8 +2282,10 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                           "field_fwd MCDROPOUT: unknown bits in drop_sites=%d", p->drop_sites);
             if (p->mfma16_blob && !features) {
                 const bool head0 = a.drop_on && a.drop_sites != (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1);   // non-default sites
-                if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, true>, MF_LDS_F16, a, st);
-                else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true>, MF_LDS_F16, a, st);
+                if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, true, true>, MF_LDS_F16, a, st);
+                else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true>, MF_LDS_F16, a, st);
+                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, false, true>, MF_LDS_F16, a, st);
+                else if (a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, true>, MF_LDS_F16, a, st);
                 else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob) {
