@@ -1738,13 +1738,19 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                     o[c] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + lds[MF_H2_OFF + 192 + c];
                 }
             }
-            if (valid && h == 0) {
+            // Epilogue split over the two lane halves (both hold the three colour sums after the exchange; the density
+            // logit, row 0, lives in the h = 0 half): h = 0 finishes (density, red), h = 1 (green, blue) -- two
+            // exponentials, two reciprocals and two stores per lane instead of four, four and four on half the lanes.
+            if (valid) {
                 const OutIndex q = out_index(a, k, ts);
-                a.density[q.dens] = a.p.average_init_density * __expf(t[0]) * sel;
-                a.rgb[q.rgb] = mf_sigmoid_fast(o[0]);
-                a.rgb[q.rgb + q.rgb_stride] = mf_sigmoid_fast(o[1]);
-                a.rgb[q.rgb + 2 * q.rgb_stride] = mf_sigmoid_fast(o[2]);
-                if (MODE == UNERF_FIELD_ACTIVE) a.aux[q.aux] = unerf_softplus(t[8]) + a.p.beta_min;
+                const float x = h ? o[1] : o[0];
+                const float y = h ? -o[2] : t[0];                 // h = 1: exp(-blue) for its sigmoid; h = 0: exp(logit)
+                const float ey = __expf(y);
+                const float vy = h ? __builtin_amdgcn_rcpf(1.f + ey) : a.p.average_init_density * ey * sel;
+                a.rgb[q.rgb + (h ? q.rgb_stride : 0)] = mf_sigmoid_fast(x);
+                float* py = h ? a.rgb + (q.rgb + 2 * q.rgb_stride) : a.density + q.dens;
+                *py = vy;
+                if (MODE == UNERF_FIELD_ACTIVE && h == 0) a.aux[q.aux] = unerf_softplus(t[8]) + a.p.beta_min;
             }
         }
     }
@@ -2513,17 +2519,37 @@ struct CompArgs {
 // RAGGED: S is not a multiple of 16 (SPL = ceil(S / 16)); the slots k >= S of the last lanes are masked: their bin
 // edges collapse onto edge S (delta = 0), density and weight are 0, and they are excluded from the median count
 // and from the "last sample" background colour.  The aligned instantiations are unchanged.
-template <int SPL, bool RAGGED = false>
-__device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int64_t r, int l16, float (&o8)[8]) {
+// The pass-independent part of a ray's composite: this lane's bin widths and mid-points (SPL + 1 spacing->Euclidean
+// conversions, one IEEE division each).  The K-pass kernel computes it once per ray, not once per pass.
+template <int SPL>
+struct CompGeom {
+    float delta[SPL], steps[SPL];
+};
+template <int SPL, bool RAGGED>
+__device__ __forceinline__ CompGeom<SPL> composite_geom(const CompArgs& a, int64_t r, int l16) {
     const int S = a.S, k0 = l16 * SPL;
     const float* sb = a.sbins + r * (S + 1);
-    float eu[SPL + 1], delta[SPL], steps[SPL], dens[SPL], w[SPL];
+    float eu[SPL + 1];
+    CompGeom<SPL> gm;
 #pragma unroll
     for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[RAGGED ? min(k0 + e, S) : k0 + e], a.s_near, a.s_far);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
-        delta[e] = eu[e + 1] - eu[e];
-        steps[e] = (eu[e] + eu[e + 1]) / 2.f;
+        gm.delta[e] = eu[e + 1] - eu[e];
+        gm.steps[e] = (eu[e] + eu[e + 1]) / 2.f;
+    }
+    return gm;
+}
+
+template <int SPL, bool RAGGED = false>
+__device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int64_t r, int l16, float (&o8)[8],
+                                              const CompGeom<SPL>& gm) {
+    const int S = a.S, k0 = l16 * SPL;
+    float delta[SPL], steps[SPL], dens[SPL], w[SPL];
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        delta[e] = gm.delta[e];
+        steps[e] = gm.steps[e];
         dens[e] = (!RAGGED || k0 + e < S) ? a.density[g * S + k0 + e] : 0.f;
     }
     // colours requested with the densities, one 12-byte load per sample (the three channels as separate dword
@@ -2611,7 +2637,8 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
     const bool ok = g < G;
     if (!ok) g = G - 1;
     float o8[8];
-    composite_one<SPL, RAGGED>(a, g, g % a.R, l16, o8);
+    const int64_t r = g % a.R;
+    composite_one<SPL, RAGGED>(a, g, r, l16, o8, composite_geom<SPL, RAGGED>(a, r, l16));
     if (ok && l16 == 0) {
         float4* o = reinterpret_cast<float4*>(a.out + g * 8);
         o[0] = make_float4(o8[0], o8[1], o8[2], o8[3]);
@@ -2633,9 +2660,10 @@ __global__ __launch_bounds__(256) void composite_moments_kernel(CompArgs a, floa
     float mine[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) mine[c] = 0.f;
+    const CompGeom<SPL> gm = composite_geom<SPL, RAGGED>(a, r, l16);   // bin edges are the same in every pass
     for (int b = 0; b < a.B; ++b) {
         float o8[8];
-        composite_one<SPL, RAGGED>(a, (int64_t)b * a.R + r, r, l16, o8);
+        composite_one<SPL, RAGGED>(a, (int64_t)b * a.R + r, r, l16, o8, gm);
         if (l16 == b) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) mine[c] = o8[c];
