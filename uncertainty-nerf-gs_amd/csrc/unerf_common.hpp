@@ -94,6 +94,13 @@ __device__ __forceinline__ float unerf_s2e(float b, float s_near, float s_far) {
     return unerf_spacing_inv(b * s_far + (1.f - b) * s_near);
 }
 
+// exp for the sampler and compositing kernels (proposal densities, get_weights): the hardware exponential
+// (v_exp_f32 after one multiply by log2 e; ~2 ulp, plus |x| 2^-24 relative from the scaled argument) instead of
+// the ~15-instruction libm expf.  These kernels are VALU-issue bound and take two exponentials per sample; the
+// arguments are -delta*sigma and -cumsum (results in [0,1], where both forms are limited by the rounding of a number
+// near 1) or a density logit.  The exact-fp32 / VALU field kernels keep expf.
+__device__ __forceinline__ float unerf_exp(float x) { return __expf(x); }
+
 __device__ __forceinline__ float unerf_nan_to_num(float w) {
     if (w != w) return 0.f;
     if (w > FLT_MAX) return FLT_MAX;

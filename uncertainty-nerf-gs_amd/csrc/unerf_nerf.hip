@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
         o = fmaf(__int_as_float(max(__float_as_int(h2[j].x), 0)), w1t[2 * j], o);
         o = fmaf(__int_as_float(max(__float_as_int(h2[j].y), 0)), w1t[2 * j + 1], o);
     }
-    a.out[idx] = a.avg * expf(o) * sel;
+    a.out[idx] = a.avg * unerf_exp(o) * sel;
 }
 
 // Patch-schedule form of prop_density_kernel with the per-RAY traffic staged through LDS.  A workgroup is an 8x8
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
             o = fmaf(__int_as_float(max(__float_as_int(h2[j].x), 0)), w1t[2 * j], o);
             o = fmaf(__int_as_float(max(__float_as_int(h2[j].y), 0)), w1t[2 * j + 1], o);
         }
-        dens = a.avg * expf(o) * sel;
+        dens = a.avg * unerf_exp(o) * sel;
     }
     if (a.vec4) {  // uniform: n % 4 == 0 and a 16-byte aligned output: the ray's 4 densities leave as one store
         s_out[lane][wv] = dens;
@@ -644,8 +644,8 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
     float carry = group_excl_scan<64>(lsum, lane);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-        float alpha = 1.f - expf(-dd[e]);
-        float T = expf(-(carry + lexcl[e]));
+        float alpha = 1.f - unerf_exp(-dd[e]);
+        float T = unerf_exp(-(carry + lexcl[e]));
         w[e] = (k0 + e < n) ? unerf_nan_to_num(alpha * T) : 0.f;
         if (a.weights_out && ray_ok && k0 + e < n) a.weights_out[r * n + k0 + e] = w[e];
     }
@@ -2494,8 +2494,8 @@ __device__ __forceinline__ void group_weights(const float (&dens)[SPL], const fl
     float carry = group_excl_scan<16>(ls, l16);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
-        float alpha = 1.f - expf(-dd[e]);
-        float T = expf(-(carry + lex[e]));
+        float alpha = 1.f - unerf_exp(-dd[e]);
+        float T = unerf_exp(-(carry + lex[e]));
         w[e] = unerf_nan_to_num(alpha * T);
     }
 }
@@ -2831,8 +2831,8 @@ __global__ __launch_bounds__(256) void composite_sm_kernel(CompSmArgs a) {
                     const float* cp = a.rgb + plane * 3 * R + r;
                     const float r0 = unerf_nan_to_num(cp[0]), g0 = unerf_nan_to_num(cp[R]), bl0 = unerf_nan_to_num(cp[2 * R]);
                     const float dd = delta * dens;
-                    const float alpha = 1.f - expf(-dd);
-                    const float T = expf(-cum[j]);
+                    const float alpha = 1.f - unerf_exp(-dd);
+                    const float T = unerf_exp(-cum[j]);
                     cum[j] += dd;
                     const float w = unerf_nan_to_num(alpha * T);
                     cr[j] += w * r0;
