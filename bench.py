@@ -65,8 +65,9 @@ def _issue_profile(method, K):
     """Instruction-issue cycles of the field kernel per launch, from the committed rocprofv3 --pmc pass of this
     command (profiles/issue_<method>.json, written by benchmarks/summarize_pmc.py): on gfx950 MFMA and VALU
     instructions share one issue pipe per SIMD and never overlap (benchmarks/mfma_valu_overlap_probe.hip), so
-    busy cycles = 4 x SQ_ACTIVE_INST_VALU (counted in quad-cycles) + SQ_VALU_MFMA_BUSY_CYCLES is the work the
-    instruction stream needs, a property of the code (not of the clock it ran at)."""
+    4 cycles per VALU instruction + 32 per f16 MFMA, with the exact instruction counts SQ_INSTS_VALU / SQ_INSTS_MFMA,
+    is the work the instruction stream needs -- a property of the code (not of the clock it ran at), and a lower
+    bound (instructions that hold the pipe for two slots are counted as one)."""
     f = os.path.join(ROOT, "profiles", f"issue_{method}.json")
     if not os.path.exists(f):
         return None
@@ -179,9 +180,9 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
         roof.update({"bound": "valu-issue", "achieved": ach, "peak": ISSUE_PEAK_GCYC, "unit": "Gcycle/s",
                      "frac": ach / ISSUE_PEAK_GCYC,
                      "note": "VALU and MFMA instructions share one issue pipe per SIMD on gfx950 and do not overlap "
-                             "(benchmarks/mfma_valu_overlap_probe.hip); achieved = (4 x VALU-active quad-cycles + MFMA-busy "
-                             "cycles) of one launch, from the committed PMC pass, over the live launch time; peak = 1024 SIMDs x "
-                             "2.4 GHz.  The engine clock under this load is ~2.07 GHz, so 0.86 is the practical ceiling",
+                             "(benchmarks/mfma_valu_overlap_probe.hip); achieved = (4 x VALU instructions + 32 x f16 MFMAs) of one "
+                             "launch, exact counts from the committed PMC pass, over the live launch time; peak = 1024 SIMDs x "
+                             "2.4 GHz.  The engine clock under this load is 1.9-2.1 GHz, so ~0.85 is the practical ceiling",
                      "issue_source": prof["source"], "valu_insts_per_ray": prof["valu_insts_per_launch"] / prof["rays_per_launch"],
                      "mfma_insts_per_ray": prof["mfma_insts_per_launch"] / prof["rays_per_launch"],
                      "simd_busy_frac_under_profiler": prof.get("busy_frac")})

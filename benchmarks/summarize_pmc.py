@@ -36,10 +36,10 @@ def reduce(src, dst):
             w.writerow([k, c, n, f"{v / n:.6f}", f"{d / n:.3f}"])
 
 
-FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false, false>", "field_kernel_mfma16<0, false>", "field_kernel_mfma<0, false, false>",
-                            "field_kernel_mfma<0, false>"),
-                 "mcdropout": ("field_kernel_mfma16<1, false, false, true>", "field_kernel_mfma16<1, false, false>", "field_kernel_mfma16<1, false>", "field_kernel_mfma<1, false, false>",
-                               "field_kernel_mfma<1, false>")}
+# the dominant field kernel of a method = the first kernel name with one of these prefixes (template arguments after the
+# prefix -- tcnn / sites / drop flags -- vary with the round)
+FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false", "field_kernel_mfma<0, false"),
+                 "mcdropout": ("field_kernel_mfma16<1, false", "field_kernel_mfma<1, false")}
 
 
 def summary(d, tag):
@@ -61,7 +61,7 @@ def summary(d, tag):
                "kernels": kernels}
         with open(os.path.join(d, f"{tag}_{method}_pmc_summary.json"), "w") as f:
             json.dump(out, f, indent=1)
-        fk = next((k for k in FIELD_KERNELS[method] if k in kernels), None)
+        fk = next((k for pre in FIELD_KERNELS[method] for k in sorted(kernels) if k.startswith(pre)), None)
         if fk and "FETCH_SIZE" in kernels[fk] and "WRITE_SIZE" in kernels[fk]:
             t = {"method": method, "K": 8 if method == "mcdropout" else 0, "rays_per_launch": 262144,
                  "source": f"profiles/{tag}_{method}_pmc_fetch.csv + {tag}_{method}_pmc_write.csv "
@@ -77,16 +77,26 @@ def summary(d, tag):
         need = ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")
         if fk and all(c in kernels[fk] for c in need):
             kk = kernels[fk]
-            # SQ_ACTIVE_INST_VALU counts quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (32 per v_mfma_f32_32x32x16_f16);
-            # GRBM_GUI_ACTIVE is summed over the 8 XCDs -> elapsed cycles of one XCD x 1024 SIMDs = available cycles
-            issue = 4.0 * kk["SQ_ACTIVE_INST_VALU"] + kk["SQ_VALU_MFMA_BUSY_CYCLES"]
+            # Issue cycles a launch NEEDS: 4 per wave64 VALU instruction, 32 per v_mfma_f32_32x32x16_f16 (the costs
+            # benchmarks/mfma_valu_overlap_probe.hip measures; the two classes share the SIMD's issue pipe and do not
+            # overlap).  SQ_INSTS_VALU (which includes the MFMAs) and SQ_INSTS_MFMA are exact instruction counts, so this
+            # is a property of the instruction stream and a LOWER bound of the busy cycles: instructions that hold the
+            # pipe longer (v_fma_mix*, v_exp, v_rcp, v_permlane32_swap: ~2 slots) are counted as one.  The busy counters
+            # themselves are kept next to it: 4 x SQ_ACTIVE_INST_VALU (quad-cycles) + SQ_VALU_MFMA_BUSY_CYCLES counts
+            # the issue cycles of an MFMA in both terms and can exceed the elapsed SIMD cycles by a few percent.
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs -> elapsed cycles of one XCD x 1024 SIMDs = available cycles.
+            valu_n = kk["SQ_INSTS_VALU"] - kk["SQ_INSTS_MFMA"]
+            issue = 4.0 * valu_n + 32.0 * kk["SQ_INSTS_MFMA"]
+            counters = 4.0 * kk["SQ_ACTIVE_INST_VALU"] + kk["SQ_VALU_MFMA_BUSY_CYCLES"]
             simd_cycles = kk["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
             j = {"method": method, "K": 8 if method == "mcdropout" else 0, "rays_per_launch": 262144, "kernel_name": fk,
                  "source": f"profiles/{tag}_{method}_pmc_sq.csv (rocprofv3 --pmc, own pass)",
                  "issue_cycles_per_launch": issue,
+                 "definition": "4 x (SQ_INSTS_VALU - SQ_INSTS_MFMA) + 32 x SQ_INSTS_MFMA",
+                 "valu_insts_per_launch": valu_n, "mfma_insts_per_launch": kk["SQ_INSTS_MFMA"],
                  "valu_active_quad_cycles": kk["SQ_ACTIVE_INST_VALU"], "mfma_busy_cycles": kk["SQ_VALU_MFMA_BUSY_CYCLES"],
-                 "valu_insts_per_launch": kk["SQ_INSTS_VALU"] - kk["SQ_INSTS_MFMA"], "mfma_insts_per_launch": kk["SQ_INSTS_MFMA"],
                  "simd_cycles_per_launch": simd_cycles, "busy_frac": issue / simd_cycles,
+                 "busy_frac_from_busy_counters": counters / simd_cycles,
                  "engine_clock_GHz_under_profiler": kk["GRBM_GUI_ACTIVE"] / 8.0 / (kk["avg_dur_us"] * 1e3)}
             with open(os.path.join(d, f"issue_{method}.json"), "w") as f:
                 json.dump(j, f, indent=1)
