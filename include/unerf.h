@@ -48,6 +48,24 @@ int unerf_generate_rays(const float* c2w_host, float fx, float fy, float cx, flo
                         int64_t ray_start, int64_t count, float* origins, float* directions,
                         float* pixel_area, void* stream);
 
+/* Oriented crop box (`obb_box` of Model.get_outputs_for_camera / get_outputs_for_camera_unc,
+ * models/laplace/laplace_model.py:403-415, models/ensemble/ensemble_pipeline.py:144-157): what
+ * Cameras.generate_rays(..., obb_box=box) does to the bundle -- nears / fars from the ray / box slab test
+ * (nerfstudio.utils.math.intersect_obb: t clamped to [0,1e10], a miss = 1e10 for both) -- expressed as per-ray
+ * first-level spacing bins under the launch-wide planes (near, far):
+ *   sbins[r,i] = (b_i s(far_r) + (1-b_i) s(near_r) - s(near)) / (s(far) - s(near)),  b = sbins_row [n+1].
+ * Feed sbins [R,n+1] (stride n+1) to unerf_proposal_density / unerf_weights_pdf_resample; every later stage is
+ * unchanged.  world_to_box: HOST 12 floats, inverse([R|T]) 3x4 row-major; half_extent: HOST 3 floats (S/2).
+ * nears / fars [R] may be NULL.  Rays that miss: planes 1e10 as upstream; their samples collapse onto `far`
+ * (upstream they are at infinity, pixels undefined), giving zero accumulation. */
+int unerf_ray_box_bins(const float* origins, const float* directions, int64_t R, const float* world_to_box_host,
+                       const float* half_extent_host, float near, float far, const float* sbins_row, int n,
+                       float* sbins, float* nears, float* fars, void* stream);
+/* The same fold for a bundle that already carries planes (RayBundle.nears / fars [R], e.g. made by
+ * camera.generate_rays(obb_box=...) on the nerfstudio side; SceneCollider.forward keeps planes that are set). */
+int unerf_ray_planes_bins(const float* nears, const float* fars, int64_t R, float near, float far,
+                          const float* sbins_row, int n, float* sbins, void* stream);
+
 /* ------------------------------------------------------------- hash grid --
  * Replaces HashEncoding(implementation="torch").forward called at
  * models/activenerfacto/activenerfacto_field.py:140-147,

@@ -266,10 +266,37 @@ def spacing_fn_inv(x: torch.Tensor) -> torch.Tensor:
     return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
 
 
-def spacing_to_euclidean(bins: torch.Tensor, near: float, far: float) -> torch.Tensor:
-    s_near = spacing_fn(torch.tensor(near, dtype=torch.float32))
-    s_far = spacing_fn(torch.tensor(far, dtype=torch.float32))
+def spacing_to_euclidean(bins: torch.Tensor, near, far) -> torch.Tensor:
+    """near / far: python floats (NearFarCollider planes) or per-ray tensors [R,1] (RayBundle.nears / fars, e.g. from an
+    obb_box intersection)"""
+    s_near = spacing_fn(torch.as_tensor(near, dtype=torch.float32))
+    s_far = spacing_fn(torch.as_tensor(far, dtype=torch.float32))
     return spacing_fn_inv(bins * s_far + (1 - bins) * s_near)
+
+
+def intersect_obb(origins: torch.Tensor, directions: torch.Tensor, R: torch.Tensor, T: torch.Tensor, S: torch.Tensor,
+                  max_bound: float = 1e10, invalid_value: float = 1e10):
+    """[UPSTREAM-RECALL nerfstudio.utils.math.intersect_obb / intersect_aabb, nerfstudio 1.1.0] ray / oriented-box
+    intersection as `Cameras.generate_rays(..., obb_box=box)` uses it to set RayBundle.nears / fars (which the
+    NearFarCollider then leaves alone): rays are moved into the box frame with inverse([R|T]), slab test against
+    +-S/2, t clamped to [0, max_bound], rays that miss get invalid_value for both.  -> nears [N,1], fars [N,1]"""
+    H = torch.eye(4)
+    H[:3, :3], H[:3, 3] = R, T
+    Hw2b = torch.inverse(H)
+    o = torch.cat([origins, torch.ones_like(origins[..., :1])], dim=-1)
+    o = torch.matmul(Hw2b, o.T).T[..., :3]
+    d = torch.matmul(Hw2b[:3, :3], directions.T).T
+    lo, hi = -S / 2, S / 2
+    tx_min = (lo - o) / d
+    tx_max = (hi - o) / d
+    t_min = torch.stack((tx_min, tx_max)).amin(dim=0).amax(dim=-1)
+    t_max = torch.stack((tx_min, tx_max)).amax(dim=0).amin(dim=-1)
+    t_min = torch.clamp(t_min, min=0, max=max_bound)
+    t_max = torch.clamp(t_max, min=0, max=max_bound)
+    cond = t_max <= t_min
+    t_min = torch.where(cond, torch.full_like(t_min, invalid_value), t_min)
+    t_max = torch.where(cond, torch.full_like(t_max, invalid_value), t_max)
+    return t_min[..., None], t_max[..., None]
 
 
 def initial_spacing_bins(num_samples: int) -> torch.Tensor:
@@ -684,17 +711,19 @@ class NerfScene:
     prop_average_init_density: float = 0.01
 
 
-def _sample(scene: NerfScene, origins, directions):
-    bins, wl, bl = proposal_sample(origins, directions, scene.near, scene.far, scene.prop_nets, scene.num_prop,
+def _sample(scene: NerfScene, origins, directions, nears=None, fars=None):
+    near = scene.near if nears is None else nears
+    far = scene.far if fars is None else fars
+    bins, wl, bl = proposal_sample(origins, directions, near, far, scene.prop_nets, scene.num_prop,
                                    scene.num_nerf, scene.prop_average_init_density)
-    eb = spacing_to_euclidean(bins, scene.near, scene.far)
+    eb = spacing_to_euclidean(bins, near, far)
     return eb, wl, bl
 
 
-def _prop_depths(scene, wl, bl):
+def _prop_depths(scene, wl, bl, nears=None, fars=None):
     out = {}
     for i, (w, b) in enumerate(zip(wl, bl)):
-        eb = spacing_to_euclidean(b, scene.near, scene.far)
+        eb = spacing_to_euclidean(b, scene.near if nears is None else nears, scene.far if fars is None else fars)
         out[f"prop_depth_{i}"] = render_depth_median(w, (eb[..., :-1] + eb[..., 1:]) / 2)
     return out
 
@@ -721,16 +750,17 @@ def active_compose(eb, density, rgb, beta) -> Dict[str, torch.Tensor]:
     return out
 
 
-def active_outputs(scene: NerfScene, origins, directions) -> Dict[str, torch.Tensor]:
-    """[REF activenerfacto_model.py:83-152] one chunk of rays [R,3]."""
-    eb, wl, bl = _sample(scene, origins, directions)
+def active_outputs(scene: NerfScene, origins, directions, nears=None, fars=None) -> Dict[str, torch.Tensor]:
+    """[REF activenerfacto_model.py:83-152] one chunk of rays [R,3]; nears / fars [R,1]: per-ray planes of the bundle
+    (obb_box), else the collider's constants."""
+    eb, wl, bl = _sample(scene, origins, directions, nears, fars)
     density, rgb, beta = active_field(origins, directions, eb, scene.field)
     out = active_compose(eb, density, rgb, beta)
-    out.update(_prop_depths(scene, wl, bl))
+    out.update(_prop_depths(scene, wl, bl, nears, fars))
     return out
 
 
-def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, density, rgb):
+def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, density, rgb, nears=None, fars=None):
     """[UPSTREAM NerfactoModel.get_outputs] rgb/accumulation/depth/expected_depth/prop_depth_i."""
     deltas = eb[..., 1:] - eb[..., :-1]
     steps = (eb[..., :-1] + eb[..., 1:]) / 2
@@ -741,19 +771,22 @@ def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, den
         "depth": render_depth_median(w, steps),
         "expected_depth": render_depth_expected(w, steps),
     }
-    out.update(_prop_depths(scene, wl, bl))
+    out.update(_prop_depths(scene, wl, bl, nears, fars))
     return out
 
 
 def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, p_drop: float,
-                      ray_offset: int = 0, drop_sites: int = 5, autocast: Optional[torch.dtype] = None) -> Dict[str, torch.Tensor]:
+                      ray_offset: int = 0, drop_sites: int = 5, autocast: Optional[torch.dtype] = None,
+                      nears=None, fars=None, ray_ids: Optional[np.ndarray] = None) -> Dict[str, torch.Tensor]:
     """[REF mcdropout_models.py:94-131] K stochastic passes of one chunk + mean / unbiased std.
     Masks come from the shared counter RNG keyed by the global sample index
-    (ray_offset+r)*S+s, so chunking does not change them."""
+    (ray_offset+r)*S+s, so chunking does not change them (ray_ids [R]: the rays' global indices when they are not
+    a contiguous run)."""
     R = origins.shape[0]
     S = scene.num_nerf
-    eb, wl, bl = _sample(scene, origins, directions)  # deterministic: identical in every pass
-    sidx = ((np.arange(R, dtype=np.int64)[:, None] + ray_offset) * S + np.arange(S)[None, :]).reshape(-1)
+    eb, wl, bl = _sample(scene, origins, directions, nears, fars)  # deterministic: identical in every pass
+    rid = np.arange(R, dtype=np.int64) + ray_offset if ray_ids is None else np.asarray(ray_ids, dtype=np.int64)
+    sidx = (rid[:, None] * S + np.arange(S)[None, :]).reshape(-1)
     outs = []
     for k in range(K):
         # drop_sites bits: 1 trunk (mask stream 0), 2 head hidden-0 (stream 2), 4 head hidden-1 (stream 1)
@@ -761,7 +794,7 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
         kh0 = torch.from_numpy(mc_keep_mask(seed, k, sidx, 2, 64, p_drop)) if drop_sites & 2 else None
         kh = torch.from_numpy(mc_keep_mask(seed, k, sidx, 1, 64, p_drop)) if drop_sites & 4 else None
         density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop, keep_head0=kh0, autocast=autocast)
-        outs.append(nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb))
+        outs.append(nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb, nears, fars))
     res = {}
     for key in outs[0].keys():
         el = torch.stack([o[key] for o in outs], dim=0)
@@ -799,18 +832,19 @@ def laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise: Optional[torc
 
 
 def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
-                    depth_noise: Optional[torch.Tensor], use_deterministic_density: bool = False) -> Dict[str, torch.Tensor]:
+                    depth_noise: Optional[torch.Tensor], use_deterministic_density: bool = False,
+                    nears=None, fars=None) -> Dict[str, torch.Tensor]:
     """[REF laplace_model.py:456-556] is_inference=True.
     use_deterministic_density=False: density = sampled-head mean (NOT selector-masked), depth from the mean of the
     weights of D Normal(mu_d, sigma_d) density draws; depth_noise [D,R,S] = the standard-normal draw behind them.
     use_deterministic_density=True (laplace_field.py:501-506): density = the plain mean head, selector-masked
     (is_inference=False branch of get_density), colour still sampled, depth from the ordinary weights."""
-    eb, wl, bl = _sample(scene, origins, directions)
+    eb, wl, bl = _sample(scene, origins, directions, nears, fars)
     mu_d, var_d, mu_rgb, var_rgb = laplace_field(origins, directions, eb, scene.field, ws_density, ws_rgb)
     if use_deterministic_density:
         mu_d, _ = laplace_field_deterministic(origins, directions, eb, scene.field)
     out = laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise, use_deterministic_density)
-    out.update(_prop_depths(scene, wl, bl))
+    out.update(_prop_depths(scene, wl, bl, nears, fars))
     return out
 
 

@@ -26,7 +26,7 @@ def test_header_symbols_all_bound_and_exported(lib):
 
 def test_version_and_error_string(lib):
     h = lib.load()
-    assert h.unerf_version() == 1100
+    assert h.unerf_version() == 1101
     assert isinstance(h.unerf_last_error(), bytes)
 
 

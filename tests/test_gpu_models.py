@@ -283,3 +283,39 @@ def test_nerfstudio_plugin_model_renders_like_the_mirror(dev):
         assert torch.equal(got[k], want[k]), k
     one = model.get_outputs(RayBundle(origins=o[:100], directions=d[:100]))
     assert one["rgb"].shape == (100, 3) and torch.isfinite(one["rgb_var"]).all()
+
+
+def test_model_obb_box_equals_a_bundle_that_carries_the_box_planes(dev):
+    """get_outputs_for_camera(camera, obb_box=box) [UPSTREAM Model.get_outputs_for_camera: generate_rays(obb_box=...)]
+    == get_outputs_for_camera_ray_bundle(bundle with nears / fars from the same box): the two routes into
+    render.crop_bins (unerf_ray_box_bins / unerf_ray_planes_bins) agree, and the ensemble pipeline hands the box on."""
+    from types import SimpleNamespace
+    from uncertainty_nerf_gs_amd import ensemble, ops, plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=3, kind="active", log2T=14, prop_log2T=12)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["active-nerfacto"]())
+    model = cfg._target(cfg, num_train_data=4)
+    model.load_state_dict(_state_dict_from_tensors(t, "active"))
+    H, W = 30, 44
+    cam = _camera(H, W)
+    th = 0.5
+    box = SimpleNamespace(R=torch.tensor([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]],
+                                         dtype=torch.float32),
+                          T=torch.tensor([0.03, 0.02, -0.01]), S=torch.tensor([0.4, 0.5, 0.3]))
+    with torch.cuda.device(dev):
+        out = model.get_outputs_for_camera(cam, obb_box=box)
+        plain = model.get_outputs_for_camera(cam)
+        o, d, _ = ops.generate_rays(cam.camera_to_worlds[0], 0.9 * W, 0.9 * W, W / 2, H / 2, H, W, dev)
+        nears, fars = O.intersect_obb(o.cpu(), d.cpu(), box.R, box.T, box.S)
+        bundle = SimpleNamespace(origins=o.view(H, W, 3), directions=d.view(H, W, 3), nears=nears.view(H, W, 1).to(dev),
+                                 fars=fars.view(H, W, 1).to(dev))
+        via = model.get_outputs_for_camera_ray_bundle(bundle)
+        ens = ensemble.EnsemblePipeline([model, model]).get_ensemble_outputs_for_camera_ray_bundle(cam, obb_box=box)
+    hit = (fars > nears).view(H, W)
+    assert 0.1 < hit.float().mean() < 0.9
+    inner = hit.to(dev)
+    assert (out["rgb"] - plain["rgb"])[inner].abs().max() > 1e-3           # the crop changes the picture
+    assert out["accumulation"][~inner].abs().max() < 1e-6                   # outside the box: empty
+    # planes computed on the device vs by the oracle differ by an ulp -> compare with a float tolerance
+    for k, tol in (("rgb", 2e-5), ("accumulation", 1e-4)):
+        assert (out[k] - via[k])[inner].abs().max() < tol, k
+    assert torch.equal(ens["rgb"], out["rgb"]) and ens["rgb_var_epi"].abs().max() == 0     # two copies of one member

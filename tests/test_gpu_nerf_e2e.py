@@ -350,3 +350,93 @@ def test_full_size_mcdropout_and_laplace_degenerate_to_the_deterministic_render(
     # accumulation comes from the depth draws Normal(mu_d, sqrt(var_d)): with identical rows var_d is pure rounding
     # noise (E[p^2] - E[p]^2 ~ 1e-7 p^2) and its square root amplifies the difference between the two kernel sets
     assert (lap["accumulation"] - lap_exact["accumulation"]).abs().max() <= 2e-4
+
+
+def _rot(axis, th):
+    a = torch.tensor(axis, dtype=torch.float64)
+    a = a / a.norm()
+    K = torch.tensor([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]], dtype=torch.float64)
+    return (torch.eye(3, dtype=torch.float64) + math.sin(th) * K + (1 - math.cos(th)) * (K @ K)).float()
+
+
+@pytest.mark.parametrize("kind", ["active", "mcdropout", "laplace"])
+def test_obb_box_crop_matches_generate_rays_with_an_oriented_box(dev, kind):
+    """get_outputs_for_camera(camera, obb_box=box): the bundle's nears / fars come from the ray / box slab test
+    (Cameras.generate_rays(obb_box=...), laplace_model.py:413) and the sampler spaces its bins between THEM.  The HIP
+    path folds the per-ray planes into the first level's bins (unerf_ray_box_bins); the oracle passes nears / fars
+    through the sampler like the reference.  Rays that miss are undefined upstream (samples at infinity) and render
+    empty here."""
+    from uncertainty_nerf_gs_amd import ops, render, synthetic
+    t = synthetic.make_scene_tensors(seed=6, kind=kind, log2T=14, prop_log2T=12)
+    sc = O.scene_from_tensors(t)
+    H, W, chunk = 36, 44, 512
+    cam, c2w = _cam(H, W), synthetic.orbit_c2w(1.3)
+    Rm, T, S = _rot([0.3, -0.5, 1.0], 0.7), torch.tensor([0.05, -0.04, 0.02]), torch.tensor([0.5, 0.34, 0.4])
+    w2b = ops.world_to_box(Rm, T)
+    o, d = _oracle_rays(c2w, cam)
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    nears, fars = O.intersect_obb(o, d, Rm, T, S)
+    hit = (fars > nears).reshape(-1)
+    assert 0.2 < hit.float().mean() < 0.9, hit.float().mean()       # the box covers part of the frame
+    # the planes themselves
+    row = render._linspace_bins(256).to(dev)
+    bins, (gn, gf) = ops.ray_box_bins(o.to(dev), d.to(dev), w2b, S, sc.near, sc.far, row, want_planes=True)
+    ghit = (gf > gn).reshape(-1).cpu()
+    assert (ghit != hit).float().mean() < 2e-3                       # only grazing rays may differ
+    both = hit & ghit
+    torch.testing.assert_close(gn.cpu()[both], nears[both], rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(gf.cpu()[both], fars[both], rtol=2e-5, atol=1e-6)
+    assert (gn.cpu()[~ghit] == 1e10).all() and (gf.cpu()[~ghit] == 1e10).all()
+    eb = O.spacing_to_euclidean(bins.cpu()[both], sc.near, sc.far)                 # the fold: same euclidean edges
+    torch.testing.assert_close(eb, O.spacing_to_euclidean(row.cpu()[None], nears[both], fars[both]), rtol=2e-4, atol=1e-6)
+
+    if kind == "active":
+        sd = synthetic.scene_to_device(t, dev)
+        fn = lambda oo, dd, nn, ff, idx: O.active_outputs(sc, oo, dd, nn, ff)
+        kw = dict(keep_density=True)
+    elif kind == "mcdropout":
+        sd = synthetic.scene_to_device(t, dev, K=4, seed=9, p_drop=0.2)
+        fn = lambda oo, dd, nn, ff, idx: O.mcdropout_outputs(sc, oo, dd, 4, 9, 0.2, nears=nn, fars=ff, ray_ids=idx.numpy())
+        kw = {}
+    else:
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=3, n_samples=30)
+        sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+        noise = torch.randn(20, H * W, 48, generator=torch.Generator().manual_seed(4))
+        fn = lambda oo, dd, nn, ff, idx: O.laplace_outputs(sc, oo, dd, wsd, wsr, noise[:, idx], nears=nn, fars=ff)
+        kw = dict(depth_noise=noise.to(dev), depth_draws=20)
+    sd.chunk_rays = chunk
+    out = render.render_rays(sd, o.to(dev), d.to(dev), init_bins=bins, **kw)
+    # the oracle renders the rays that hit, chunk by chunk (the expected-depth clip bounds are per chunk; the misses of a
+    # chunk sit on the far plane here and cannot lower its minimum)
+    ref = {}
+    for a in range(0, H * W, chunk):
+        idx = torch.nonzero(both[a:a + chunk]).reshape(-1) + a
+        if idx.numel() == 0:
+            continue
+        r = fn(o[idx], d[idx], nears[idx], fars[idx], idx)
+        for k, v in r.items():
+            ref.setdefault(k, torch.zeros((H * W,) + v.shape[1:]))[idx] = v
+    sel = torch.nonzero(both).reshape(-1)
+    pick = lambda x: x.cpu()[sel]
+    assert set(ref) <= set(out), set(ref) - set(out)
+    _img_close(pick(out["rgb"]), ref["rgb"][sel], 5e-5, 0, "rgb")
+    _img_close(pick(out["accumulation"]), ref["accumulation"][sel], 2e-4, 0, "accumulation")
+    _img_close(pick(out["rgb_std"]), ref["rgb_std"][sel], 2e-5, 5e-3, "rgb_std", max_bad_frac=2e-3)
+    _img_close(pick(out["expected_depth"]), ref["expected_depth"][sel], 0, 1e-3, "expected_depth", max_bad_frac=5e-3)
+    _img_close(pick(out["depth"]), ref["depth"][sel], 0, 1e-3, "depth", max_bad_frac=2e-2)
+    _img_close(pick(out["prop_depth_0"]), ref["prop_depth_0"][sel], 0, 1e-3, "prop_depth_0", max_bad_frac=1e-2)
+    # every hit pixel's depth lies inside its own box interval, and the crop changes the picture
+    dep = pick(out["depth"]).reshape(-1)
+    assert ((dep >= nears[sel].reshape(-1) * (1 - 1e-4)) & (dep <= fars[sel].reshape(-1) * (1 + 1e-4))).all()
+    full = render.render_rays(sd, o.to(dev), d.to(dev), **kw)
+    assert (pick(full["rgb"]) - pick(out["rgb"])).abs().max() > 1e-3
+    # the misses: finite everywhere, nothing accumulated
+    miss = torch.nonzero(~ghit).reshape(-1)
+    for k, v in out.items():
+        assert torch.isfinite(v.cpu()[miss]).all(), k
+    assert out["accumulation"].cpu()[miss].abs().max() == 0
+    if kind == "active":
+        # the camera entry point (launch groups, on-device ray generation) gives the same image as the flat bundle
+        img = render.render_camera(sd, c2w, rays_per_launch=1024, obb=(w2b, S), **cam, **kw)
+        torch.testing.assert_close(img["rgb"].reshape(-1, 3)[sel.to(dev)], out["rgb"][sel.to(dev)], rtol=0, atol=2e-6)
+        assert img["accumulation"].reshape(-1)[miss.to(dev)].abs().max() == 0

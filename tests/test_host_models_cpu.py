@@ -144,3 +144,36 @@ def test_mcdropout_field_dropout_layer_options():
     import pytest
     with pytest.raises(NotImplementedError):
         F.NerfactoMCDropoutField(rgb_dropout_layers=[0], **kw)
+
+
+def test_oracle_intersect_obb_known_answers_and_per_ray_planes():
+    """intersect_obb is restated from nerfstudio.utils.math (not in this image: upstream recall) -- pinned
+    here to hand-computed slab intersections; per-ray nears / fars through the sampler reduce to the scalar planes."""
+    import math
+    from oracle import nerf_oracle as O
+    S = torch.tensor([2.0, 1.0, 4.0])
+    o = torch.tensor([[-3.0, 0.0, 0.0], [-3.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.25, 5.0], [-3.0, 2.0, 0.0]])
+    d = torch.tensor([[1.0, 0.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]])
+    n, f = O.intersect_obb(o, d, torch.eye(3), torch.zeros(3), S)
+    #        enters x=-1 at t=2, leaves x=1 at t=4 | box behind the ray | starts inside: near clamps to 0 | along z | passes beside
+    assert n.reshape(-1).tolist() == [2.0, 1e10, 0.0, 3.0, 1e10] and f.reshape(-1).tolist() == [4.0, 1e10, 0.5, 7.0, 1e10]
+    # a rotated, shifted box is the same test in the box frame
+    th = 0.6
+    R = torch.tensor([[math.cos(th), -math.sin(th), 0.0], [math.sin(th), math.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    T = torch.tensor([0.3, -0.2, 0.1])
+    n2, f2 = O.intersect_obb(o @ R.T + T, d @ R.T, R, T, S)
+    torch.testing.assert_close(n2, n, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(f2, f, rtol=1e-5, atol=1e-5)
+    # sampler with per-ray planes equal to the collider's constants == the scalar path
+    from uncertainty_nerf_gs_amd import synthetic
+    t = synthetic.make_scene_tensors(seed=3, kind="active", log2T=10, prop_log2T=9)
+    sc = O.scene_from_tensors(t)
+    oo = torch.tensor([[0.5, 0.1, 0.1], [0.4, -0.3, 0.2]])
+    dd = torch.nn.functional.normalize(-oo + torch.tensor([[0.0, 0.05, 0.0], [0.02, 0.0, 0.0]]), dim=-1)
+    a = O.active_outputs(sc, oo, dd)
+    b = O.active_outputs(sc, oo, dd, torch.full((2, 1), sc.near), torch.full((2, 1), sc.far))
+    for k in a:
+        torch.testing.assert_close(a[k], b[k], rtol=0, atol=0)
+    # ... and a narrower interval keeps every depth inside it
+    c = O.active_outputs(sc, oo, dd, torch.tensor([[0.3], [0.25]]), torch.tensor([[0.8], [0.9]]))
+    assert ((c["depth"] >= torch.tensor([[0.3], [0.25]])) & (c["depth"] <= torch.tensor([[0.8], [0.9]]))).all()

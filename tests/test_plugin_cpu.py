@@ -4,6 +4,7 @@ configs instantiate nerfstudio `Model` subclasses; state-dict names follow the r
 nerfstudio's argument types (RayBundle, camera, obb_box) and forward to the HIP mirrors.  Uses the real nerfstudio when
 it is importable, else the stand-in of tests/stubs/ (README there)."""
 import importlib
+import math
 import os
 import sys
 
@@ -130,14 +131,31 @@ def test_rendering_methods_take_nerfstudio_types_and_forward_to_the_mirror(monke
 
     def fake_render_camera(scene, c2w, **kw):
         seen["camera"] = (tuple(c2w.shape), kw["H"], kw["W"])
+        seen["obb"] = kw.get("obb")
         return {"rgb": torch.zeros(kw["H"], kw["W"], 3)}
 
     monkeypatch.setattr(render, "render_camera", fake_render_camera)
     cam = models.Camera(torch.eye(4)[None, :3], torch.tensor([[50.0]]), torch.tensor([[50.0]]), torch.tensor([[4.5]]),
                         torch.tensor([[3.0]]), torch.tensor([[H]]), torch.tensor([[W]]))
     assert model.get_outputs_for_camera(cam, obb_box=None)["rgb"].shape == (H, W, 3) and seen["camera"] == ((3, 4), H, W)
-    with pytest.raises(NotImplementedError):
-        model.get_outputs_for_camera(cam, obb_box=object())
+    assert seen["obb"] is None
+    # an OrientedBox (R, T, S) becomes the inverse rigid transform + the edge lengths render.crop_bins takes
+    th = 0.3
+    Rm = torch.tensor([[math.cos(th), -math.sin(th), 0.0], [math.sin(th), math.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    box = type("Box", (), {"R": Rm, "T": torch.tensor([0.5, -0.25, 1.0]), "S": torch.tensor([1.0, 2.0, 3.0])})()
+    model.get_outputs_for_camera(cam, obb_box=box)
+    w2b, S = seen["obb"]
+    assert torch.allclose(w2b[:, :3], Rm.T, atol=1e-6) and torch.allclose(w2b[:, 3], -(Rm.T @ box.T), atol=1e-6)
+    assert torch.equal(S, box.S)
+    # a bundle that already carries planes keeps them (SceneCollider.forward): they become first-level bins
+    monkeypatch.setattr(render, "crop_bins", lambda scene, o, d, obb=None, nears=None, fars=None:
+                        seen.__setitem__("planes", (nears.shape, fars.shape)) or torch.zeros(o.shape[0], 257))
+    monkeypatch.setattr(render, "render_rays", lambda scene, o, d, **kw:
+                        seen.__setitem__("init", kw["init_bins"].shape) or {"rgb": torch.zeros(o.shape[0], 3)})
+    b2 = RayBundle(origins=torch.zeros(H, W, 3), directions=torch.ones(H, W, 3), nears=torch.zeros(H, W, 1),
+                   fars=torch.ones(H, W, 1))
+    model.get_outputs_for_camera_ray_bundle(b2)
+    assert seen["planes"] == ((H * W,), (H * W,)) and seen["init"] == (H * W, 257)
 
 
 def test_splat_model_plugin_surface():

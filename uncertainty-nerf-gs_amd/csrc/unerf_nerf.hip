@@ -32,7 +32,7 @@ int unerf_check_launch(const char* what) {
     return UNERF_OK;
 }
 extern "C" const char* unerf_last_error(void) { return g_err; }
-extern "C" int unerf_version(void) { return 1100; }   // 1100: round-2 ABI (drop_sites, sample_major planes, aabb, ...)
+extern "C" int unerf_version(void) { return 1101; }   // 11xx: round-2 ABI (drop_sites, sample_major planes, aabb, ...); 1101: ray_box_bins / ray_planes_bins
 extern "C" int unerf_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -222,6 +222,92 @@ extern "C" int unerf_generate_rays(const float* c2w, float fx, float fy, float c
     a.start = ray_start; a.count = count; a.o = origins; a.d = directions; a.pa = pixel_area;
     hipLaunchKernelGGL(raygen_kernel, dim3(blocks_for(count, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return unerf_check_launch("generate_rays");
+}
+
+// ---- oriented crop box: per-ray planes folded into the first level's spacing bins ----
+// Cameras.generate_rays(..., obb_box=box) sets RayBundle.nears / fars from the ray / box slab test and the collider then
+// keeps them; the sampler maps its [0,1] spacing bins through each ray's own planes.  Every kernel after this one takes
+// ONE pair of planes (near0, far0) per launch, so the per-ray planes are folded into the bins instead:
+//   b' = (b s(far_r) + (1 - b) s(near_r) - s(near0)) / (s(far0) - s(near0))
+// gives the same euclidean edges under (near0, far0), and the pdf resampling is affine in the bins, so every later
+// level stays consistent without knowing about the box.
+struct BoxBinsArgs {
+    const float* o; const float* d; const float* row;   // rays, shared [n+1] spacing row
+    float w2b[12];                                       // inverse([R|T]) as 3x4 row-major
+    float half[3];
+    float near0, far0;
+    int64_t R; int n;
+    float* bins; float* nears; float* fars;              // [R,n+1], [R], [R] (planes may be null)
+    const float* in_nears; const float* in_fars;         // given: the bundle's own planes, no box test
+};
+
+__global__ __launch_bounds__(256) void box_bins_kernel(BoxBinsArgs a) {
+    int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int lane = threadIdx.x & 63;
+    float ox = a.o[r * 3], oy = a.o[r * 3 + 1], oz = a.o[r * 3 + 2];
+    float dx = a.d[r * 3], dy = a.d[r * 3 + 1], dz = a.d[r * 3 + 2];
+    float tmin = -INFINITY, tmax = INFINITY;
+    if (a.in_nears) {
+        tmin = a.in_nears[r];
+        tmax = a.in_fars[r];
+    } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* m = a.w2b + c * 4;
+        float bo = ((m[0] * ox + m[1] * oy) + m[2] * oz) + m[3];
+        float bd = (m[0] * dx + m[1] * dy) + m[2] * dz;
+        float t0 = (-a.half[c] - bo) / bd, t1 = (a.half[c] - bo) / bd;
+        tmin = fmaxf(tmin, fminf(t0, t1));
+        tmax = fminf(tmax, fmaxf(t0, t1));
+    }
+    tmin = fminf(fmaxf(tmin, 0.f), 1e10f);
+    tmax = fminf(fmaxf(tmax, 0.f), 1e10f);
+    if (!(tmax > tmin)) tmin = tmax = 1e10f;             // a miss: both planes at the invalid value
+    }
+    if (lane == 0) {
+        if (a.nears) a.nears[r] = tmin;
+        if (a.fars) a.fars[r] = tmax;
+    }
+    // a miss upstream puts every sample at s_inv(s(1e10)) = s_inv(1.f) = inf, i.e. undefined pixels; here its samples
+    // collapse onto the far plane (zero-length intervals -> zero weights, accumulation 0), which keeps everything finite
+    const float sn = unerf_spacing_fn(fminf(tmin, a.far0)), sf = unerf_spacing_fn(fminf(tmax, a.far0));
+    const float sn0 = unerf_spacing_fn(a.near0), inv = 1.f / (unerf_spacing_fn(a.far0) - sn0);
+    for (int i = lane; i <= a.n; i += 64) {
+        float b = a.row[i];
+        // sf == sn (a miss, or an empty interval): every edge the same float, so all later lerps b0 + t (b1 - b0) and
+        // interval lengths are exactly degenerate
+        a.bins[r * (a.n + 1) + i] = ((sf == sn ? sn : (b * sf + (1.f - b) * sn)) - sn0) * inv;
+    }
+}
+
+extern "C" int unerf_ray_box_bins(const float* origins, const float* directions, int64_t R, const float* world_to_box,
+                                  const float* half_extent, float near, float far, const float* sbins_row, int n,
+                                  float* sbins, float* nears, float* fars, void* stream) {
+    UNERF_REQUIRE(origins && directions && world_to_box && half_extent && sbins_row && sbins, "ray_box_bins: null pointer");
+    UNERF_REQUIRE(R >= 0 && n >= 1 && far > near && near >= 0.f, "ray_box_bins: R=%lld n=%d near=%g far=%g",
+                  (long long)R, n, (double)near, (double)far);
+    if (R == 0) return UNERF_OK;
+    BoxBinsArgs a;
+    for (int i = 0; i < 12; ++i) a.w2b[i] = world_to_box[i];
+    for (int i = 0; i < 3; ++i) a.half[i] = half_extent[i];
+    a.o = origins; a.d = directions; a.row = sbins_row; a.near0 = near; a.far0 = far; a.R = R; a.n = n;
+    a.bins = sbins; a.nears = nears; a.fars = fars; a.in_nears = a.in_fars = nullptr;
+    hipLaunchKernelGGL(box_bins_kernel, dim3(blocks_for(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return unerf_check_launch("ray_box_bins");
+}
+
+extern "C" int unerf_ray_planes_bins(const float* nears, const float* fars, int64_t R, float near, float far,
+                                     const float* sbins_row, int n, float* sbins, void* stream) {
+    UNERF_REQUIRE(nears && fars && sbins_row && sbins, "ray_planes_bins: null pointer");
+    UNERF_REQUIRE(R >= 0 && n >= 1 && far > near && near >= 0.f, "ray_planes_bins: R=%lld n=%d near=%g far=%g",
+                  (long long)R, n, (double)near, (double)far);
+    if (R == 0) return UNERF_OK;
+    BoxBinsArgs a = {};
+    a.row = sbins_row; a.near0 = near; a.far0 = far; a.R = R; a.n = n;
+    a.bins = sbins; a.in_nears = nears; a.in_fars = fars;
+    hipLaunchKernelGGL(box_bins_kernel, dim3(blocks_for(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return unerf_check_launch("ray_planes_bins");
 }
 
 // ======================================================================================

@@ -116,6 +116,8 @@ SIGNATURES = {
     "unerf_version": (_i, []),
     "unerf_device_count": (_i, []),
     "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "unerf_ray_box_bins": (_i, [_vp, _vp, _i64, _fp, _fp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp]),
+    "unerf_ray_planes_bins": (_i, [_vp, _vp, _i64, _f, _f, _vp, _i, _vp, _vp]),
     "unerf_hashgrid_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "unerf_hashgrid_fwd_tcnn": (_i, [_vp, _vp, C.POINTER(TcnnLevel), _i64, _i, _vp, _vp, _vp]),
     "unerf_proposal_density": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, C.POINTER(DensityNet), _f, _vp, _i64, _i, _vp]),

@@ -218,19 +218,24 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
 
     @torch.no_grad()
     def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, torch.Tensor]:
-        if obb_box is not None:
-            raise NotImplementedError("obb_box cropping is not built")
+        """[UPSTREAM Model.get_outputs_for_camera] camera.generate_rays(camera_indices=0, keep_shape=True,
+        obb_box=obb_box) + the chunked render.  obb_box: anything with `.R` [3,3], `.T` [3], `.S` [3] (nerfstudio's
+        OrientedBox); rays get their planes from the box (render.crop_bins), rays that miss it render empty."""
         c2w, cam = _camera_args(camera)
-        return render.render_camera(self.device_scene(), c2w, rays_per_launch=self.rays_per_launch,
+        obb = None if obb_box is None else (ops.world_to_box(obb_box.R, obb_box.T), torch.as_tensor(obb_box.S).detach().cpu())
+        return render.render_camera(self.device_scene(), c2w, rays_per_launch=self.rays_per_launch, obb=obb,
                                     **cam, **self._render_kwargs())
 
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle, directions: Optional[torch.Tensor] = None):
         """Model.get_outputs_for_camera_ray_bundle(camera_ray_bundle: RayBundle) (mcdropout_models.py:94-96): any object
         with `.origins` / `.directions` [H,W,3] -- a nerfstudio RayBundle from `camera.generate_rays(keep_shape=True)` --
-        or, for callers without nerfstudio, the two tensors (origins, directions)."""
+        or, for callers without nerfstudio, the two tensors (origins, directions).  A bundle that carries `nears` and
+        `fars` (generate_rays with an obb_box) keeps them, as SceneCollider.forward does."""
+        nears = fars = None
         if directions is None:
             origins, directions = camera_ray_bundle.origins, camera_ray_bundle.directions
+            nears, fars = getattr(camera_ray_bundle, "nears", None), getattr(camera_ray_bundle, "fars", None)
         else:
             origins = camera_ray_bundle
         H, W = origins.shape[:2]
@@ -239,13 +244,18 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         directions = directions.to(device=scene0.device, dtype=torch.float32)
         scene = self.device_scene(origins.device)
         o, d = origins.reshape(-1, 3).contiguous(), directions.reshape(-1, 3).contiguous()
+        init = None
+        if nears is not None and fars is not None:
+            init = render.crop_bins(scene, o, d, nears=nears.to(device=o.device, dtype=torch.float32).reshape(-1),
+                                    fars=fars.to(device=o.device, dtype=torch.float32).reshape(-1))
         rpl = max(scene.chunk_rays, (self.rays_per_launch // scene.chunk_rays) * scene.chunk_rays)
         from .ops import new_clip_buffer
         clip = new_clip_buffer(H * W, scene.chunk_rays, o.device)
         lists: Dict[str, List[torch.Tensor]] = {}
         for s in range(0, H * W, rpl):
             out = render.render_rays(scene, o[s:s + rpl], d[s:s + rpl], ray_offset=s, total_rays=H * W, clip=clip,
-                                     image_width=W, **self._render_kwargs())
+                                     image_width=W, init_bins=None if init is None else init[s:s + rpl],
+                                     **self._render_kwargs())
             for k, v in out.items():
                 lists.setdefault(k, []).append(v)
         return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}
@@ -257,19 +267,26 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         a flat bundle of rays -- any object with `.origins` / `.directions` [R,3] (a nerfstudio RayBundle), or an
         (origins, directions) pair -- rendered as ONE reference chunk (the per-chunk expected-depth clip bounds are
         those of this bundle, as in the reference when `forward` is called on a chunk)."""
+        nears = fars = None
         if isinstance(ray_bundle, (tuple, list)):
             o, d = ray_bundle
         else:
             o, d = ray_bundle.origins, ray_bundle.directions
+            nears, fars = getattr(ray_bundle, "nears", None), getattr(ray_bundle, "fars", None)
         scene = self.device_scene(o.device if o.is_cuda else None)
         o = o.reshape(-1, 3).to(device=scene.device, dtype=torch.float32).contiguous()
         d = d.reshape(-1, 3).to(device=scene.device, dtype=torch.float32).contiguous()
+        init = None
+        if nears is not None and fars is not None:   # planes already on the bundle: the collider leaves them
+            init = render.crop_bins(scene, o, d, nears=nears.to(device=o.device, dtype=torch.float32).reshape(-1),
+                                    fars=fars.to(device=o.device, dtype=torch.float32).reshape(-1))
         from .ops import new_clip_buffer
         R = o.shape[0]
         clip = new_clip_buffer(R, max(R, 1), o.device)                 # one chunk = the whole bundle
         saved, scene.chunk_rays = scene.chunk_rays, max(R, 1)
         try:
-            return render.render_rays(scene, o, d, ray_offset=0, total_rays=R, clip=clip, **self._render_kwargs())
+            return render.render_rays(scene, o, d, ray_offset=0, total_rays=R, clip=clip, init_bins=init,
+                                      **self._render_kwargs())
         finally:
             scene.chunk_rays = saved
 

@@ -91,6 +91,42 @@ def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
     return o, d, pa
 
 
+def world_to_box(R, T) -> torch.Tensor:
+    """inverse([R|T]) [3,4] of an OrientedBox (R [3,3], T [3]) -- the transform intersect_obb applies to the rays"""
+    H = torch.eye(4, dtype=torch.float64)
+    H[:3, :3] = torch.as_tensor(R, dtype=torch.float64).cpu()
+    H[:3, 3] = torch.as_tensor(T, dtype=torch.float64).cpu().reshape(3)
+    return torch.inverse(H)[:3].to(torch.float32).contiguous()
+
+
+def ray_box_bins(origins, directions, w2b: torch.Tensor, S, near: float, far: float, sbins_row: torch.Tensor,
+                 want_planes: bool = False):
+    """per-ray first-level spacing bins [R,n+1] for an oriented crop box (include/unerf.h: unerf_ray_box_bins);
+    w2b = world_to_box(R, T), S = the box's edge lengths.  -> bins, (nears [R,1], fars [R,1]) | None"""
+    lib = _l.load()
+    R, n = origins.shape[0], sbins_row.numel() - 1
+    out = torch.empty(R, n + 1, device=origins.device, dtype=torch.float32)
+    nf = torch.empty(2, R, 1, device=origins.device, dtype=torch.float32) if want_planes else None
+    half = (C.c_float * 3)(*[float(v) / 2 for v in torch.as_tensor(S).reshape(-1)[:3]])
+    with _ctx(origins.device):
+        _run("ray_box_bins", lambda: lib.unerf_ray_box_bins(_p(origins), _p(directions), R, _host12(w2b), half, near, far,
+                                                            _p(sbins_row), n, _p(out), _p(nf[0]) if want_planes else None,
+                                                            _p(nf[1]) if want_planes else None, _stream()))
+    return out, ((nf[0], nf[1]) if want_planes else None)
+
+
+def ray_planes_bins(nears, fars, near: float, far: float, sbins_row: torch.Tensor) -> torch.Tensor:
+    """per-ray first-level spacing bins [R,n+1] for a bundle that carries its own planes (RayBundle.nears / fars)"""
+    lib = _l.load()
+    nears, fars = nears.reshape(-1).contiguous(), fars.reshape(-1).contiguous()
+    R, n = nears.shape[0], sbins_row.numel() - 1
+    out = torch.empty(R, n + 1, device=nears.device, dtype=torch.float32)
+    with _ctx(nears.device):
+        _run("ray_planes_bins", lambda: lib.unerf_ray_planes_bins(_p(nears), _p(fars), R, near, far, _p(sbins_row), n, _p(out),
+                                                                  _stream()))
+    return out
+
+
 # ------------------------------------------------------------- hash grid ---------------
 
 def hashgrid_fwd(xyz: torch.Tensor, table: torch.Tensor, scalings: torch.Tensor, log2T: int,

@@ -73,9 +73,12 @@ class NerfSceneDev:
 
 
 def sample_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Tensor, clip: Optional[torch.Tensor],
-                ray_offset: int = 0, want_prop_depth: bool = True, image_width: int = 0):
-    """ProposalNetworkSampler at eval.  -> (final spacing bins [R,S+1], [prop_depth_0, prop_depth_1])"""
-    sb = scene.const("bins", scene.num_prop[0])
+                ray_offset: int = 0, want_prop_depth: bool = True, image_width: int = 0,
+                init_bins: Optional[torch.Tensor] = None):
+    """ProposalNetworkSampler at eval.  -> (final spacing bins [R,S+1], [prop_depth_0, prop_depth_1])
+    init_bins [R, num_prop[0]+1]: per-ray first-level bins (a bundle with its own nears / fars: `crop_bins`), else
+    the shared uniform row"""
+    sb = scene.const("bins", scene.num_prop[0]) if init_bins is None else init_bins
     prop_depths = []
     n_iter = len(scene.props)
     for lvl in range(n_iter):
@@ -104,9 +107,23 @@ def _uses_split(scene: NerfSceneDev) -> bool:
                 and f.tcnn_levels is None)
 
 
-def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: int, image_width: int = 0):
+def crop_bins(scene: NerfSceneDev, origins, directions, obb=None, nears=None, fars=None) -> Optional[torch.Tensor]:
+    """First-level bins for rays whose planes are not the collider's: `obb` = (world_to_box [3,4], S [3]) of an
+    OrientedBox -- what Cameras.generate_rays(..., obb_box=box) does to the bundle (laplace_model.py:413,
+    ensemble_pipeline.py:157) -- or the bundle's own nears / fars [R,1]."""
+    row = scene.const("bins", scene.num_prop[0])
+    if obb is not None:
+        return ops.ray_box_bins(origins, directions, obb[0], obb[1], scene.near, scene.far, row)[0]
+    if nears is not None and fars is not None:
+        return ops.ray_planes_bins(nears, fars, scene.near, scene.far, row)
+    return None
+
+
+def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: int, image_width: int = 0,
+                   init_bins: Optional[torch.Tensor] = None):
     """-> (final spacing bins, prop depths, feature planes | None)"""
-    sb, prop_depths = sample_rays(scene, origins, directions, clip, ray_offset, image_width=image_width)
+    sb, prop_depths = sample_rays(scene, origins, directions, clip, ray_offset, image_width=image_width,
+                                  init_bins=init_bins)
     feats = ops.field_gather(origins, directions, sb, scene.field, scene.near, scene.far) if _uses_split(scene) else None
     return sb, prop_depths, feats
 
@@ -169,7 +186,8 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
 
 
 def render_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Tensor, ray_offset: int = 0,
-                total_rays: Optional[int] = None, clip: Optional[torch.Tensor] = None, **shade_kw) -> Dict[str, torch.Tensor]:
+                total_rays: Optional[int] = None, clip: Optional[torch.Tensor] = None,
+                init_bins: Optional[torch.Tensor] = None, **shade_kw) -> Dict[str, torch.Tensor]:
     """Render rays [R,3] with the scene's method (field.mode).  Output keys follow the reference:
       ACTIVE     activenerfacto_model.py:117-127   rgb accumulation depth expected_depth rgb_var rgb_std
                                                    depth_var depth_std prop_depth_i (+density)
@@ -181,15 +199,15 @@ def render_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Te
     if clip is None:
         clip = ops.new_clip_buffer((total_rays or (ray_offset + R)), scene.chunk_rays, origins.device)
     sb, prop_depths, feats = sampling_stage(scene, origins, directions, clip, ray_offset,
-                                            image_width=shade_kw.get("image_width", 0))
+                                            image_width=shade_kw.get("image_width", 0), init_bins=init_bins)
     return shading_stage(scene, origins, directions, sb, prop_depths, feats, clip, ray_offset, **shade_kw)
 
 
 def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int,
-                  rays_per_launch: int = 1 << 18, overlap: bool = False, **shade_kw) -> Dict[str, torch.Tensor]:
+                  rays_per_launch: int = 1 << 18, overlap: bool = False, obb=None, **shade_kw) -> Dict[str, torch.Tensor]:
     """get_outputs_for_camera: generate the H*W rays on device, render them in row-major launch
     groups, return images [H,W,C].  With `overlap`, sampling (group g+1) and shading (group g) run on
-    two streams."""
+    two streams.  obb = (world_to_box [3,4], S [3]): the oriented crop box of `obb_box` (see crop_bins)."""
     _l.require_gpu()
     total = H * W
     dev = scene.device
@@ -203,7 +221,8 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
         if not overlap or len(starts) == 1:
             for start in starts:
                 o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start))
-                out = render_rays(scene, o, d, ray_offset=start, total_rays=total, clip=clip, image_width=W, **shade_kw)
+                out = render_rays(scene, o, d, ray_offset=start, total_rays=total, clip=clip, image_width=W,
+                                  init_bins=crop_bins(scene, o, d, obb), **shade_kw)
                 for k, v in out.items():
                     lists.setdefault(k, []).append(v)
         else:
@@ -213,7 +232,8 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
             for start in starts:
                 with torch.cuda.stream(s_samp):
                     o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start))
-                    sb, pds, feats = sampling_stage(scene, o, d, clip, start, image_width=W)
+                    sb, pds, feats = sampling_stage(scene, o, d, clip, start, image_width=W,
+                                                    init_bins=crop_bins(scene, o, d, obb))
                     ev = torch.cuda.Event()
                     ev.record(s_samp)
                     for t in (o, d, sb, feats, *pds):   # handed to the other stream: keep the allocator honest
