@@ -1630,6 +1630,22 @@ __device__ __forceinline__ f32x16 mf16_mac(const float* lds, int slab, int lane,
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
     return acc;
 }
+// two row blocks against one B operand, the two accumulator chains interleaved: an MFMA whose SrcC is the result of
+// the MFMA right before it issues 16 cycles late (benchmarks/mfma_data_probe.hip: 48 instead of 32 cycles per
+// instruction in a single dependent chain), an independent MFMA in between hides that
+__device__ __forceinline__ void mf16_mac2(const float* lds, int slab_a, int slab_b, int lane, const f16x8& bhi, const f16x8& blo,
+                                          f32x16& o0, f32x16& o1) {
+    const f16x8 ahi0 = *reinterpret_cast<const f16x8*>(lds + slab_a * 512 + lane * 4);
+    const f16x8 alo0 = *reinterpret_cast<const f16x8*>(lds + slab_a * 512 + 256 + lane * 4);
+    const f16x8 ahi1 = *reinterpret_cast<const f16x8*>(lds + slab_b * 512 + lane * 4);
+    const f16x8 alo1 = *reinterpret_cast<const f16x8*>(lds + slab_b * 512 + 256 + lane * 4);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo0, bhi, o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo1, bhi, o1, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi0, blo, o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1, blo, o1, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi0, bhi, o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1, bhi, o1, 0, 0, 0);
+}
 // a 64-wide layer input held as two accumulator blocks (units 0..31 in v0, 32..63 in v1) against the
 // 4 k-steps x NB row blocks of slabs starting at `slab0` (slab = slab0 + NB*step + block)
 template <int NB>
@@ -1639,8 +1655,8 @@ __device__ __forceinline__ void mf16_layer64(const float* lds, int slab0, int la
     for (int s = 0; s < 4; ++s) {
         f16x8 bhi, blo;
         mf16_split(s < 2 ? v0 : v1, s & 1, bhi, blo);
-        o0 = mf16_mac(lds, slab0 + NB * s, lane, bhi, blo, o0);
-        if (NB == 2) o1 = mf16_mac(lds, slab0 + NB * s + 1, lane, bhi, blo, o1);
+        if (NB == 2) mf16_mac2(lds, slab0 + NB * s, slab0 + NB * s + 1, lane, bhi, blo, o0, o1);
+        else o0 = mf16_mac(lds, slab0 + NB * s, lane, bhi, blo, o0);
     }
 }
 
@@ -1712,8 +1728,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 mine[q] = __uint_as_float((__float_as_uint(sh[8 + q]) & hm) | (__float_as_uint(sh[q]) & ~hm));
             f16x8 bhi, blo;
             mf16_split8(mine, bhi, blo);
-            csh0 = mf16_mac(lds, 10, lane, bhi, blo, csh0);
-            csh1 = mf16_mac(lds, 11, lane, bhi, blo, csh1);
+            mf16_mac2(lds, 10, 11, lane, bhi, blo, csh0, csh1);
         }
 
         // layer 0: 32 -> 64 (this half's 16 features = two k-steps), ReLU; the 64 hidden units are the trunk
@@ -1725,8 +1740,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             for (int st = 0; st < 2; ++st) {
                 f16x8 bhi, blo;
                 mf16_split(feat, st, bhi, blo);
-                hid0 = mf16_mac(lds, 2 * st, lane, bhi, blo, hid0);
-                hid1 = mf16_mac(lds, 2 * st + 1, lane, bhi, blo, hid1);
+                mf16_mac2(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hid0, hid1);
             }
             hid0 = mf_relu(hid0);
             hid1 = mf_relu(hid1);
@@ -1770,8 +1784,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             {
                 f16x8 bhi, blo;
                 mf16_split(t, 0, bhi, blo);
-                c0 = mf16_mac(lds, 8, lane, bhi, blo, c0);
-                c1 = mf16_mac(lds, 9, lane, bhi, blo, c1);
+                mf16_mac2(lds, 8, 9, lane, bhi, blo, c0, c1);
             }
             c0 = mf_relu(c0);
             c1 = mf_relu(c1);
@@ -1785,8 +1798,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                     uint32_t mw[8];
                     mf_mask_words_at(mw, st >> 1, h, base0_h0, 2u, k);
                     mf16_apply_masks(bhi, blo, mw, st & 1, a.keep_pk);
-                    d0 = mf16_mac(lds, 12 + 2 * st, lane, bhi, blo, d0);
-                    d1 = mf16_mac(lds, 12 + 2 * st + 1, lane, bhi, blo, d1);
+                    mf16_mac2(lds, 12 + 2 * st, 12 + 2 * st + 1, lane, bhi, blo, d0, d1);
                 }
             } else {
                 mf16_layer64<2>(lds, 12, lane, c0, c1, d0, d1);
@@ -2145,8 +2157,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         for (int st = 0; st < 2; ++st) {
             f16x8 bhi, blo;
             mf16_split(feat, st, bhi, blo);
-            hb0 = mf16_mac(lds, 2 * st, lane, bhi, blo, hb0);
-            hb1 = mf16_mac(lds, 2 * st + 1, lane, bhi, blo, hb1);
+            mf16_mac2(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hb0, hb1);
         }
         // the 64 base outputs feed both mlp_hidden (geo) and the sampled density rows: split them once
         f16x8 xhi[4], xlo[4];
@@ -2168,8 +2179,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         {
             f16x8 bhi, blo;
             mf16_split(t, 0, bhi, blo);
-            c0 = mf16_mac(lds, 8, lane, bhi, blo, c0);
-            c1 = mf16_mac(lds, 9, lane, bhi, blo, c1);
+            mf16_mac2(lds, 8, 9, lane, bhi, blo, c0, c1);
             float sh[16];
             float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
             if (a.p.sh_remap) {
@@ -2184,8 +2194,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
             for (int q = 0; q < 8; ++q)
                 mine[q] = __uint_as_float((__float_as_uint(sh[8 + q]) & hm) | (__float_as_uint(sh[q]) & ~hm));
             mf16_split8(mine, bhi, blo);
-            c0 = mf16_mac(lds, 10, lane, bhi, blo, c0);
-            c1 = mf16_mac(lds, 11, lane, bhi, blo, c1);
+            mf16_mac2(lds, 10, 11, lane, bhi, blo, c0, c1);
         }
         c0 = mf_relu(c0);
         c1 = mf_relu(c1);

@@ -14,7 +14,8 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-LIB_PATH = os.path.join(CSRC, "libunerf.so")
+# UNERF_LIB: another build of the same ABI, for A/B timing on one box (benchmarks/ab_bench.sh); unset in normal use
+LIB_PATH = os.environ.get("UNERF_LIB") or os.path.join(CSRC, "libunerf.so")
 SOURCES = ["unerf_nerf.hip", "unerf_splat.hip"]
 # -amdgpu-mfma-vgpr-form: gfx950 has one unified register file; let the MFMAs write their accumulators to
 # ordinary VGPRs so ReLU / dropout / the next layer's B operand read them without v_accvgpr_read copies
