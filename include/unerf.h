@@ -230,7 +230,7 @@ typedef struct {
        into the layer behind each active site (ops.pack_field_mfma16). */
     int drop_sites;
     /* LAPLACE: 1 = density_activation "softplus" (laplace_model.py:151, laplace_field.py:323) instead of trunc_exp on
-       the (sampled) density head; unerf_laplace_ggn_diag supports trunc_exp only. */
+       the (sampled) density head (unerf_laplace_ggn_diag: dsigma/dpre = 1 - exp(-sigma) instead of sigma). */
     int lap_softplus;
     /* as unerf_density_net: 1 = normalise positions with the scene box instead of the contraction */
     int use_aabb;

@@ -176,15 +176,19 @@ def test_laplace_model_deterministic_density_matches_oracle(dev):
         assert bad.double().mean() <= 1e-2, (k, (got - want).abs().max().item())
 
 
-def test_laplace_compute_hessian_naive_matches_autograd_oracle(dev):
+@pytest.mark.parametrize("activation", ["trunc_exp", "softplus"])
+def test_laplace_compute_hessian_naive_matches_autograd_oracle(dev, activation):
     """GGN fitting (laplace_model.py:343-400): closed-form Jacobian kernels vs one autograd backward per
-    rendered value on the CPU oracle, through the Model method the eval script calls."""
+    rendered value on the CPU oracle, through the Model method the eval script calls; both density activations of
+    NerfactoLaplaceModelConfig (laplace_model.py:151)."""
     from uncertainty_nerf_gs_amd import plugin, synthetic
     t = synthetic.make_scene_tensors(seed=4, kind="laplace", log2T=14, prop_log2T=12)
     cfg = _small_cfg(plugin.MODEL_CONFIGS["nerfacto-laplace"]())
+    cfg.density_activation = activation
     model = cfg._target(cfg, num_train_data=4)
     model.load_state_dict(_state_dict_from_tensors(t, "laplace"))
     sc = O.scene_from_tensors(t)
+    sc.field.density_activation = "softplus" if activation == "softplus" else "exp"
     batches, want_d, want_r = [], torch.zeros(65), torch.zeros(195)
     for theta, (H, W) in ((2.0, (6, 8)), (0.4, (5, 9))):   # 48 + 45 rays: the second batch is not a multiple of 32
         cam = _camera(H, W, theta)

@@ -1981,7 +1981,8 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         // density head: mean / variance of exp(w_s . hb + b_s) over the n_lap sampled rows
         float mu_d, mu2_d = 0.f;
         if (CAPTURE) {
-            mu_d = expf(mf_half_dot(a.p.ws_density, h, hb0, hb1) + a.p.ws_density[64]) * sel;
+            const float pre_d = mf_half_dot(a.p.ws_density, h, hb0, hb1) + a.p.ws_density[64];
+            mu_d = (a.p.lap_softplus ? unerf_softplus(pre_d) : expf(pre_d)) * sel;
             if (valid) {
                 mf_store_units(a.aux, n, 0, h, hb0);
                 mf_store_units(a.aux, n, 1, h, hb1);
@@ -2425,7 +2426,8 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
 //   C_c = sum_i w_i c_ic + (1 - sum_i w_i) c_{S-1,c}          (background = last sample)
 // in closed form.  Last colour layer, row c, input unit k (h = colour hidden, s' = c(1-c)):
 //   dC_c/dW_ck = sum_i (w_i + [i = S-1] T_end) s'_ic h_ik
-// density layer, unit k (x = base_mlp output, sigma = exp(.) * selector so dsigma/dpre = sigma):
+// density layer, unit k (x = base_mlp output, sigma = exp(.) * selector so dsigma/dpre = sigma; with the softplus
+// activation dsigma/dpre = 1 - exp(-sigma) takes the place of the last factor sigma_i):
 //   dC_c/dw_k = sum_i delta_i [ (1 - alpha_i) T_i c_ic - sum_{j>i} w_j c_jc - T_end c_{S-1,c} ] sigma_i x_ik
 // (bias: x = h = 1).  One wave per ray: lane i prepares sample i's scalars with wave scans, then lane k
 // accumulates unit k over the samples.  Per-wave partial sums, reduced in a fixed order (deterministic).
@@ -2437,6 +2439,7 @@ struct GgnArgs {
     int S;
     float s_near, s_far;
     const float* sigma;  // [R,S]
+    int softplus;        // density activation: 0 trunc_exp (dsigma/dpre = sigma), 1 softplus (dsigma/dpre = 1 - exp(-sigma))
     const float* rgb;    // [R,S,3]
     const float* X;      // [R,S,64] base_mlp output
     const float* Hc;     // [R,S,64] colour hidden (input of mlp_rgb_ll)
@@ -2458,6 +2461,9 @@ __global__ __launch_bounds__(256) void laplace_ggn_kernel(GgnArgs a) {
         float c[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) c[k] = unerf_nan_to_num(a.rgb[(r * S + i) * 3 + k]);
+        // dsigma / d(pre-activation): exp -> sigma itself; softplus -> sigmoid(pre) = 1 - exp(-softplus(pre)), and the
+        // selector (0 or 1) that multiplies sigma carries over (sigma = 0 -> derivative 0)
+        const float dsig = a.softplus ? -expm1f(-sig) : sig;
         const float dd = in ? delta * sig : 0.f;
         const float em = expf(-dd);  // 1 - alpha
         const float T = expf(-group_excl_scan<64>(dd, lane));
@@ -2473,7 +2479,7 @@ __global__ __launch_bounds__(256) void laplace_ggn_kernel(GgnArgs a) {
             const float pred = tot + Tf * bg;
             // eval-mode renderer clamps to [0,1]: the gradient passes only inside (torch.clamp backward)
             const float live = (pred >= 0.f && pred <= 1.f && in) ? 1.f : 0.f;
-            g[k] = live * delta * (em * T * c[k] - (tot - incl) - Tf * bg) * sig;
+            g[k] = live * delta * (em * T * c[k] - (tot - incl) - Tf * bg) * dsig;
             const float wt = w + (lane == S - 1 ? Tf : 0.f);
             q[k] = live * wt * c[k] * (1.f - c[k]);
         }
@@ -2557,7 +2563,6 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     FieldArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
     a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = 0;
-    UNERF_REQUIRE(!p->lap_softplus, "laplace_ggn_diag: the closed-form Jacobian is built for the trunc_exp density activation only");
     a.p = *p; a.density = sigma; a.rgb = col; a.aux = X; a.aux2 = Hc; a.features = nullptr;
     a.keep_hi = 0; a.keep_pk = 0; a.drop_on = 0; a.drop_sites = 0; a.drop_scale = 1.f;
     a.box = make_norm_box(p->use_aabb, p->aabb);
@@ -2566,7 +2571,7 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     else launch_matrix_kernel(field_kernel_mfma_laplace<true>, MF_LDS_FP32, a, st);
     GgnArgs g;
     g.sbins = sbins; g.R = R; g.S = S; g.s_near = a.s_near; g.s_far = a.s_far;
-    g.sigma = sigma; g.rgb = col; g.X = X; g.Hc = Hc; g.partials = partials;
+    g.sigma = sigma; g.softplus = p->lap_softplus; g.rgb = col; g.X = X; g.Hc = Hc; g.partials = partials;
     const int blocks = ggn_blocks(R);
     hipLaunchKernelGGL(laplace_ggn_kernel, dim3(blocks), dim3(256), 0, st, g);
     hipLaunchKernelGGL(laplace_ggn_reduce_kernel, dim3(2), dim3(256), 0, st, partials, blocks * 4, ggn_density, ggn_rgb);

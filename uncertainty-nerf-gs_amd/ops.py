@@ -681,8 +681,6 @@ def laplace_ggn_diag(origins, directions, sbins, field: FieldDev, density_mean: 
     lib = _l.load()
     if field.mode != _l.FIELD_LAPLACE:
         raise _l.UnerfError("laplace_ggn_diag needs a LAPLACE field")
-    if field.lap_softplus:
-        raise NotImplementedError("GGN fitting is built for density_activation='trunc_exp' (the reference default) only")
     R, S = sbins.shape[0], sbins.shape[1] - 1
     dev = origins.device
     cs = field.cstruct()
