@@ -17,6 +17,9 @@
  *   - all functions return 0 on success, <0 on error; unerf_last_error() gives
  *     a thread-local message;
  *   - fp32 everywhere; row-major; rays are in image row-major order;
+ *   - a count of zero (R, N, count = 0: an empty chunk, a rank without views, a crop that keeps nothing) is a
+ *     successful no-op and the per-element pointers may then be NULL; parameter structs and host pointers must
+ *     still be valid.  Exceptions: unerf_splat_count_intersects / unerf_splat_bin_sort need N >= 1;
  *   - there is NO CPU implementation behind these symbols.
  */
 #ifndef UNERF_H

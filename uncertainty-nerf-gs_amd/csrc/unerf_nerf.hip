@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a) {
 extern "C" int unerf_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, int H, int W,
                                    int64_t ray_start, int64_t count, float* origins, float* directions,
                                    float* pixel_area, void* stream) {
-    UNERF_REQUIRE(c2w && origins && directions, "generate_rays: null pointer");
+    UNERF_REQUIRE(c2w && (count == 0 || (origins && directions)), "generate_rays: null pointer");
     UNERF_REQUIRE(H > 0 && W > 0 && ray_start >= 0 && count >= 0 && ray_start + count <= (int64_t)H * W,
                   "generate_rays: ray range [%lld,+%lld) outside %dx%d", (long long)ray_start, (long long)count, H, W);
     if (count == 0) return UNERF_OK;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void box_bins_kernel(BoxBinsArgs a) {
 extern "C" int unerf_ray_box_bins(const float* origins, const float* directions, int64_t R, const float* world_to_box,
                                   const float* half_extent, float near, float far, const float* sbins_row, int n,
                                   float* sbins, float* nears, float* fars, void* stream) {
-    UNERF_REQUIRE(origins && directions && world_to_box && half_extent && sbins_row && sbins, "ray_box_bins: null pointer");
+    UNERF_REQUIRE(world_to_box && half_extent && (R == 0 || (origins && directions && sbins_row && sbins)), "ray_box_bins: null pointer");
     UNERF_REQUIRE(R >= 0 && n >= 1 && far > near && near >= 0.f, "ray_box_bins: R=%lld n=%d near=%g far=%g",
                   (long long)R, n, (double)near, (double)far);
     if (R == 0) return UNERF_OK;
@@ -299,7 +299,7 @@ extern "C" int unerf_ray_box_bins(const float* origins, const float* directions,
 
 extern "C" int unerf_ray_planes_bins(const float* nears, const float* fars, int64_t R, float near, float far,
                                      const float* sbins_row, int n, float* sbins, void* stream) {
-    UNERF_REQUIRE(nears && fars && sbins_row && sbins, "ray_planes_bins: null pointer");
+    UNERF_REQUIRE(R == 0 || (nears && fars && sbins_row && sbins), "ray_planes_bins: null pointer");
     UNERF_REQUIRE(R >= 0 && n >= 1 && far > near && near >= 0.f, "ray_planes_bins: R=%lld n=%d near=%g far=%g",
                   (long long)R, n, (double)near, (double)far);
     if (R == 0) return UNERF_OK;
@@ -598,7 +598,7 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
                                       int64_t sbins_stride, int64_t R, int n, float near_plane, float far_plane,
                                       const unerf_density_net* net, float average_init_density, float* density_out,
                                       int64_t ray_offset, int image_width, void* stream) {
-    UNERF_REQUIRE(origins && directions && sbins && net && density_out, "proposal_density: null pointer");
+    UNERF_REQUIRE(net && (R == 0 || (origins && directions && sbins && density_out)), "proposal_density: null pointer");
     UNERF_REQUIRE(net->table && (net->scalings || net->tcnn_levels) && net->w0t && net->b0 && net->w1t && net->b1,
                   "proposal_density: null pointer inside unerf_density_net");
     UNERF_REQUIRE(R >= 0 && n >= 1, "proposal_density: bad R/n");
@@ -848,7 +848,7 @@ extern "C" int unerf_weights_pdf_resample(const float* density, const float* sbi
                                           float histogram_padding, float eps, float* sbins_out, float* prop_depth_out,
                                           float* weights_out, float* clip_minmax, int64_t ray_offset,
                                           int64_t chunk_rays, void* stream) {
-    UNERF_REQUIRE(density && sbins && u && sbins_out, "weights_pdf_resample: null pointer");
+    UNERF_REQUIRE(R <= 0 || (density && sbins && u && sbins_out), "weights_pdf_resample: null pointer");
     UNERF_REQUIRE(n >= 1 && n <= PDF_MAXN, "weights_pdf_resample: n=%d outside [1,%d]", n, PDF_MAXN);
     UNERF_REQUIRE(m >= 1 && m + 1 <= PDF_MAXN, "weights_pdf_resample: m=%d outside [1,%d]", m, PDF_MAXN - 1);
     UNERF_REQUIRE(sbins_stride == 0 || sbins_stride >= n + 1, "weights_pdf_resample: sbins_stride < n+1");
@@ -2270,7 +2270,7 @@ __global__ __launch_bounds__(256) void field_gather_kernel(GatherArgs a) {
 extern "C" int unerf_field_gather(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
                                   float near_plane, float far_plane, const float* table, const float* scalings, int L,
                                   int log2T, float* feature_planes, void* stream) {
-    UNERF_REQUIRE(origins && directions && sbins && table && scalings && feature_planes, "field_gather: null pointer");
+    UNERF_REQUIRE(table && scalings && (R == 0 || (origins && directions && sbins && feature_planes)), "field_gather: null pointer");
     UNERF_REQUIRE(L >= 1 && L <= 32 && log2T >= 1 && log2T <= 24 && R >= 0 && S >= 1, "field_gather: bad L/log2T/R/S");
     if (R == 0) return UNERF_OK;
     GatherArgs a;
@@ -2327,7 +2327,7 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                                float near_plane, float far_plane, int64_t ray_offset, const unerf_field_params* p,
                                const float* features, float* density, float* rgb, float* aux, float* aux2,
                                void* stream) {
-    UNERF_REQUIRE(origins && directions && sbins && p && density && rgb, "field_fwd: null pointer");
+    UNERF_REQUIRE(p && (R == 0 || (origins && directions && sbins && density && rgb)), "field_fwd: null pointer");
     UNERF_REQUIRE(p->table && (p->scalings || p->tcnn_levels) && p->w0t && p->b0 && p->w1t && p->b1 && p->h0t &&
                       p->hb0 && p->h1t && p->hb1 && p->h2t && p->hb2,
                   "field_fwd: null weight pointer");
@@ -2823,7 +2823,7 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
                                    const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane,
                                    const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, float* out,
                                    void* stream) {
-    UNERF_REQUIRE(density && rgb && sbins && out, "composite_var: null pointer");
+    UNERF_REQUIRE(R == 0 || (density && rgb && sbins && out), "composite_var: null pointer");
     UNERF_REQUIRE(B >= 1 && R >= 0, "composite_var: bad B/R");
     UNERF_REQUIRE(S >= 1 && S <= 256, "composite_var: S=%d outside [1,256]", S);
     UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "composite_var: chunk_rays must be > 0 with clip_minmax");
@@ -2841,7 +2841,7 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
 extern "C" int unerf_composite_moments(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
                                        float near_plane, float far_plane, const float* clip_minmax, int64_t ray_offset,
                                        int64_t chunk_rays, float* mean_out, float* var_out, void* stream) {
-    UNERF_REQUIRE(density && rgb && sbins && mean_out && var_out, "composite_moments: null pointer");
+    UNERF_REQUIRE(R == 0 || (density && rgb && sbins && mean_out && var_out), "composite_moments: null pointer");
     UNERF_REQUIRE(B >= 1 && B <= 16 && R >= 0, "composite_moments: B=%d outside [1,16] (use composite_var + moments)", B);
     UNERF_REQUIRE(S >= 1 && S <= 256, "composite_moments: S=%d outside [1,256]", S);
     UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "composite_moments: chunk_rays must be > 0 with clip_minmax");
@@ -3008,7 +3008,7 @@ static int composite_planes_launch(const float* density, const float* rgb, const
                                    int64_t R, int S, float near_plane, float far_plane, const float* clip_minmax,
                                    int64_t ray_offset, int64_t chunk_rays, float* out, float* mean_out, float* var_out,
                                    void* stream, const char* what) {
-    UNERF_REQUIRE(density && rgb && sbins, "%s: null pointer", what);
+    UNERF_REQUIRE(R == 0 || (density && rgb && sbins), "%s: null pointer", what);
     UNERF_REQUIRE(B >= 1 && R >= 0 && S >= 1, "%s: bad B/R/S", what);
     UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "%s: chunk_rays must be > 0 with clip_minmax", what);
     if (R == 0) return UNERF_OK;
@@ -3027,7 +3027,7 @@ extern "C" int unerf_composite_var_planes(const float* density, const float* rgb
                                           int B, int64_t R, int S, float near_plane, float far_plane,
                                           const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, float* out,
                                           void* stream) {
-    UNERF_REQUIRE(out, "composite_var_planes: null pointer");
+    UNERF_REQUIRE(R == 0 || out, "composite_var_planes: null pointer");
     return composite_planes_launch(density, rgb, beta, sbins, B, R, S, near_plane, far_plane, clip_minmax, ray_offset,
                                    chunk_rays, out, nullptr, nullptr, stream, "composite_var_planes");
 }
@@ -3036,7 +3036,7 @@ extern "C" int unerf_composite_moments_planes(const float* density, const float*
                                               int64_t R, int S, float near_plane, float far_plane,
                                               const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays,
                                               float* mean_out, float* var_out, void* stream) {
-    UNERF_REQUIRE(mean_out && var_out, "composite_moments_planes: null pointer");
+    UNERF_REQUIRE(R == 0 || (mean_out && var_out), "composite_moments_planes: null pointer");
     UNERF_REQUIRE(B >= 2, "composite_moments_planes: B=%d (the unbiased variance needs at least two passes)", B);
     return composite_planes_launch(density, rgb, nullptr, sbins, B, R, S, near_plane, far_plane, clip_minmax, ray_offset,
                                    chunk_rays, nullptr, mean_out, var_out, stream, "composite_moments_planes");
@@ -3151,7 +3151,7 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
 extern "C" int unerf_laplace_depth_weights(const float* density_mu, const float* density_var, const float* sbins,
                                            int64_t R, int S, float near_plane, float far_plane, const float* noise,
                                            int D, uint32_t seed, int64_t ray_offset, float* weights_out, void* stream) {
-    UNERF_REQUIRE(density_mu && density_var && sbins && weights_out, "laplace_depth_weights: null pointer");
+    UNERF_REQUIRE(R == 0 || (density_mu && density_var && sbins && weights_out), "laplace_depth_weights: null pointer");
     UNERF_REQUIRE(D >= 1 && R >= 0 && S >= 1 && S <= 256, "laplace_depth_weights: bad D/R/S");
     if (R == 0) return UNERF_OK;
     LapDepthArgs a;
@@ -3186,7 +3186,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
 }
 
 extern "C" int unerf_moments(const float* x, int K, int64_t N, int C, float* mean, float* var, void* stream) {
-    UNERF_REQUIRE(x && mean, "moments: null pointer");
+    UNERF_REQUIRE(N == 0 || (x && mean), "moments: null pointer");
     UNERF_REQUIRE(K >= 1 && N >= 0 && C >= 1, "moments: bad K/N/C");
     if (N == 0) return UNERF_OK;
     hipLaunchKernelGGL(moments_kernel, dim3(blocks_for(N * C, 256)), dim3(256), 0, (hipStream_t)stream, x, K, N * C,

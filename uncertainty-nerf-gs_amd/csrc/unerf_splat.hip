@@ -151,8 +151,8 @@ extern "C" int unerf_splat_project(const float* means3d, const float* scales, fl
                                    int block_width, float clip_thresh, int64_t N, float* xys, float* depths,
                                    int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit,
                                    float* cov3d, void* stream) {
-    UNERF_REQUIRE(means3d && scales && quats && viewmat && xys && depths && radii && conics && compensation &&
-                      num_tiles_hit && cov3d,
+    UNERF_REQUIRE(viewmat && (N == 0 || (means3d && scales && quats && xys && depths && radii && conics && compensation &&
+                                       num_tiles_hit && cov3d)),
                   "splat_project: null pointer");
     UNERF_REQUIRE(H > 0 && W > 0 && block_width > 0 && block_width <= 16 && N >= 0, "splat_project: bad H/W/block/N");
     if (N == 0) return UNERF_OK;
@@ -249,9 +249,9 @@ __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float*
 extern "C" int unerf_splat_sh_colors(int degree, const float* means3d, const float* cam_pos, const float* sh_coeffs,
                                      const float* log_unc, float beta_min, int64_t N, float* colors_out,
                                      float* beta_out, void* stream) {
-    UNERF_REQUIRE(means3d && cam_pos && sh_coeffs && colors_out, "splat_sh_colors: null pointer");
+    UNERF_REQUIRE(cam_pos && (N <= 0 || (means3d && sh_coeffs && colors_out)), "splat_sh_colors: null pointer");
     UNERF_REQUIRE(degree >= -1 && degree <= 3, "splat_sh_colors: degree %d outside [-1,3]", degree);
-    UNERF_REQUIRE(!beta_out || log_unc, "splat_sh_colors: beta_out without log_unc");
+    UNERF_REQUIRE(!beta_out || log_unc || N <= 0, "splat_sh_colors: beta_out without log_unc");
     UNERF_REQUIRE(((uintptr_t)sh_coeffs & 15u) == 0, "splat_sh_colors: sh_coeffs must be 16-byte aligned");
     if (N <= 0) return UNERF_OK;
     hipLaunchKernelGGL(sh_colors_kernel<false>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
@@ -263,10 +263,10 @@ extern "C" int unerf_splat_sh_colors(int degree, const float* means3d, const flo
 extern "C" int unerf_splat_sh_colors_split(int degree, const float* means3d, const float* cam_pos, const float* features_dc,
                                            const float* features_rest, const float* log_unc, float beta_min, int64_t N,
                                            float* colors_out, float* beta_out, void* stream) {
-    UNERF_REQUIRE(means3d && cam_pos && features_dc && colors_out, "splat_sh_colors_split: null pointer");
+    UNERF_REQUIRE(cam_pos && (N <= 0 || (means3d && features_dc && colors_out)), "splat_sh_colors_split: null pointer");
     UNERF_REQUIRE(degree >= -1 && degree <= 3, "splat_sh_colors_split: degree %d outside [-1,3]", degree);
-    UNERF_REQUIRE(degree <= 0 || features_rest, "splat_sh_colors_split: degree %d needs features_rest", degree);
-    UNERF_REQUIRE(!beta_out || log_unc, "splat_sh_colors_split: beta_out without log_unc");
+    UNERF_REQUIRE(degree <= 0 || N <= 0 || features_rest, "splat_sh_colors_split: degree %d needs features_rest", degree);
+    UNERF_REQUIRE(!beta_out || log_unc || N <= 0, "splat_sh_colors_split: beta_out without log_unc");
     if (N <= 0) return UNERF_OK;
     hipLaunchKernelGGL(sh_colors_kernel<true>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
                        means3d, cam_pos[0], cam_pos[1], cam_pos[2], features_dc, features_rest, log_unc, beta_min, N,
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void depth_sqdiff_kernel(const float* __restri
 
 extern "C" int unerf_splat_depth_sqdiff(const float* xys, const float* depths, const float* depth_img, int stride,
                                         int ch, int H, int W, int64_t N, float* sq_diff_out, void* stream) {
-    UNERF_REQUIRE(xys && depths && depth_img && sq_diff_out, "splat_depth_sqdiff: null pointer");
+    UNERF_REQUIRE(N <= 0 || (xys && depths && depth_img && sq_diff_out), "splat_depth_sqdiff: null pointer");
     UNERF_REQUIRE(stride >= 1 && ch >= 0 && ch < stride, "splat_depth_sqdiff: bad stride/ch");
     if (N <= 0) return UNERF_OK;
     hipLaunchKernelGGL(depth_sqdiff_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, xys, depths,

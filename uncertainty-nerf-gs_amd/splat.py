@@ -64,6 +64,8 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     config_sh_degree == 0 selects the sigmoid(features_dc) colours of :247-248."""
     _l.require_gpu()
     background = background.to(gp["means"].device, torch.float32)
+    if gp["means"].shape[0] == 0:          # no splats at all: the same picture as "nothing visible" (:239-240)
+        return empty_outputs(W, H, background)
     if crop_ids is not None:
         crop_ids = crop_ids.reshape(-1).to(gp["means"].device)
         if int(crop_ids.sum().item()) == 0:
