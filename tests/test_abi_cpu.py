@@ -56,6 +56,38 @@ def test_bad_shapes_are_rejected(lib):
     assert rc == -1 and b"C=9" in h.unerf_last_error()
 
 
+def test_zero_counts_are_no_ops_and_oversized_inputs_are_refused(lib):
+    """include/unerf.h conventions: R / N / count = 0 returns UNERF_OK without touching the per-element pointers (no
+    launch, so this runs without a GPU); sample counters beyond 32 bits (the RNG counter / flat index) are refused."""
+    h = lib.load()
+    c2w = (C.c_float * 12)(*([0.0] * 12))
+    assert h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, 4, 4, 16, 0, None, None, None, None) == 0
+    assert h.unerf_moments(None, 8, 0, 3, None, None, None) == 0
+    assert h.unerf_composite_var(None, None, None, None, None, 2, 0, 48, 0.05, 1000.0, None, 0, 32768, None, None) == 0
+    assert h.unerf_composite_moments(None, None, None, 8, 0, 48, 0.05, 1000.0, None, 0, 32768, None, None, None) == 0
+    assert h.unerf_weights_pdf_resample(None, None, 0, 0, 256, 0.05, 1000.0, None, 96, 0.01, 1e-5, None, None, None, None, 0,
+                                        32768, None) == 0
+    assert h.unerf_laplace_depth_weights(None, None, None, 0, 48, 0.05, 1000.0, None, 100, 0, 0, None, None) == 0
+    w2b, half = (C.c_float * 12)(*([0.0] * 12)), (C.c_float * 3)(1.0, 1.0, 1.0)
+    assert h.unerf_ray_box_bins(None, None, 0, w2b, half, 0.05, 1000.0, None, 256, None, None, None, None) == 0
+    assert h.unerf_ray_planes_bins(None, None, 0, 0.05, 1000.0, None, 256, None, None) == 0
+    vm = (C.c_float * 12)(*([0.0] * 12))
+    assert h.unerf_splat_project(None, None, 1.0, None, vm, 1.0, 1.0, 0.0, 0.0, 16, 16, 16, 0.01, 0, None, None, None, None,
+                                 None, None, None, None) == 0
+    assert h.unerf_splat_depth_sqdiff(None, None, None, 1, 0, 16, 16, 0, None, None) == 0
+    # ... but a non-zero count still needs its pointers
+    assert h.unerf_ray_planes_bins(None, None, 5, 0.05, 1000.0, None, 256, None, None) == -1
+    assert b"null pointer" in h.unerf_last_error()
+    # near must lie in front of far; bins need at least one interval
+    assert h.unerf_ray_planes_bins(1, 1, 5, 10.0, 1.0, 1, 256, 1, None) == -1
+    fp = lib.FieldParams()
+    for name in ("table", "scalings", "w0t", "b0", "w1t", "b1", "h0t", "hb0", "h1t", "hb1", "h2t", "hb2"):
+        setattr(fp, name, 1)
+    fp.L, fp.log2T, fp.mode, fp.out1 = 16, 19, 0, 17
+    rc = h.unerf_field_fwd(1, 1, 1, 1 << 27, 48, 0.05, 1000.0, 0, C.byref(fp), None, 1, 1, 1, None, None)
+    assert rc == -1 and b"32 bits" in h.unerf_last_error()
+
+
 def test_ops_refuse_cpu_tensors(lib):
     import torch
     from uncertainty_nerf_gs_amd import ops
