@@ -38,6 +38,10 @@ extern "C" {
 const char* unerf_last_error(void);
 /* Library/ABI version (major*1000+minor). */
 int unerf_version(void);
+/* Build switches that change what the operand blobs must look like (bit mask).  UNERF_BUILD_TRUNK_FOLD: the
+ * MCDROPOUT split-f16 kernels expect the four trunk-out slabs of mfma16_blob folded (see unerf_field_params). */
+#define UNERF_BUILD_TRUNK_FOLD 1
+int unerf_build_flags(void);
 /* Number of visible HIP devices (<=0: none -> every other call fails with UNERF_ERR_HIP). */
 int unerf_device_count(void);
 
@@ -212,7 +216,9 @@ typedef struct {
        as hi = f16(x), lo = f16(x - hi) and hi*hi + hi*lo + lo*hi is accumulated in fp32 on
        v_mfma_f32_32x32x16_f16: fp32-equivalent results (relative deviation ~1e-7 from the exact kernels) at a
        third of the matrix-pipe time of the fp32-input MFMA, which runs at the vector rate.  NULL selects the
-       exact-fp32 kernels above. */
+       exact-fp32 kernels above.  With UNERF_BUILD_TRUNK_FOLD (unerf_build_flags) MCDROPOUT expects the four
+       trunk-out slabs folded: their second operand holds rows 0..15 = W_hi and rows 16..31 = W_lo, so the 16-row
+       layer takes two MFMAs per k-step instead of three (ops.pack_field_mfma16(fold_trunk=True)). */
     const float* mfma16_blob;
     const float* lap16_blob;
     /* Scheduling hint, 0 = none: the rays [ray_offset, ray_offset + R) of this call are consecutive pixels of a

@@ -318,9 +318,11 @@ def test_field_laplace_softplus_density_activation(dev, use_mfma, precision):
     _close(rgb[0], mu_rgb, 0, 2e-5, "mu_rgb")
     exp_fp = copy.copy(sc.field)
     assert not torch.allclose(O.laplace_field(o, d, eb, exp_fp, wsd, wsr)[0], mu_d)      # the activation matters
-    with pytest.raises(NotImplementedError):
-        ops.laplace_ggn_diag(o.to(dev), d.to(dev), sb.to(dev), sd.field, wsd[0], wsr[0], NEAR, FAR,
-                             torch.zeros(65, device=dev), torch.zeros(195, device=dev))
+    # GGN fitting takes the activation's derivative (1 - exp(-sigma) instead of sigma); the values are checked against
+    # autograd in tests/test_gpu_models.py::test_laplace_compute_hessian_naive_matches_autograd_oracle[softplus]
+    gd, gr = torch.zeros(65, device=dev), torch.zeros(195, device=dev)
+    ops.laplace_ggn_diag(o.to(dev), d.to(dev), sb.to(dev), sd.field, wsd[0], wsr[0], NEAR, FAR, gd, gr)
+    assert torch.isfinite(gd).all() and torch.isfinite(gr).all() and gd.abs().sum() > 0
 
 
 @pytest.mark.parametrize("B,S", [(1, 48), (3, 48), (1, 96), (2, 16), (1, 256),

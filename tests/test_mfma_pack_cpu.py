@@ -3,6 +3,7 @@ field_kernel_mfma's dataflow computes the same network.  The kernel's dataflow i
 numpy with the documented v_mfma_f32_32x32x2_f32 lane maps (cdna_hip_programming.md section 3):
 A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D row = (r&3)+8(r>>2)+4(l>>5), col = l&31."""
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -268,6 +269,46 @@ def test_split_f16_slabs_reproduce_the_mlp():
     np.testing.assert_allclose(trunk[:, :17], t_ref.numpy(), rtol=0, atol=3e-6)
     assert np.all(trunk[:, 17:] == 0)
     np.testing.assert_allclose(hidden2, x.numpy(), rtol=0, atol=5e-6)
+
+
+def test_folded_trunk_slabs_give_both_weight_halves_from_one_mfma():
+    """fold_trunk (the MCDROPOUT kernels' 16-row trunk-out layer): the slab's second operand = rows 0..15 W_hi, rows
+    16..31 W_lo, so MFMA(second, a_hi) + MFMA(first, a_lo), registers r + 8 added onto r, is W a to ~2^-22"""
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g) * 0.3
+    w0, b0, w1, b1 = rnd(64, 32), rnd(64), rnd(16, 64), rnd(16)
+    h0, hb0, h1, hb1, h2, hb2 = rnd(64, 31), rnd(64), rnd(64, 64), rnd(64), rnd(3, 64), rnd(3)
+    plain = ops.pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2)
+    fold = ops.pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, fold_trunk=True)
+    raw = lambda blob: blob[:ops.MF16_SLABS * ops.MF16_SLAB_FLOATS].contiguous().view(torch.int16).view(torch.float16).view(
+        ops.MF16_SLABS, 2, 64, 8)
+    rp, rf = raw(plain), raw(fold)
+    keep = [s for s in range(ops.MF16_SLABS) if not 4 <= s < 8]
+    assert torch.equal(rp[keep], rf[keep]) and torch.equal(rp[4:8, 0], rf[4:8, 0]) and torch.equal(plain[ops.MFMA_BIAS_OFF:], fold[ops.MFMA_BIAS_OFF:])
+    lane = torch.arange(64)
+    lower, upper = (lane & 31) < 16, (lane & 31) >= 16
+    assert torch.equal(rf[4:8, 1][:, lower], rp[4:8, 0][:, lower])                       # rows 0..15: W_hi again
+    assert torch.equal(rf[4:8, 1][:, upper], rp[4:8, 1][:, lower])                       # rows 16..31: W_lo of row - 16
+    assert (rp[4:8, :, upper] == 0).all()                                                # 16 output rows only
+    # emulate the two MFMAs per k-step on hi / lo activation halves
+    hid = (torch.randn(32, 64, generator=g, dtype=torch.float64) * 0.7).clamp_min(0)
+    hid_hi = hid.to(torch.float16).double()
+    hid_lo = (hid - hid_hi).to(torch.float16).double()
+    j = I_
+    acc = np.zeros((16, 64))
+    first, mixed = rf[:, 0].double().numpy(), rf[:, 1].double().numpy()
+    for st in range(4):
+        regs = lambda v: np.stack([v[j, 32 * (st >> 1) + unit(8 * (st & 1) + e, H_)] for e in range(8)], axis=1)
+        acc = mfma16(first[4 + st], regs(hid_lo.numpy()), acc)
+        acc = mfma16(mixed[4 + st], regs(hid_hi.numpy()), acc)
+    acc[:8] += acc[8:]
+    t = np.zeros((32, 16))
+    for r in range(8):
+        t[j, unit(r, H_)] = acc[r]
+    ref = hid @ w1.double().T
+    np.testing.assert_allclose(t, ref.numpy(), rtol=0, atol=3e-6)
+    with pytest.raises(AssertionError):                                                  # 17 rows (ACTIVE) cannot fold
+        ops.pack_field_mfma16(w0, b0, rnd(17, 64), rnd(17), h0, hb0, h1, hb1, h2, hb2, fold_trunk=True)
 
 
 def test_split_f16_halves_are_a_22_bit_representation():

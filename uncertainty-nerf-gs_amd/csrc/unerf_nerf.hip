@@ -31,8 +31,18 @@ int unerf_check_launch(const char* what) {
     }
     return UNERF_OK;
 }
+// ---- build switches measured against each other on one box (benchmarks/exp_kpass_variants.sh,
+// profiles/r2_exp_kpass_variants.json); the defaults are what ships.  unerf_build_flags() reports them, and the host
+// packs the operands to match (ops.pack_field_mfma16: fold_trunk).
+#ifndef UNERF_TRUNK_FOLD
+#define UNERF_TRUNK_FOLD 1       // K-pass kernel, 16-row trunk-out layer: two MFMAs per k-step (-1 % kernel time)
+#endif
+#ifndef UNERF_TRUNK_RESIDENT
+#define UNERF_TRUNK_RESIDENT 1   // ... and its operands kept in registers across the passes (-3.5 %)
+#endif
 extern "C" const char* unerf_last_error(void) { return g_err; }
-extern "C" int unerf_version(void) { return 1101; }   // 11xx: round-2 ABI (drop_sites, sample_major planes, aabb, ...); 1101: ray_box_bins / ray_planes_bins
+extern "C" int unerf_build_flags(void) { return UNERF_TRUNK_FOLD ? UNERF_BUILD_TRUNK_FOLD : 0; }
+extern "C" int unerf_version(void) { return 1102; }   // 11xx: round-2 ABI (drop_sites, sample_major planes, aabb, ...); 1101: ray_box_bins / ray_planes_bins; 1102: build flags, folded trunk-out slabs
 extern "C" int unerf_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -1646,6 +1656,22 @@ __device__ __forceinline__ void mf16_mac2(const float* lds, int slab_a, int slab
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi0, bhi, o0, 0, 0, 0);
     o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1, bhi, o1, 0, 0, 0);
 }
+// Folded slab (ops.pack_field_mfma16: fold_trunk) of a layer with <= 16 output rows: the slab's second operand holds
+// rows 0..15 = W_hi and rows 16..31 = W_lo, so one MFMA against the hi halves of the activations produces W_hi a_hi in
+// accumulator registers 0..7 and W_lo a_hi in registers 8..15 of the same lane (row(r + 8) = row(r) + 16); the first
+// operand (W_hi, rows 16..31 zero) takes the lo halves.  Two MFMAs per k-step instead of three; the caller adds
+// registers r + 8 onto r once per layer (mf16_fold_rows).
+__device__ __forceinline__ f32x16 mf16_mac_fold_ops(const f16x8& ahi, const f16x8& amix, const f16x8& bhi, const f16x8& blo,
+                                                    f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(amix, bhi, acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ f32x16 mf16_fold_rows(f32x16 acc) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] += acc[r + 8];
+    return acc;
+}
 // a 64-wide layer input held as two accumulator blocks (units 0..31 in v0, 32..63 in v1) against the
 // 4 k-steps x NB row blocks of slabs starting at `slab0` (slab = slab0 + NB*step + block)
 template <int NB>
@@ -1749,6 +1775,18 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         }
 
         const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
+        // variants: the trunk-out operands (4 k-steps x 2 quads = 32 VGPRs) kept in registers across the passes; the
+        // 16-row trunk-out layer of MCDROPOUT folded into two MFMAs per k-step
+        constexpr bool TRUNK_RESIDENT = UNERF_TRUNK_RESIDENT && MODE == UNERF_FIELD_MCDROPOUT && DROP && !SITES;
+        constexpr bool FOLD = UNERF_TRUNK_FOLD && MODE == UNERF_FIELD_MCDROPOUT;
+        f16x8 ta0[4], ta1[4];   // first / second operand of trunk slab 4 + st
+        if (TRUNK_RESIDENT) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                ta0[st] = *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + lane * 4);
+                ta1[st] = *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + 256 + lane * 4);
+            }
+        }
         constexpr bool drop = DROP;   // host: a.drop_on
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         uint32_t mk0[8], mk1[8], mk2[8], mk3[8];
@@ -1771,14 +1809,45 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 mf_mask_step(mk2);
                 mf_mask_step(mk3);
             }
+#if defined(UNERF_PROBE_EXTRA_VALU)   // experiment builds only (benchmarks/exp_issue_model.sh): N independent VALU per pass
+            {
+                uint32_t dummy = (uint32_t)k;
+#pragma unroll
+                for (int q = 0; q < UNERF_PROBE_EXTRA_VALU; ++q) asm volatile("v_alignbit_b32 %0, %0, %0, 5" : "+v"(dummy));
+                asm volatile("" ::"v"(dummy));
+            }
+#endif
+#if defined(UNERF_PROBE_EXTRA_MFMA)   // ... or N independent MFMAs per pass
+            {
+                f32x16 junk = {0};
+#pragma unroll
+                for (int q = 0; q < UNERF_PROBE_EXTRA_MFMA; ++q) junk = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhi[0], hlo[0], junk, 0, 0, 0);
+                asm volatile("" ::"v"(junk));
+            }
+#endif
             // trunk out: 64 -> out1 rows (row 0 density, 1..15 geo, 16 beta) from the (masked) hidden operands
             f32x16 t = mf16_bias(lds, 2, h);
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 f16x8 bhi = hhi[st], blo = hlo[st];
                 if (drop_trunk) mf16_apply_masks(bhi, blo, st < 2 ? mk0 : mk1, st & 1, a.keep_pk);
-                t = mf16_mac(lds, 4 + st, lane, bhi, blo, t);
+                f16x8 a0, a1;
+                if (TRUNK_RESIDENT) {
+                    a0 = ta0[st];
+                    a1 = ta1[st];
+                } else {
+                    a0 = *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + lane * 4);
+                    a1 = *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + 256 + lane * 4);
+                }
+                if (FOLD) {
+                    t = mf16_mac_fold_ops(a0, a1, bhi, blo, t);
+                } else {   // a0 = W_hi, a1 = W_lo: small terms first
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bhi, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, blo, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bhi, t, 0, 0, 0);
+                }
             }
+            if (FOLD) t = mf16_fold_rows(t);
             // colour 0: geo rows of t (registers 0..7 = one k-step) on top of the SH partial sum, ReLU
             f32x16 c0 = csh0, c1 = csh1;
             {

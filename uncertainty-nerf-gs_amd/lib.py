@@ -44,6 +44,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     box); concurrent callers (one process per GPU) serialise on a lock file and the library is
     replaced atomically, so nobody dlopens a half-written file."""
     import fcntl
+    if os.environ.get("UNERF_LIB"):
+        # an explicitly chosen build (A/B timing): never rebuilt from the in-tree sources, used as it is
+        if not os.path.exists(LIB_PATH):
+            raise UnerfError(f"UNERF_LIB={LIB_PATH} does not exist")
+        return LIB_PATH
     digest, stamp = _source_digest(), LIB_PATH + ".sha256"
 
     def fresh():
@@ -106,6 +111,7 @@ class FieldParams(C.Structure):
 
 
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
+BUILD_TRUNK_FOLD = 1   # include/unerf.h: UNERF_BUILD_TRUNK_FOLD
 DROP_TRUNK, DROP_HEAD0, DROP_HEAD1 = 1, 2, 4     # include/unerf.h: UNERF_DROP_*
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -115,6 +121,7 @@ _fp = C.POINTER(C.c_float)
 SIGNATURES = {
     "unerf_last_error": (C.c_char_p, []),
     "unerf_version": (_i, []),
+    "unerf_build_flags": (_i, []),
     "unerf_device_count": (_i, []),
     "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "unerf_ray_box_bins": (_i, [_vp, _vp, _i64, _fp, _fp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp]),

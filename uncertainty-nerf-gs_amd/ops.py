@@ -7,6 +7,7 @@ stated), contiguous and on a HIP device; nothing is silently copied to or from t
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -297,6 +298,7 @@ class FieldDev:
     packed_drop_scale: float = 1.0               # the inverted-dropout scale folded into mfma16_blob at pack time
     drop_sites: int = 0                          # UNERF_DROP_* bits (0 = reference default: trunk + last head layer)
     packed_drop_sites: int = 0                   # ... and the layers it was folded into
+    packed_mode: int = -1                        # the mode mfma16_blob was laid out for (MCDROPOUT: folded trunk-out slabs)
     lap_softplus: int = 0                        # LAPLACE: density_activation "softplus" instead of trunc_exp
     aabb: Optional[Tuple[float, ...]] = None     # 6 floats: scene-box normalisation instead of the contraction
 
@@ -318,7 +320,9 @@ class FieldDev:
         kw["packed_drop_sites"] = cls._sites(int(kw.get("drop_sites", 0)))
         blob16 = pack_field_mfma16(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
                                    geo_first_unit=0 if lap else 1, drop_scale=kw["packed_drop_scale"],
-                                   drop_sites=kw["packed_drop_sites"])
+                                   drop_sites=kw["packed_drop_sites"],
+                                   fold_trunk=mode == _l.FIELD_MCDROPOUT and bool(_l.load().unerf_build_flags() & _l.BUILD_TRUNK_FOLD))
+        kw["packed_mode"] = mode
         kw["mfma16_blob"] = None if blob16 is None else f(blob16)   # None (weights beyond the f16 range): exact kernels
         lap_blob = None
         if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
@@ -347,6 +351,8 @@ class FieldDev:
             raise _l.UnerfError(
                 f"FieldDev: K={self.K}, p_drop={self.p_drop} do not match the dropout scale {self.packed_drop_scale:.6g} "
                 "packed into mfma16_blob; rebuild the FieldDev (from_torch) after changing K or p_drop")
+        if use16 and self.packed_mode >= 0 and (self.packed_mode == _l.FIELD_MCDROPOUT) != (self.mode == _l.FIELD_MCDROPOUT):
+            raise _l.UnerfError("FieldDev: mfma16_blob was laid out for another mode; rebuild the FieldDev (from_torch)")
         return _l.FieldParams(
             self.mode, _p(self.table), _p(self.scalings), self.scalings.numel(), self.log2T,
             _p(self.w0t), _p(self.b0), _p(self.w1t), _p(self.b1), self.b1.numel(),
@@ -454,13 +460,17 @@ def _split_f16(w: torch.Tensor):
 
 
 def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit: int = 1,
-                      drop_scale: float = 1.0, drop_sites: int = 5) -> torch.Tensor:
+                      drop_scale: float = 1.0, drop_sites: int = 5, fold_trunk: bool = False) -> torch.Tensor:
     """Same arguments and same blob size as pack_field_mfma; the first 10240 floats hold the 20 split-f16
     A-operand slabs [slab][hi|lo][lane][8 halves], the bias rows and the rgb layer follow (fp32).
     drop_scale = 1/(1-p) when MC-dropout masks are applied in front of the trunk-out and rgb layers: the
-    inverted-dropout scale is folded into those two weight matrices (the kernel then only zeroes units)."""
+    inverted-dropout scale is folded into those two weight matrices (the kernel then only zeroes units).
+    fold_trunk (MCDROPOUT with UNERF_BUILD_TRUNK_FOLD; needs <= 16 trunk-out rows): the second operand of the four
+    trunk-out slabs holds rows 0..15 = W_hi, rows 16..31 = W_lo, so ONE MFMA against the activations' hi halves yields
+    both W_hi a_hi (rows 0..15) and W_lo a_hi (rows 16..31 = the same lane's registers 8..15)."""
     f = lambda t: t.detach().to("cpu", torch.float32)
     w0f, w1f, h0f, h1f = map(f, (w0, w1, h0, h1))
+    h2 = f(h2)
     # the scale sits in the layer BEHIND each active dropout site (include/unerf.h: UNERF_DROP_*)
     if drop_sites & 1:
         w1f = w1f * float(drop_scale)
@@ -490,10 +500,14 @@ def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit:
         for b in range(2):
             slabs[12 + 2 * s + b] = h1f[32 * b + row, 32 * (s >> 1) + _mf16_unit(s & 1, g, e)]
     hi, lo = _split_f16(slabs)
+    if fold_trunk:   # second operand of the trunk-out slabs: rows 0..15 = W_hi, rows 16..31 = W_lo of row - 16
+        assert out1 <= 16, "fold_trunk: the trunk output must fit 16 MFMA rows"
+        for s in range(4):
+            lo[4 + s] = torch.where(row < 16, hi[4 + s], lo[4 + s][(lane & 15) + 32 * (lane >> 5)])
     frag = torch.stack([hi, lo], dim=1).contiguous()      # [slab][hi|lo][lane][8]
     head = frag.view(torch.int16).reshape(-1).view(torch.float32)
     assert head.numel() == MF16_SLABS * MF16_SLAB_FLOATS == MFMA_BIAS_OFF
-    tail = pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, f(h2) * (float(drop_scale) if drop_sites & 4 else 1.0), hb2,
+    tail = pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2 * (float(drop_scale) if drop_sites & 4 else 1.0), hb2,
                            geo_first_unit)[MFMA_BIAS_OFF:]
     return torch.cat([head, tail])
 
