@@ -41,6 +41,7 @@ int unerf_version(void);
 /* Build switches that change what the operand blobs must look like (bit mask).  UNERF_BUILD_TRUNK_FOLD: the
  * MCDROPOUT split-f16 kernels expect the four trunk-out slabs of mfma16_blob folded (see unerf_field_params). */
 #define UNERF_BUILD_TRUNK_FOLD 1
+#define UNERF_BUILD_LAP_EXP2 2   /* lap16_blob rows carry their activation's base change (see unerf_field_params) */
 int unerf_build_flags(void);
 /* Number of visible HIP devices (<=0: none -> every other call fails with UNERF_ERR_HIP). */
 int unerf_device_count(void);
@@ -218,7 +219,10 @@ typedef struct {
        third of the matrix-pipe time of the fp32-input MFMA, which runs at the vector rate.  NULL selects the
        exact-fp32 kernels above.  With UNERF_BUILD_TRUNK_FOLD (unerf_build_flags) MCDROPOUT expects the four
        trunk-out slabs folded: their second operand holds rows 0..15 = W_hi and rows 16..31 = W_lo, so the 16-row
-       layer takes two MFMAs per k-step instead of three (ops.pack_field_mfma16(fold_trunk=True)). */
+        layer takes two MFMAs per k-step instead of three (ops.pack_field_mfma16(fold_trunk=True)).  With
+       UNERF_BUILD_LAP_EXP2 lap16_blob's rows (weights and bias) carry the base change of their activation: density
+       rows x log2(e) (unscaled when lap_softplus = 1), colour rows x -log2(e), and the kernel applies the bare hardware
+       exp2 (padded rows: bias -1e30 for the density head, +1e30 for the colour heads -> they contribute 0). */
     const float* mfma16_blob;
     const float* lap16_blob;
     /* Scheduling hint, 0 = none: the rays [ray_offset, ray_offset + R) of this call are consecutive pixels of a

@@ -311,6 +311,27 @@ def test_folded_trunk_slabs_give_both_weight_halves_from_one_mfma():
         ops.pack_field_mfma16(w0, b0, rnd(17, 64), rnd(17), h0, hb0, h1, hb1, h2, hb2, fold_trunk=True)
 
 
+def test_laplace_heads_with_the_base_change_folded_into_the_rows():
+    """exp2_rows (UNERF_BUILD_LAP_EXP2): density rows x log2 e, colour rows x -log2 e (weights and bias), padded rows
+    keep a bias that makes exp2 / (1 / (1 + exp2)) vanish; softplus density rows stay unscaled"""
+    g = torch.Generator().manual_seed(6)
+    rnd = lambda *s: torch.randn(*s, generator=g) * 0.3
+    n = 100
+    ws_d, ws_r = rnd(n, 65), rnd(n, 195)
+    plain = ops.pack_laplace_heads16(ws_d, ws_r)
+    sd, sr = (ws_d.double() * ops.LOG2E).float(), (ws_r.double() * -ops.LOG2E).float()
+    scaled = ops.pack_laplace_heads16(ws_d, ws_r, exp2_rows=True)
+    want = ops.pack_laplace_heads16(sd, sr)
+    assert torch.equal(scaled[:ops.LAP_BIAS_OFF], want[:ops.LAP_BIAS_OFF])
+    tail = want[ops.LAP_BIAS_OFF:].view(4, ops.LAP_BLOCKS, 2, 16).clone()
+    assert (tail == ops.LAP_PAD_BIAS).sum() == 4 * (128 - n)
+    tail[1:][tail[1:] == ops.LAP_PAD_BIAS] = -ops.LAP_PAD_BIAS
+    assert torch.equal(scaled[ops.LAP_BIAS_OFF:], tail.reshape(-1))
+    soft = ops.pack_laplace_heads16(ws_d, ws_r, exp2_rows=True, softplus=True)
+    q = ops.LAP_BIAS_OFF // 4                                   # fragments of head 0 (density)
+    assert torch.equal(soft[:q], plain[:q]) and torch.equal(soft[q:ops.LAP_BIAS_OFF], scaled[q:ops.LAP_BIAS_OFF])
+
+
 def test_split_f16_halves_are_a_22_bit_representation():
     g = torch.Generator().manual_seed(4)
     w = torch.randn(4096, generator=g) * torch.logspace(-3, 2, 4096)

@@ -37,11 +37,16 @@ int unerf_check_launch(const char* what) {
 #ifndef UNERF_TRUNK_FOLD
 #define UNERF_TRUNK_FOLD 1       // K-pass kernel, 16-row trunk-out layer: two MFMAs per k-step (-1 % kernel time)
 #endif
+#ifndef UNERF_LAP_EXP2
+#define UNERF_LAP_EXP2 1         // LAPLACE: lap16_blob rows pre-scaled by +-log2(e), bare exp2 in the epilogue
+#endif
 #ifndef UNERF_TRUNK_RESIDENT
 #define UNERF_TRUNK_RESIDENT 1   // ... and its operands kept in registers across the passes (-3.5 %)
 #endif
 extern "C" const char* unerf_last_error(void) { return g_err; }
-extern "C" int unerf_build_flags(void) { return UNERF_TRUNK_FOLD ? UNERF_BUILD_TRUNK_FOLD : 0; }
+extern "C" int unerf_build_flags(void) {
+    return (UNERF_TRUNK_FOLD ? UNERF_BUILD_TRUNK_FOLD : 0) | (UNERF_LAP_EXP2 ? UNERF_BUILD_LAP_EXP2 : 0);
+}
 extern "C" int unerf_version(void) { return 1102; }   // 11xx: round-2 ABI (drop_sites, sample_major planes, aabb, ...); 1101: ray_box_bins / ray_planes_bins; 1102: build flags, folded trunk-out slabs
 extern "C" int unerf_device_count(void) {
     int n = 0;
@@ -2139,12 +2144,15 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
 // matrix work cut 5x the exp / rcp epilogues (quarter-rate transcendentals) are the larger half, so register
 // quads that only hold padding rows (rows >= n_lap) are skipped.
 // --------------------------------------------------------------------------------------
-template <bool SIGMOID>
+// ACT: 0 exp, 1 sigmoid, 2 softplus.  With UNERF_LAP_EXP2 the rows of lap16_blob carry the base change
+// (ops.pack_laplace_heads16: density rows x log2 e, colour rows x -log2 e), so exp / sigmoid are the bare v_exp_f32
+// (+ v_rcp_f32); softplus rows are unscaled.  The running sums of p and p^2 are one packed fma per activation,
+// (s1, s2) += (p, p) * (1, p), instead of a multiply and a packed add.
+template <int ACT>
 __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int q, int n_lap, int lane,
                                               const f16x8 (&bhi)[4], const f16x8 (&blo)[4], int h, float& sum1,
-                                              float& sum2, int softplus = 0) {
-    sum1 = 0.f;
-    sum2 = 0.f;
+                                              float& sum2) {
+    unerf_v2f s12 = {0.f, 0.f}, pr = {1.f, 0.f};
     f16x8 cur[8], nxt[8];
     {
         const float* f = lap + (size_t)((q * LAP_BLOCKS + 0) * 8) * 256 + lane * 4;
@@ -2175,9 +2183,19 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
             if (8 * qd < rows) {  // uniform
 #pragma unroll
                 for (int r = 4 * qd; r < 4 * qd + 4; ++r) {
-                    float p = SIGMOID ? __builtin_amdgcn_rcpf(1.f + __expf(-acc[r])) : (softplus ? mf_softplus_fast(acc[r]) : __expf(acc[r]));
-                    sum1 += p;
-                    sum2 += p * p;
+                    float p;
+                    if (ACT == 2) {
+                        p = mf_softplus_fast(acc[r]);
+                    } else {
+                        const float e = UNERF_LAP_EXP2 ? __builtin_amdgcn_exp2f(acc[r]) : __expf(ACT == 1 ? -acc[r] : acc[r]);
+                        p = ACT == 1 ? __builtin_amdgcn_rcpf(1.f + e) : e;
+                    }
+                    // (s1, s2) += (p, p) * (1, p): both factors read from the pair P = (1, p) through op_sel (src0 takes
+                    // the high dword for both lanes, src1 low / high).  Spelled with vector types the compiler builds the
+                    // two factor pairs with a v_mov each.  s_nop: a transcendental's result (p comes from v_exp / v_rcp)
+                    // needs one wait state before a VALU instruction the compiler cannot see may read it.
+                    pr.y = p;
+                    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(s12) : "v"(pr));
                 }
             }
         }
@@ -2187,8 +2205,8 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
             for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
         }
     }
-    sum1 += __shfl_xor(sum1, 32, 64);
-    sum2 += __shfl_xor(sum2, 32, 64);
+    sum1 = s12.x + __shfl_xor(s12.x, 32, 64);
+    sum2 = s12.y + __shfl_xor(s12.y, 32, 64);
 }
 
 template <bool TCNN>
@@ -2237,7 +2255,8 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
 #pragma unroll
         for (int st = 0; st < 4; ++st) t = mf16_mac(lds, 4 + st, lane, xhi[st], xlo[st], t);
         float d1, d2;
-        mf16_lap_head<false>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2, a.p.lap_softplus);
+        if (a.p.lap_softplus) mf16_lap_head<2>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);   // uniform
+        else mf16_lap_head<0>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
         float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
         if (a.p.lap_mask_density) {  // use_deterministic_density: selector-masked mean, no variance
             mu_d *= sel;
@@ -2278,7 +2297,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float c1s, c2s;
-            mf16_lap_head<true>(a.p.lap16_blob, 1 + c, a.p.n_lap, lane, xhi, xlo, h, c1s, c2s);
+            mf16_lap_head<1>(a.p.lap16_blob, 1 + c, a.p.n_lap, lane, xhi, xlo, h, c1s, c2s);
             mu_c[c] = c1s * inv_n;
             vsum += fmaxf(c2s * inv_n - mu_c[c] * mu_c[c], 0.f);
         }

@@ -111,7 +111,7 @@ class FieldParams(C.Structure):
 
 
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
-BUILD_TRUNK_FOLD = 1   # include/unerf.h: UNERF_BUILD_TRUNK_FOLD
+BUILD_TRUNK_FOLD, BUILD_LAP_EXP2 = 1, 2   # include/unerf.h: UNERF_BUILD_*
 DROP_TRUNK, DROP_HEAD0, DROP_HEAD1 = 1, 2, 4     # include/unerf.h: UNERF_DROP_*
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32

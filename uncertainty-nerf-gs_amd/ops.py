@@ -298,6 +298,7 @@ class FieldDev:
     packed_drop_scale: float = 1.0               # the inverted-dropout scale folded into mfma16_blob at pack time
     drop_sites: int = 0                          # UNERF_DROP_* bits (0 = reference default: trunk + last head layer)
     packed_drop_sites: int = 0                   # ... and the layers it was folded into
+    packed_lap_softplus: int = -1                # the density activation lap16_blob's density rows were scaled for
     packed_mode: int = -1                        # the mode mfma16_blob was laid out for (MCDROPOUT: folded trunk-out slabs)
     lap_softplus: int = 0                        # LAPLACE: density_activation "softplus" instead of trunc_exp
     aabb: Optional[Tuple[float, ...]] = None     # 6 floats: scene-box normalisation instead of the contraction
@@ -327,8 +328,11 @@ class FieldDev:
         lap_blob = None
         if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
             lap_blob = f(pack_laplace_heads(kw["ws_density"], kw["ws_rgb"]))
-            lap16 = pack_laplace_heads16(kw["ws_density"], kw["ws_rgb"])
+            lap16 = pack_laplace_heads16(kw["ws_density"], kw["ws_rgb"],
+                                         exp2_rows=bool(_l.load().unerf_build_flags() & _l.BUILD_LAP_EXP2),
+                                         softplus=bool(kw.get("lap_softplus", 0)))
             kw["lap16_blob"] = None if lap16 is None else f(lap16)
+            kw["packed_lap_softplus"] = int(bool(kw.get("lap_softplus", 0)))
         return cls(mode, f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
                    f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
                    mfma_blob=blob, lap_blob=lap_blob, **kw)
@@ -351,6 +355,10 @@ class FieldDev:
             raise _l.UnerfError(
                 f"FieldDev: K={self.K}, p_drop={self.p_drop} do not match the dropout scale {self.packed_drop_scale:.6g} "
                 "packed into mfma16_blob; rebuild the FieldDev (from_torch) after changing K or p_drop")
+        if (use16 and self.lap16_blob is not None and self.packed_lap_softplus >= 0
+                and self.packed_lap_softplus != int(bool(self.lap_softplus))):
+            raise _l.UnerfError("FieldDev: lap_softplus changed since from_torch(): lap16_blob's density rows carry (or "
+                                "lack) the log2(e) factor of the other activation; rebuild the FieldDev")
         if use16 and self.packed_mode >= 0 and (self.packed_mode == _l.FIELD_MCDROPOUT) != (self.mode == _l.FIELD_MCDROPOUT):
             raise _l.UnerfError("FieldDev: mfma16_blob was laid out for another mode; rebuild the FieldDev (from_torch)")
         return _l.FieldParams(
@@ -550,11 +558,22 @@ def pack_laplace_heads(ws_density: torch.Tensor, ws_rgb: torch.Tensor) -> torch.
     return blob
 
 
-def pack_laplace_heads16(ws_density: torch.Tensor, ws_rgb: torch.Tensor) -> torch.Tensor:
-    """Split-f16 form of pack_laplace_heads (same size, same bias region): fragments
-    [head q][block b][k-step s][hi|lo][lane][8 halves], k order = accumulator order of the 64 hidden units."""
+LOG2E = 1.4426950408889634
+
+
+def pack_laplace_heads16(ws_density: torch.Tensor, ws_rgb: torch.Tensor, exp2_rows: bool = False,
+                         softplus: bool = False) -> torch.Tensor:
+    """Split-f16 form of pack_laplace_heads (same size, same bias layout): fragments
+    [head q][block b][k-step s][hi|lo][lane][8 halves], k order = accumulator order of the 64 hidden units.
+    exp2_rows (UNERF_BUILD_LAP_EXP2): the rows (weights and bias) carry the base change of the activation behind
+    them, so that the kernel's epilogue is the bare hardware exp2 -- density rows x log2(e) (exp(x) = 2^(x log2 e); left
+    alone when the density activation is softplus), colour rows x -log2(e) (sigmoid(x) = 1 / (1 + 2^(-x log2 e)))."""
     wd = ws_density.detach().to("cpu", torch.float32)
     wr = ws_rgb.detach().to("cpu", torch.float32)
+    if exp2_rows:
+        wd = (wd.double() * (1.0 if softplus else LOG2E)).to(torch.float32)
+        wr = (wr.double() * -LOG2E).to(torch.float32)
+        ws_density, ws_rgb = wd, wr
     n = wd.shape[0]
     assert wd.shape == (n, 65) and wr.shape == (n, 195) and 1 <= n <= 32 * LAP_BLOCKS
     if max(float(abs(wd).max()), float(abs(wr).max())) >= F16_OPERAND_LIMIT:
@@ -574,7 +593,10 @@ def pack_laplace_heads16(ws_density: torch.Tensor, ws_rgb: torch.Tensor) -> torc
     frag = torch.stack([hi, lo], dim=3).contiguous()       # [q][b][s][hi|lo][lane][8]
     head = frag.view(torch.int16).reshape(-1).view(torch.float32)
     assert head.numel() == LAP_BIAS_OFF
-    return torch.cat([head, pack_laplace_heads(ws_density, ws_rgb)[LAP_BIAS_OFF:]])
+    tail = pack_laplace_heads(ws_density, ws_rgb)[LAP_BIAS_OFF:].clone().view(4, LAP_BLOCKS, 2, 16)
+    if exp2_rows:   # padded rows: bias -1e30 in front of exp2 (-> 0); in front of 1 / (1 + exp2(.)) the sign flips with the rows
+        tail[1:][tail[1:] == LAP_PAD_BIAS] = -LAP_PAD_BIAS
+    return torch.cat([head, tail.reshape(-1)])
 
 
 # ------------------------------------------------------- proposal sampling -------------
