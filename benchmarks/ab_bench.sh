@@ -3,14 +3,17 @@
 #   here:        build the variant to compare against into benchmarks/build_probe/libunerf_base.so
 #                (e.g. `git stash; hipcc ... -o benchmarks/build_probe/libunerf_base.so csrc/*.hip; git stash pop`)
 #   on the box:  bash benchmarks/ab_bench.sh [method] [tag]   -> gpurun_out/ab_<tag>.json
-# alternates the in-tree library ("new") and the base library three times each.
+# alternates the "new" library (benchmarks/build_probe/libunerf_new.so when it exists, else the in-tree one -- which
+# bench.py rebuilds from the sources if they changed since it was built) and the base library three times each.
 cd "$(dirname "$0")/.."
 METHOD=${1:-mcdropout}
 TAG=${2:-$METHOD}
 ALT=$PWD/benchmarks/build_probe/libunerf_base.so
+NEW=$PWD/benchmarks/build_probe/libunerf_new.so   # optional: an explicit "new" build (e.g. with -D switches); else the in-tree library
+[ -f "$NEW" ] && NEWENV="UNERF_LIB=$NEW" || NEWENV="UNERF_NOP=1"
 mkdir -p gpurun_out
 for rep in 1 2 3; do
-    python bench.py --method $METHOD --steps 5 --warmup 2 --no-cpu-baseline --no-exact-check 2>/dev/null | tail -1 > gpurun_out/_new_$rep.json
+    env $NEWENV python bench.py --method $METHOD --steps 5 --warmup 2 --no-cpu-baseline --no-exact-check 2>/dev/null | tail -1 > gpurun_out/_new_$rep.json
     UNERF_LIB=$ALT python bench.py --method $METHOD --steps 5 --warmup 2 --no-cpu-baseline --no-exact-check 2>/dev/null | tail -1 > gpurun_out/_base_$rep.json
 done
 python - "$TAG" <<'PY'
