@@ -182,7 +182,10 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
                      "note": "VALU and MFMA instructions share one issue pipe per SIMD on gfx950 and do not overlap "
                              "(benchmarks/mfma_valu_overlap_probe.hip); achieved = (4 x VALU instructions + 32 x f16 MFMAs) of one "
                              "launch, exact counts from the committed PMC pass, over the live launch time; peak = 1024 SIMDs x "
-                             "2.4 GHz.  The engine clock under this load is 1.9-2.1 GHz, so ~0.85 is the practical ceiling",
+                             "2.4 GHz.  The engine clock under this load is 1.9-2.1 GHz, so ~0.85 is the practical ceiling; what "
+                             "the kernel leaves of it is latency of its dependent MFMA -> split -> MFMA chain at two waves per "
+                             "SIMD (DESIGN.md 4.5: removing 32 independent VALU instructions per pass changed nothing, keeping "
+                             "32 operand registers resident bought 2.5 %)",
                      "issue_source": prof["source"], "valu_insts_per_ray": prof["valu_insts_per_launch"] / prof["rays_per_launch"],
                      "mfma_insts_per_ray": prof["mfma_insts_per_launch"] / prof["rays_per_launch"],
                      "simd_busy_frac_under_profiler": prof.get("busy_frac")})
