@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage: multi_ab.sh method lib1 lib2 ... (names in benchmarks/build_probe/libunerf_<name>.so)
+cd "$(dirname "$0")/.."
+M=$1; shift
+mkdir -p gpurun_out
+for rep in 1 2 3; do for v in "$@"; do
+  UNERF_LIB=$PWD/benchmarks/build_probe/libunerf_$v.so python bench.py --method $M --steps 4 --warmup 2 --no-cpu-baseline --no-exact-check 2>/dev/null | tail -1 > gpurun_out/_m_${v}_$rep.json
+done; done
+python - "$@" <<'PY'
+import json, sys
+out={}
+for v in sys.argv[1:]:
+    rs=[json.load(open(f"gpurun_out/_m_{v}_{i}.json")) for i in (1,2,3)]
+    out[v]=[round(r["roofline"]["avg_launch_ms"],4) for r in rs]
+print(json.dumps(out))
+json.dump(out, open("gpurun_out/multi_ab.json","w"))
+PY

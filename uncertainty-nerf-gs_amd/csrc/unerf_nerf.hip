@@ -1830,6 +1830,13 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 asm volatile("" ::"v"(junk));
             }
 #endif
+            // Wave priority: low through the matrix layers of a pass, high from the rgb layer to the end of the pass --
+            // and, after the last pass, through the next tile's gathers.  The tail (packed-fma chains, the half exchange,
+            // exp / rcp, stores) and the gather prologue are short instruction streams that wait on latencies; letting
+            // them go first when both waves of a SIMD are ready takes 4.2 % off the K = 8 kernel (same box, six
+            // placements tried: benchmarks/multi_ab.sh, profiles/r2_exp_setprio.json); high priority for the matrix
+            // layers instead gives 1.3 %, for the prologue alone nothing.
+            __builtin_amdgcn_s_setprio(0);
             // trunk out: 64 -> out1 rows (row 0 density, 1..15 geo, 16 beta) from the (masked) hidden operands
             f32x16 t = mf16_bias(lds, 2, h);
 #pragma unroll
@@ -1883,6 +1890,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 d0 = mf_dropout_keep(d0, mk2, a.keep_hi);
                 d1 = mf_dropout_keep(d1, mk3, a.keep_hi);
             }
+            __builtin_amdgcn_s_setprio(1);
             // colour 2: 64 -> 3 on the VALU in fp32 (weights pre-scaled by the dropout scale when masks are on).
             // MFMA and VALU instructions share one issue pipe on gfx950 and never overlap
             // (benchmarks/mfma_valu_overlap_probe.hip: 32 cycles per f16 MFMA + 4 per VALU instruction, additive at
