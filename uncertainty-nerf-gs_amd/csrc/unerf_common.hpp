@@ -101,11 +101,11 @@ __device__ __forceinline__ float unerf_s2e(float b, float s_near, float s_far) {
 // near 1) or a density logit.  The exact-fp32 / VALU field kernels keep expf.
 __device__ __forceinline__ float unerf_exp(float x) { return __expf(x); }
 
+// torch.nan_to_num: NaN -> 0, +-inf -> +-FLT_MAX.  The clamp is one v_med3_f32 (three instructions in all instead of the
+// six of three compare / select pairs; these sit in the per-sample loops of the PDF and composite kernels).
 __device__ __forceinline__ float unerf_nan_to_num(float w) {
-    if (w != w) return 0.f;
-    if (w > FLT_MAX) return FLT_MAX;
-    if (w < -FLT_MAX) return -FLT_MAX;
-    return w;
+    const float c = __builtin_amdgcn_fmed3f(w, -FLT_MAX, FLT_MAX);
+    return (w != w) ? 0.f : c;
 }
 
 // ---- SceneContraction(inf) -> (x+2)/4 -> selector mask ------------------------------

@@ -3171,13 +3171,16 @@ __device__ __forceinline__ void unerf_normal_pair_from_hash(uint32_t base, float
 // sigma_i) the weights are (1 - e_i) * prod_{j<i} e_j -- the transmittance as a running product (a 16-lane
 // multiplicative scan) instead of a second exp of the running sum.  The 100-draw mean absorbs the ~1e-6
 // difference from get_weights' exp(-cumsum) form (tests/test_gpu_nerf_kernels.py: explicit-noise parity).
+// nd2 = -delta * log2(e), formed once per sample outside the draw loop, makes the exponential the bare v_exp_f32.
+// (1 - e) * T is >= 0 or NaN here (e in [0, 1] unless a density is NaN), so nan_to_num is one v_max_f32 with 0 --
+// the general form costs three compares and three selects per weight, a sixth of this kernel's instructions.
 template <int SPL>
-__device__ __forceinline__ void group_weights_fast(const float (&dens)[SPL], const float (&delta)[SPL], int l16,
+__device__ __forceinline__ void group_weights_fast(const float (&dens)[SPL], const float (&nd2)[SPL], int l16,
                                                    float (&w)[SPL]) {
     float em[SPL], lex[SPL], lp = 1.f;
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
-        em[e] = __expf(-(delta[e] * dens[e]));
+        em[e] = __builtin_amdgcn_exp2f(nd2[e] * dens[e]);
         lex[e] = lp;      // product of this lane's earlier samples
         lp *= em[e];
     }
@@ -3190,7 +3193,7 @@ __device__ __forceinline__ void group_weights_fast(const float (&dens)[SPL], con
     incl *= dpp_f_or<0x118>(incl, 1.f);
     const float carry = dpp_f_or<0x111>(incl, 1.f);
 #pragma unroll
-    for (int e = 0; e < SPL; ++e) w[e] = unerf_nan_to_num((1.f - em[e]) * (carry * lex[e]));
+    for (int e = 0; e < SPL; ++e) w[e] = fmaxf((1.f - em[e]) * (carry * lex[e]), 0.f);
 }
 
 template <int SPL, bool RAGGED = false>
@@ -3201,12 +3204,13 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
     if (!ok) r = a.R - 1;
     const int S = a.S, k0 = l16 * SPL;
     const float* sb = a.sbins + r * (S + 1);
-    float eu[SPL + 1], delta[SPL], mu[SPL], sd[SPL], wsum[SPL], dens[SPL], w[SPL];
+    float eu[SPL + 1], delta[SPL], nd2[SPL], mu[SPL], sd[SPL], wsum[SPL], dens[SPL], w[SPL];
 #pragma unroll
     for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[RAGGED ? min(k0 + e, S) : k0 + e], a.s_near, a.s_far);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
         delta[e] = eu[e + 1] - eu[e];
+        nd2[e] = -delta[e] * 1.4426950408889634f;
         const bool live = !RAGGED || k0 + e < S;   // masked slots: mu = sd = 0 -> density 0, delta 0
         mu[e] = live ? a.mu[r * S + k0 + e] : 0.f;
         float s = live ? sqrtf(a.var[r * S + k0 + e]) : 0.f;
@@ -3232,8 +3236,8 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
         for (int q = 0; q < 2; ++q) {
             if (d0 + q < a.D) {
 #pragma unroll
-                for (int e = 0; e < SPL; ++e) dens[e] = fmaxf(mu[e] + sd[e] * z[q][e], 0.f);
-                group_weights_fast<SPL>(dens, delta, l16, w);
+                for (int e = 0; e < SPL; ++e) dens[e] = fmaxf(fmaf(sd[e], z[q][e], mu[e]), 0.f);
+                group_weights_fast<SPL>(dens, nd2, l16, w);
 #pragma unroll
                 for (int e = 0; e < SPL; ++e) wsum[e] += w[e];
             }
