@@ -153,8 +153,9 @@ class EnsemblePipeline:
     and `get_ensemble_outputs_for_camera_ray_bundle(camera, obb_box)` (:144-191), which is what
     scripts/eval_uncertainty.py:1127 calls.  The reference keeps all M members in one process and renders them
     in sequence; here a process holds M / world_size of them (all M without torch.distributed, one per GPU under
-    `torchrun`), and the per-pixel moments go through aggregate / aggregate_distributed.  Loading the members'
-    checkpoints (ensemble_pipeline.py:62-108) is nerfstudio's pipeline code and stays there: pass built Models."""
+    `torchrun`), and the per-pixel moments go through aggregate / aggregate_distributed.  Pass built Models; the
+    members' checkpoints (ensemble_pipeline.py:62-108, ensemble_utils.py:36-110) are read by
+    `checkpoints.load_ensemble(models, config_paths)`."""
 
     def __init__(self, models: Sequence, group=None, moments_fn: Optional[MomentsFn] = None):
         self.models = torch.nn.ModuleList(models) if all(isinstance(m, torch.nn.Module) for m in models) else list(models)
