@@ -323,3 +323,27 @@ def test_model_obb_box_equals_a_bundle_that_carries_the_box_planes(dev):
     for k, tol in (("rgb", 2e-5), ("accumulation", 1e-4)):
         assert (out[k] - via[k])[inner].abs().max() < tol, k
     assert torch.equal(ens["rgb"], out["rgb"]) and ens["rgb_var_epi"].abs().max() == 0     # two copies of one member
+
+
+def test_model_loaded_from_a_run_directory_renders_like_its_source(dev, tmp_path):
+    """checkpoints.load_model: the latest `step-*.ckpt` of a `nerfstudio_models` directory (pipeline state dict with
+    the `_model.` prefix, next to optimizer state) into a fresh Model mirror -> the same image as the model it was
+    saved from"""
+    from uncertainty_nerf_gs_amd import checkpoints, plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=3, kind="active", log2T=14, prop_log2T=12)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["active-nerfacto"]())
+    src = cfg._target(cfg, num_train_data=4)
+    src.load_state_dict(_state_dict_from_tensors(t, "active"))
+    d = tmp_path / "run" / "nerfstudio_models"
+    d.mkdir(parents=True)
+    for step, scale in ((100, 0.5), (2000, 1.0)):      # the older checkpoint holds different weights
+        sd = {"_model." + k: v * scale for k, v in src.state_dict().items()}
+        torch.save({"step": step, "pipeline": sd, "optimizers": {}}, d / f"step-{step:09d}.ckpt")
+    dst = cfg._target(cfg, num_train_data=4)
+    path, step = checkpoints.load_model(dst, d)
+    assert step == 2000 and path.name == "step-000002000.ckpt"
+    cam = _camera(24, 32)
+    with torch.cuda.device(dev):
+        a, b = src.get_outputs_for_camera(cam), dst.get_outputs_for_camera(cam)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
