@@ -592,11 +592,17 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
             for (int j = 0; j < HID / 2; ++j) h2[j] = __builtin_elementwise_fma(fk, w0p[k * (HID / 2) + j], h2[j]);
         }
         float o = a.net.b1[0];
+#if defined(UNERF_PROBE_NO_PROP_MLP)   // experiment build only: how much of this kernel is its MLP?  (wrong results)
+        (void)h2; (void)w1t;
+#pragma unroll
+        for (int k = 0; k < 2 * L; ++k) o += feat[k];
+#else
 #pragma unroll
         for (int j = 0; j < HID / 2; ++j) {
             o = fmaf(__int_as_float(max(__float_as_int(h2[j].x), 0)), w1t[2 * j], o);
             o = fmaf(__int_as_float(max(__float_as_int(h2[j].y), 0)), w1t[2 * j + 1], o);
         }
+#endif
         dens = a.avg * unerf_exp(o) * sel;
     }
     if (a.vec4) {  // uniform: n % 4 == 0 and a 16-byte aligned output: the ray's 4 densities leave as one store
