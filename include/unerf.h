@@ -119,7 +119,8 @@ typedef struct {
        then has (dense_dim[l])^3 cells, dense_dim = scalings[l]+1, stored x-fastest from cell offset
        dense_off[l] in `dense` as float4 = { table[hash(x,y,z)], table[hash(x+1,y,z)] }: the same values the
        hashed lookup returns, but both x-neighbours of a cell edge arrive in ONE 16-byte load (4 instead of 8
-       gather instructions per level; the texture-address unit bounds these kernels). */
+       gather instructions per level; the texture-address unit bounds these kernels).  2 <= dense_dim <= 640 (32-bit
+       byte offsets); ops.DENSE_LEVEL_BYTES makes copies of the levels up to resolution 128. */
     const float* dense;
     int n_dense;
     int dense_off[8];

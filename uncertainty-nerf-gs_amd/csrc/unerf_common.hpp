@@ -266,9 +266,9 @@ __device__ __forceinline__ float2 unerf_dense_level(const float4* __restrict__ c
     int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
     int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
     float ox = sx - (float)fx, oy = sy - (float)fy, oz = sz - (float)fz;
-    // 32-bit byte offsets off a uniform base.  dim <= 255 (checked by the caller): every product below stays under
-    // 2^24, so the index arithmetic runs on the full-rate 24-bit multiply-add (v_mad_u32_u24) instead of six
-    // quarter-rate v_mul_lo_u32 per level.
+    // 32-bit byte offsets off a uniform base.  dim <= 640 (checked by the caller): every OPERAND below stays under
+    // 2^24 (v_mad_u32_u24 multiplies the low 24 bits of its operands exactly into 32), and the cell index dim^3 under
+    // 2^28, so its byte offset (x 16) fits 32 bits.
     const char* base = reinterpret_cast<const char*>(cells);
     const uint32_t udim = (uint32_t)dim;
     const uint32_t rcc = __umul24((uint32_t)cz, udim) + (uint32_t)cy, rfc = __umul24((uint32_t)cz, udim) + (uint32_t)fy;

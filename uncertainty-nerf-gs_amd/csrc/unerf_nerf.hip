@@ -629,7 +629,7 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
     UNERF_REQUIRE(net->n_dense >= 0 && net->n_dense <= 8 && net->n_dense <= net->L && (net->n_dense == 0 || net->dense),
                   "proposal_density: bad dense level description");
     for (int l = 0; l < net->n_dense; ++l)  // a level is addressed with 32-bit byte offsets
-        UNERF_REQUIRE(net->dense_dim[l] >= 2 && net->dense_dim[l] <= 255, "proposal_density: dense_dim[%d]=%d outside [2,255]",
+        UNERF_REQUIRE(net->dense_dim[l] >= 2 && net->dense_dim[l] <= 640, "proposal_density: dense_dim[%d]=%d outside [2,640]",
                       l, net->dense_dim[l]);
     if (R == 0) return UNERF_OK;
     PropArgs a;
