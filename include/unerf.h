@@ -36,8 +36,30 @@ extern "C" {
 #define UNERF_ERR_HIP -2     /* HIP runtime error (launch, no device) */
 
 const char* unerf_last_error(void);
-/* Library/ABI version (major*1000+minor). */
+/* Library/ABI version (major*1000+minor).  A binding built against this header must find exactly UNERF_ABI_VERSION
+ * (struct layouts and argument lists change with it; uncertainty-nerf-gs_amd/lib.py::load checks). */
+#define UNERF_ABI_VERSION 1200
 int unerf_version(void);
+
+/* Spacing function of the proposal sampler's initial sampler, passed behind every (near_plane, far_plane) pair:
+ *   UNERF_SPACING_PIECEWISE  UniformLinDispPiecewiseSampler, nerfacto's default (proposal_initial_sampler="piecewise"):
+ *                            s(x) = x/2 (x < 1) else 1 - 1/(2x); spacing bin b -> s^-1(b s(far) + (1 - b) s(near))
+ *   UNERF_SPACING_UNIFORM    UniformSampler (proposal_initial_sampler="uniform", the reference's few-view configuration,
+ *                            /root/reference/README.md:153): identity spacing, b -> b far + (1 - b) near
+ * [UPSTREAM nerfstudio 1.1.0 NerfactoModel.populate_modules / ray_samplers.SpacedSampler]. */
+#define UNERF_SPACING_PIECEWISE 0
+#define UNERF_SPACING_UNIFORM 1
+
+/* RGBRenderer(background_color=config.background_color) at eval (activenerfacto_model.py:98 -> nerfstudio 1.1.0
+ * renderers.RGBRenderer.forward / combine_rgb), for the composite and GGN entry points:
+ *   UNERF_BG_LAST_SAMPLE  "last_sample" (nerfacto default): comp + rgb[..., -1, :] (1 - accumulation)
+ *   UNERF_BG_NONE         "random": at eval the composited colour is returned unblended
+ *   UNERF_BG_COLOR        "white" / "black" (or any constant): comp + background_rgb (1 - accumulation);
+ *                         background_rgb = 3 HOST floats
+ * followed in every case by the eval-mode clamp to [0, 1]. */
+#define UNERF_BG_LAST_SAMPLE 0
+#define UNERF_BG_NONE 1
+#define UNERF_BG_COLOR 2
 /* Build switches that change what the operand blobs must look like (bit mask).  UNERF_BUILD_TRUNK_FOLD: the
  * MCDROPOUT split-f16 kernels expect the four trunk-out slabs of mfma16_blob folded (see unerf_field_params). */
 #define UNERF_BUILD_TRUNK_FOLD 1
@@ -67,11 +89,11 @@ int unerf_generate_rays(const float* c2w_host, float fx, float fy, float cx, flo
  * nears / fars [R] may be NULL.  Rays that miss: planes 1e10 as upstream; their samples collapse onto `far`
  * (upstream they are at infinity, pixels undefined), giving zero accumulation. */
 int unerf_ray_box_bins(const float* origins, const float* directions, int64_t R, const float* world_to_box_host,
-                       const float* half_extent_host, float near, float far, const float* sbins_row, int n,
+                       const float* half_extent_host, float near, float far, int spacing, const float* sbins_row, int n,
                        float* sbins, float* nears, float* fars, void* stream);
 /* The same fold for a bundle that already carries planes (RayBundle.nears / fars [R], e.g. made by
  * camera.generate_rays(obb_box=...) on the nerfstudio side; SceneCollider.forward keeps planes that are set). */
-int unerf_ray_planes_bins(const float* nears, const float* fars, int64_t R, float near, float far,
+int unerf_ray_planes_bins(const float* nears, const float* fars, int64_t R, float near, float far, int spacing,
                           const float* sbins_row, int n, float* sbins, void* stream);
 
 /* ------------------------------------------------------------- hash grid --
@@ -139,11 +161,11 @@ typedef struct {
  * Replaces HashMLPDensityField.density_fn as invoked by ProposalNetworkSampler
  * (call site models/activenerfacto/activenerfacto_model.py:89,
  * models/laplace/laplace_model.py:210,459).  Sample i of ray r sits at the mid-point of
- * spacing bins [i, i+1] (converted to euclidean with the piecewise-linear-in-disparity
- * spacing fn and near/far).  sbins: [R, n+1] with row stride `sbins_stride`
+ * spacing bins [i, i+1] (converted to euclidean with the spacing fn `spacing` = UNERF_SPACING_*
+ * and near/far).  sbins: [R, n+1] with row stride `sbins_stride`
  * (0 = one shared row, the initial uniform bins).  density_out [R,n]. */
 int unerf_proposal_density(const float* origins, const float* directions, const float* sbins,
-                           int64_t sbins_stride, int64_t R, int n, float near_plane, float far_plane,
+                           int64_t sbins_stride, int64_t R, int n, float near_plane, float far_plane, int spacing,
                            const unerf_density_net* net /* host struct of device ptrs */,
                            float average_init_density, float* density_out,
                            int64_t ray_offset, int image_width /* scheduling hint, 0 = none: rays [ray_offset,
@@ -161,7 +183,7 @@ int unerf_proposal_density(const float* origins, const float* directions, const 
  * receives per-chunk min/max of the NEW samples' mid-points (the bounds
  * DepthRenderer("expected") clips to); ray_offset = index of ray 0 inside the frame. */
 int unerf_weights_pdf_resample(const float* density, const float* sbins, int64_t sbins_stride, int64_t R,
-                               int n, float near_plane, float far_plane, const float* u, int m,
+                               int n, float near_plane, float far_plane, int spacing, const float* u, int m,
                                float histogram_padding, float eps, float* sbins_out, float* prop_depth_out,
                                float* weights_out, float* clip_minmax, int64_t ray_offset,
                                int64_t chunk_rays, void* stream);
@@ -264,7 +286,7 @@ typedef struct {
  * near_plane < 0: sbins holds EUCLIDEAN bin edges instead (the starts / last end of a RaySamples made by the
  * caller's own sampler -- Field.forward(ray_samples)); far_plane is ignored then.  Not with `features`. */
 int unerf_field_fwd(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
-                    float near_plane, float far_plane, int64_t ray_offset,
+                    float near_plane, float far_plane, int spacing, int64_t ray_offset,
                     const unerf_field_params* p /* host struct */,
                     const float* features /* NULL, or the planes written by unerf_field_gather */,
                     float* density, float* rgb, float* aux, float* aux2, void* stream);
@@ -274,14 +296,14 @@ int unerf_field_fwd(const float* origins, const float* directions, const float* 
  * one XCD's L2 -- so sweeping level by level runs the gathers out of L2 instead of the Infinity
  * Cache; unerf_field_fwd(features=...) then skips its own lookup.  Same values bit for bit. */
 int unerf_field_gather(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
-                       float near_plane, float far_plane, const float* table, const float* scalings, int L,
+                       float near_plane, float far_plane, int spacing, const float* table, const float* scalings, int L,
                        int log2T, float* feature_planes, void* stream);
 
 /* Laplace depth path: models/laplace/laplace_model.py:486-507.  mean over D draws of
  * get_weights(relu(mu + max(sqrt(var),1e-10) * eps)).  noise [D,R,S] or NULL (then the
  * built-in counter RNG with `seed`).  weights_out [R,S]. */
 int unerf_laplace_depth_weights(const float* density_mu, const float* density_var, const float* sbins,
-                                int64_t R, int S, float near_plane, float far_plane, const float* noise, int D,
+                                int64_t R, int S, float near_plane, float far_plane, int spacing, const float* noise, int D,
                                 uint32_t seed, int64_t ray_offset, float* weights_out, void* stream);
 
 /* Laplace GGN fitting: NerfactoLaplaceModel.compute_hessian_naive (models/laplace/laplace_model.py:343-400),
@@ -294,7 +316,8 @@ int unerf_laplace_depth_weights(const float* density_mu, const float* density_va
  * unerf_field_fwd, S <= 64.  workspace: unerf_laplace_ggn_workspace_bytes(R, S) bytes of device scratch. */
 size_t unerf_laplace_ggn_workspace_bytes(int64_t R, int S);
 int unerf_laplace_ggn_diag(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
-                           float near_plane, float far_plane, const unerf_field_params* p /* host struct */,
+                           float near_plane, float far_plane, int spacing, const unerf_field_params* p /* host struct */,
+                           int background, const float* background_rgb_host /* UNERF_BG_*: the renderer the loss sees */,
                            void* workspace, size_t workspace_bytes, float* ggn_density, float* ggn_rgb,
                            void* stream);
 
@@ -306,18 +329,20 @@ int unerf_laplace_ggn_diag(const float* origins, const float* directions, const 
  * weights_alt [R,S] (NULL or the laplace mean sampled weights: then accumulation, depth,
  * expected depth and depth_var use it while rgb and rgb_var use get_weights(density)).
  * clip_minmax as produced by unerf_weights_pdf_resample.  1 <= S <= 256, any value.
+ * background / background_rgb_host: UNERF_BG_* (above).
  * out [B,R,8] = rgb(3), accumulation, depth(median), expected_depth, rgb_var, depth_var(+1e-5). */
 int unerf_composite_var(const float* density, const float* rgb, const float* beta, const float* weights_alt,
-                        const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane,
-                        const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, float* out,
-                        void* stream);
+                        const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane, int spacing,
+                        const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, int background,
+                        const float* background_rgb_host, float* out, void* stream);
 
 /* Fused K-pass form of the two calls above/below for MC-dropout: composites the B <= 16 passes of every
  * ray and reduces them in registers.  mean_out / var_out [R,8] over the passes of
  * rgb(3), accumulation, depth, expected_depth, rgb_var, depth_var (var unbiased, B-1). */
 int unerf_composite_moments(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
-                            float near_plane, float far_plane, const float* clip_minmax, int64_t ray_offset,
-                            int64_t chunk_rays, float* mean_out, float* var_out, void* stream);
+                            float near_plane, float far_plane, int spacing, const float* clip_minmax, int64_t ray_offset,
+                            int64_t chunk_rays, int background, const float* background_rgb_host, float* mean_out,
+                            float* var_out, void* stream);
 
 /* The same two reductions over the sample-major planes unerf_field_fwd writes with sample_major = 1
  * (density [B,S,R], rgb [B,S,3,R], beta [S,R] or NULL): one lane per ray walks the samples front to back, so
@@ -325,11 +350,13 @@ int unerf_composite_moments(const float* density, const float* rgb, const float*
  * of mcdropout_models.py:116-126 are reduced to mean / unbiased variance in the same thread.
  * out [B,R,8]; mean_out / var_out [R,8] (B >= 2); channel order as unerf_composite_var. */
 int unerf_composite_var_planes(const float* density, const float* rgb, const float* beta, const float* sbins, int B,
-                               int64_t R, int S, float near_plane, float far_plane, const float* clip_minmax,
-                               int64_t ray_offset, int64_t chunk_rays, float* out, void* stream);
+                               int64_t R, int S, float near_plane, float far_plane, int spacing, const float* clip_minmax,
+                               int64_t ray_offset, int64_t chunk_rays, int background, const float* background_rgb_host,
+                               float* out, void* stream);
 int unerf_composite_moments_planes(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
-                                   float near_plane, float far_plane, const float* clip_minmax, int64_t ray_offset,
-                                   int64_t chunk_rays, float* mean_out, float* var_out, void* stream);
+                                   float near_plane, float far_plane, int spacing, const float* clip_minmax,
+                                   int64_t ray_offset, int64_t chunk_rays, int background,
+                                   const float* background_rgb_host, float* mean_out, float* var_out, void* stream);
 
 /* ------------------------------------------------------ moments over K --
  * Replaces torch.stack(...).mean(0) / .std(0) / .var(0) over MC passes

@@ -266,11 +266,16 @@ def spacing_fn_inv(x: torch.Tensor) -> torch.Tensor:
     return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
 
 
-def spacing_to_euclidean(bins: torch.Tensor, near, far) -> torch.Tensor:
+def spacing_to_euclidean(bins: torch.Tensor, near, far, uniform: bool = False) -> torch.Tensor:
     """near / far: python floats (NearFarCollider planes) or per-ray tensors [R,1] (RayBundle.nears / fars, e.g. from an
-    obb_box intersection)"""
-    s_near = spacing_fn(torch.as_tensor(near, dtype=torch.float32))
-    s_far = spacing_fn(torch.as_tensor(far, dtype=torch.float32))
+    obb_box intersection).  uniform: [UPSTREAM nerfstudio 1.1.0 ray_samplers.UniformSampler, selected by
+    NerfactoModelConfig.proposal_initial_sampler="uniform" -- the reference's few-view runs, README.md:153] spacing_fn =
+    spacing_fn_inv = identity, so SpacedSampler's `spacing_to_euclidean_fn` is x far + (1 - x) near."""
+    near, far = torch.as_tensor(near, dtype=torch.float32), torch.as_tensor(far, dtype=torch.float32)
+    if uniform:
+        return bins * far + (1 - bins) * near
+    s_near = spacing_fn(near)
+    s_far = spacing_fn(far)
     return spacing_fn_inv(bins * s_far + (1 - bins) * s_near)
 
 
@@ -380,7 +385,7 @@ def density_field(positions: torch.Tensor, net: GridMLP, average_init_density: f
 
 
 def proposal_sample(origins, directions, near, far, prop_nets: List[GridMLP], num_prop: Tuple[int, ...],
-                    num_nerf: int, average_init_density: float):
+                    num_nerf: int, average_init_density: float, uniform: bool = False):
     """ProposalNetworkSampler.generate_ray_samples at eval (anneal = 1, no jitter).
     Returns (final spacing bins [R,num_nerf+1], weights_list, spacing_bins_list)."""
     R = origins.shape[0]
@@ -393,7 +398,7 @@ def proposal_sample(origins, directions, near, far, prop_nets: List[GridMLP], nu
             n_new = num_prop[lvl] if lvl < n_iter else num_nerf
             bins = pdf_resample(weights, bins, n_new)
         if lvl < n_iter:
-            eb = spacing_to_euclidean(bins, near, far)
+            eb = spacing_to_euclidean(bins, near, far, uniform)
             pos = sample_positions(origins, directions, eb)
             dens = density_field(pos, prop_nets[lvl], average_init_density)
             weights = get_weights(dens, eb[..., 1:] - eb[..., :-1])
@@ -406,12 +411,25 @@ def proposal_sample(origins, directions, near, far, prop_nets: List[GridMLP], nu
 # L0.8 renderers                                          [UPSTREAM nerfstudio]
 # --------------------------------------------------------------------------
 
-def render_rgb(rgb: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
-    """RGBRenderer, eval, background_color='last_sample'.  rgb [R,S,3], weights [R,S]."""
+BACKGROUND_COLORS = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0)}
+
+
+def render_rgb(rgb: torch.Tensor, weights: torch.Tensor, background="last_sample") -> torch.Tensor:
+    """[UPSTREAM nerfstudio 1.1.0 RGBRenderer.forward / combine_rgb] at eval.  rgb [R,S,3], weights [R,S].
+    background (NerfactoModelConfig.background_color): "last_sample" (default) blends rgb[..., -1, :] (1 - acc);
+    "random" returns the composited colour without blending ("as if the background color was black"); "white" /
+    "black" (or a 3-vector) blend a constant colour.  nan_to_num before, clamp to [0,1] after."""
     rgb = torch.nan_to_num(rgb)
     comp = torch.sum(weights[..., None] * rgb, dim=-2)
     acc = torch.sum(weights, dim=-1, keepdim=True)
-    comp = comp + rgb[..., -1, :] * (1.0 - acc)
+    if isinstance(background, str) and background == "random":
+        return torch.clamp(comp, 0.0, 1.0)
+    if isinstance(background, str) and background == "last_sample":
+        bg = rgb[..., -1, :]
+    else:
+        bg = torch.tensor(BACKGROUND_COLORS[background] if isinstance(background, str) else background,
+                          dtype=torch.float32).expand(comp.shape)
+    comp = comp + bg * (1.0 - acc)
     return torch.clamp(comp, 0.0, 1.0)
 
 
@@ -687,7 +705,7 @@ def laplace_ggn_diag(scene: "NerfScene", origins, directions):
         eb, _, _ = _sample(scene, origins, directions)
     density, rgb = laplace_field_deterministic(origins, directions, eb, fp)
     w = get_weights(density, eb[..., 1:] - eb[..., :-1])
-    pred = render_rgb(rgb, w)
+    pred = render_rgb(rgb, w, scene.background)
     diag = [torch.zeros_like(q) for q in params]
     flat = pred.reshape(-1)
     for i in range(flat.numel()):
@@ -709,26 +727,29 @@ class NerfScene:
     num_prop: Tuple[int, ...] = (256, 96)
     num_nerf: int = 48
     prop_average_init_density: float = 0.01
+    uniform_spacing: bool = False          # proposal_initial_sampler="uniform" (UniformSampler) instead of "piecewise"
+    background: object = "last_sample"     # background_color: "last_sample" | "random" | "white" | "black" | (r,g,b)
 
 
 def _sample(scene: NerfScene, origins, directions, nears=None, fars=None):
     near = scene.near if nears is None else nears
     far = scene.far if fars is None else fars
     bins, wl, bl = proposal_sample(origins, directions, near, far, scene.prop_nets, scene.num_prop,
-                                   scene.num_nerf, scene.prop_average_init_density)
-    eb = spacing_to_euclidean(bins, near, far)
+                                   scene.num_nerf, scene.prop_average_init_density, scene.uniform_spacing)
+    eb = spacing_to_euclidean(bins, near, far, scene.uniform_spacing)
     return eb, wl, bl
 
 
 def _prop_depths(scene, wl, bl, nears=None, fars=None):
     out = {}
     for i, (w, b) in enumerate(zip(wl, bl)):
-        eb = spacing_to_euclidean(b, scene.near if nears is None else nears, scene.far if fars is None else fars)
+        eb = spacing_to_euclidean(b, scene.near if nears is None else nears, scene.far if fars is None else fars,
+                                  scene.uniform_spacing)
         out[f"prop_depth_{i}"] = render_depth_median(w, (eb[..., :-1] + eb[..., 1:]) / 2)
     return out
 
 
-def active_compose(eb, density, rgb, beta) -> Dict[str, torch.Tensor]:
+def active_compose(eb, density, rgb, beta, background="last_sample") -> Dict[str, torch.Tensor]:
     """[REF activenerfacto_model.py:94-127] everything get_outputs does after the field call: eb [R,S+1] Euclidean
     bin edges, density / beta [R,S], rgb [R,S,3].  Pinned to the reference's own code by
     tests/golden/nerf_model_glue.npz (fake-self run of ActiveNerfactoModel.get_outputs)."""
@@ -736,7 +757,7 @@ def active_compose(eb, density, rgb, beta) -> Dict[str, torch.Tensor]:
     steps = (eb[..., :-1] + eb[..., 1:]) / 2
     w = get_weights(density, deltas)
     out = {
-        "rgb": render_rgb(rgb, w),
+        "rgb": render_rgb(rgb, w, background),
         "accumulation": render_accumulation(w),
         "depth": render_depth_median(w, steps),
         "expected_depth": render_depth_expected(w, steps),
@@ -755,7 +776,7 @@ def active_outputs(scene: NerfScene, origins, directions, nears=None, fars=None)
     (obb_box), else the collider's constants."""
     eb, wl, bl = _sample(scene, origins, directions, nears, fars)
     density, rgb, beta = active_field(origins, directions, eb, scene.field)
-    out = active_compose(eb, density, rgb, beta)
+    out = active_compose(eb, density, rgb, beta, scene.background)
     out.update(_prop_depths(scene, wl, bl, nears, fars))
     return out
 
@@ -766,7 +787,7 @@ def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, den
     steps = (eb[..., :-1] + eb[..., 1:]) / 2
     w = get_weights(density, deltas)
     out = {
-        "rgb": render_rgb(rgb, w),
+        "rgb": render_rgb(rgb, w, scene.background),
         "accumulation": render_accumulation(w),
         "depth": render_depth_median(w, steps),
         "expected_depth": render_depth_expected(w, steps),
@@ -805,7 +826,7 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
 
 
 def laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise: Optional[torch.Tensor],
-                    use_deterministic_density: bool = False) -> Dict[str, torch.Tensor]:
+                    use_deterministic_density: bool = False, background="last_sample") -> Dict[str, torch.Tensor]:
     """[REF laplace_model.py:471-530] everything get_outputs_unc does after the field call: weights from mu_d,
     rgb / rgb_var from those weights, then (unless use_deterministic_density) D density draws
     relu(mu_d + max(sqrt(var_d), 1e-10) * noise), their mean weights, and depth / expected depth / accumulation
@@ -813,7 +834,7 @@ def laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise: Optional[torc
     deltas = eb[..., 1:] - eb[..., :-1]
     steps = (eb[..., :-1] + eb[..., 1:]) / 2
     w = get_weights(mu_d, deltas)
-    rgb = render_rgb(mu_rgb, w)
+    rgb = render_rgb(mu_rgb, w, background)
     rgb_var = render_uncertainty(var_rgb, w ** 2)
     if use_deterministic_density:
         wm = w
@@ -843,7 +864,7 @@ def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
     mu_d, var_d, mu_rgb, var_rgb = laplace_field(origins, directions, eb, scene.field, ws_density, ws_rgb)
     if use_deterministic_density:
         mu_d, _ = laplace_field_deterministic(origins, directions, eb, scene.field)
-    out = laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise, use_deterministic_density)
+    out = laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise, use_deterministic_density, scene.background)
     out.update(_prop_depths(scene, wl, bl, nears, fars))
     return out
 
@@ -908,4 +929,6 @@ def scene_from_tensors(t: dict) -> NerfScene:
         fp.density_w, fp.density_b = f["density_w"], f["density_b"]
     return NerfScene(field=fp, prop_nets=[grid(p) for p in t["props"]], near=float(t["near"]), far=float(t["far"]),
                      num_prop=tuple(t["num_prop"]), num_nerf=int(t["num_nerf"]),
-                     prop_average_init_density=float(t["prop_average_init_density"]))
+                     prop_average_init_density=float(t["prop_average_init_density"]),
+                     uniform_spacing=t.get("proposal_initial_sampler", "piecewise") == "uniform",
+                     background=t.get("background_color", "last_sample"))

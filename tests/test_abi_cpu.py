@@ -26,7 +26,7 @@ def test_header_symbols_all_bound_and_exported(lib):
 
 def test_version_and_error_string(lib):
     h = lib.load()
-    assert h.unerf_version() == 1102
+    assert h.unerf_version() == lib.ABI_VERSION == 1200
     assert h.unerf_build_flags() & lib.BUILD_TRUNK_FOLD          # the shipped build folds the K-pass trunk-out slabs
     assert isinstance(h.unerf_last_error(), bytes)
 
@@ -36,8 +36,13 @@ def test_null_pointers_are_rejected_before_launch(lib):
     rc = h.unerf_hashgrid_fwd(None, None, None, 10, 16, 19, None, None, None)
     assert rc == -1
     assert b"null pointer" in h.unerf_last_error()
-    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 300, 0.05, 1000.0, None, 0, 32768, 1, None)
+    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 300, 0.05, 1000.0, 0, None, 0, 32768, 0, None, 1, None)
     assert rc == -1 and b"outside [1,256]" in h.unerf_last_error()
+    # unknown background mode / a constant colour without its 3 floats
+    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 48, 0.05, 1000.0, 0, None, 0, 32768, 7, None, 1, None)
+    assert rc == -1 and b"background=7" in h.unerf_last_error()
+    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 48, 0.05, 1000.0, 0, None, 0, 32768, lib.BG_COLOR, None, 1, None)
+    assert rc == -1 and b"background_rgb" in h.unerf_last_error()
     rc = h.unerf_moments(None, 8, 4, 3, None, None, None)
     assert rc == -1
 
@@ -48,9 +53,9 @@ def test_bad_shapes_are_rejected(lib):
     rc = h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, 4, 4, 10, 10, 1, 1, None, None)
     assert rc == -1 and b"outside" in h.unerf_last_error()
     net = lib.DensityNet(1, 1, 7, 17, 1, 1, 1, 1, 16, None, 0)
-    rc = h.unerf_proposal_density(1, 1, 1, 0, 4, 256, 0.05, 1000.0, C.byref(net), 0.01, 1, 0, 0, None)
+    rc = h.unerf_proposal_density(1, 1, 1, 0, 4, 256, 0.05, 1000.0, 0, C.byref(net), 0.01, 1, 0, 0, None)
     assert rc == -1 and b"unsupported" in h.unerf_last_error()
-    rc = h.unerf_weights_pdf_resample(1, 1, 0, 4, 300, 0.05, 1000.0, 1, 96, 0.01, 1e-5, 1, None, None, None, 0, 32768,
+    rc = h.unerf_weights_pdf_resample(1, 1, 0, 4, 300, 0.05, 1000.0, 0, 1, 96, 0.01, 1e-5, 1, None, None, None, 0, 32768,
                                       None)
     assert rc == -1 and b"outside" in h.unerf_last_error()
     rc = h.unerf_splat_rasterize(None, 1, 1, 1, 1, 1, None, 9, 16, 16, 16, 1, 1, None, None)
@@ -64,28 +69,28 @@ def test_zero_counts_are_no_ops_and_oversized_inputs_are_refused(lib):
     c2w = (C.c_float * 12)(*([0.0] * 12))
     assert h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, 4, 4, 16, 0, None, None, None, None) == 0
     assert h.unerf_moments(None, 8, 0, 3, None, None, None) == 0
-    assert h.unerf_composite_var(None, None, None, None, None, 2, 0, 48, 0.05, 1000.0, None, 0, 32768, None, None) == 0
-    assert h.unerf_composite_moments(None, None, None, 8, 0, 48, 0.05, 1000.0, None, 0, 32768, None, None, None) == 0
-    assert h.unerf_weights_pdf_resample(None, None, 0, 0, 256, 0.05, 1000.0, None, 96, 0.01, 1e-5, None, None, None, None, 0,
+    assert h.unerf_composite_var(None, None, None, None, None, 2, 0, 48, 0.05, 1000.0, 0, None, 0, 32768, 0, None, None, None) == 0
+    assert h.unerf_composite_moments(None, None, None, 8, 0, 48, 0.05, 1000.0, 0, None, 0, 32768, 0, None, None, None, None) == 0
+    assert h.unerf_weights_pdf_resample(None, None, 0, 0, 256, 0.05, 1000.0, 1, None, 96, 0.01, 1e-5, None, None, None, None, 0,
                                         32768, None) == 0
-    assert h.unerf_laplace_depth_weights(None, None, None, 0, 48, 0.05, 1000.0, None, 100, 0, 0, None, None) == 0
+    assert h.unerf_laplace_depth_weights(None, None, None, 0, 48, 0.05, 1000.0, 0, None, 100, 0, 0, None, None) == 0
     w2b, half = (C.c_float * 12)(*([0.0] * 12)), (C.c_float * 3)(1.0, 1.0, 1.0)
-    assert h.unerf_ray_box_bins(None, None, 0, w2b, half, 0.05, 1000.0, None, 256, None, None, None, None) == 0
-    assert h.unerf_ray_planes_bins(None, None, 0, 0.05, 1000.0, None, 256, None, None) == 0
+    assert h.unerf_ray_box_bins(None, None, 0, w2b, half, 0.05, 1000.0, 0, None, 256, None, None, None, None) == 0
+    assert h.unerf_ray_planes_bins(None, None, 0, 0.05, 1000.0, 0, None, 256, None, None) == 0
     vm = (C.c_float * 12)(*([0.0] * 12))
     assert h.unerf_splat_project(None, None, 1.0, None, vm, 1.0, 1.0, 0.0, 0.0, 16, 16, 16, 0.01, 0, None, None, None, None,
                                  None, None, None, None) == 0
     assert h.unerf_splat_depth_sqdiff(None, None, None, 1, 0, 16, 16, 0, None, None) == 0
     # ... but a non-zero count still needs its pointers
-    assert h.unerf_ray_planes_bins(None, None, 5, 0.05, 1000.0, None, 256, None, None) == -1
+    assert h.unerf_ray_planes_bins(None, None, 5, 0.05, 1000.0, 0, None, 256, None, None) == -1
     assert b"null pointer" in h.unerf_last_error()
     # near must lie in front of far; bins need at least one interval
-    assert h.unerf_ray_planes_bins(1, 1, 5, 10.0, 1.0, 1, 256, 1, None) == -1
+    assert h.unerf_ray_planes_bins(1, 1, 5, 10.0, 1.0, 0, 1, 256, 1, None) == -1
     fp = lib.FieldParams()
     for name in ("table", "scalings", "w0t", "b0", "w1t", "b1", "h0t", "hb0", "h1t", "hb1", "h2t", "hb2"):
         setattr(fp, name, 1)
     fp.L, fp.log2T, fp.mode, fp.out1 = 16, 19, 0, 17
-    rc = h.unerf_field_fwd(1, 1, 1, 1 << 27, 48, 0.05, 1000.0, 0, C.byref(fp), None, 1, 1, 1, None, None)
+    rc = h.unerf_field_fwd(1, 1, 1, 1 << 27, 48, 0.05, 1000.0, 0, 0, C.byref(fp), None, 1, 1, 1, None, None)
     assert rc == -1 and b"32 bits" in h.unerf_last_error()
 
 
@@ -95,6 +100,15 @@ def test_ops_refuse_cpu_tensors(lib):
     x = torch.rand(8, 3)
     with pytest.raises(lib.UnerfError, match="no CPU path"):
         ops.hashgrid_fwd(x, torch.rand(16 << 4, 2), torch.ones(16), 4)
+
+
+def test_library_of_another_abi_version_is_refused(lib, monkeypatch):
+    """UNERF_LIB may point at a build that is never rebuilt; a library whose unerf_version() is not the one
+    the ctypes layouts were written for must not be driven"""
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "ABI_VERSION", lib.ABI_VERSION + 1)
+    with pytest.raises(lib.UnerfError, match="ABI version"):
+        lib.load()
 
 
 def test_missing_library_fails_loudly(lib, monkeypatch, tmp_path):

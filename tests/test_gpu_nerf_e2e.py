@@ -440,3 +440,126 @@ def test_obb_box_crop_matches_generate_rays_with_an_oriented_box(dev, kind):
         img = render.render_camera(sd, c2w, rays_per_launch=1024, obb=(w2b, S), **cam, **kw)
         torch.testing.assert_close(img["rgb"].reshape(-1, 3)[sel.to(dev)], out["rgb"][sel.to(dev)], rtol=0, atol=2e-6)
         assert img["accumulation"].reshape(-1)[miss.to(dev)].abs().max() == 0
+
+
+# ---- round 3: the reference's documented few-view configuration (README.md:153) --------------------------------------
+#   --pipeline.model.disable-scene-contraction True --pipeline.model.near-plane 1. --pipeline.model.far-plane 100.
+#   --pipeline.model.proposal-initial-sampler uniform --pipeline.model.background-color random --pipeline.model.max-res 4096
+
+def _fewview_tensors(kind, background, seed=21, half=128.0):
+    """half = 128: the scene box holds every sample of a camera at radius 3 with far = 100, so no sample sits on a box
+    face (a HARD edge: see test_disable_scene_contraction_uses_the_scene_box); half = 4 puts the far half of every ray
+    outside the box (selector 0)."""
+    from uncertainty_nerf_gs_amd import synthetic
+    t = synthetic.make_scene_tensors(seed=seed, kind=kind, log2T=14, prop_log2T=12, max_res=4096)
+    t["near"], t["far"] = 1.0, 100.0
+    t["proposal_initial_sampler"] = "uniform"
+    t["background_color"] = background
+    t["aabb"] = torch.tensor([[-half, -half, -half], [half, half, half]])   # scene box: disable_scene_contraction
+    return t
+
+
+@pytest.mark.parametrize("background", ["random", "white", "black", "last_sample"])
+@pytest.mark.parametrize("kind", ["active", "mcdropout", "laplace"])
+def test_fewview_configuration_uniform_sampler_backgrounds_scene_box(dev, kind, background):
+    """uniform initial sampler x every background x near 1 / far 100 x max_res 4096 x scene box, all three methods,
+    full camera path: same north-star gates as the default configuration"""
+    from uncertainty_nerf_gs_amd import lib as L, ops, render, synthetic
+    t = _fewview_tensors(kind, background)
+    sc = O.scene_from_tensors(t)
+    assert sc.uniform_spacing and sc.background == background and sc.field.grid.aabb is not None
+    H, W = 36, 48
+    cam = _cam(H, W)
+    c2w = synthetic.orbit_c2w(0.9, radius=3.0, height=0.6)   # outside the near plane's reach of the box centre
+    o, d = _oracle_rays(c2w, cam)
+    if kind == "active":
+        sd = synthetic.scene_to_device(t, dev)
+        sd.chunk_rays = 512
+        out = render.render_camera(sd, c2w, rays_per_launch=1024, keep_density=True, **cam)
+        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=512)
+    elif kind == "mcdropout":
+        sd = synthetic.scene_to_device(t, dev, K=8, seed=5, p_drop=0.2)
+        sd.chunk_rays = 512
+        out = render.render_camera(sd, c2w, rays_per_launch=1024, **cam)
+        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 5, 0.2, ray_offset=off), o, d, chunk=512)
+    else:
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=5, n_samples=30)
+        sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+        noise = torch.randn(20, H * W, 48, generator=torch.Generator().manual_seed(8))
+        od, dd_, _ = ops.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, dev)
+        out = {k: v.view(H, W, -1) for k, v in render.render_rays(sd, od, dd_, depth_noise=noise.to(dev), depth_draws=20).items()}
+        ref = {k: v.view(H, W, -1) for k, v in O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise).items()}
+    assert sd.spacing == L.SPACING_UNIFORM and sd.field.aabb is not None
+    assert set(ref) <= set(out), set(ref) - set(out)
+    _gates(f"fewview-{kind}-{background}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _img_close(out["rgb"], ref["rgb"], 1e-4, 0, "rgb")
+    _img_close(out["accumulation"], ref["accumulation"], 3e-4, 0, "accumulation")
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=1e-2)
+    _img_close(out["depth"], ref["depth"], 0, 1e-3, "median depth", max_bad_frac=2e-2)
+    if background != "last_sample":   # the knob matters: the default renderer gives another image
+        t2 = dict(t)
+        t2["background_color"] = "last_sample"
+        if kind == "active":
+            alt = O.render_camera(lambda oo, dd, off: O.active_outputs(O.scene_from_tensors(t2), oo, dd), o, d, chunk=512)
+            assert (alt["rgb"] - ref["rgb"]).abs().max() > 1e-3
+
+
+def test_fewview_configuration_with_rays_leaving_the_scene_box(dev):
+    """the same configuration with a box the rays leave half way (selector 0 beyond it).  A box face is a hard edge: a
+    resampled sample within ~1e-4 of it (far = 100, CDF differences of 1e-6) can fall on different sides in the two
+    pipelines and take or lose its whole density -- a few pixels per frame; everything else agrees as above."""
+    from uncertainty_nerf_gs_amd import render, synthetic
+    t = _fewview_tensors("active", "random", half=4.0)
+    sc = O.scene_from_tensors(t)
+    H, W = 36, 48
+    cam, c2w = _cam(H, W), synthetic.orbit_c2w(0.9, radius=3.0, height=0.6)
+    o, d = _oracle_rays(c2w, cam)
+    sd = synthetic.scene_to_device(t, dev)
+    sd.chunk_rays = 512
+    out = render.render_camera(sd, c2w, rays_per_launch=1024, keep_density=True, **cam)
+    ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=512)
+    assert (ref["density"] == 0).float().mean() > 0.2          # a good share of the samples is outside the box
+    _img_close(out["rgb"], ref["rgb"], 1e-4, 0, "rgb", max_bad_frac=2e-2)
+    _img_close(out["rgb"], ref["rgb"], 2e-2, 0, "rgb (all pixels)")
+    _img_close(out["accumulation"], ref["accumulation"], 3e-4, 0, "accumulation", max_bad_frac=2e-2)
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=2e-2)
+    _img_close(out["density"], ref["density"], 1e-6, 1e-2, "density", max_bad_frac=5e-3)
+
+
+def test_uniform_sampler_differs_from_piecewise_and_model_config_reaches_the_kernels(dev):
+    """Model-level: NerfactoModelConfig(proposal_initial_sampler="uniform", background_color="random", near 1, far 100,
+    max_res 4096, disable_scene_contraction) loaded from a reference-named checkpoint renders like the oracle configured
+    the same way, and unlike the default sampler"""
+    from types import SimpleNamespace
+    from test_gpu_models import _state_dict_from_tensors
+    from uncertainty_nerf_gs_amd import lib as L, models
+    from uncertainty_nerf_gs_amd import synthetic
+    t = _fewview_tensors("active", "random", seed=23)
+    cfg = models.ActiveNerfactoModelConfig(
+        near_plane=1.0, far_plane=100.0, proposal_initial_sampler="uniform", background_color="random", max_res=4096,
+        disable_scene_contraction=True, log2_hashmap_size=14, average_init_density=0.01,
+        proposal_net_args_list=[
+            {"hidden_dim": 16, "log2_hashmap_size": 12, "num_levels": 5, "max_res": 128, "use_linear": False},
+            {"hidden_dim": 16, "log2_hashmap_size": 12, "num_levels": 5, "max_res": 256, "use_linear": False}])
+    m = models.ActiveNerfactoModel(cfg, scene_box=SimpleNamespace(aabb=t["aabb"]), num_train_data=4)
+    m.load_state_dict(_state_dict_from_tensors(t, "active"))
+    H, W = 24, 32
+    c2w = synthetic.orbit_c2w(0.9, radius=3.0, height=0.6)
+    cam = models.Camera(c2w, 0.9 * W, 0.9 * W, W / 2, H / 2, H, W)
+    with torch.cuda.device(dev):
+        out = m.get_outputs_for_camera(cam)
+    sd = m.device_scene()
+    assert sd.spacing == L.SPACING_UNIFORM and sd.background[0] == L.BG_NONE and (sd.near, sd.far) == (1.0, 100.0)
+    assert float(sd.field.scalings[-1]) >= 4094.0 and sd.field.aabb is not None
+    sc = O.scene_from_tensors(t)
+    o, d = _oracle_rays(c2w, _cam(H, W))
+    ref = O.active_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3))
+    _img_close(out["rgb"].view(-1, 3), ref["rgb"], 1e-4, 0, "rgb", max_bad_frac=2e-2)
+    _img_close(out["accumulation"].view(-1, 1), ref["accumulation"], 3e-4, 0, "accumulation", max_bad_frac=2e-2)
+    sc.uniform_spacing = False
+    alt = O.active_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3))
+    assert (alt["expected_depth"] - ref["expected_depth"]).abs().max() > 1e-2
+    with pytest.raises(ValueError, match="proposal_initial_sampler"):
+        cfg.proposal_initial_sampler = "log"
+        m.invalidate()
+        m.device_scene()

@@ -626,3 +626,113 @@ def test_proposal_patch_kernel_ragged_sample_counts(dev, n, shared):
     ref = O.density_field(O.sample_positions(o, d, O.spacing_to_euclidean(sb.expand(R, -1) if shared else sb, NEAR, FAR)),
                           sc.prop_nets[0], 0.01)
     _close(b, ref, 2e-5, 1e-7, "density")
+
+
+# ---- round 3: proposal_initial_sampler="uniform" (identity spacing) and the RGBRenderer backgrounds ------------------
+
+_BACKGROUNDS = ["last_sample", "random", "white", "black"]
+
+
+@pytest.mark.parametrize("background", _BACKGROUNDS)
+@pytest.mark.parametrize("B,S", [(1, 48), (3, 48), (2, 17)])
+def test_composite_backgrounds_match_oracle(dev, background, B, S):
+    """NerfactoModelConfig.background_color through every composite entry point: group kernels, fused K-pass moments,
+    the sample-major plane kernels (README.md:153 of the reference trains with background-color random)"""
+    from uncertainty_nerf_gs_amd import ops
+    g = torch.Generator().manual_seed(B * 77 + S)
+    R = 97
+    dens = torch.exp(torch.randn(B, R, S, generator=g) * 2.0)
+    dens[:, 0] = 0.0                      # empty ray: the pixel IS the background
+    rgb = torch.rand(B, R, S, 3, generator=g)
+    sb = torch.sort(torch.rand(R, S + 1, generator=g), dim=-1).values
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    deltas = eb[:, 1:] - eb[:, :-1]
+    bg = ops.background_of(background)
+    out = ops.composite_var(dens.to(dev), rgb.to(dev), sb.to(dev), NEAR, FAR, background=bg).cpu()
+    refs = []
+    for b in range(B):
+        ref = O.render_rgb(rgb[b], O.get_weights(dens[b], deltas), background)
+        refs.append(ref)
+        _close(out[b, :, 0:3], ref, 0, 3e-6, f"rgb, background {background}")
+    want0 = {"random": torch.zeros(3), "black": torch.zeros(3), "white": torch.ones(3), "last_sample": rgb[0, 0, -1]}[background]
+    _close(out[0, 0, 0:3], want0, 0, 1e-6, "empty ray shows the background")
+    dp, cp = dens.permute(0, 2, 1).contiguous().to(dev), rgb.permute(0, 2, 3, 1).contiguous().to(dev)
+    outp = ops.composite_var_planes(dp, cp, sb.to(dev), NEAR, FAR, background=bg).cpu()
+    _close(outp[..., 0:3], torch.stack(refs), 0, 3e-6, "planes rgb")
+    if B >= 2:
+        mean, _ = ops.composite_moments(dens.to(dev), rgb.to(dev), sb.to(dev), NEAR, FAR, background=bg)
+        _close(mean.cpu()[:, 0:3], torch.stack(refs).mean(0), 0, 3e-6, "K-pass mean rgb")
+        meanp, _ = ops.composite_moments_planes(dp, cp, sb.to(dev), NEAR, FAR, background=bg)
+        _close(meanp.cpu()[:, 0:3], torch.stack(refs).mean(0), 0, 3e-6, "K-pass mean rgb (planes)")
+
+
+def test_uniform_spacing_proposal_pdf_composite_match_oracle(dev):
+    """UNERF_SPACING_UNIFORM (UniformSampler: euclid = b far + (1 - b) near) in the proposal density, PDF / weights and
+    composite kernels, with the few-view planes near 1 / far 100"""
+    from uncertainty_nerf_gs_amd import lib as L, ops, render
+    near, far = 1.0, 100.0
+    t, sc, sd = _scene("active", dev)
+    o, d = _rays()
+    R = o.shape[0]
+    g = torch.Generator().manual_seed(11)
+    for level, n in ((0, 256), (1, 96)):
+        sb = O.initial_spacing_bins(n) if level == 0 else torch.sort(torch.rand(R, n + 1, generator=g), dim=-1).values
+        sb_ref = sb[None].expand(R, -1) if level == 0 else sb
+        eb = O.spacing_to_euclidean(sb_ref, near, far, uniform=True)
+        assert abs(float(eb[0, 0]) - near) < 1e-5 and (level or abs(float(eb[0, -1]) - far) < 1e-3)
+        ref = O.density_field(O.sample_positions(o, d, eb), sc.prop_nets[level], 0.01)
+        for width in (0, 32):   # thread-per-sample and 8x8-patch kernels
+            got = ops.proposal_density(o.to(dev), d.to(dev), sb.contiguous().to(dev), sd.props[level], near, far, 0.01,
+                                       image_width=width, spacing=L.SPACING_UNIFORM)
+            _close(got, ref, 3e-5, 1e-9, f"uniform-spacing proposal density level {level} (image_width {width})")
+        dens = ref.clone()
+        w_ref = O.get_weights(dens, eb[:, 1:] - eb[:, :-1])
+        m = 96 if level == 0 else 48
+        new_ref = O.pdf_resample(w_ref, sb_ref, m)
+        pd_ref = O.render_depth_median(w_ref, (eb[:, :-1] + eb[:, 1:]) / 2)
+        new, pd, w = ops.weights_pdf_resample(dens.to(dev), sb.contiguous().to(dev), render._pdf_u(m).to(dev), near, far,
+                                              want_weights=True, spacing=L.SPACING_UNIFORM)
+        _close(w, w_ref, 2e-5, 1e-7, "weights (uniform spacing)")
+        _close(new, new_ref, 0, 3e-6, "resampled bins (uniform spacing)", max_bad_frac=2e-4)
+        _close(pd, pd_ref, 1e-5, 0, "prop depth (uniform spacing)", max_bad_frac=0.02)
+    S = 48
+    dens = torch.exp(torch.randn(1, R, S, generator=g) * 2.0)
+    rgb = torch.rand(1, R, S, 3, generator=g)
+    sb = torch.sort(torch.rand(R, S + 1, generator=g), dim=-1).values
+    eb = O.spacing_to_euclidean(sb, near, far, uniform=True)
+    steps = (eb[:, :-1] + eb[:, 1:]) / 2
+    w = O.get_weights(dens[0], eb[:, 1:] - eb[:, :-1])
+    out = ops.composite_var(dens.to(dev), rgb.to(dev), sb.to(dev), near, far, spacing=L.SPACING_UNIFORM).cpu()
+    _close(out[0, :, 0:3], O.render_rgb(rgb[0], w), 0, 3e-6, "rgb (uniform spacing)")
+    _close(out[0, :, 3:4], O.render_accumulation(w), 2e-6, 1e-7, "accumulation (uniform spacing)")
+    _close(out[0, :, 4:5], O.render_depth_median(w, steps), 1e-6, 0, "median depth (uniform spacing)", max_bad_frac=0.02)
+    ed = torch.sum(w * steps, -1, keepdim=True) / (torch.sum(w, -1, keepdim=True) + 1e-10)
+    _close(out[0, :, 5:6], ed, 2e-5, 1e-6, "expected depth (uniform spacing)")
+
+
+def test_uniform_spacing_crop_box_bins(dev):
+    """unerf_ray_box_bins / unerf_ray_planes_bins fold per-ray planes into the first-level bins with the identity
+    spacing too: the Euclidean edges under the launch-wide planes are b far_r + (1 - b) near_r"""
+    from uncertainty_nerf_gs_amd import lib as L, ops
+    near, far = 1.0, 100.0
+    g = torch.Generator().manual_seed(3)
+    R, n = 77, 256
+    nears = 1.0 + torch.rand(R, generator=g) * 5
+    fars = nears + 1.0 + torch.rand(R, generator=g) * 50
+    row = O.initial_spacing_bins(n)
+    bins = ops.ray_planes_bins(nears.to(dev), fars.to(dev), near, far, row.to(dev), spacing=L.SPACING_UNIFORM).cpu()
+    eu = O.spacing_to_euclidean(bins, near, far, uniform=True)
+    want = O.spacing_to_euclidean(row[None].expand(R, -1), nears[:, None], fars[:, None], uniform=True)
+    _close(eu, want, 2e-5, 1e-5, "per-ray planes under uniform spacing")
+
+
+def test_spacing_and_background_arguments_are_validated(dev):
+    from uncertainty_nerf_gs_amd import lib as L, ops
+    dens, rgb = torch.rand(1, 4, 16, device=dev), torch.rand(1, 4, 16, 3, device=dev)
+    sb = torch.sort(torch.rand(4, 17, device=dev), dim=-1).values
+    with pytest.raises(L.UnerfError, match="spacing=5"):
+        ops.composite_var(dens, rgb, sb, NEAR, FAR, spacing=5)
+    with pytest.raises(L.UnerfError, match="background=9"):
+        ops.composite_var(dens, rgb, sb, NEAR, FAR, background=(9, None))
+    with pytest.raises(L.UnerfError, match="background_color"):
+        ops.background_of("purple-ish")

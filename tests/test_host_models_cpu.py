@@ -47,9 +47,26 @@ def test_laplace_field_keys_and_quirks():
 
 
 def test_proposal_field_keys():
+    """nerfstudio 1.1.0 HashMLPDensityField: mlp_base = MLPWithHashEncoding (encoder / mlp, mirrored under model.{0,1})
+    + the four buffers every upstream field registers"""
     p = F.HashMLPDensityField(log2_hashmap_size=6)
     keys = set(p.state_dict())
-    assert {"encoding.hash_table", "mlp_base.0.hash_table", "mlp_base.1.layers.0.weight", "mlp_base.1.layers.1.bias"} <= keys
+    assert {"mlp_base.encoder.hash_table", "mlp_base.model.0.hash_table", "mlp_base.mlp.layers.0.weight",
+            "mlp_base.model.1.layers.1.bias", "aabb", "max_res", "num_levels", "log2_hashmap_size"} <= keys
+    assert p.encoding is p.mlp_base.encoder and len(list(p.parameters())) == 5
+    pt = F.HashMLPDensityField(log2_hashmap_size=6, implementation="tcnn")
+    assert {"mlp_base.encoder.tcnn_encoding.params", "mlp_base.mlp.tcnn_encoding.params"} <= set(pt.state_dict())
+    n_mlp, n_grid = pt.mlp_base.fused_tcnn_sizes()
+    assert n_mlp == 16 * 16 + 16 * 16 and n_grid == pt.encoding.table.numel()   # 10 -> 16 padded inputs, 1 -> 16 padded outputs
+
+
+def test_plain_nerfacto_field_keys():
+    f = F.NerfactoField(num_images=3, **SMALL)
+    keys = set(f.state_dict())
+    for k in ("mlp_base.encoder.hash_table", "mlp_base.mlp.layers.1.bias", "mlp_base.model.1.layers.0.weight",
+              "mlp_head.layers.2.weight", "embedding_appearance.embedding.weight", "aabb", "max_res"):
+        assert k in keys, k
+    assert f.state_dict()["mlp_base.mlp.layers.1.weight"].shape == (16, 64)   # density + 15 geo
 
 
 def test_model_configs_match_reference_defaults():
@@ -72,7 +89,7 @@ def test_model_loads_nerfstudio_style_checkpoint_keys():
     m.load_state_dict(ckpt)
     for k, v in src.state_dict().items():
         assert torch.equal(m.state_dict()[k], v + 1.0), k
-    assert "proposal_networks.1.mlp_base.1.layers.0.weight" in m.state_dict()
+    assert "proposal_networks.1.mlp_base.mlp.layers.0.weight" in m.state_dict()
 
 
 def test_splat_model_resizes_on_load():
@@ -137,10 +154,12 @@ def test_mcdropout_field_dropout_layer_options():
     assert f.drop_sites == (L.DROP_TRUNK | L.DROP_HEAD1) and isinstance(f.mlp_base[2], nn.Dropout) and isinstance(f.mlp_head[4], nn.Dropout)
     f = F.NerfactoMCDropoutField(density_dropout_layers=False, rgb_dropout_layers=[1, -1], **kw)
     assert f.drop_sites == (L.DROP_HEAD0 | L.DROP_HEAD1)
-    assert [type(m).__name__ for m in f.mlp_base] == ["Linear", "ReLU", "Linear"]
+    # the parent's trunk stays (mcdropout_fields.py:112): upstream NerfactoField.mlp_base = MLPWithHashEncoding
+    assert isinstance(f.mlp_base, F.MLPWithHashEncoding) and not hasattr(f, "mlp_base_grid")
+    assert "mlp_base.encoder.hash_table" in f.state_dict() and "mlp_base.mlp.layers.1.weight" in f.state_dict()
     assert [type(m).__name__ for m in f.mlp_head] == ["Linear", "ReLU", "Dropout", "Linear", "ReLU", "Dropout", "Linear", "Sigmoid"]
     f = F.NerfactoMCDropoutField(density_dropout_layers=False, rgb_dropout_layers=[], **kw)
-    assert f.drop_sites == 0 and not any(isinstance(m, nn.Dropout) for m in list(f.mlp_base) + list(f.mlp_head))
+    assert f.drop_sites == 0 and not any(isinstance(m, nn.Dropout) for m in f.modules())
     import pytest
     with pytest.raises(NotImplementedError):
         F.NerfactoMCDropoutField(rgb_dropout_layers=[0], **kw)

@@ -97,9 +97,14 @@ def test_nerf_model_is_a_nerfstudio_model_with_the_references_state_dict_names(n
     assert set(groups) == {"proposal_networks", "fields"} and len(groups["fields"]) > 0
     assert model.get_training_callbacks(None) == []
     # loading a nerfstudio pipeline checkpoint (keys carry the `_model.` prefix): the mirror's tensors are the model's
-    sd = {"_model." + k: torch.full_like(v, 0.25) for k, v in model.state_dict().items() if k.startswith("field.")}
-    model.load_state_dict(sd)
+    sd = {"_model." + k: torch.full_like(v, 0.25) for k, v in model.state_dict().items()
+          if k.startswith(("field.", "proposal_networks.")) and v.is_floating_point()}
+    res = model.load_state_dict(sd, strict=True)      # nerfstudio's pipeline passes strict=True first
+    assert res.missing_keys == [] and res.unexpected_keys == [] and res.loaded == res.expected > 0
     assert float(model.field.state_dict()[want[0][len("field."):]].flatten()[0]) == 0.25
+    # a checkpoint that does not cover the model (here: no proposal networks) must not load "successfully"
+    with pytest.raises(RuntimeError, match="not in the checkpoint"):
+        model.load_state_dict({k: v for k, v in sd.items() if k.startswith("_model.field.")})
     assert model._mirror.field is model.field
     with pytest.raises(NotImplementedError):
         model.get_loss_dict({}, {})

@@ -59,8 +59,8 @@ def test_tcnn_checkpoint_key_names_and_sizes():
     keys = set(m.state_dict())
     for k in ("field.mlp_base_grid.tcnn_encoding.params", "field.mlp_base.0.tcnn_encoding.params",
               "field.mlp_base_mlp.tcnn_encoding.params", "field.mlp_base.1.tcnn_encoding.params",
-              "field.mlp_head.tcnn_encoding.params", "proposal_networks.0.encoding.tcnn_encoding.params",
-              "proposal_networks.0.mlp_base.0.tcnn_encoding.params", "proposal_networks.1.mlp_base.1.tcnn_encoding.params",
+              "field.mlp_head.tcnn_encoding.params", "proposal_networks.0.mlp_base.encoder.tcnn_encoding.params",
+              "proposal_networks.1.mlp_base.mlp.tcnn_encoding.params",
               "field.embedding_appearance.embedding.weight"):
         assert k in keys, k
     assert not any("hash_table" in k or ".layers." in k for k in keys)
@@ -69,7 +69,7 @@ def test_tcnn_checkpoint_key_names_and_sizes():
     assert sd["field.mlp_base_grid.tcnn_encoding.params"].numel() == 2 * (lv[-1][2] + lv[-1][3])
     assert sd["field.mlp_base_mlp.tcnn_encoding.params"].numel() == 64 * 32 + 32 * 64      # 17 outputs pad to 32
     assert sd["field.mlp_head.tcnn_encoding.params"].numel() == 64 * 64 + 64 * 64 + 16 * 64  # 63 inputs pad to 64
-    assert sd["proposal_networks.0.mlp_base.1.tcnn_encoding.params"].numel() == 16 * 16 + 16 * 16
+    assert sd["proposal_networks.0.mlp_base.mlp.tcnn_encoding.params"].numel() == 16 * 16 + 16 * 16
     # mc-dropout / laplace keep their torch create_mlp heads; only the grid is a tcnn module (mcdropout_fields.py:115-135)
     for method, grid_key, torch_key in (("nerfacto-mcdropout", "field.mlp_base_grid.tcnn_encoding.params", "field.mlp_base.3.weight"),
                                         ("nerfacto-laplace", "field.base_grid.tcnn_encoding.params", "field.mlp_rgb_ll.weight")):

@@ -43,22 +43,44 @@ def checkpoint_path(load_dir: PathLike, load_step: Optional[int] = None) -> Tupl
     return path, int(load_step)
 
 
-def read_pipeline_state(path: PathLike) -> Tuple[Dict[str, torch.Tensor], int]:
-    """-> (pipeline state dict, step) of one checkpoint file, on the CPU (ensemble_utils.py:71-72)"""
+def read_pipeline_state(path: PathLike, trust_pickle: Optional[bool] = None) -> Tuple[Dict[str, torch.Tensor], int]:
+    """-> (pipeline state dict, step) of one checkpoint file, on the CPU (ensemble_utils.py:71-72).
+    Read with torch's safe unpickler (tensors and plain containers only).  The reference calls the unrestricted
+    `torch.load(load_path, map_location="cpu")`, which runs whatever a pickle asks for; that is available here only as
+    an explicit choice -- `trust_pickle=True` or UNERF_TRUST_CHECKPOINT_PICKLE=1 -- and only after the safe unpickler
+    has refused the file's CONTENT (pickle.UnpicklingError: older nerfstudio versions stored config objects next to
+    the tensors); I/O errors and corrupt files are reported as they are."""
+    import pickle
+    if trust_pickle is None:
+        trust_pickle = os.environ.get("UNERF_TRUST_CHECKPOINT_PICKLE", "0") == "1"
     try:
         state = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:   # checkpoints of older nerfstudio versions pickle config objects next to the tensors
+    except pickle.UnpicklingError as e:
+        if not trust_pickle:
+            raise pickle.UnpicklingError(
+                f"{path}: holds objects the safe unpickler refuses ({e}); pass trust_pickle=True (or set "
+                "UNERF_TRUST_CHECKPOINT_PICKLE=1) to unpickle a checkpoint you trust") from e
         state = torch.load(path, map_location="cpu", weights_only=False)
     if "pipeline" not in state:
         raise KeyError(f"{path}: no 'pipeline' entry (keys: {sorted(state)})")
     return state["pipeline"], int(state.get("step", -1))
 
 
-def load_model(model, load_dir: PathLike, load_step: Optional[int] = None) -> Tuple[Path, int]:
-    """Load one Model mirror from a `nerfstudio_models` directory.  -> (path loaded, step)"""
+def load_model(model, load_dir: PathLike, load_step: Optional[int] = None, strict: bool = False) -> Tuple[Path, int]:
+    """Load one Model mirror from a `nerfstudio_models` directory.  -> (path loaded, step).  Raises (RuntimeError from
+    the model's load_state_dict, with the path added) when the checkpoint does not cover the model's parameters: a
+    run of another method, implementation or key layout must not render from random weights.  The load report
+    (models.IncompatibleKeys: ignored keys, tensor counts) is kept as `model.last_load_report`."""
     path, step = checkpoint_path(load_dir, load_step)
     sd, saved_step = read_pipeline_state(path)
-    model.load_state_dict(sd)
+    try:
+        report = model.load_state_dict(sd, strict=strict)
+    except RuntimeError as e:
+        raise RuntimeError(f"{path}: {e}") from e
+    try:
+        model.last_load_report = report
+    except Exception:   # a frozen / slotted model object: the report is informational
+        pass
     return path, saved_step if saved_step >= 0 else step
 
 

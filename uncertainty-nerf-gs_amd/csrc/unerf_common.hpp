@@ -90,8 +90,13 @@ __host__ __device__ __forceinline__ float unerf_spacing_fn(float x) {
 __host__ __device__ __forceinline__ float unerf_spacing_inv(float x) {
     return x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x);
 }
-__device__ __forceinline__ float unerf_s2e(float b, float s_near, float s_far) {
-    return unerf_spacing_inv(b * s_far + (1.f - b) * s_near);
+// `lin` (uniform over a launch): UNERF_SPACING_UNIFORM -- nerfstudio's UniformSampler as the proposal sampler's initial
+// sampler (proposal_initial_sampler="uniform", /root/reference/README.md:153): spacing_fn = its inverse = identity, so
+// s_near / s_far are the planes themselves and a bin maps to b far + (1 - b) near.
+__host__ __device__ __forceinline__ float unerf_spacing_of(float x, int lin) { return lin ? x : unerf_spacing_fn(x); }
+__device__ __forceinline__ float unerf_s2e(float b, float s_near, float s_far, int lin) {
+    const float t = b * s_far + (1.f - b) * s_near;
+    return lin ? t : unerf_spacing_inv(t);
 }
 
 // exp for the sampler and compositing kernels (proposal densities, get_weights): the hardware exponential

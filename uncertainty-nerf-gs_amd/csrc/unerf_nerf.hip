@@ -47,7 +47,10 @@ extern "C" const char* unerf_last_error(void) { return g_err; }
 extern "C" int unerf_build_flags(void) {
     return (UNERF_TRUNK_FOLD ? UNERF_BUILD_TRUNK_FOLD : 0) | (UNERF_LAP_EXP2 ? UNERF_BUILD_LAP_EXP2 : 0);
 }
-extern "C" int unerf_version(void) { return 1102; }   // 11xx: round-2 ABI (drop_sites, sample_major planes, aabb, ...); 1101: ray_box_bins / ray_planes_bins; 1102: build flags, folded trunk-out slabs
+// 11xx: round-2 ABI (drop_sites, sample_major planes, aabb, ...); 1101: ray_box_bins / ray_planes_bins; 1102: build flags,
+// folded trunk-out slabs; 12xx: round-3 ABI -- `spacing` (UNERF_SPACING_*) behind every near / far pair, `background`
+// (UNERF_BG_*) on the composite / GGN entry points
+extern "C" int unerf_version(void) { return UNERF_ABI_VERSION; }
 extern "C" int unerf_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -70,6 +73,26 @@ static inline unerf_norm_box make_norm_box(int use_aabb, const float* aabb) {
     }
     return b;
 }
+// RGBRenderer(background_color=...) at eval [UPSTREAM nerfstudio 1.1.0 renderers.RGBRenderer.combine_rgb / forward]:
+// "last_sample": comp + rgb[..., -1, :] (1 - acc); "random": comp as it is (no blending at eval, "as if the background
+// were black"); "white" / "black": comp + colour (1 - acc); then clamp to [0, 1].
+template <typename Args>
+static inline int unerf_set_background(Args& a, int background, const float* rgb_host, const char* what) {
+    if (background != UNERF_BG_LAST_SAMPLE && background != UNERF_BG_NONE && background != UNERF_BG_COLOR) {
+        unerf_set_error("%s: background=%d (expected UNERF_BG_LAST_SAMPLE / _NONE / _COLOR)", what, background);
+        return UNERF_ERR_ARG;
+    }
+    if (background == UNERF_BG_COLOR && !rgb_host) {
+        unerf_set_error("%s: UNERF_BG_COLOR needs background_rgb (3 host floats)", what);
+        return UNERF_ERR_ARG;
+    }
+    a.bg_mode = background;
+    for (int c = 0; c < 3; ++c) a.bg[c] = (background == UNERF_BG_COLOR) ? rgb_host[c] : 0.f;
+    return UNERF_OK;
+}
+
+#define UNERF_REQUIRE_SPACING(sp) \
+    UNERF_REQUIRE((sp) == UNERF_SPACING_PIECEWISE || (sp) == UNERF_SPACING_UNIFORM, "spacing=%d (expected UNERF_SPACING_*)", (int)(sp))
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 // Division of an index < 2^31 by a launch-invariant divisor (samples per ray): one multiply-high and a
@@ -251,6 +274,7 @@ struct BoxBinsArgs {
     float w2b[12];                                       // inverse([R|T]) as 3x4 row-major
     float half[3];
     float near0, far0;
+    int lin;                                             // UNERF_SPACING_*
     int64_t R; int n;
     float* bins; float* nears; float* fars;              // [R,n+1], [R], [R] (planes may be null)
     const float* in_nears; const float* in_fars;         // given: the bundle's own planes, no box test
@@ -260,13 +284,13 @@ __global__ __launch_bounds__(256) void box_bins_kernel(BoxBinsArgs a) {
     int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= a.R) return;
     const int lane = threadIdx.x & 63;
-    float ox = a.o[r * 3], oy = a.o[r * 3 + 1], oz = a.o[r * 3 + 2];
-    float dx = a.d[r * 3], dy = a.d[r * 3 + 1], dz = a.d[r * 3 + 2];
     float tmin = -INFINITY, tmax = INFINITY;
-    if (a.in_nears) {
+    if (a.in_nears) {   // the bundle's own planes: a.o / a.d are null here
         tmin = a.in_nears[r];
         tmax = a.in_fars[r];
     } else {
+    const float ox = a.o[r * 3], oy = a.o[r * 3 + 1], oz = a.o[r * 3 + 2];
+    const float dx = a.d[r * 3], dy = a.d[r * 3 + 1], dz = a.d[r * 3 + 2];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* m = a.w2b + c * 4;
@@ -286,8 +310,8 @@ __global__ __launch_bounds__(256) void box_bins_kernel(BoxBinsArgs a) {
     }
     // a miss upstream puts every sample at s_inv(s(1e10)) = s_inv(1.f) = inf, i.e. undefined pixels; here its samples
     // collapse onto the far plane (zero-length intervals -> zero weights, accumulation 0), which keeps everything finite
-    const float sn = unerf_spacing_fn(fminf(tmin, a.far0)), sf = unerf_spacing_fn(fminf(tmax, a.far0));
-    const float sn0 = unerf_spacing_fn(a.near0), inv = 1.f / (unerf_spacing_fn(a.far0) - sn0);
+    const float sn = unerf_spacing_of(fminf(tmin, a.far0), a.lin), sf = unerf_spacing_of(fminf(tmax, a.far0), a.lin);
+    const float sn0 = unerf_spacing_of(a.near0, a.lin), inv = 1.f / (unerf_spacing_of(a.far0, a.lin) - sn0);
     for (int i = lane; i <= a.n; i += 64) {
         float b = a.row[i];
         // sf == sn (a miss, or an empty interval): every edge the same float, so all later lerps b0 + t (b1 - b0) and
@@ -297,8 +321,8 @@ __global__ __launch_bounds__(256) void box_bins_kernel(BoxBinsArgs a) {
 }
 
 extern "C" int unerf_ray_box_bins(const float* origins, const float* directions, int64_t R, const float* world_to_box,
-                                  const float* half_extent, float near, float far, const float* sbins_row, int n,
-                                  float* sbins, float* nears, float* fars, void* stream) {
+                                  const float* half_extent, float near, float far, int spacing, const float* sbins_row,
+                                  int n, float* sbins, float* nears, float* fars, void* stream) {
     UNERF_REQUIRE(world_to_box && half_extent && (R == 0 || (origins && directions && sbins_row && sbins)), "ray_box_bins: null pointer");
     UNERF_REQUIRE(R >= 0 && n >= 1 && far > near && near >= 0.f, "ray_box_bins: R=%lld n=%d near=%g far=%g",
                   (long long)R, n, (double)near, (double)far);
@@ -306,20 +330,20 @@ extern "C" int unerf_ray_box_bins(const float* origins, const float* directions,
     BoxBinsArgs a;
     for (int i = 0; i < 12; ++i) a.w2b[i] = world_to_box[i];
     for (int i = 0; i < 3; ++i) a.half[i] = half_extent[i];
-    a.o = origins; a.d = directions; a.row = sbins_row; a.near0 = near; a.far0 = far; a.R = R; a.n = n;
+    a.o = origins; a.d = directions; a.row = sbins_row; a.near0 = near; a.far0 = far; UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.R = R; a.n = n;
     a.bins = sbins; a.nears = nears; a.fars = fars; a.in_nears = a.in_fars = nullptr;
     hipLaunchKernelGGL(box_bins_kernel, dim3(blocks_for(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
     return unerf_check_launch("ray_box_bins");
 }
 
 extern "C" int unerf_ray_planes_bins(const float* nears, const float* fars, int64_t R, float near, float far,
-                                     const float* sbins_row, int n, float* sbins, void* stream) {
+                                     int spacing, const float* sbins_row, int n, float* sbins, void* stream) {
     UNERF_REQUIRE(R == 0 || (nears && fars && sbins_row && sbins), "ray_planes_bins: null pointer");
     UNERF_REQUIRE(R >= 0 && n >= 1 && far > near && near >= 0.f, "ray_planes_bins: R=%lld n=%d near=%g far=%g",
                   (long long)R, n, (double)near, (double)far);
     if (R == 0) return UNERF_OK;
     BoxBinsArgs a = {};
-    a.row = sbins_row; a.near0 = near; a.far0 = far; a.R = R; a.n = n;
+    a.row = sbins_row; a.near0 = near; a.far0 = far; UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.R = R; a.n = n;
     a.bins = sbins; a.in_nears = nears; a.in_fars = fars;
     hipLaunchKernelGGL(box_bins_kernel, dim3(blocks_for(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
     return unerf_check_launch("ray_planes_bins");
@@ -411,6 +435,7 @@ struct PropArgs {
     int64_t R;
     int n;
     float s_near, s_far;
+    int lin;   // UNERF_SPACING_*: 1 = identity spacing (UniformSampler)
     unerf_density_net net;
     float avg;
     float* out;
@@ -453,8 +478,8 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
         i = (int)(idx - r * a.n);
     }
     const float* sb = a.sbins + r * a.sstride;
-    float e0 = unerf_s2e(sb[i], a.s_near, a.s_far);
-    float e1 = unerf_s2e(sb[i + 1], a.s_near, a.s_far);
+    float e0 = unerf_s2e(sb[i], a.s_near, a.s_far, a.lin);
+    float e1 = unerf_s2e(sb[i + 1], a.s_near, a.s_far, a.lin);
     float t = e0 + e1;
     float px = a.origins[r * 3 + 0] + a.dirs[r * 3 + 0] * t / 2.f;
     float py = a.origins[r * 3 + 1] + a.dirs[r * 3 + 1] * t / 2.f;
@@ -536,7 +561,7 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
             // five lanes convert them ONCE for the workgroup (one conversion stream instead of two per wave; a
             // conversion is an IEEE division and the kernel is VALU-issue bound) and every lane reads them back
             const float* sb = a.sbins + i_base;
-            const float e = unerf_s2e(sb[min((int)(lane < 5u ? lane : 4u), a.n - i_base)], a.s_near, a.s_far);
+            const float e = unerf_s2e(sb[min((int)(lane < 5u ? lane : 4u), a.n - i_base)], a.s_near, a.s_far, a.lin);
             if (lane < 5u) s_e[lane][0] = e;
         } else if (wv == 1) {
             const float* sb = a.sbins + r * a.sstride + i_base;
@@ -556,7 +581,7 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
     float dens = 0.f;
     if (ray_ok && i < a.n) {
         const float t = a.sstride == 0 ? s_e[wv][0] + s_e[wv + 1][0]   // uniform: already Euclidean (same bits)
-                                       : unerf_s2e(s_e[wv][lane], a.s_near, a.s_far) + unerf_s2e(s_e[wv + 1][lane], a.s_near, a.s_far);
+                                       : unerf_s2e(s_e[wv][lane], a.s_near, a.s_far, a.lin) + unerf_s2e(s_e[wv + 1][lane], a.s_near, a.s_far, a.lin);
         float px = s_od[0][lane] + s_od[3][lane] * t / 2.f;
         float py = s_od[1][lane] + s_od[4][lane] * t / 2.f;
         float pz = s_od[2][lane] + s_od[5][lane] * t / 2.f;
@@ -616,7 +641,7 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
 }
 
 extern "C" int unerf_proposal_density(const float* origins, const float* directions, const float* sbins,
-                                      int64_t sbins_stride, int64_t R, int n, float near_plane, float far_plane,
+                                      int64_t sbins_stride, int64_t R, int n, float near_plane, float far_plane, int spacing,
                                       const unerf_density_net* net, float average_init_density, float* density_out,
                                       int64_t ray_offset, int image_width, void* stream) {
     UNERF_REQUIRE(net && (R == 0 || (origins && directions && sbins && density_out)), "proposal_density: null pointer");
@@ -634,7 +659,7 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
     if (R == 0) return UNERF_OK;
     PropArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.sstride = sbins_stride; a.R = R; a.n = n;
-    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing);
     a.net = *net; a.avg = average_init_density; a.out = density_out;
     a.box = make_norm_box(net->use_aabb, net->aabb);
     a.fd = make_fastdiv((uint32_t)n); a.small = (R * (int64_t)n < (1ll << 31)) ? 1 : 0;
@@ -681,6 +706,7 @@ struct PdfArgs {
     int64_t R;
     int n;
     float s_near, s_far;
+    int lin;   // UNERF_SPACING_*: 1 = identity spacing (UniformSampler)
     const float* u;
     int m;
     float pad, eps;
@@ -738,7 +764,7 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
     float eu[EPL + 1], w[EPL], dd[EPL];
     const int k0 = lane * EPL;
 #pragma unroll
-    for (int e = 0; e <= EPL; ++e) eu[e] = unerf_s2e(s_sb[wv][min(k0 + e, n)], a.s_near, a.s_far);
+    for (int e = 0; e <= EPL; ++e) eu[e] = unerf_s2e(s_sb[wv][min(k0 + e, n)], a.s_near, a.s_far, a.lin);
     float lsum = 0.f, lexcl[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
@@ -830,8 +856,8 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
     if (a.clip) {
         wave_lds_sync();
         if (ray_ok) {  // wave-uniform
-            float f0 = unerf_s2e(s_nb[wv][0], a.s_near, a.s_far), f1 = unerf_s2e(s_nb[wv][1], a.s_near, a.s_far);
-            float l0 = unerf_s2e(s_nb[wv][nb - 2], a.s_near, a.s_far), l1 = unerf_s2e(s_nb[wv][nb - 1], a.s_near, a.s_far);
+            float f0 = unerf_s2e(s_nb[wv][0], a.s_near, a.s_far, a.lin), f1 = unerf_s2e(s_nb[wv][1], a.s_near, a.s_far, a.lin);
+            float l0 = unerf_s2e(s_nb[wv][nb - 2], a.s_near, a.s_far, a.lin), l1 = unerf_s2e(s_nb[wv][nb - 1], a.s_near, a.s_far, a.lin);
             float first = (f0 + f1) / 2.f, last = (l0 + l1) / 2.f;
             const int64_t chunk = (a.ray_offset + r) / a.chunk_rays;
             if (chunk != cur_chunk) {
@@ -865,7 +891,7 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
 }
 
 extern "C" int unerf_weights_pdf_resample(const float* density, const float* sbins, int64_t sbins_stride, int64_t R,
-                                          int n, float near_plane, float far_plane, const float* u, int m,
+                                          int n, float near_plane, float far_plane, int spacing, const float* u, int m,
                                           float histogram_padding, float eps, float* sbins_out, float* prop_depth_out,
                                           float* weights_out, float* clip_minmax, int64_t ray_offset,
                                           int64_t chunk_rays, void* stream) {
@@ -878,7 +904,7 @@ extern "C" int unerf_weights_pdf_resample(const float* density, const float* sbi
     if (R <= 0) return UNERF_OK;
     PdfArgs a;
     a.density = density; a.sbins = sbins; a.sstride = sbins_stride; a.R = R; a.n = n;
-    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing);
     a.u = u; a.m = m; a.pad = histogram_padding; a.eps = eps; a.sbins_out = sbins_out; a.prop_depth = prop_depth_out;
     a.weights_out = weights_out; a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays;
     dim3 grid(blocks_for(R, PDF_RAYS_PER_BLOCK)), block(256);
@@ -918,6 +944,7 @@ struct FieldArgs {
     int64_t R;
     int S;
     float s_near, s_far;
+    int lin;   // UNERF_SPACING_*: 1 = identity spacing (UniformSampler)
     int64_t ray_offset;
     unerf_field_params p;
     float* density;
@@ -937,7 +964,7 @@ struct FieldArgs {
 // Bin edge -> Euclidean distance.  unerf_field_fwd(near_plane < 0) sets s_near = -1: sbins then already holds
 // Euclidean edges (RaySamples.frustums.starts / ends of a caller-made sampler) and passes through untouched.
 __device__ __forceinline__ float field_bin_edge(const FieldArgs& a, float b) {
-    return a.s_near < 0.f ? b : unerf_s2e(b, a.s_near, a.s_far);
+    return a.s_near < 0.f ? b : unerf_s2e(b, a.s_near, a.s_far, a.lin);
 }
 
 // ray of column j of ray-block rb (a tile is (rb, sample index)); invalid columns are clamped by the caller
@@ -2345,6 +2372,7 @@ struct GatherArgs {
     int64_t R;
     int S;
     float s_near, s_far;
+    int lin;   // UNERF_SPACING_*: 1 = identity spacing (UniformSampler)
     const float* table;
     const float* scalings;
     int L, log2T;
@@ -2360,7 +2388,7 @@ __global__ __launch_bounds__(256) void field_gather_kernel(GatherArgs a) {
     const int64_t r = n / a.S;
     const int s = (int)(n - r * a.S);
     const float* sb = a.sbins + r * (a.S + 1);
-    float e0 = unerf_s2e(sb[s], a.s_near, a.s_far), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+    float e0 = unerf_s2e(sb[s], a.s_near, a.s_far, a.lin), e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far, a.lin);
     float t01 = e0 + e1;
     float px = a.origins[r * 3 + 0] + a.dirs[r * 3 + 0] * t01 / 2.f;
     float py = a.origins[r * 3 + 1] + a.dirs[r * 3 + 1] * t01 / 2.f;
@@ -2372,14 +2400,14 @@ __global__ __launch_bounds__(256) void field_gather_kernel(GatherArgs a) {
 }
 
 extern "C" int unerf_field_gather(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
-                                  float near_plane, float far_plane, const float* table, const float* scalings, int L,
+                                  float near_plane, float far_plane, int spacing, const float* table, const float* scalings, int L,
                                   int log2T, float* feature_planes, void* stream) {
     UNERF_REQUIRE(table && scalings && (R == 0 || (origins && directions && sbins && feature_planes)), "field_gather: null pointer");
     UNERF_REQUIRE(L >= 1 && L <= 32 && log2T >= 1 && log2T <= 24 && R >= 0 && S >= 1, "field_gather: bad L/log2T/R/S");
     if (R == 0) return UNERF_OK;
     GatherArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
-    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing);
     a.table = table; a.scalings = scalings; a.L = L; a.log2T = log2T; a.planes = feature_planes;
     a.box = make_norm_box(0, nullptr);
     // blockIdx.x runs fastest in dispatch order, so all workgroups of level l are issued before
@@ -2428,7 +2456,7 @@ static void launch_matrix_kernel(Kern kernel, size_t lds_bytes, FieldArgs& a, hi
 }
 
 extern "C" int unerf_field_fwd(const float* origins, const float* directions, const float* sbins, int64_t R, int S,
-                               float near_plane, float far_plane, int64_t ray_offset, const unerf_field_params* p,
+                               float near_plane, float far_plane, int spacing, int64_t ray_offset, const unerf_field_params* p,
                                const float* features, float* density, float* rgb, float* aux, float* aux2,
                                void* stream) {
     UNERF_REQUIRE(p && (R == 0 || (origins && directions && sbins && density && rgb)), "field_fwd: null pointer");
@@ -2449,8 +2477,9 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     if (R == 0) return UNERF_OK;
     FieldArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
-    a.s_near = near_plane < 0.f ? -1.f : unerf_spacing_fn(near_plane);   // < 0: sbins are Euclidean edges
-    a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = ray_offset;
+    UNERF_REQUIRE_SPACING(spacing); a.lin = spacing;
+    a.s_near = near_plane < 0.f ? -1.f : unerf_spacing_of(near_plane, spacing);   // < 0: sbins are Euclidean edges
+    a.s_far = unerf_spacing_of(far_plane, spacing); a.ray_offset = ray_offset;
     a.p = *p; a.density = density; a.rgb = rgb; a.aux = aux; a.aux2 = aux2;
     a.features = features;
     a.box = make_norm_box(p->use_aabb, p->aabb);
@@ -2542,12 +2571,15 @@ struct GgnArgs {
     int64_t R;
     int S;
     float s_near, s_far;
+    int lin;   // UNERF_SPACING_*: 1 = identity spacing (UniformSampler)
     const float* sigma;  // [R,S]
     int softplus;        // density activation: 0 trunc_exp (dsigma/dpre = sigma), 1 softplus (dsigma/dpre = 1 - exp(-sigma))
     const float* rgb;    // [R,S,3]
     const float* X;      // [R,S,64] base_mlp output
     const float* Hc;     // [R,S,64] colour hidden (input of mlp_rgb_ll)
     float* partials;     // [waves][260]
+    int bg_mode;         // UNERF_BG_*: the renderer's background (LAST_SAMPLE: the formulas above; COLOR / NONE: a constant
+    float bg[3];         // colour (zero for NONE) in place of c_{S-1}, which then takes no gradient from the T_end term)
 };
 
 __global__ __launch_bounds__(256) void laplace_ggn_kernel(GgnArgs a) {
@@ -2559,7 +2591,7 @@ __global__ __launch_bounds__(256) void laplace_ggn_kernel(GgnArgs a) {
     for (int64_t r = gw; r < a.R; r += nw) {
         const float* sb = a.sbins + r * (S + 1);
         const int i = in ? lane : S - 1;
-        const float e0 = unerf_s2e(sb[i], a.s_near, a.s_far), e1 = unerf_s2e(sb[i + 1], a.s_near, a.s_far);
+        const float e0 = unerf_s2e(sb[i], a.s_near, a.s_far, a.lin), e1 = unerf_s2e(sb[i + 1], a.s_near, a.s_far, a.lin);
         const float delta = e1 - e0;
         const float sig = in ? a.sigma[r * S + i] : 0.f;
         float c[3];
@@ -2576,7 +2608,8 @@ __global__ __launch_bounds__(256) void laplace_ggn_kernel(GgnArgs a) {
         float g[3], q[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float bg = __shfl(c[k], S - 1, 64);
+            const bool last_bg = a.bg_mode == UNERF_BG_LAST_SAMPLE;
+            const float bg = last_bg ? __shfl(c[k], S - 1, 64) : a.bg[k];
             const float wc = w * c[k];
             const float incl = group_incl_scan<64>(wc, lane);
             const float tot = __shfl(incl, 63, 64);
@@ -2584,7 +2617,7 @@ __global__ __launch_bounds__(256) void laplace_ggn_kernel(GgnArgs a) {
             // eval-mode renderer clamps to [0,1]: the gradient passes only inside (torch.clamp backward)
             const float live = (pred >= 0.f && pred <= 1.f && in) ? 1.f : 0.f;
             g[k] = live * delta * (em * T * c[k] - (tot - incl) - Tf * bg) * dsig;
-            const float wt = w + (lane == S - 1 ? Tf : 0.f);
+            const float wt = w + ((last_bg && lane == S - 1) ? Tf : 0.f);
             q[k] = live * wt * c[k] * (1.f - c[k]);
         }
         float M[3] = {0.f, 0.f, 0.f}, N[3] = {0.f, 0.f, 0.f};
@@ -2641,9 +2674,9 @@ extern "C" size_t unerf_laplace_ggn_workspace_bytes(int64_t R, int S) {
 }
 
 extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directions, const float* sbins, int64_t R,
-                                      int S, float near_plane, float far_plane, const unerf_field_params* p,
-                                      void* workspace, size_t workspace_bytes, float* ggn_density, float* ggn_rgb,
-                                      void* stream) {
+                                      int S, float near_plane, float far_plane, int spacing, const unerf_field_params* p,
+                                      int background, const float* background_rgb, void* workspace, size_t workspace_bytes,
+                                      float* ggn_density, float* ggn_rgb, void* stream) {
     UNERF_REQUIRE(R >= 0 && S >= 1 && S <= 64, "laplace_ggn_diag: S=%d outside [1,64]", S);
     if (R == 0) return UNERF_OK;
     UNERF_REQUIRE(origins && directions && sbins && p && workspace && ggn_density && ggn_rgb,
@@ -2666,7 +2699,7 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     hipStream_t st = (hipStream_t)stream;
     FieldArgs a;
     a.origins = origins; a.dirs = directions; a.sbins = sbins; a.R = R; a.S = S;
-    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane); a.ray_offset = 0;
+    UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing); a.ray_offset = 0;
     a.p = *p; a.density = sigma; a.rgb = col; a.aux = X; a.aux2 = Hc; a.features = nullptr;
     a.keep_hi = 0; a.keep_pk = 0; a.drop_on = 0; a.drop_sites = 0; a.drop_scale = 1.f;
     a.box = make_norm_box(p->use_aabb, p->aabb);
@@ -2674,8 +2707,9 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     if (p->tcnn_levels) launch_matrix_kernel(field_kernel_mfma_laplace<true, true>, MF_LDS_FP32, a, st);
     else launch_matrix_kernel(field_kernel_mfma_laplace<true>, MF_LDS_FP32, a, st);
     GgnArgs g;
-    g.sbins = sbins; g.R = R; g.S = S; g.s_near = a.s_near; g.s_far = a.s_far;
+    g.sbins = sbins; g.R = R; g.S = S; g.s_near = a.s_near; g.s_far = a.s_far; g.lin = a.lin;
     g.sigma = sigma; g.softplus = p->lap_softplus; g.rgb = col; g.X = X; g.Hc = Hc; g.partials = partials;
+    if (int rc = unerf_set_background(g, background, background_rgb, "laplace_ggn_diag")) return rc;
     const int blocks = ggn_blocks(R);
     hipLaunchKernelGGL(laplace_ggn_kernel, dim3(blocks), dim3(256), 0, st, g);
     hipLaunchKernelGGL(laplace_ggn_reduce_kernel, dim3(2), dim3(256), 0, st, partials, blocks * 4, ggn_density, ggn_rgb);
@@ -2714,9 +2748,12 @@ struct CompArgs {
     int64_t R;
     int S;
     float s_near, s_far;
+    int lin;   // UNERF_SPACING_*: 1 = identity spacing (UniformSampler)
     const float* clip;
     int64_t ray_offset, chunk_rays;
     float* out;
+    int bg_mode;      // UNERF_BG_*: what RGBRenderer blends behind the samples
+    float bg[3];      // UNERF_BG_COLOR
 };
 
 // one (pass b, ray r) composite, executed by a 16-lane group; g = b*R + r.  Results are replicated on all 16 lanes.
@@ -2736,7 +2773,7 @@ __device__ __forceinline__ CompGeom<SPL> composite_geom(const CompArgs& a, int64
     float eu[SPL + 1];
     CompGeom<SPL> gm;
 #pragma unroll
-    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[RAGGED ? min(k0 + e, S) : k0 + e], a.s_near, a.s_far);
+    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[RAGGED ? min(k0 + e, S) : k0 + e], a.s_near, a.s_far, a.lin);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
         gm.delta[e] = eu[e + 1] - eu[e];
@@ -2782,12 +2819,20 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
     cb = group_sum<16>(cb);
     accw = group_sum<16>(accw);
     uvar = group_sum<16>(uvar);
-    // background_color = "last_sample"
-    const int last_lane = RAGGED ? (S - 1) / SPL : 15;   // the lane that holds sample S-1
-    float bgr = __shfl(lr, last_lane, 16), bgg = __shfl(lg, last_lane, 16), bgb = __shfl(lb, last_lane, 16);
-    cr = fminf(fmaxf(cr + bgr * (1.f - accw), 0.f), 1.f);
-    cg = fminf(fmaxf(cg + bgg * (1.f - accw), 0.f), 1.f);
-    cb = fminf(fmaxf(cb + bgb * (1.f - accw), 0.f), 1.f);
+    if (a.bg_mode == UNERF_BG_LAST_SAMPLE) {   // uniform; background_color = "last_sample", the nerfacto default
+        const int last_lane = RAGGED ? (S - 1) / SPL : 15;   // the lane that holds sample S-1
+        float bgr = __shfl(lr, last_lane, 16), bgg = __shfl(lg, last_lane, 16), bgb = __shfl(lb, last_lane, 16);
+        cr = cr + bgr * (1.f - accw);
+        cg = cg + bgg * (1.f - accw);
+        cb = cb + bgb * (1.f - accw);
+    } else if (a.bg_mode == UNERF_BG_COLOR) {  // "white" / "black"
+        cr = cr + a.bg[0] * (1.f - accw);
+        cg = cg + a.bg[1] * (1.f - accw);
+        cb = cb + a.bg[2] * (1.f - accw);
+    }                                          // UNERF_BG_NONE ("random" at eval): no blending
+    cr = fminf(fmaxf(cr, 0.f), 1.f);
+    cg = fminf(fmaxf(cg, 0.f), 1.f);
+    cb = fminf(fmaxf(cb, 0.f), 1.f);
 
     // depth-side weights: the laplace mean sampled weights when given
     float wd[SPL];
@@ -2924,9 +2969,9 @@ static inline int unerf_spl_for(int S) {
     }
 
 extern "C" int unerf_composite_var(const float* density, const float* rgb, const float* beta, const float* weights_alt,
-                                   const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane,
-                                   const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, float* out,
-                                   void* stream) {
+                                   const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane, int spacing,
+                                   const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, int background,
+                                   const float* background_rgb, float* out, void* stream) {
     UNERF_REQUIRE(R == 0 || (density && rgb && sbins && out), "composite_var: null pointer");
     UNERF_REQUIRE(B >= 1 && R >= 0, "composite_var: bad B/R");
     UNERF_REQUIRE(S >= 1 && S <= 256, "composite_var: S=%d outside [1,256]", S);
@@ -2934,8 +2979,9 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
     if (R == 0) return UNERF_OK;
     CompArgs a;
     a.density = density; a.rgb = rgb; a.beta = beta; a.walt = weights_alt; a.sbins = sbins; a.B = B; a.R = R; a.S = S;
-    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing);
     a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays; a.out = out;
+    if (int rc = unerf_set_background(a, background, background_rgb, "composite_var")) return rc;
     dim3 grid(blocks_for((int64_t)B * R, 16)), block(256);
     hipStream_t st = (hipStream_t)stream;
     UNERF_DISPATCH_SPL(S, composite_kernel, grid, block, 0, st, a);
@@ -2943,8 +2989,9 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
 }
 
 extern "C" int unerf_composite_moments(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
-                                       float near_plane, float far_plane, const float* clip_minmax, int64_t ray_offset,
-                                       int64_t chunk_rays, float* mean_out, float* var_out, void* stream) {
+                                       float near_plane, float far_plane, int spacing, const float* clip_minmax, int64_t ray_offset,
+                                       int64_t chunk_rays, int background, const float* background_rgb, float* mean_out,
+                                       float* var_out, void* stream) {
     UNERF_REQUIRE(R == 0 || (density && rgb && sbins && mean_out && var_out), "composite_moments: null pointer");
     UNERF_REQUIRE(B >= 1 && B <= 16 && R >= 0, "composite_moments: B=%d outside [1,16] (use composite_var + moments)", B);
     UNERF_REQUIRE(S >= 1 && S <= 256, "composite_moments: S=%d outside [1,256]", S);
@@ -2952,8 +2999,9 @@ extern "C" int unerf_composite_moments(const float* density, const float* rgb, c
     if (R == 0) return UNERF_OK;
     CompArgs a;
     a.density = density; a.rgb = rgb; a.beta = nullptr; a.walt = nullptr; a.sbins = sbins; a.B = B; a.R = R; a.S = S;
-    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing);
     a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays; a.out = nullptr;
+    if (int rc = unerf_set_background(a, background, background_rgb, "composite_moments")) return rc;
     dim3 grid(blocks_for(R, 16)), block(256);
     hipStream_t st = (hipStream_t)stream;
     UNERF_DISPATCH_SPL(S, composite_moments_kernel, grid, block, 0, st, a, mean_out, var_out);
@@ -2980,11 +3028,14 @@ struct CompSmArgs {
     int64_t R;
     int S;
     float s_near, s_far;
+    int lin;   // UNERF_SPACING_*: 1 = identity spacing (UniformSampler)
     const float* clip;
     int64_t ray_offset, chunk_rays;
     float* out;       // [B,R,8] (MOMENTS = false)
     float* mean_out;  // [R,8]
     float* var_out;   // [R,8]
+    int bg_mode;      // as CompArgs
+    float bg[3];
 };
 
 #define CSM_G 4   // passes per walk
@@ -3018,10 +3069,10 @@ __global__ __launch_bounds__(256) void composite_sm_kernel(CompSmArgs a) {
             m0[j] = m1[j] = m2[j] = 0.0;
             found[j] = false;
         }
-        float e0 = unerf_s2e(sb[0], a.s_near, a.s_far);
+        float e0 = unerf_s2e(sb[0], a.s_near, a.s_far, a.lin);
         float step = 0.f;
         for (int s = 0; s < S; ++s) {
-            const float e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far);
+            const float e1 = unerf_s2e(sb[s + 1], a.s_near, a.s_far, a.lin);
             const float delta = e1 - e0;
             step = (e0 + e1) / 2.f;
             e0 = e1;
@@ -3062,9 +3113,12 @@ __global__ __launch_bounds__(256) void composite_sm_kernel(CompSmArgs a) {
             if (j < nb) {
                 if (!found[j]) depth[j] = step;   // clamp(searchsorted, 0, S-1): the last sample's mid-point
                 float o8[8];
-                o8[0] = fminf(fmaxf(cr[j] + lr[j] * (1.f - accw[j]), 0.f), 1.f);   // background_color = "last_sample"
-                o8[1] = fminf(fmaxf(cg[j] + lg[j] * (1.f - accw[j]), 0.f), 1.f);
-                o8[2] = fminf(fmaxf(cb[j] + lb[j] * (1.f - accw[j]), 0.f), 1.f);
+                // RGBRenderer background (see unerf_set_background): last sample | constant colour | none
+                const bool ls = a.bg_mode == UNERF_BG_LAST_SAMPLE, none = a.bg_mode == UNERF_BG_NONE;
+                const float br = ls ? lr[j] : a.bg[0], bgn = ls ? lg[j] : a.bg[1], bb = ls ? lb[j] : a.bg[2];
+                o8[0] = fminf(fmaxf(none ? cr[j] : cr[j] + br * (1.f - accw[j]), 0.f), 1.f);
+                o8[1] = fminf(fmaxf(none ? cg[j] : cg[j] + bgn * (1.f - accw[j]), 0.f), 1.f);
+                o8[2] = fminf(fmaxf(none ? cb[j] : cb[j] + bb * (1.f - accw[j]), 0.f), 1.f);
                 o8[3] = accw[j];
                 o8[4] = depth[j];
                 float ed = wt[j] / (accw[j] + 1e-10f);
@@ -3109,18 +3163,19 @@ __global__ __launch_bounds__(256) void composite_sm_kernel(CompSmArgs a) {
 }
 
 static int composite_planes_launch(const float* density, const float* rgb, const float* beta, const float* sbins, int B,
-                                   int64_t R, int S, float near_plane, float far_plane, const float* clip_minmax,
-                                   int64_t ray_offset, int64_t chunk_rays, float* out, float* mean_out, float* var_out,
-                                   void* stream, const char* what) {
+                                   int64_t R, int S, float near_plane, float far_plane, int spacing, const float* clip_minmax,
+                                   int64_t ray_offset, int64_t chunk_rays, int background, const float* background_rgb,
+                                   float* out, float* mean_out, float* var_out, void* stream, const char* what) {
     UNERF_REQUIRE(R == 0 || (density && rgb && sbins), "%s: null pointer", what);
     UNERF_REQUIRE(B >= 1 && R >= 0 && S >= 1, "%s: bad B/R/S", what);
     UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "%s: chunk_rays must be > 0 with clip_minmax", what);
     if (R == 0) return UNERF_OK;
     CompSmArgs a;
     a.density = density; a.rgb = rgb; a.beta = beta; a.sbins = sbins; a.B = B; a.R = R; a.S = S;
-    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing);
     a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays;
     a.out = out; a.mean_out = mean_out; a.var_out = var_out;
+    if (int rc = unerf_set_background(a, background, background_rgb, what)) return rc;
     dim3 grid(blocks_for(R, 256)), block(256);
     if (out) hipLaunchKernelGGL(composite_sm_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(composite_sm_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
@@ -3128,22 +3183,23 @@ static int composite_planes_launch(const float* density, const float* rgb, const
 }
 
 extern "C" int unerf_composite_var_planes(const float* density, const float* rgb, const float* beta, const float* sbins,
-                                          int B, int64_t R, int S, float near_plane, float far_plane,
-                                          const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, float* out,
-                                          void* stream) {
+                                          int B, int64_t R, int S, float near_plane, float far_plane, int spacing,
+                                          const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, int background,
+                                          const float* background_rgb, float* out, void* stream) {
     UNERF_REQUIRE(R == 0 || out, "composite_var_planes: null pointer");
-    return composite_planes_launch(density, rgb, beta, sbins, B, R, S, near_plane, far_plane, clip_minmax, ray_offset,
-                                   chunk_rays, out, nullptr, nullptr, stream, "composite_var_planes");
+    return composite_planes_launch(density, rgb, beta, sbins, B, R, S, near_plane, far_plane, spacing, clip_minmax, ray_offset,
+                                   chunk_rays, background, background_rgb, out, nullptr, nullptr, stream, "composite_var_planes");
 }
 
 extern "C" int unerf_composite_moments_planes(const float* density, const float* rgb, const float* sbins, int B,
-                                              int64_t R, int S, float near_plane, float far_plane,
+                                              int64_t R, int S, float near_plane, float far_plane, int spacing,
                                               const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays,
-                                              float* mean_out, float* var_out, void* stream) {
+                                              int background, const float* background_rgb, float* mean_out,
+                                              float* var_out, void* stream) {
     UNERF_REQUIRE(R == 0 || (mean_out && var_out), "composite_moments_planes: null pointer");
     UNERF_REQUIRE(B >= 2, "composite_moments_planes: B=%d (the unbiased variance needs at least two passes)", B);
-    return composite_planes_launch(density, rgb, nullptr, sbins, B, R, S, near_plane, far_plane, clip_minmax, ray_offset,
-                                   chunk_rays, nullptr, mean_out, var_out, stream, "composite_moments_planes");
+    return composite_planes_launch(density, rgb, nullptr, sbins, B, R, S, near_plane, far_plane, spacing, clip_minmax, ray_offset,
+                                   chunk_rays, background, background_rgb, nullptr, mean_out, var_out, stream, "composite_moments_planes");
 }
 
 // ---- laplace depth draws --------------------------------------------------------------
@@ -3154,6 +3210,7 @@ struct LapDepthArgs {
     int64_t R;
     int S;
     float s_near, s_far;
+    int lin;   // UNERF_SPACING_*: 1 = identity spacing (UniformSampler)
     const float* noise;
     int D;
     uint32_t seed;
@@ -3212,7 +3269,7 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
     const float* sb = a.sbins + r * (S + 1);
     float eu[SPL + 1], delta[SPL], nd2[SPL], mu[SPL], sd[SPL], wsum[SPL], dens[SPL], w[SPL];
 #pragma unroll
-    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[RAGGED ? min(k0 + e, S) : k0 + e], a.s_near, a.s_far);
+    for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[RAGGED ? min(k0 + e, S) : k0 + e], a.s_near, a.s_far, a.lin);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
         delta[e] = eu[e + 1] - eu[e];
@@ -3257,14 +3314,14 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
 }
 
 extern "C" int unerf_laplace_depth_weights(const float* density_mu, const float* density_var, const float* sbins,
-                                           int64_t R, int S, float near_plane, float far_plane, const float* noise,
+                                           int64_t R, int S, float near_plane, float far_plane, int spacing, const float* noise,
                                            int D, uint32_t seed, int64_t ray_offset, float* weights_out, void* stream) {
     UNERF_REQUIRE(R == 0 || (density_mu && density_var && sbins && weights_out), "laplace_depth_weights: null pointer");
     UNERF_REQUIRE(D >= 1 && R >= 0 && S >= 1 && S <= 256, "laplace_depth_weights: bad D/R/S");
     if (R == 0) return UNERF_OK;
     LapDepthArgs a;
     a.mu = density_mu; a.var = density_var; a.sbins = sbins; a.R = R; a.S = S;
-    a.s_near = unerf_spacing_fn(near_plane); a.s_far = unerf_spacing_fn(far_plane);
+    UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing);
     a.noise = noise; a.D = D; a.seed = seed; a.ray_offset = ray_offset; a.out = weights_out;
     dim3 grid(blocks_for(R, 16)), block(256);
     hipStream_t st = (hipStream_t)stream;

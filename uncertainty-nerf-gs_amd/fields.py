@@ -174,20 +174,67 @@ class Embedding(nn.Module):
         return self.embedding.weight.mean(dim)
 
 
-class HashMLPDensityField(nn.Module):
-    """Proposal network.  Keys: encoding.hash_table (= mlp_base.0.hash_table), mlp_base.1.layers.{0,1}.*"""
+class MLPWithHashEncoding(nn.Module):
+    """[UPSTREAM nerfstudio 1.1.0 field_components.mlp.MLPWithHashEncoding -- the block the reference's authors split
+    apart at activenerfacto_field.py:124-157; upstream's NerfactoField.mlp_base and HashMLPDensityField.mlp_base are
+    this module].  State-dict keys:
+      implementation="torch": `encoder.hash_table`, `mlp.layers.{i}.{weight,bias}`, and the same tensors again under
+                              `model.0.*` / `model.1.*` (upstream keeps `model = Sequential(encoder, mlp)`);
+      implementation="tcnn":  upstream holds ONE tcnn.NetworkWithInputEncoding whose `params` vector is the
+                              FullyFusedMLP weights followed by the HashGrid parameters (`model.params`).  This mirror
+                              keeps the two parts as `mlp.tcnn_encoding.params` / `encoder.tcnn_encoding.params`;
+                              models.remap_checkpoint_keys splits a fused vector by size when a checkpoint has one."""
 
-    def __init__(self, num_layers=2, hidden_dim=16, num_levels=5, max_res=128, base_res=16, log2_hashmap_size=17,
-                 average_init_density=1.0, implementation="torch"):
+    def __init__(self, num_levels=16, min_res=16, max_res=1024, log2_hashmap_size=19, features_per_level=2,
+                 num_layers=2, layer_width=64, out_dim=1, implementation="torch"):
+        super().__init__()
+        self.implementation = implementation
+        self.encoder = HashEncoding(num_levels, min_res, max_res, log2_hashmap_size, features_per_level,
+                                    implementation=implementation)
+        self.mlp = MLP(self.encoder.get_out_dim(), num_layers, layer_width, out_dim, implementation=implementation)
+        if implementation == "torch":
+            self.model = nn.Sequential(self.encoder, self.mlp)
+
+    def fused_tcnn_sizes(self) -> Tuple[int, int]:
+        """(FullyFusedMLP values, HashGrid values) of a fused NetworkWithInputEncoding vector"""
+        assert self.implementation == "tcnn"
+        return self.mlp.tcnn_encoding.params.numel(), self.encoder.tcnn_encoding.params.numel()
+
+
+class _FieldBuffers:
+    """[UPSTREAM nerfstudio 1.1.0 NerfactoField / HashMLPDensityField __init__] the four buffers every field registers
+    (and every checkpoint therefore carries): aabb, max_res, num_levels, log2_hashmap_size"""
+
+    def _register_field_buffers(self, aabb, max_res, num_levels, log2_hashmap_size):
+        self.register_buffer("aabb", torch.zeros(2, 3) if aabb is None else torch.as_tensor(aabb, dtype=torch.float32))
+        self.register_buffer("max_res", torch.tensor(max_res))
+        self.register_buffer("num_levels", torch.tensor(num_levels))
+        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
+
+
+class HashMLPDensityField(nn.Module, _FieldBuffers):
+    """Proposal network [UPSTREAM nerfstudio 1.1.0 fields/density_fields.py].  Own keys: `mlp_base.encoder.*`,
+    `mlp_base.mlp.layers.{0,1}.*` (+ `mlp_base.model.{0,1}.*`), the MLPWithHashEncoding layout; the older
+    `encoding.*` / `mlp_base.{0,1}.*` names (HashEncoding + Sequential) are accepted as aliases on load
+    (models.remap_checkpoint_keys)."""
+
+    def __init__(self, aabb=None, num_layers=2, hidden_dim=16, num_levels=5, max_res=128, base_res=16, log2_hashmap_size=17,
+                 average_init_density=1.0, implementation="torch", use_linear=False, **_unused):
         super().__init__()
         assert num_layers == 2, "proposal kernels are built for Linear-ReLU-Linear"
+        if use_linear:
+            raise NotImplementedError("use_linear=True proposal networks (grid + one Linear) are not built")
         self.average_init_density = average_init_density
-        self.encoding = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, implementation=implementation)
-        self.mlp_base = nn.Sequential(self.encoding, MLP(self.encoding.get_out_dim(), num_layers, hidden_dim, 1,
-                                                         implementation=implementation))
+        self._register_field_buffers(aabb, max_res, num_levels, log2_hashmap_size)
+        self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, 2, num_layers, hidden_dim, 1,
+                                            implementation=implementation)
+
+    @property
+    def encoding(self) -> "HashEncoding":
+        return self.mlp_base.encoder
 
     def to_device(self, device) -> ops.DensityNetDev:
-        (w0, b0), (w1, b1) = self.mlp_base[1].linear_layers()
+        (w0, b0), (w1, b1) = self.mlp_base.mlp.linear_layers()
         return ops.DensityNetDev.from_torch(self.encoding.table, self.encoding.scalings, self.encoding.log2_hashmap_size,
                                             w0, b0, w1, b1, device, tcnn_levels=self.encoding.tcnn_levels)
 
@@ -226,7 +273,7 @@ class HashMLPDensityField(nn.Module):
         return {FieldHeadNames.DENSITY: density}
 
 
-class _NerfactoFieldBase(nn.Module):
+class _NerfactoFieldBase(nn.Module, _FieldBuffers):
     """Pieces shared with nerfstudio NerfactoField: colour head input = SH16 + geo15 + appearance32."""
 
     def __init__(self, num_images, geo_feat_dim=15, appearance_embedding_dim=32,
@@ -296,6 +343,7 @@ class ActiveNerfactoField(_NerfactoFieldBase):
         super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
                          implementation)
         assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        self._register_field_buffers(aabb, max_res, num_levels, log2_hashmap_size)
         self.beta_min = beta_min
         self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
                                           implementation=implementation)
@@ -343,28 +391,36 @@ class NerfactoMCDropoutField(_NerfactoFieldBase):
         self.drop_sites = ((_l.DROP_TRUNK if density_dropout_layers else 0) | (_l.DROP_HEAD0 if 1 in rgb_dropout_layers else 0)
                            | (_l.DROP_HEAD1 if (-1 in rgb_dropout_layers or 2 in rgb_dropout_layers) else 0))
         self.dropout_rate = dropout_rate
-        self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
-                                          implementation=implementation)
-        # density_dropout_layers=False leaves the parent's trunk in place (mcdropout_fields.py:112, :162-166); it is the
-        # same Linear-ReLU-Linear without the Dropout module (state-dict indices 0, 2 instead of 0, 3)
-        self.mlp_base = create_mlp(self.mlp_base_grid.get_out_dim(), num_layers, hidden_dim, 1 + geo_feat_dim,
-                                   activation=nn.ReLU, dropout_layers=[-1] if density_dropout_layers else None,
-                                   dropout_rate=dropout_rate)
+        self._register_field_buffers(aabb, max_res, num_levels, log2_hashmap_size)
+        if density_dropout_layers:
+            self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
+                                              implementation=implementation)
+            self.mlp_base = create_mlp(self.mlp_base_grid.get_out_dim(), num_layers, hidden_dim, 1 + geo_feat_dim,
+                                       activation=nn.ReLU, dropout_layers=[-1], dropout_rate=dropout_rate)
+        else:
+            # density_dropout_layers=False leaves the PARENT's trunk in place (mcdropout_fields.py:112, :162-166):
+            # upstream NerfactoField.mlp_base = MLPWithHashEncoding, keys mlp_base.encoder.* / mlp_base.mlp.layers.*
+            self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
+                                                num_layers, hidden_dim, 1 + geo_feat_dim, implementation=implementation)
         self.mlp_head = create_mlp(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color, hidden_dim_color, 3,
                                    activation=nn.ReLU, out_activation=nn.Sigmoid, dropout_layers=rgb_dropout_layers,
                                    dropout_rate=dropout_rate)
 
     def to_device(self, device, mc_samples=10, seed=0, **kw) -> ops.FieldDev:
-        bl = [m for m in self.mlp_base if isinstance(m, nn.Linear)]
+        if self.density_dropout_layers:
+            grid = self.mlp_base_grid
+            (w0, b0), (w1, b1) = [(m.weight, m.bias) for m in self.mlp_base if isinstance(m, nn.Linear)]
+        else:
+            grid = self.mlp_base.encoder
+            (w0, b0), (w1, b1) = self.mlp_base.mlp.linear_layers()
         hl = [m for m in self.mlp_head if isinstance(m, nn.Linear)]
         # no Dropout module anywhere: the K passes are identical -- p = 0 switches the mask generation off
         p_drop = self.dropout_rate if self.drop_sites else 0.0
         return ops.FieldDev.from_torch(
-            _l.FIELD_MCDROPOUT, self.mlp_base_grid.table, self.mlp_base_grid.scalings,
-            self.mlp_base_grid.log2_hashmap_size, bl[0].weight, bl[0].bias, bl[1].weight, bl[1].bias,
+            _l.FIELD_MCDROPOUT, grid.table, grid.scalings, grid.log2_hashmap_size, w0, b0, w1, b1,
             [m.weight for m in hl], [m.bias for m in hl], self.eval_appearance(), device,
             average_init_density=self.average_init_density, K=mc_samples, seed=seed, p_drop=p_drop,
-            drop_sites=self.drop_sites, **self._grid_kw(self.mlp_base_grid), **kw)
+            drop_sites=self.drop_sites, **self._grid_kw(grid), **kw)
 
     def _forward_kw(self):
         return {"mc_samples": 0}   # eval-mode Dropout is the identity; the K stochastic passes are the Model's job
@@ -375,6 +431,39 @@ class NerfactoMCDropoutField(_NerfactoFieldBase):
         layer shared): {DENSITY [K,R,S,1], RGB [K,R,S,3]}; masks keyed by (seed, pass, ray_offset*S + sample)."""
         f, (density, rgb, _, _) = self._run(ray_samples, ray_offset, mc_samples=mc_samples, seed=seed)
         return {FieldHeadNames.DENSITY: density.unsqueeze(-1), FieldHeadNames.RGB: rgb}
+
+
+class NerfactoField(_NerfactoFieldBase):
+    """[UPSTREAM nerfstudio 1.1.0 fields/nerfacto_field.py] the plain nerfacto field -- what an ensemble member of
+    `nerfacto` runs (README.md:106-108, ensemble_utils.py:149-156) and the parent of the three fields above.
+    Keys: mlp_base.encoder.hash_table, mlp_base.mlp.layers.{0,1}.* (MLPWithHashEncoding; tcnn: one fused
+    mlp_base.model.params vector), mlp_head.layers.{0,1,2}.* (tcnn: mlp_head.tcnn_encoding.params),
+    embedding_appearance.embedding.weight; buffers aabb, max_res, num_levels, log2_hashmap_size.
+    Rendered by the MCDROPOUT kernel mode with the mask generation off (one deterministic pass)."""
+
+    def __init__(self, aabb=None, num_images=1, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_levels=16,
+                 base_res=16, max_res=2048, log2_hashmap_size=19, num_layers_color=3, features_per_level=2,
+                 hidden_dim_color=64, appearance_embedding_dim=32, use_average_appearance_embedding=False,
+                 spatial_distortion=None, implementation="torch", average_init_density=1.0, **_unused):
+        super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
+                         implementation)
+        assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        self._register_field_buffers(aabb, max_res, num_levels, log2_hashmap_size)
+        self.average_init_density = average_init_density
+        self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
+                                            num_layers, hidden_dim, 1 + geo_feat_dim, implementation=implementation)
+        self.mlp_head = MLP(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color, hidden_dim_color, 3,
+                            implementation=implementation)
+
+    def to_device(self, device, **kw) -> ops.FieldDev:
+        g = self.mlp_base.encoder
+        (w0, b0), (w1, b1) = self.mlp_base.mlp.linear_layers()
+        h = self.mlp_head.linear_layers()
+        kw.pop("mc_samples", None)
+        return ops.FieldDev.from_torch(
+            _l.FIELD_MCDROPOUT, g.table, g.scalings, g.log2_hashmap_size, w0, b0, w1, b1,
+            [w for w, _ in h], [b for _, b in h], self.eval_appearance(), device,
+            average_init_density=self.average_init_density, K=0, p_drop=0.0, **self._grid_kw(g), **kw)
 
 
 class NerfactoLaplaceField(_NerfactoFieldBase):

@@ -110,7 +110,10 @@ class FieldParams(C.Structure):
     ]
 
 
+ABI_VERSION = 1200                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
+SPACING_PIECEWISE, SPACING_UNIFORM = 0, 1         # include/unerf.h: UNERF_SPACING_*
+BG_LAST_SAMPLE, BG_NONE, BG_COLOR = 0, 1, 2       # include/unerf.h: UNERF_BG_*
 BUILD_TRUNK_FOLD, BUILD_LAP_EXP2 = 1, 2   # include/unerf.h: UNERF_BUILD_*
 DROP_TRUNK, DROP_HEAD0, DROP_HEAD1 = 1, 2, 4     # include/unerf.h: UNERF_DROP_*
 
@@ -124,24 +127,25 @@ SIGNATURES = {
     "unerf_build_flags": (_i, []),
     "unerf_device_count": (_i, []),
     "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
-    "unerf_ray_box_bins": (_i, [_vp, _vp, _i64, _fp, _fp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp]),
-    "unerf_ray_planes_bins": (_i, [_vp, _vp, _i64, _f, _f, _vp, _i, _vp, _vp]),
+    "unerf_ray_box_bins": (_i, [_vp, _vp, _i64, _fp, _fp, _f, _f, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "unerf_ray_planes_bins": (_i, [_vp, _vp, _i64, _f, _f, _i, _vp, _i, _vp, _vp]),
     "unerf_hashgrid_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "unerf_hashgrid_fwd_tcnn": (_i, [_vp, _vp, C.POINTER(TcnnLevel), _i64, _i, _vp, _vp, _vp]),
-    "unerf_proposal_density": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, C.POINTER(DensityNet), _f, _vp, _i64, _i, _vp]),
-    "unerf_weights_pdf_resample": (_i, [_vp, _vp, _i64, _i64, _i, _f, _f, _vp, _i, _f, _f, _vp, _vp, _vp, _vp,
+    "unerf_proposal_density": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _i, C.POINTER(DensityNet), _f, _vp, _i64, _i, _vp]),
+    "unerf_weights_pdf_resample": (_i, [_vp, _vp, _i64, _i64, _i, _f, _f, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp,
                                         _i64, _i64, _vp]),
-    "unerf_field_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i64, C.POINTER(FieldParams), _vp, _vp, _vp, _vp, _vp,
+    "unerf_field_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i, _i64, C.POINTER(FieldParams), _vp, _vp, _vp, _vp, _vp,
                              _vp]),
-    "unerf_field_gather": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
-    "unerf_laplace_depth_weights": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp, _i, _u32, _i64, _vp, _vp]),
+    "unerf_field_gather": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "unerf_laplace_depth_weights": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i, _vp, _i, _u32, _i64, _vp, _vp]),
     "unerf_laplace_ggn_workspace_bytes": (C.c_size_t, [_i64, _i]),
-    "unerf_laplace_ggn_diag": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, C.POINTER(FieldParams), _vp, C.c_size_t, _vp, _vp,
-                                    _vp]),
-    "unerf_composite_var": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp]),
-    "unerf_composite_moments": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp, _vp]),
-    "unerf_composite_var_planes": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp]),
-    "unerf_composite_moments_planes": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "unerf_laplace_ggn_diag": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i, C.POINTER(FieldParams), _i, _fp, _vp, C.c_size_t,
+                                    _vp, _vp, _vp]),
+    "unerf_composite_var": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp]),
+    "unerf_composite_moments": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp, _vp]),
+    "unerf_composite_var_planes": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp]),
+    "unerf_composite_moments_planes": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp,
+                                            _vp]),
     "unerf_moments": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "unerf_splat_project": (_i, [_vp, _vp, _f, _vp, _fp, _f, _f, _f, _f, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp]),
@@ -175,6 +179,12 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # the ctypes Structures and argument lists above are one ABI: a library of another one (UNERF_LIB pointing at a
+    # stale A/B build) would be driven with mismatched layouts and answer with silent garbage
+    got = lib.unerf_version()
+    if got != ABI_VERSION:
+        raise UnerfError(f"{LIB_PATH}: ABI version {got}, this binding is written for {ABI_VERSION} "
+                         "(rebuild: python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
 

@@ -101,7 +101,7 @@ def world_to_box(R, T) -> torch.Tensor:
 
 
 def ray_box_bins(origins, directions, w2b: torch.Tensor, S, near: float, far: float, sbins_row: torch.Tensor,
-                 want_planes: bool = False):
+                 want_planes: bool = False, spacing: int = 0):
     """per-ray first-level spacing bins [R,n+1] for an oriented crop box (include/unerf.h: unerf_ray_box_bins);
     w2b = world_to_box(R, T), S = the box's edge lengths.  -> bins, (nears [R,1], fars [R,1]) | None"""
     lib = _l.load()
@@ -111,19 +111,19 @@ def ray_box_bins(origins, directions, w2b: torch.Tensor, S, near: float, far: fl
     half = (C.c_float * 3)(*[float(v) / 2 for v in torch.as_tensor(S).reshape(-1)[:3]])
     with _ctx(origins.device):
         _run("ray_box_bins", lambda: lib.unerf_ray_box_bins(_p(origins), _p(directions), R, _host12(w2b), half, near, far,
-                                                            _p(sbins_row), n, _p(out), _p(nf[0]) if want_planes else None,
+                                                            spacing, _p(sbins_row), n, _p(out), _p(nf[0]) if want_planes else None,
                                                             _p(nf[1]) if want_planes else None, _stream()))
     return out, ((nf[0], nf[1]) if want_planes else None)
 
 
-def ray_planes_bins(nears, fars, near: float, far: float, sbins_row: torch.Tensor) -> torch.Tensor:
+def ray_planes_bins(nears, fars, near: float, far: float, sbins_row: torch.Tensor, spacing: int = 0) -> torch.Tensor:
     """per-ray first-level spacing bins [R,n+1] for a bundle that carries its own planes (RayBundle.nears / fars)"""
     lib = _l.load()
     nears, fars = nears.reshape(-1).contiguous(), fars.reshape(-1).contiguous()
     R, n = nears.shape[0], sbins_row.numel() - 1
     out = torch.empty(R, n + 1, device=nears.device, dtype=torch.float32)
     with _ctx(nears.device):
-        _run("ray_planes_bins", lambda: lib.unerf_ray_planes_bins(_p(nears), _p(fars), R, near, far, _p(sbins_row), n, _p(out),
+        _run("ray_planes_bins", lambda: lib.unerf_ray_planes_bins(_p(nears), _p(fars), R, near, far, spacing, _p(sbins_row), n, _p(out),
                                                                   _stream()))
     return out
 
@@ -612,7 +612,7 @@ def pack_laplace_heads16(ws_density: torch.Tensor, ws_rgb: torch.Tensor, exp2_ro
 
 def proposal_density(origins, directions, sbins, net: DensityNetDev, near: float, far: float,
                      average_init_density: float, n: Optional[int] = None, ray_offset: int = 0,
-                     image_width: int = 0) -> torch.Tensor:
+                     image_width: int = 0, spacing: int = 0) -> torch.Tensor:
     """sbins: [n+1] shared row or [R,n+1] per ray -> density [R,n].  image_width > 0: the rays are pixels
     [ray_offset, ray_offset + R) of a row-major image (8x8-pixel-patch schedule, same results)."""
     lib = _l.load()
@@ -623,14 +623,15 @@ def proposal_density(origins, directions, sbins, net: DensityNetDev, near: float
     cs = net.cstruct()
     with _ctx(origins.device):
         _run(f"proposal_density_{n}", lambda: lib.unerf_proposal_density(_p(origins), _p(directions), _p(sbins), stride, R, n, near, far,
-                                            C.byref(cs), average_init_density, _p(out), ray_offset, image_width,
+                                            spacing, C.byref(cs), average_init_density, _p(out), ray_offset, image_width,
                                             _stream()))
     return out
 
 
 def weights_pdf_resample(density, sbins, u, near: float, far: float, histogram_padding: float = 0.01,
                          eps: float = 1e-5, want_prop_depth: bool = True, want_weights: bool = False,
-                         clip_minmax: Optional[torch.Tensor] = None, ray_offset: int = 0, chunk_rays: int = 1 << 15):
+                         clip_minmax: Optional[torch.Tensor] = None, ray_offset: int = 0, chunk_rays: int = 1 << 15,
+                         spacing: int = 0):
     """-> (new sbins [R,m+1], prop_depth [R,1] | None, weights [R,n] | None)"""
     lib = _l.load()
     R, n = density.shape
@@ -640,7 +641,7 @@ def weights_pdf_resample(density, sbins, u, near: float, far: float, histogram_p
     pd = torch.empty(R, 1, device=density.device, dtype=torch.float32) if want_prop_depth else None
     w = torch.empty(R, n, device=density.device, dtype=torch.float32) if want_weights else None
     with _ctx(density.device):
-        _run(f"weights_pdf_resample_{n}", lambda: lib.unerf_weights_pdf_resample(_p(density), _p(sbins), stride, R, n, near, far, _p(u), m,
+        _run(f"weights_pdf_resample_{n}", lambda: lib.unerf_weights_pdf_resample(_p(density), _p(sbins), stride, R, n, near, far, spacing, _p(u), m,
                                                 histogram_padding, eps, _p(out), _p(pd), _p(w), _p(clip_minmax),
                                                 ray_offset, chunk_rays, _stream()))
     return out, pd, w
@@ -657,7 +658,7 @@ def new_clip_buffer(num_rays: int, chunk_rays: int, device) -> torch.Tensor:
 # ------------------------------------------------------------ main field ---------------
 
 def field_gather(origins, directions, sbins, field: FieldDev, near: float, far: float,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, spacing: int = 0) -> torch.Tensor:
     """level-major hash-grid lookup of the final samples -> feature planes [L, R*S, 2]"""
     lib = _l.load()
     R, S = sbins.shape[0], sbins.shape[1] - 1
@@ -666,7 +667,7 @@ def field_gather(origins, directions, sbins, field: FieldDev, near: float, far: 
         out = torch.empty(L, R * S, 2, device=origins.device, dtype=torch.float32)
     with _ctx(origins.device):
         _run("field_gather", lambda: lib.unerf_field_gather(_p(origins), _p(directions), _p(sbins), R, S, near, far,
-                                                            _p(field.table), _p(field.scalings), L, field.log2T,
+                                                            spacing, _p(field.table), _p(field.scalings), L, field.log2T,
                                                             _p(out), _stream()))
     return out
 
@@ -678,7 +679,7 @@ def supports_planes(field: FieldDev) -> bool:
 
 def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0,
               features: Optional[torch.Tensor] = None, image_width: int = 0, euclidean_bins: bool = False,
-              sample_major: bool = False):
+              sample_major: bool = False, spacing: int = 0):
     """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h).  image_width > 0 tells the kernel that
     rays [ray_offset, ray_offset+R) are consecutive pixels of a row-major image (8x4-pixel tiles: same results).
     euclidean_bins: `sbins` holds Euclidean bin edges (a caller-made RaySamples) instead of spacing-domain bins.
@@ -702,24 +703,25 @@ def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: flo
     cs.image_width = int(image_width)
     cs.sample_major = 1 if sample_major else 0
     with _ctx(dev):
-        _run("field_fwd", lambda: lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, ray_offset,
+        _run("field_fwd", lambda: lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, spacing, ray_offset,
                                      C.byref(cs), _p(features), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()))
     return density, rgb, aux, aux2
 
 
 def laplace_depth_weights(density_mu, density_var, sbins, near: float, far: float, noise: Optional[torch.Tensor],
-                          D: int = 100, seed: int = 0, ray_offset: int = 0) -> torch.Tensor:
+                          D: int = 100, seed: int = 0, ray_offset: int = 0, spacing: int = 0) -> torch.Tensor:
     lib = _l.load()
     R, S = density_mu.shape
     out = torch.empty(R, S, device=density_mu.device, dtype=torch.float32)
     with _ctx(out.device):
         _run("laplace_depth_weights", lambda: lib.unerf_laplace_depth_weights(_p(density_mu), _p(density_var), _p(sbins), R, S, near, far,
-                                                 _p(noise), D, seed & 0xFFFFFFFF, ray_offset, _p(out), _stream()))
+                                                 spacing, _p(noise), D, seed & 0xFFFFFFFF, ray_offset, _p(out), _stream()))
     return out
 
 
 def laplace_ggn_diag(origins, directions, sbins, field: FieldDev, density_mean: torch.Tensor, rgb_mean: torch.Tensor,
-                     near: float, far: float, ggn_density: torch.Tensor, ggn_rgb: torch.Tensor) -> None:
+                     near: float, far: float, ggn_density: torch.Tensor, ggn_rgb: torch.Tensor, spacing: int = 0,
+                     background=None) -> None:
     """One batch of NerfactoLaplaceModel.compute_hessian_naive (laplace_model.py:343-400): adds the batch's
     diagonal GGN of the summed-MSE loss to ggn_density [65] / ggn_rgb [195] in place.  density_mean [65] and
     rgb_mean [195] are the flattened mean last layers (weight row-major, then bias)."""
@@ -737,61 +739,96 @@ def laplace_ggn_diag(origins, directions, sbins, field: FieldDev, density_mean: 
     cs.mfma_blob = _p(field.mfma_blob)
     nbytes = lib.unerf_laplace_ggn_workspace_bytes(R, S)
     ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+    bg_mode, bg_rgb = _background(background)
     with _ctx(dev):
         _run("laplace_ggn_diag", lambda: lib.unerf_laplace_ggn_diag(_p(origins), _p(directions), _p(sbins), R, S, near, far,
-                                                                   C.byref(cs), _p(ws), nbytes, _p(ggn_density),
+                                                                   spacing, C.byref(cs), bg_mode, bg_rgb, _p(ws), nbytes, _p(ggn_density),
                                                                    _p(ggn_rgb), _stream()))
 
 
+def background_of(name) -> Tuple[int, Optional[Tuple[float, float, float]]]:
+    """config.background_color -> (UNERF_BG_* mode, constant colour | None).  [UPSTREAM nerfstudio 1.1.0 RGBRenderer:
+    "last_sample" blends the last sample's colour, "random" returns the composited colour unblended at eval, "white" /
+    "black" (utils.colors.COLORS_DICT) blend a constant; a 3-vector is a constant colour.]"""
+    if name is None or (isinstance(name, str) and name == "last_sample"):
+        return _l.BG_LAST_SAMPLE, None
+    if isinstance(name, str):
+        if name == "random":
+            return _l.BG_NONE, None
+        colors = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0), "red": (1.0, 0.0, 0.0), "green": (0.0, 1.0, 0.0),
+                  "blue": (0.0, 0.0, 1.0)}
+        if name not in colors:
+            raise _l.UnerfError(f"background_color={name!r}: expected last_sample, random, white, black")
+        return _l.BG_COLOR, colors[name]
+    vals = tuple(float(v) for v in torch.as_tensor(name).reshape(-1))
+    if len(vals) != 3:
+        raise _l.UnerfError("background colour must have 3 components")
+    return _l.BG_COLOR, vals
+
+
+def _background(background):
+    """(mode, rgb) as produced by background_of (None = last_sample) -> (int, host float[3] | None) for the C ABI"""
+    if background is None:
+        return _l.BG_LAST_SAMPLE, None
+    mode, rgb = background
+    return int(mode), (None if rgb is None else (C.c_float * 3)(*[float(v) for v in rgb]))
+
+
 def composite_var(density, rgb, sbins, near: float, far: float, beta=None, weights_alt=None, clip_minmax=None,
-                  ray_offset: int = 0, chunk_rays: int = 1 << 15) -> torch.Tensor:
+                  ray_offset: int = 0, chunk_rays: int = 1 << 15, spacing: int = 0, background=None) -> torch.Tensor:
     """density [B,R,S] -> out [B,R,8] = rgb3, accumulation, depth, expected_depth, rgb_var, depth_var"""
     lib = _l.load()
     B, R, S = density.shape
     out = torch.empty(B, R, 8, device=density.device, dtype=torch.float32)
+    bg_mode, bg_rgb = _background(background)
     with _ctx(out.device):
         _run("composite_var", lambda: lib.unerf_composite_var(_p(density), _p(rgb), _p(beta), _p(weights_alt), _p(sbins), B, R, S, near,
-                                         far, _p(clip_minmax), ray_offset, chunk_rays, _p(out), _stream()))
+                                         far, spacing, _p(clip_minmax), ray_offset, chunk_rays, bg_mode, bg_rgb, _p(out),
+                                         _stream()))
     return out
 
 
 def composite_moments(density, rgb, sbins, near: float, far: float, clip_minmax=None, ray_offset: int = 0,
-                      chunk_rays: int = 1 << 15):
+                      chunk_rays: int = 1 << 15, spacing: int = 0, background=None):
     """density [B<=16,R,S], rgb [B,R,S,3] -> (mean [R,8], var [R,8]) over the B passes (fused composite + moments)"""
     lib = _l.load()
     B, R, S = density.shape
     mean = torch.empty(R, 8, device=density.device, dtype=torch.float32)
     var = torch.empty(R, 8, device=density.device, dtype=torch.float32)
+    bg_mode, bg_rgb = _background(background)
     with _ctx(mean.device):
         _run("composite_moments", lambda: lib.unerf_composite_moments(_p(density), _p(rgb), _p(sbins), B, R, S, near, far,
-                                                                      _p(clip_minmax), ray_offset, chunk_rays, _p(mean),
-                                                                      _p(var), _stream()))
+                                                                      spacing, _p(clip_minmax), ray_offset, chunk_rays,
+                                                                      bg_mode, bg_rgb, _p(mean), _p(var), _stream()))
     return mean, var
 
 
 def composite_var_planes(density, rgb, sbins, near: float, far: float, beta=None, clip_minmax=None,
-                         ray_offset: int = 0, chunk_rays: int = 1 << 15) -> torch.Tensor:
+                         ray_offset: int = 0, chunk_rays: int = 1 << 15, spacing: int = 0, background=None) -> torch.Tensor:
     """planes density [B,S,R], rgb [B,S,3,R], beta [S,R] -> out [B,R,8] (channels as composite_var)"""
     lib = _l.load()
     B, S, R = density.shape
     out = torch.empty(B, R, 8, device=density.device, dtype=torch.float32)
+    bg_mode, bg_rgb = _background(background)
     with _ctx(out.device):
         _run("composite_var", lambda: lib.unerf_composite_var_planes(_p(density), _p(rgb), _p(beta), _p(sbins), B, R, S, near, far,
-                                                                    _p(clip_minmax), ray_offset, chunk_rays, _p(out), _stream()))
+                                                                    spacing, _p(clip_minmax), ray_offset, chunk_rays, bg_mode,
+                                                                    bg_rgb, _p(out), _stream()))
     return out
 
 
 def composite_moments_planes(density, rgb, sbins, near: float, far: float, clip_minmax=None, ray_offset: int = 0,
-                             chunk_rays: int = 1 << 15):
+                             chunk_rays: int = 1 << 15, spacing: int = 0, background=None):
     """planes density [B>=2,S,R], rgb [B,S,3,R] -> (mean [R,8], var [R,8]) over the B passes"""
     lib = _l.load()
     B, S, R = density.shape
     mean = torch.empty(R, 8, device=density.device, dtype=torch.float32)
     var = torch.empty(R, 8, device=density.device, dtype=torch.float32)
+    bg_mode, bg_rgb = _background(background)
     with _ctx(mean.device):
         _run("composite_moments", lambda: lib.unerf_composite_moments_planes(_p(density), _p(rgb), _p(sbins), B, R, S, near, far,
-                                                                             _p(clip_minmax), ray_offset, chunk_rays,
-                                                                             _p(mean), _p(var), _stream()))
+                                                                             spacing, _p(clip_minmax), ray_offset, chunk_rays,
+                                                                             bg_mode, bg_rgb, _p(mean), _p(var), _stream()))
     return mean, var
 
 

@@ -54,6 +54,11 @@ MODEL_CONFIGS = {
     "active-nerfacto": lambda: models.ActiveNerfactoModelConfig(eval_num_rays_per_chunk=1 << 15,
                                                                 average_init_density=0.01),
     "active-splatfacto": lambda: models.ActiveSplatfactoModelConfig(),
+    # upstream's own methods, as ensemble members (README.md:106-108: "train a nerfacto or splatfacto model using
+    # different seeds"; ensemble_utils.py:149-156).  nerfstudio registers these two itself: no entry point here.
+    # [UPSTREAM nerfstudio 1.1.0 method_configs["nerfacto"]: eval_num_rays_per_chunk = 1 << 15, average_init_density = 0.01]
+    "nerfacto": lambda: models.PlainNerfactoModelConfig(eval_num_rays_per_chunk=1 << 15, average_init_density=0.01),
+    "splatfacto": lambda: models.SplatfactoModelConfig(),
 }
 
 DESCRIPTIONS = {   # the reference's description strings

@@ -53,6 +53,11 @@ class NerfSceneDev:
     num_nerf: int = 48
     prop_average_init_density: float = 0.01
     chunk_rays: int = 1 << 15
+    # proposal_initial_sampler: lib.SPACING_PIECEWISE (nerfacto default) | lib.SPACING_UNIFORM (README.md:153 of the reference)
+    spacing: int = 0
+    # RGBRenderer background as (UNERF_BG_* mode, colour | None) from ops.background_of(config.background_color);
+    # None = "last_sample"
+    background: Optional[Tuple] = None
     split_gather: bool = False  # True: level-major gather kernel + feature planes instead of the fused lookup
     # field outputs as sample-major planes + lane-per-ray composite (ACTIVE / MCDROPOUT).  Measured alternative, off by
     # default: the plane stores cut the field kernel's write traffic to the algorithmic bytes, but the lane-per-ray
@@ -83,13 +88,14 @@ def sample_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Te
     n_iter = len(scene.props)
     for lvl in range(n_iter):
         dens = ops.proposal_density(origins, directions, sb, scene.props[lvl], scene.near, scene.far,
-                                    scene.prop_average_init_density, ray_offset=ray_offset, image_width=image_width)
+                                    scene.prop_average_init_density, ray_offset=ray_offset, image_width=image_width,
+                                    spacing=scene.spacing)
         m = scene.num_prop[lvl + 1] if lvl + 1 < n_iter else scene.num_nerf
         last = lvl + 1 == n_iter
         sb, pd, _ = ops.weights_pdf_resample(dens, sb, scene.const("u", m), scene.near, scene.far,
                                              want_prop_depth=want_prop_depth,
                                              clip_minmax=clip if last else None, ray_offset=ray_offset,
-                                             chunk_rays=scene.chunk_rays)
+                                             chunk_rays=scene.chunk_rays, spacing=scene.spacing)
         prop_depths.append(pd)
     return sb, prop_depths
 
@@ -113,9 +119,9 @@ def crop_bins(scene: NerfSceneDev, origins, directions, obb=None, nears=None, fa
     ensemble_pipeline.py:157) -- or the bundle's own nears / fars [R,1]."""
     row = scene.const("bins", scene.num_prop[0])
     if obb is not None:
-        return ops.ray_box_bins(origins, directions, obb[0], obb[1], scene.near, scene.far, row)[0]
+        return ops.ray_box_bins(origins, directions, obb[0], obb[1], scene.near, scene.far, row, spacing=scene.spacing)[0]
     if nears is not None and fars is not None:
-        return ops.ray_planes_bins(nears, fars, scene.near, scene.far, row)
+        return ops.ray_planes_bins(nears, fars, scene.near, scene.far, row, spacing=scene.spacing)
     return None
 
 
@@ -124,7 +130,8 @@ def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: i
     """-> (final spacing bins, prop depths, feature planes | None)"""
     sb, prop_depths = sample_rays(scene, origins, directions, clip, ray_offset, image_width=image_width,
                                   init_bins=init_bins)
-    feats = ops.field_gather(origins, directions, sb, scene.field, scene.near, scene.far) if _uses_split(scene) else None
+    feats = (ops.field_gather(origins, directions, sb, scene.field, scene.near, scene.far, spacing=scene.spacing)
+             if _uses_split(scene) else None)
     return sb, prop_depths, feats
 
 
@@ -136,8 +143,9 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
     # composite walks them with a lane per ray; LAPLACE keeps the ray-major layout its depth-draw kernel reads
     planes = scene.sample_major and feats is None and ops.supports_planes(f)
     density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset, features=feats,
-                                            image_width=image_width, sample_major=planes)
-    kw = dict(clip_minmax=clip, ray_offset=ray_offset, chunk_rays=scene.chunk_rays)
+                                            image_width=image_width, sample_major=planes, spacing=scene.spacing)
+    kw = dict(clip_minmax=clip, ray_offset=ray_offset, chunk_rays=scene.chunk_rays, spacing=scene.spacing,
+              background=scene.background)
     res: Dict[str, torch.Tensor] = {}
     if f.mode == _l.FIELD_ACTIVE:
         if planes:
@@ -174,7 +182,8 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
     else:
         # use_deterministic_density (laplace_model.py:486-507 is skipped): depth from the ordinary weights
         walt = None if f.lap_mask_density else ops.laplace_depth_weights(
-            density[0], aux, sb, scene.near, scene.far, depth_noise, depth_draws, depth_seed, ray_offset)
+            density[0], aux, sb, scene.near, scene.far, depth_noise, depth_draws, depth_seed, ray_offset,
+            spacing=scene.spacing)
         out = ops.composite_var(density, rgb, sb, scene.near, scene.far, beta=aux2, weights_alt=walt, **kw)[0]
         u = _unpack(out)
         res = {"rgb": u["rgb"], "rgb_std": u["rgb_var"].sqrt(), "accumulation": u["accumulation"],

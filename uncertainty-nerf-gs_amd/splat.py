@@ -59,6 +59,9 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
                               config_sh_degree: Optional[int] = None) -> Dict[str, Optional[torch.Tensor]]:
     """gp: gauss_params on the device (means, scales, quats, features_dc, features_rest, opacities,
     log_uncertainties).  Returns the reference's output dict (:359-367) as [H,W,C] tensors.
+    Without `log_uncertainties` in gp: plain splatfacto [UPSTREAM nerfstudio 1.1.0 SplatfactoModel.get_outputs, the
+    parent the reference extends and the member type of its splat ensembles] -- rgb + depth blended in one 4-channel
+    pass, outputs rgb / depth / accumulation / background only.
     crop_ids: bool [N] from `crop_box.within(means)` (:174-180, 202-217) -- only those splats are rendered.
     sh_degree: the active degree n = min(step // interval, config.sh_degree) (:244);
     config_sh_degree == 0 selects the sigmoid(features_dc) colours of :247-248."""
@@ -85,15 +88,23 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     if config_sh_degree is not None and config_sh_degree <= 0:
         sh_degree = -1                                     # kernel: colours = sigmoid(features_dc)
     # the reference concatenates features_dc and features_rest first (:242-243); the kernel reads them in place
+    plain = "log_uncertainties" not in gp
     rgbs, beta = ops.splat_sh_colors_split(sh_degree, means, c2w[:3, 3], gp["features_dc"].contiguous(),
                                            gp["features_rest"].contiguous(),
-                                           gp["log_uncertainties"].reshape(-1).contiguous(), beta_min)
+                                           None if plain else gp["log_uncertainties"].reshape(-1).contiguous(), beta_min)
     opac = torch.sigmoid(gp["opacities"]).reshape(-1)
     if rasterize_mode == "antialiased":
         opac = opac * comp
     elif rasterize_mode != "classic":
         raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
     opac = opac.contiguous()
+    if plain:
+        cols = torch.cat([rgbs, depths[:, None]], dim=1).contiguous()
+        bg4 = torch.cat([background.to(dev, torch.float32), torch.zeros(1, device=dev)])
+        img, fT, _ = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg4, block_width)
+        ops.splat_alpha_normalize(img, 3, fT)       # depth = where(alpha > 0, d / alpha, max(d))
+        return {"rgb": torch.clamp(img[..., 0:3], max=1.0), "depth": img[..., 3:4], "accumulation": (1.0 - fT)[..., None],
+                "background": background}
     cols = torch.cat([rgbs, beta[:, None], depths[:, None]], dim=1).contiguous()
     bg5 = torch.cat([background.to(dev, torch.float32), torch.zeros(2, device=dev)])
     img, fT, _ = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg5, block_width)

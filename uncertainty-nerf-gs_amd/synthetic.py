@@ -115,7 +115,10 @@ def scene_to_device(t: Dict, device, **field_kw) -> NerfSceneDev:
             p.aabb = box
     return NerfSceneDev(field=fd, props=props, near=float(t["near"]), far=float(t["far"]),
                         num_prop=tuple(t["num_prop"]), num_nerf=int(t["num_nerf"]),
-                        prop_average_init_density=float(t["prop_average_init_density"]))
+                        prop_average_init_density=float(t["prop_average_init_density"]),
+                        spacing=(_l.SPACING_UNIFORM if t.get("proposal_initial_sampler", "piecewise") == "uniform"
+                                 else _l.SPACING_PIECEWISE),
+                        background=ops.background_of(t.get("background_color", "last_sample")))
 
 
 def laplace_weight_samples(t: Dict, seed: int = 42, n_samples: int = 100, prior_prec: float = 1.0,
