@@ -13,9 +13,14 @@ HBM before the timed region; synthetic seeded data, random-init weights of the n
 Without --method the headline is the north-star target config (BASELINE.json configs[2]): nerfacto-mcdropout with
 K = 8 fused passes; active-nerfacto, nerfacto-laplace and active-splatfacto follow as `sub_records` of the same line.
 
-N>1 is launched by torch.distributed.run (one rank per GPU).  Rays are independent, so ranks
-render different cameras of the orbit with replicated weights and no data-path collective
-("weak" scaling); the barrier + max-over-ranks timing uses RCCL.
+N>1 runs one rank per GPU under torch.distributed.run: either the caller launches it that way, or plain
+`python bench.py --gpus N` starts `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` itself as
+a child process (before this process has touched the GPU) and relays rank 0's JSON line and the child's exit code.
+Rays are independent, so ranks render different cameras of the orbit with replicated weights and no data-path
+collective ("weak" scaling); the barrier + max-over-ranks timing uses RCCL.  The default run also carries
+`sub_records.ensemble`: the 8-member nerfacto ensemble of BASELINE.json configs[3], members sharded over the ranks
+(8 / N per GPU), per-pixel moments through ONE all_to_all + ONE all_gather over RCCL -- strong scaling, the north-star's
+">= 6x at 8 GPUs" figure is value(N=8) / value(N=1) of that record.
 Prints ONE JSON line on rank 0 (contract in the task statement), carrying `roofline` for the
 dominant kernel and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same rays).
 """
@@ -75,7 +80,7 @@ def _issue_profile(method, K):
     return j if j.get("K", 0) == K else None
 
 
-def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check=True, want_cpu=True):
+def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check=True, want_cpu=True, precision=None):
     """One NeRF method through the whole frame path; returns the record (headline fields + roofline + cpu_baseline)."""
     from uncertainty_nerf_gs_amd import ops, render, synthetic
     t = synthetic.make_scene_tensors(seed=0, kind=method)   # full nerfacto shape: 16x2^19x2 + 2 x 5x2^17x2
@@ -86,7 +91,7 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
         kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
     scene = synthetic.scene_to_device(t, dev, **kw)
-    scene.field.precision = "fp32" if (args.exact_fp32 or args.split_gather) else "f16x2"
+    scene.field.precision = precision or ("fp32" if (args.exact_fp32 or args.split_gather) else args.precision)
     scene.split_gather = args.split_gather
     H, W = args.height, args.width
     cam = dict(synthetic.CAMERA_1080P)
@@ -149,11 +154,16 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
 
     rec = {"value": mrays, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "exact_fp32_kernels": exact}
     split = scene.field.precision == "f16x2"
+    single = scene.field.precision == "f16"
     rec["workload"] = (f"{method}-nerfacto {W}x{H} render with variance" + (f", K={K} MC-dropout passes" if K else "")
                        + (", 100 last-layer Laplace samples" if method == "laplace" else "")
                        + (", density [H,W,48] kept" if method == "active" else ""))
     rec["dense_layers"] = ("fp32 operands split into two f16 halves, 3 products on v_mfma_f32_32x32x16_f16, "
-                           "fp32 accumulate (fp32-equivalent, DESIGN.md 4.2)" if split else "exact fp32 (v_mfma_f32_32x32x2_f32)")
+                           "fp32 accumulate (fp32-equivalent, DESIGN.md 4.2)" if split else
+                           "f16 operands (one product per MAC on v_mfma_f32_32x32x16_f16), fp32 accumulate: the reference's eval "
+                           "precision (forced autocast fp16, mcdropout_models.py:86-92; tcnn FullyFusedMLP)" if single
+                           else "exact fp32 (v_mfma_f32_32x32x2_f32)")
+    rec["precision"] = scene.field.precision
     if rank != 0:
         return rec
     ksum = timer.summary()
@@ -166,11 +176,11 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     # are cache resident (the gather rate can exceed the DRAM peak) and the f16 matrix pipe is a third busy.
     gather_gbs = a["bytes"] * rays_per_launch / avg_s / 1e9
     mfma_ach = a["flops"] * rays_per_launch / avg_s / 1e12
-    mfma_peak = F16_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
+    mfma_peak = F16_PEAK_TFLOPS if (split or single) else FP32_PEAK_TFLOPS
     mfma_issued = 3.0 * mfma_ach if split else mfma_ach
     roof = {"kernel": dom, "avg_launch_ms": ksum[dom]["avg_ms"], "launches": ksum[dom]["launches"],
             "rays_per_launch": rays_per_launch}
-    prof = _issue_profile(method, K) if dom == "field_fwd" and split else None
+    prof = _issue_profile(method + ("_f16" if single else ""), K) if dom == "field_fwd" and (split or single) else None
     if prof is not None:
         # the roof that binds: instruction issue (VALU + MFMA share one pipe per SIMD).  achieved = issue cycles the
         # launch's instruction stream needs (PMC, per launch of prof["rays_per_launch"] rays) / live launch duration;
@@ -200,12 +210,12 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     roof["other_roofs"] = {"algorithmic_gather_GBps": gather_gbs,
                            "algorithmic_gather_note": "8 B per hash-grid corner; tables are L2 / Infinity-Cache resident, so "
                                                       "this is a cache-gather rate and may exceed the DRAM peak",
-                           "algorithmic_TFLOPs": mfma_ach, "matrix_pipe": "f16 (3 products per MAC)" if split else "fp32",
+                           "algorithmic_TFLOPs": mfma_ach, "matrix_pipe": "f16 (3 products per MAC)" if split else ("f16 (1 product per MAC)" if single else "fp32"),
                            "issued_matrix_TFLOPs": mfma_issued, "matrix_frac": mfma_issued / mfma_peak}
     roof["algorithmic_bytes_per_ray"] = a["bytes"]
     roof["algorithmic_flops_per_ray"] = a["flops"]
     roof["traffic"] = None
-    tfile = os.path.join(ROOT, "profiles", f"traffic_{method}.json")
+    tfile = os.path.join(ROOT, "profiles", f"traffic_{method}{'_f16' if single else ''}.json")
     if os.path.exists(tfile):  # HBM-side bytes from committed rocprofv3 --pmc passes of this command
         tj = json.load(open(tfile))
         tk = tj.get("kernels", {}).get(dom)
@@ -225,6 +235,24 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     return rec
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run (one rank
+    per GPU, rendezvous on 127.0.0.1) as a CHILD process -- never an exec of this one, and before anything here has
+    initialised the GPU -- stream its output through, and return its exit code.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +269,9 @@ def main():
     ap.add_argument("--rays-per-launch", type=int, default=1 << 18)
     ap.add_argument("--overlap", action="store_true", help="sampling / shading stages on two HIP streams (experiment)")
     ap.add_argument("--split-gather", action="store_true", help="level-major gather kernel + feature planes (experiment)")
+    ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f16", "fp32"],
+                    help="dense layers: f16x2 = split-f16 (fp32-equivalent, default); f16 = one f16 product per MAC, fp32 "
+                         "accumulate (the reference's autocast / tcnn precision); fp32 = exact fp32-input MFMA")
     ap.add_argument("--exact-fp32", action="store_true",
                     help="dense layers on the exact fp32-input MFMA kernels instead of the split-f16 ones")
     ap.add_argument("--no-exact-check", action="store_true",
@@ -250,13 +281,15 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))      # nothing has touched the GPU in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
-            sys.exit(2)
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus})", file=sys.stderr)
+        sys.exit(2)
 
     from uncertainty_nerf_gs_amd import lib
     lib.build_library()
@@ -264,10 +297,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    comm = {"world_size": 1, "backend": None}
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else "?"
+        comm = {"world_size": dist.get_world_size(), "backend": f"{dist.get_backend()} (RCCL {ver}, torch.distributed, "
+                                                               "one process per GPU)"}
 
     default_run = args.method is None
     method = args.method or "mcdropout"
@@ -276,22 +313,32 @@ def main():
         if rank == 0:
             print(json.dumps(line))
     elif method == "ensemble":
-        bench_ensemble(args, rank, world, dev, dist)
-        return
+        line = bench_ensemble(args, rank, world, dev, dist, args.steps, args.warmup)
+        if rank == 0:
+            line.update(comm)
+            print(json.dumps(line))
     else:
         K = args.mc_samples if method == "mcdropout" else 0
         rec = run_nerf(args, method, K, args.steps, args.warmup, rank, world, dev, dist, exact_check=not args.no_exact_check)
         subs = None
+        if default_run and not args.no_sub_records and args.members % world == 0:
+            # BASELINE.json configs[3] at every N: the M-member nerfacto ensemble sharded over the ranks (strong scaling)
+            ens = bench_ensemble(args, rank, world, dev, dist, 3, 1)
+            if rank == 0:
+                subs = {"ensemble": {k: ens[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config")}}
         if default_run and not args.no_sub_records and world == 1:
             # the other single-GPU configs of BASELINE.json, each with its own per-kernel times (fewer steps: the
             # default run must stay within minutes); the headline above is the north-star target config
-            subs = {}
-            for m in ("active", "laplace"):
-                r = run_nerf(args, m, 0, 3, 1, rank, world, dev, dist, exact_check=False, want_cpu=False)
-                subs[m] = {"value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
-                           "workload": r["workload"], "per_kernel_ms_per_frame": r["roofline"]["per_kernel_ms_per_frame"],
-                           "roofline": {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
-                                                                          "avg_launch_ms", "traffic")}}
+            # the headline's workload with the dense layers at the REFERENCE's own eval precision (opt-in, --precision f16):
+            # one f16 product per MAC, fp32 accumulate = torch.autocast(float16), forced by mcdropout_models.py:86-92
+            for name, m, kk, prec in (("mcdropout_f16", "mcdropout", K, "f16"), ("active", "active", 0, None), ("laplace", "laplace", 0, None)):
+                r = run_nerf(args, m, kk, 3, 1, rank, world, dev, dist, exact_check=False, want_cpu=False, precision=prec)
+                subs[name] = {"value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
+                              "workload": r["workload"], "per_kernel_ms_per_frame": r["roofline"]["per_kernel_ms_per_frame"],
+                              "dtype": "f16 operands, f32 accumulate" if prec == "f16" else "f32 (split-f16 operands, f32-equivalent)",
+                              "dense_layers": r["dense_layers"],
+                              "roofline": {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                                             "avg_launch_ms", "traffic")}}
             sp = bench_splat(args, rank, world, dev, dist, 5, 2)
             subs["splat"] = {"value": sp["value"], "unit": sp["unit"], "ms_per_step": sp["ms_per_step"], "steps": 5, "warmup": 2,
                              "workload": sp["config"]["workload"],
@@ -309,6 +356,7 @@ def main():
                            "parallelism": f"views x{world}" if world > 1 else "single"},
                 "roofline": rec["roofline"], "cpu_baseline": rec["cpu_baseline"], "exact_fp32_kernels": rec["exact_fp32_kernels"],
             }
+            line.update(comm)
             if subs is not None:
                 line["sub_records"] = subs
             print(json.dumps(line))
@@ -316,28 +364,50 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_ensemble(args, rank, world, dev, dist):
-    """config 4: M-member nerfacto ensemble (ensemble_pipeline.py:144-191), members sharded over the ranks
-    (M/N per GPU; 1 per GPU at N = M = 8).  Every rank renders the SAME camera with its own members, then the
-    per-pixel moments are formed exactly (two-pass) on pixel slices after an RCCL all_gather.  Strong scaling:
+def nerfacto_member_state_dict(t):
+    """synthetic weights -> a plain `nerfacto` pipeline checkpoint in nerfstudio 1.1.0's key layout
+    (MLPWithHashEncoding: mlp_base.encoder / mlp_base.mlp; `_model.` prefix), what an ensemble member's
+    step-*.ckpt holds (ensemble_utils.py:71-72, :149-150)"""
+    f = t["field"]
+    sd = {"field.mlp_base.encoder.hash_table": f["table"]}
+    for i, (w, b) in enumerate(((f["w0"], f["b0"]), (f["w1"], f["b1"]))):
+        sd[f"field.mlp_base.mlp.layers.{i}.weight"], sd[f"field.mlp_base.mlp.layers.{i}.bias"] = w, b
+    for i in range(3):
+        sd[f"field.mlp_head.layers.{i}.weight"], sd[f"field.mlp_head.layers.{i}.bias"] = f["head_w"][i], f["head_b"][i]
+    sd["field.embedding_appearance.embedding.weight"] = f["appearance"][None]
+    for i, p in enumerate(t["props"]):
+        sd[f"proposal_networks.{i}.mlp_base.encoder.hash_table"] = p["table"]
+        for j, (w, b) in enumerate(((p["w0"], p["b0"]), (p["w1"], p["b1"]))):
+            sd[f"proposal_networks.{i}.mlp_base.mlp.layers.{j}.weight"] = w
+            sd[f"proposal_networks.{i}.mlp_base.mlp.layers.{j}.bias"] = b
+    return {"_model." + k: v for k, v in sd.items()}
+
+
+def bench_ensemble(args, rank, world, dev, dist, steps, warmup):
+    """config 3: M-member nerfacto ensemble (ensemble_pipeline.py:144-191), members sharded over the ranks
+    (M/N per GPU; 1 per GPU at N = M = 8).  Members are plain `nerfacto` models (ensemble_utils.py:149-150) loaded from
+    checkpoints in upstream's key layout.  Every rank renders the SAME camera with its own members, then the per-pixel
+    moments are formed exactly (two-pass) on pixel slices: one all_to_all + one all_gather over RCCL.  Strong scaling:
     the frame's total work (M renders) is fixed, so value = frame rays / time grows with N."""
-    from uncertainty_nerf_gs_amd import ensemble, ops, render, synthetic
+    from uncertainty_nerf_gs_amd import ensemble, models, plugin, synthetic
     M = args.members
     assert M % world == 0, "members must divide evenly over the ranks"
     mine = [rank * (M // world) + i for i in range(M // world)]
-    scenes = [synthetic.scene_to_device(synthetic.make_scene_tensors(seed=100 + m, kind="mcdropout"), dev, K=0)
-              for m in mine]   # plain nerfacto members (dropout off): seeds 100..100+M-1
+    members = []
+    for m in mine:   # seeds 100..100+M-1
+        model = plugin.build_model("nerfacto", num_train_data=1)
+        t = synthetic.make_scene_tensors(seed=100 + m, kind="mcdropout")
+        t["field"]["b1"][0] += 4.6      # nerfacto's field carries average_init_density = 0.01: keep the scene as opaque
+        model.load_state_dict(nerfacto_member_state_dict(t), strict=True)
+        model.rays_per_launch = args.rays_per_launch
+        members.append(model)
+    pipe = ensemble.EnsemblePipeline(members)
     H, W = args.height, args.width
-    cam = dict(synthetic.CAMERA_1080P)
-    cam.update(H=H, W=W, cx=W / 2, cy=H / 2)
-    poses = [synthetic.orbit_c2w(2 * math.pi * i / 24) for i in range(24)]
+    cams = [models.Camera(synthetic.orbit_c2w(2 * math.pi * i / 24), 1111.0 * W / 1920, 1111.0 * W / 1920, W / 2, H / 2, H, W)
+            for i in range(24)]
 
     def frame(i):
-        outs = [render.render_camera(sc, poses[i % 24], rays_per_launch=args.rays_per_launch, **cam) for sc in scenes]
-        outs = [{k: o[k] for k in ("rgb", "accumulation", "depth", "expected_depth")} for o in outs]
-        if dist is None:
-            return ensemble.aggregate(outs)
-        return ensemble.aggregate_distributed(outs)
+        return pipe.get_ensemble_outputs_for_camera_ray_bundle(cams[i % 24])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -345,33 +415,33 @@ def bench_ensemble(args, rank, world, dev, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        out = frame(i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = frame(args.warmup + i)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    with torch.cuda.device(dev):
+        for i in range(warmup):
+            out = frame(i)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = frame(warmup + i)
+        sync_all()
+        elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out["rgb"]).all() and "rgb_std" in out
-    if rank == 0:
-        line = {
-            "metric": "Mrays/s (+var), Mip-NeRF360-shaped 1080p, M-member ensemble", "value": H * W * args.steps / elapsed / 1e6,
-            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{M}-member nerfacto ensemble {W}x{H}, per-pixel mean/std over members",
-                       "members": M, "members_per_gpu": M // world, "member_render_rays_per_s": M * H * W * args.steps / elapsed,
-                       "parallelism": f"ensemble members x{world} (all_gather + exact two-pass moments)"},
-            "roofline": None, "cpu_baseline": None,
-        }
-        print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    del pipe, members
+    torch.cuda.empty_cache()
+    return {
+        "metric": "Mrays/s (+var), Mip-NeRF360-shaped 1080p, M-member ensemble", "value": H * W * steps / elapsed / 1e6,
+        "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{M}-member nerfacto ensemble {W}x{H}, per-pixel mean/std over members",
+                   "members": M, "members_per_gpu": M // world, "member_render_Mrays_per_s": M * H * W * steps / elapsed / 1e6,
+                   "parallelism": (f"ensemble members x{world} (all_to_all of pixel slices + exact two-pass moments + all_gather, RCCL)"
+                                   if world > 1 else "single GPU: members rendered in sequence, moments on the device")},
+        "roofline": None, "cpu_baseline": None,
+    }
 
 
 def bench_splat(args, rank, world, dev, dist, steps, warmup):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Test of the issue model "kernel time = 4 x VALU + 32 x MFMA cycles" on the K-pass field kernel: the same kernel with
-# N extra independent VALU instructions, or N extra MFMAs, per MC-dropout pass (UNERF_PROBE_EXTRA_* in unerf_nerf.hip).
+# N extra independent VALU instructions, or N extra MFMAs, per MC-dropout pass (inserted into copies of unerf_nerf.hip by benchmarks/probe_source.py).
 #   here:        bash benchmarks/exp_issue_model.sh build
 #   on the box:  bash benchmarks/exp_issue_model.sh run    -> gpurun_out/exp_issue_model.json
 #                bash benchmarks/exp_issue_model.sh clocks -> gpurun_out/exp_issue_model_clocks.json (GRBM_GUI_ACTIVE per
@@ -11,12 +11,17 @@ FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -shared -mll
 SRC="uncertainty-nerf-gs_amd/csrc/unerf_nerf.hip uncertainty-nerf-gs_amd/csrc/unerf_splat.hip"
 if [ "$1" = build ]; then
     mkdir -p $B
+    # the probe code lives in benchmarks/probe_source.py, which writes patched COPIES of the product source
+    SPLAT=uncertainty-nerf-gs_amd/csrc/unerf_splat.hip
     /opt/rocm/bin/hipcc $FLAGS -o $B/libunerf_v0.so $SRC &
-    /opt/rocm/bin/hipcc $FLAGS -DUNERF_PROBE_EXTRA_VALU=32 -o $B/libunerf_valu32.so $SRC &
-    /opt/rocm/bin/hipcc $FLAGS -DUNERF_PROBE_EXTRA_VALU=64 -o $B/libunerf_valu64.so $SRC &
+    for v in valu32:--extra-valu=32 valu64:--extra-valu=64 mfma4:--extra-mfma=4 mfma8:--extra-mfma=8; do
+        python benchmarks/probe_source.py ${v#*:} -o $B/unerf_nerf_${v%%:*}.hip
+    done
+    /opt/rocm/bin/hipcc $FLAGS -o $B/libunerf_valu32.so $B/unerf_nerf_valu32.hip $SPLAT &
+    /opt/rocm/bin/hipcc $FLAGS -o $B/libunerf_valu64.so $B/unerf_nerf_valu64.hip $SPLAT &
     wait
-    /opt/rocm/bin/hipcc $FLAGS -DUNERF_PROBE_EXTRA_MFMA=4 -o $B/libunerf_mfma4.so $SRC &
-    /opt/rocm/bin/hipcc $FLAGS -DUNERF_PROBE_EXTRA_MFMA=8 -o $B/libunerf_mfma8.so $SRC &
+    /opt/rocm/bin/hipcc $FLAGS -o $B/libunerf_mfma4.so $B/unerf_nerf_mfma4.hip $SPLAT &
+    /opt/rocm/bin/hipcc $FLAGS -o $B/libunerf_mfma8.so $B/unerf_nerf_mfma8.hip $SPLAT &
     wait
     exit 0
 fi

@@ -271,6 +271,14 @@ typedef struct {
     /* as unerf_density_net: 1 = normalise positions with the scene box instead of the contraction */
     int use_aabb;
     float aabb[6];
+    /* 1 (with mfma16_blob / lap16_blob): REFERENCE-PRECISION dense layers -- one f16 product per MAC, fp32 accumulation:
+       every operand is rounded to f16 once (the hi halves of the blobs, v_cvt_pk_f16_f32 of the activations) and the lo
+       halves are not used.  That is the arithmetic of the Linear layers under torch.autocast(float16), which the
+       reference forces at eval (models/mcdropout/mcdropout_models.py:86-92), and no narrower than tiny-cuda-nn's
+       FullyFusedMLP (fp16 weights, activations and accumulators; the reference's default implementation="tcnn",
+       models/activenerfacto/activenerfacto_field.py:89).  0: the split form above (fp32-equivalent).  Biases, the
+       64 -> 3 colour layer and every activation function stay fp32 in both forms. */
+    int f16_single;
 } unerf_field_params;
 #define UNERF_DROP_TRUNK 1
 #define UNERF_DROP_HEAD0 2
@@ -330,19 +338,23 @@ int unerf_laplace_ggn_diag(const float* origins, const float* directions, const 
  * expected depth and depth_var use it while rgb and rgb_var use get_weights(density)).
  * clip_minmax as produced by unerf_weights_pdf_resample.  1 <= S <= 256, any value.
  * background / background_rgb_host: UNERF_BG_* (above).
+ * nonfinite_flag (DEVICE int32, may be NULL): |= 1 (atomically, once per offending wave) when a density or colour
+ * read by this call is NaN.  The renderers turn NaN into 0 (nan_to_num, as upstream does), which would hide the one
+ * failure mode of the f16 matrix kernels -- an operand at or beyond 65504 (hi = inf, lo = -inf -> NaN); the host
+ * checks the word once per frame and re-renders the launch group with the exact-fp32 kernels (render.OverflowGuard).
  * out [B,R,8] = rgb(3), accumulation, depth(median), expected_depth, rgb_var, depth_var(+1e-5). */
 int unerf_composite_var(const float* density, const float* rgb, const float* beta, const float* weights_alt,
                         const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane, int spacing,
                         const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, int background,
-                        const float* background_rgb_host, float* out, void* stream);
+                        const float* background_rgb_host, int32_t* nonfinite_flag, float* out, void* stream);
 
 /* Fused K-pass form of the two calls above/below for MC-dropout: composites the B <= 16 passes of every
  * ray and reduces them in registers.  mean_out / var_out [R,8] over the passes of
  * rgb(3), accumulation, depth, expected_depth, rgb_var, depth_var (var unbiased, B-1). */
 int unerf_composite_moments(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
                             float near_plane, float far_plane, int spacing, const float* clip_minmax, int64_t ray_offset,
-                            int64_t chunk_rays, int background, const float* background_rgb_host, float* mean_out,
-                            float* var_out, void* stream);
+                            int64_t chunk_rays, int background, const float* background_rgb_host, int32_t* nonfinite_flag,
+                            float* mean_out, float* var_out, void* stream);
 
 /* The same two reductions over the sample-major planes unerf_field_fwd writes with sample_major = 1
  * (density [B,S,R], rgb [B,S,3,R], beta [S,R] or NULL): one lane per ray walks the samples front to back, so
@@ -352,11 +364,12 @@ int unerf_composite_moments(const float* density, const float* rgb, const float*
 int unerf_composite_var_planes(const float* density, const float* rgb, const float* beta, const float* sbins, int B,
                                int64_t R, int S, float near_plane, float far_plane, int spacing, const float* clip_minmax,
                                int64_t ray_offset, int64_t chunk_rays, int background, const float* background_rgb_host,
-                               float* out, void* stream);
+                               int32_t* nonfinite_flag, float* out, void* stream);
 int unerf_composite_moments_planes(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
                                    float near_plane, float far_plane, int spacing, const float* clip_minmax,
                                    int64_t ray_offset, int64_t chunk_rays, int background,
-                                   const float* background_rgb_host, float* mean_out, float* var_out, void* stream);
+                                   const float* background_rgb_host, int32_t* nonfinite_flag, float* mean_out,
+                                   float* var_out, void* stream);
 
 /* ------------------------------------------------------ moments over K --
  * Replaces torch.stack(...).mean(0) / .std(0) / .var(0) over MC passes

@@ -166,11 +166,11 @@ def unpack_tcnn_mlp(params: torch.Tensor, in_dim: int, width: int, n_hidden_laye
 # --------------------------------------------------------------------------
 
 def mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor],
-                out_activation: Optional[str] = None) -> torch.Tensor:
-    """nerfstudio MLP.pytorch_fwd: ReLU on all but the last layer."""
+                out_activation: Optional[str] = None, autocast: Optional[torch.dtype] = None) -> torch.Tensor:
+    """nerfstudio MLP.pytorch_fwd: ReLU on all but the last layer.  autocast: see _linear."""
     n = len(weights)
     for i, (w, b) in enumerate(zip(weights, biases)):
-        x = F.linear(x, w, b)
+        x = _linear(x, w, b, autocast)
         if i < n - 1:
             x = F.relu(x)
     if out_activation == "sigmoid":
@@ -562,18 +562,21 @@ def _color_inputs(directions: torch.Tensor, S: int, geo: torch.Tensor, appearanc
     return torch.cat([d, geo, app], dim=-1).reshape(R * S, -1)
 
 
-def active_field(origins, directions, euclid_bins, fp: FieldParams):
-    """[REF activenerfacto_field.py:162-215]  -> density [R,S], rgb [R,S,3], beta [R,S]"""
+def active_field(origins, directions, euclid_bins, fp: FieldParams, autocast: Optional[torch.dtype] = None):
+    """[REF activenerfacto_field.py:162-215]  -> density [R,S], rgb [R,S,3], beta [R,S]
+    autocast: low-precision Linear layers (see _linear) -- the reference's default implementation="tcnn" runs both MLPs
+    as fp16 FullyFusedMLPs (activenerfacto_field.py:89, 148-156)"""
     R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
     pos = sample_positions(origins, directions, euclid_bins)
     p, sel = normalized_positions(pos, fp.grid.aabb)
     feat = grid_encode(p.reshape(-1, 3), fp.grid)
-    h = mlp_forward(feat, fp.grid.weights, fp.grid.biases).view(R, S, -1)
+    h = mlp_forward(feat, fp.grid.weights, fp.grid.biases, autocast=autocast).view(R, S, -1)
     g = fp.geo_feat_dim
     dens_pre, geo, unc_pre = h[..., 0], h[..., 1:1 + g], h[..., 1 + g]
     density = fp.average_init_density * torch.exp(dens_pre) * sel
     beta = F.softplus(unc_pre) + fp.beta_min
-    rgb = mlp_forward(_color_inputs(directions, S, geo, fp.appearance, fp.sh_remap), fp.head_w, fp.head_b, "sigmoid")
+    rgb = mlp_forward(_color_inputs(directions, S, geo, fp.appearance, fp.sh_remap), fp.head_w, fp.head_b, "sigmoid",
+                      autocast=autocast)
     return density, rgb.view(R, S, 3), beta
 
 
@@ -619,7 +622,8 @@ def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trun
     return density, rgb.view(R, S, 3)
 
 
-def sample_laplace(weight_samples: torch.Tensor, activation: str, x: torch.Tensor, out_dim: int):
+def sample_laplace(weight_samples: torch.Tensor, activation: str, x: torch.Tensor, out_dim: int,
+                   autocast: Optional[torch.dtype] = None):
     """[REF laplace_field.py:528-568] with the randn draw lifted out: `weight_samples` [n,P] are
     the already-formed mu + randn*std rows (weight [out,in] row-major, then bias).
     Sequential accumulation order as the reference loop."""
@@ -630,7 +634,7 @@ def sample_laplace(weight_samples: torch.Tensor, activation: str, x: torch.Tenso
     for s in range(n):
         w = weight_samples[s, : out_dim * in_dim].view(out_dim, in_dim)
         b = weight_samples[s, out_dim * in_dim:]
-        pred = F.linear(x, w, b)
+        pred = _linear(x, w, b, autocast)
         pred = {"exp": torch.exp, "softplus": F.softplus, "sigmoid": torch.sigmoid}[activation](pred)
         mu = mu + pred
         mu2 = mu2 + pred ** 2
@@ -647,7 +651,7 @@ def laplace_weight_samples(mu_q: torch.Tensor, diag_ggn: torch.Tensor, prior_pre
 
 
 def laplace_field(origins, directions, euclid_bins, fp: FieldParams, ws_density: torch.Tensor,
-                  ws_rgb: torch.Tensor):
+                  ws_rgb: torch.Tensor, autocast: Optional[torch.dtype] = None):
     """[REF laplace_field.py:279-362, 365-485, 487-525] is_inference=True,
     use_deterministic_density=False.  Quirks kept: base_mlp is a bare Linear (no ReLU,
     utils.py:22-23); returned mu_d is NOT selector-masked (laplace_field.py:356-362).
@@ -656,13 +660,15 @@ def laplace_field(origins, directions, euclid_bins, fp: FieldParams, ws_density:
     pos = sample_positions(origins, directions, euclid_bins)
     p, _sel = normalized_positions(pos, fp.grid.aabb)
     feat = grid_encode(p.reshape(-1, 3), fp.grid)
-    hb = F.linear(feat, fp.grid.weights[0], fp.grid.biases[0])
-    geo = F.linear(hb, fp.hidden_w, fp.hidden_b).view(R, S, -1)
-    mu_d, var_d = sample_laplace(ws_density, fp.density_activation, hb, 1)
+    # autocast is an EMULATION switch for measuring the f16 kernels against: the reference itself runs these layers in
+    # fp32 (`.float()` at laplace_field.py:305 and :460, no autocast wrapper around the Laplace model)
+    hb = _linear(feat, fp.grid.weights[0], fp.grid.biases[0], autocast)
+    geo = _linear(hb, fp.hidden_w, fp.hidden_b, autocast).view(R, S, -1)
+    mu_d, var_d = sample_laplace(ws_density, fp.density_activation, hb, 1, autocast)
     x = _color_inputs(directions, S, geo, fp.appearance, fp.sh_remap)
-    x = F.relu(F.linear(x, fp.head_w[0], fp.head_b[0]))
-    x = F.relu(F.linear(x, fp.head_w[1], fp.head_b[1]))
-    mu_rgb, var_rgb = sample_laplace(ws_rgb, "sigmoid", x, 3)
+    x = F.relu(_linear(x, fp.head_w[0], fp.head_b[0], autocast))
+    x = F.relu(_linear(x, fp.head_w[1], fp.head_b[1], autocast))
+    mu_rgb, var_rgb = sample_laplace(ws_rgb, "sigmoid", x, 3, autocast)
     var_rgb = F.relu(var_rgb).mean(dim=-1)
     return mu_d.view(R, S), var_d.view(R, S), mu_rgb.view(R, S, 3), var_rgb.view(R, S)
 
@@ -771,11 +777,13 @@ def active_compose(eb, density, rgb, beta, background="last_sample") -> Dict[str
     return out
 
 
-def active_outputs(scene: NerfScene, origins, directions, nears=None, fars=None) -> Dict[str, torch.Tensor]:
+def active_outputs(scene: NerfScene, origins, directions, nears=None, fars=None,
+                   autocast: Optional[torch.dtype] = None) -> Dict[str, torch.Tensor]:
     """[REF activenerfacto_model.py:83-152] one chunk of rays [R,3]; nears / fars [R,1]: per-ray planes of the bundle
-    (obb_box), else the collider's constants."""
+    (obb_box), else the collider's constants.  autocast: the MAIN field's Linear layers in low precision (the proposal
+    networks stay fp32 here as they do in the kernels)."""
     eb, wl, bl = _sample(scene, origins, directions, nears, fars)
-    density, rgb, beta = active_field(origins, directions, eb, scene.field)
+    density, rgb, beta = active_field(origins, directions, eb, scene.field, autocast)
     out = active_compose(eb, density, rgb, beta, scene.background)
     out.update(_prop_depths(scene, wl, bl, nears, fars))
     return out
@@ -794,6 +802,14 @@ def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, den
     }
     out.update(_prop_depths(scene, wl, bl, nears, fars))
     return out
+
+
+def nerfacto_outputs(scene: NerfScene, origins, directions, nears=None, fars=None) -> Dict[str, torch.Tensor]:
+    """[UPSTREAM nerfstudio 1.1.0 NerfactoModel.get_outputs at eval] plain nerfacto, the member model of the reference's
+    NeRF ensembles (ensemble_utils.py:149-150): NerfactoField = the mc-dropout field's graph without Dropout modules."""
+    eb, wl, bl = _sample(scene, origins, directions, nears, fars)
+    density, rgb = mcdropout_field(origins, directions, eb, scene.field, None, None, 0.0)
+    return nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb, nears, fars)
 
 
 def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, p_drop: float,
@@ -854,14 +870,14 @@ def laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise: Optional[torc
 
 def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
                     depth_noise: Optional[torch.Tensor], use_deterministic_density: bool = False,
-                    nears=None, fars=None) -> Dict[str, torch.Tensor]:
+                    nears=None, fars=None, autocast: Optional[torch.dtype] = None) -> Dict[str, torch.Tensor]:
     """[REF laplace_model.py:456-556] is_inference=True.
     use_deterministic_density=False: density = sampled-head mean (NOT selector-masked), depth from the mean of the
     weights of D Normal(mu_d, sigma_d) density draws; depth_noise [D,R,S] = the standard-normal draw behind them.
     use_deterministic_density=True (laplace_field.py:501-506): density = the plain mean head, selector-masked
     (is_inference=False branch of get_density), colour still sampled, depth from the ordinary weights."""
     eb, wl, bl = _sample(scene, origins, directions, nears, fars)
-    mu_d, var_d, mu_rgb, var_rgb = laplace_field(origins, directions, eb, scene.field, ws_density, ws_rgb)
+    mu_d, var_d, mu_rgb, var_rgb = laplace_field(origins, directions, eb, scene.field, ws_density, ws_rgb, autocast)
     if use_deterministic_density:
         mu_d, _ = laplace_field_deterministic(origins, directions, eb, scene.field)
     out = laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise, use_deterministic_density, scene.background)

@@ -288,3 +288,15 @@ def active_splatfacto_outputs(gp: Dict[str, np.ndarray], c2w, fx, fy, cx, cy, H,
     return {"rgb": rgb, "depth": depth, "accumulation": alpha, "background": _f(background), "uncertainty": unc,
             "rgb_var": unc ** 2, "rgb_std": unc, "depth_var": depth_var, "depth_std": torch.sqrt(tt(depth_var)).numpy(),
             "_proj": pr, "_sort": (I, cum, keys, gids, bins), "_sqdiff": diff ** 2}
+
+
+def splatfacto_outputs(gp: Dict[str, np.ndarray], c2w, fx, fy, cx, cy, H, W, background, **kw) -> Dict[str, np.ndarray]:
+    """[UPSTREAM nerfstudio 1.1.0 SplatfactoModel.get_outputs, eval branch] plain splatfacto -- the parent whose
+    get_outputs the reference extends (activesplatfacto_model.py:142-319 up to the depth pass) and the member type of
+    its splat ensembles (ensemble_utils.py:153-156): rgb (clamped at 1), depth = where(alpha > 0, d / alpha, max d),
+    accumulation, background.  Restated as the corresponding outputs of the active model with the uncertainty channel
+    unused (the rasteriser's blending weights do not depend on it)."""
+    gp = dict(gp)
+    gp.setdefault("log_uncertainties", np.zeros((np.asarray(gp["means"]).shape[0], 1), f32))
+    out = active_splatfacto_outputs(gp, c2w, fx, fy, cx, cy, H, W, background, **kw)
+    return {k: out[k] for k in ("rgb", "depth", "accumulation", "background")}

@@ -36,12 +36,12 @@ def test_null_pointers_are_rejected_before_launch(lib):
     rc = h.unerf_hashgrid_fwd(None, None, None, 10, 16, 19, None, None, None)
     assert rc == -1
     assert b"null pointer" in h.unerf_last_error()
-    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 300, 0.05, 1000.0, 0, None, 0, 32768, 0, None, 1, None)
+    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 300, 0.05, 1000.0, 0, None, 0, 32768, 0, None, None, 1, None)
     assert rc == -1 and b"outside [1,256]" in h.unerf_last_error()
     # unknown background mode / a constant colour without its 3 floats
-    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 48, 0.05, 1000.0, 0, None, 0, 32768, 7, None, 1, None)
+    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 48, 0.05, 1000.0, 0, None, 0, 32768, 7, None, None, 1, None)
     assert rc == -1 and b"background=7" in h.unerf_last_error()
-    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 48, 0.05, 1000.0, 0, None, 0, 32768, lib.BG_COLOR, None, 1, None)
+    rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 48, 0.05, 1000.0, 0, None, 0, 32768, lib.BG_COLOR, None, None, 1, None)
     assert rc == -1 and b"background_rgb" in h.unerf_last_error()
     rc = h.unerf_moments(None, 8, 4, 3, None, None, None)
     assert rc == -1
@@ -69,8 +69,8 @@ def test_zero_counts_are_no_ops_and_oversized_inputs_are_refused(lib):
     c2w = (C.c_float * 12)(*([0.0] * 12))
     assert h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, 4, 4, 16, 0, None, None, None, None) == 0
     assert h.unerf_moments(None, 8, 0, 3, None, None, None) == 0
-    assert h.unerf_composite_var(None, None, None, None, None, 2, 0, 48, 0.05, 1000.0, 0, None, 0, 32768, 0, None, None, None) == 0
-    assert h.unerf_composite_moments(None, None, None, 8, 0, 48, 0.05, 1000.0, 0, None, 0, 32768, 0, None, None, None, None) == 0
+    assert h.unerf_composite_var(None, None, None, None, None, 2, 0, 48, 0.05, 1000.0, 0, None, 0, 32768, 0, None, None, None, None) == 0
+    assert h.unerf_composite_moments(None, None, None, 8, 0, 48, 0.05, 1000.0, 0, None, 0, 32768, 0, None, None, None, None, None) == 0
     assert h.unerf_weights_pdf_resample(None, None, 0, 0, 256, 0.05, 1000.0, 1, None, 96, 0.01, 1e-5, None, None, None, None, 0,
                                         32768, None) == 0
     assert h.unerf_laplace_depth_weights(None, None, None, 0, 48, 0.05, 1000.0, 0, None, 100, 0, 0, None, None) == 0

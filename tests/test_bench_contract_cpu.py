@@ -40,7 +40,7 @@ def test_committed_bench_line_has_every_contract_field():
     assert abs(want - r["achieved"]) < 1e-6 * want
     assert os.path.exists(os.path.join(ROOT, iss["source"].split(" ")[0]))
     subs = d["sub_records"]
-    assert set(subs) == {"active", "laplace", "splat"}
+    assert {"active", "laplace", "splat"} <= set(subs)
     for k, v in subs.items():
         assert v["value"] > 0 and v["ms_per_step"] > 0 and v["per_kernel_ms_per_frame"], k
     assert "density [H,W,48] kept" in subs["active"]["workload"]
@@ -50,9 +50,23 @@ def test_committed_bench_line_has_every_contract_field():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"]
 
 
-def test_bench_refuses_multi_gpu_without_a_launcher():
-    """--gpus N > 1 must come through torch.distributed.run (one process per GPU); a bare call says so"""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+def test_bench_launches_its_own_ranks_for_multi_gpu():
+    """The driver's command is `python bench.py --gpus N`: without a launcher around it the script starts
+    torch.distributed.run itself (a child process, one rank per GPU).  On this GPU-less box the RANKS then fail at
+    require_gpu(); the parent neither refuses (rc 2) nor touches the GPU, and hands the child's exit code on."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert "torch.distributed.run" in p.stderr and "--nproc-per-node=2" in p.stderr, p.stderr[-2000:]
+    import torch
+    if not torch.cuda.is_available():
+        assert p.returncode not in (0, 2), (p.returncode, p.stderr[-2000:])
+        assert "no HIP device visible" in p.stderr, p.stderr[-3000:]       # raised inside the ranks
+        assert p.stdout.strip() == ""
+
+
+def test_a_rank_count_that_contradicts_gpus_is_refused():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="4")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
                        timeout=300)
-    assert p.returncode == 2 and "torch.distributed.run" in p.stderr
+    assert p.returncode == 2 and "WORLD_SIZE=4" in p.stderr

@@ -251,6 +251,81 @@ def test_splat_model_get_outputs(dev):
         assert torch.equal(out[k], ref[k]), k
 
 
+def _nerfacto_upstream_state_dict(t, layout="encoder-mlp"):
+    """synthetic weights (kind="mcdropout": 16-wide trunk) -> a plain `nerfacto` pipeline checkpoint in nerfstudio
+    1.1.0's MLPWithHashEncoding layout (`model-sequential`: only the model.{0,1} alias names)"""
+    f = t["field"]
+    enc, mlp = ("model.0.", "model.1.") if layout == "model-sequential" else ("encoder.", "mlp.")
+    sd = {f"field.mlp_base.{enc}hash_table": f["table"]}
+    for i, (w, b) in enumerate(((f["w0"], f["b0"]), (f["w1"], f["b1"]))):
+        sd[f"field.mlp_base.{mlp}layers.{i}.weight"], sd[f"field.mlp_base.{mlp}layers.{i}.bias"] = w, b
+    for i in range(3):
+        sd[f"field.mlp_head.layers.{i}.weight"], sd[f"field.mlp_head.layers.{i}.bias"] = f["head_w"][i], f["head_b"][i]
+    sd["field.embedding_appearance.embedding.weight"] = f["appearance"][None].repeat(4, 1)
+    for i, p in enumerate(t["props"]):
+        sd[f"proposal_networks.{i}.mlp_base.{enc}hash_table"] = p["table"]
+        for j, (w, b) in enumerate(((p["w0"], p["b0"]), (p["w1"], p["b1"]))):
+            sd[f"proposal_networks.{i}.mlp_base.{mlp}layers.{j}.weight"] = w
+            sd[f"proposal_networks.{i}.mlp_base.{mlp}layers.{j}.bias"] = b
+    return {"_model." + k: v for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("layout", ["encoder-mlp", "model-sequential"])
+def test_plain_nerfacto_member_from_an_upstream_layout_checkpoint(dev, layout):
+    """ensemble_utils.py:149-150: ensembles are built from plain `nerfacto` runs.  NerfactoModel loaded from upstream's
+    MLPWithHashEncoding key layout renders like the oracle's plain-nerfacto restatement."""
+    from uncertainty_nerf_gs_amd import plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=12, kind="mcdropout", log2T=14, prop_log2T=12)
+    # upstream's nerfacto hands config.average_init_density (0.01 in its method config) to the field AND the proposal nets
+    t["field"]["average_init_density"] = 0.01
+    t["field"]["b1"][0] += 4.6     # ... so shift the density logit to keep the synthetic scene as opaque as before
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["nerfacto"]())
+    model = cfg._target(cfg, num_train_data=4)
+    rep = model.load_state_dict(_nerfacto_upstream_state_dict(t, layout), strict=True)
+    assert rep.unexpected_keys == [] and rep.loaded == rep.expected
+    H, W = 36, 48
+    cam = _camera(H, W, theta=1.4)
+    with torch.cuda.device(dev):
+        out = model.get_outputs_for_camera(cam)
+    assert set(out) == {"rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1"}
+    o, d, _ = O.generate_rays(cam.camera_to_worlds[0], 0.9 * W, 0.9 * W, W / 2, H / 2, H, W)
+    ref = O.nerfacto_outputs(O.scene_from_tensors(t), o.reshape(-1, 3), d.reshape(-1, 3))
+    for k, atol, rtol, frac in (("rgb", 5e-5, 0, 0.0), ("accumulation", 2e-4, 0, 0.0), ("expected_depth", 0, 1e-3, 5e-3),
+                                ("depth", 0, 1e-3, 2e-2)):
+        got, want = out[k].reshape(H * W, -1).cpu().double(), ref[k].double()
+        bad = (got - want).abs() > atol + rtol * want.abs()
+        assert bad.double().mean() <= frac, (k, (got - want).abs().max().item())
+
+
+def test_plain_splatfacto_member(dev):
+    """ensemble_utils.py:153-154: splat ensembles are built from plain `splatfacto` runs (no log_uncertainties)"""
+    from oracle import splat_oracle as SO
+    from uncertainty_nerf_gs_amd import ensemble, plugin, synthetic
+    gp = synthetic.make_splat_tensors(7, 3000)
+    gp["scales"] = gp["scales"] + 1.5
+    gp.pop("log_uncertainties")
+    m = plugin.build_model("splatfacto", num_points=5)
+    m.load_state_dict({f"_model.gauss_params.{k}": v for k, v in gp.items()}, strict=True)
+    m.to(dev)
+    H, W = 40, 56
+    from uncertainty_nerf_gs_amd import models
+    cam = models.Camera(synthetic.orbit_c2w(0.9, radius=2.5, height=0.5), 60.0, 60.0, W / 2, H / 2, H, W)
+    out = m.get_outputs(cam)
+    assert set(out) == {"rgb", "depth", "accumulation", "background"}
+    bg = np.array([0.1490, 0.1647, 0.2157], np.float32)
+    ref = SO.splatfacto_outputs({k: v.numpy() for k, v in gp.items()}, cam.camera_to_worlds.numpy(), 60.0, 60.0, W / 2, H / 2,
+                                H, W, bg)
+    for k, tol in (("rgb", 2e-5), ("depth", 2e-4), ("accumulation", 2e-5)):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], atol=tol, rtol=tol, err_msg=k)
+    # two such members aggregate through the ensemble's no-std branch (rgb / depth std over the members)
+    m2 = plugin.build_model("splatfacto", num_points=5)
+    gp2 = {k: v + 0.01 * torch.randn(v.shape, generator=torch.Generator().manual_seed(1)) for k, v in gp.items()}
+    m2.load_state_dict({f"gauss_params.{k}": v for k, v in gp2.items()})
+    m2.to(dev)
+    agg = ensemble.aggregate([out, m2.get_outputs(cam)])
+    assert {"rgb_std", "depth_std"} <= set(agg) and agg["rgb_std"].shape == (H, W, 1)
+
+
 def test_nerfstudio_plugin_model_renders_like_the_mirror(dev):
     """The nerfstudio-facing Model subclass of plugin.py (real nerfstudio when installed, else tests/stubs): built from
     the registered MethodSpecification, loaded from a reference-style pipeline checkpoint, called with a RayBundle --
@@ -273,7 +348,8 @@ def test_nerfstudio_plugin_model_renders_like_the_mirror(dev):
     ref_model.config.log2_hashmap_size, ref_model.config.proposal_net_args_list = 12, cfg.proposal_net_args_list
     ref_model = type(ref_model)(ref_model.config, num_train_data=2)
     # a pipeline checkpoint as the reference writes it: `_model.` prefix (ensemble_pipeline.py:77-91)
-    sd = {"_model." + k: torch.randn_like(v) * (0.05 if "hash_table" not in k else 0.3) for k, v in ref_model.state_dict().items()}
+    sd = {"_model." + k: (torch.randn_like(v) * (0.05 if "hash_table" not in k else 0.3) if v.is_floating_point() and "aabb" not in k else v)
+          for k, v in ref_model.state_dict().items()}
     model.load_state_dict(sd)
     ref_model.load_state_dict(sd)
     H, W = 24, 40

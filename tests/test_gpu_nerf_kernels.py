@@ -679,7 +679,8 @@ def test_uniform_spacing_proposal_pdf_composite_match_oracle(dev):
         sb = O.initial_spacing_bins(n) if level == 0 else torch.sort(torch.rand(R, n + 1, generator=g), dim=-1).values
         sb_ref = sb[None].expand(R, -1) if level == 0 else sb
         eb = O.spacing_to_euclidean(sb_ref, near, far, uniform=True)
-        assert abs(float(eb[0, 0]) - near) < 1e-5 and (level or abs(float(eb[0, -1]) - far) < 1e-3)
+        if level == 0:
+            assert abs(float(eb[0, 0]) - near) < 1e-5 and abs(float(eb[0, -1]) - far) < 1e-3
         ref = O.density_field(O.sample_positions(o, d, eb), sc.prop_nets[level], 0.01)
         for width in (0, 32):   # thread-per-sample and 8x8-patch kernels
             got = ops.proposal_density(o.to(dev), d.to(dev), sb.contiguous().to(dev), sd.props[level], near, far, 0.01,
@@ -736,3 +737,58 @@ def test_spacing_and_background_arguments_are_validated(dev):
         ops.composite_var(dens, rgb, sb, NEAR, FAR, background=(9, None))
     with pytest.raises(L.UnerfError, match="background_color"):
         ops.background_of("purple-ish")
+
+
+@pytest.mark.parametrize("K", [0, 3, 8])
+def test_field_f16_single_product_mode(dev, K):
+    """unerf_field_params.f16_single: every pass of the K-pass kernel against the fp32 oracle (f16 operand rounding:
+    relative 5e-4 per operand, logits good to ~2e-3) and against the oracle's autocast(float16) emulation"""
+    from uncertainty_nerf_gs_amd import ops
+    seed, p = 1234, 0.2
+    t, sc, sd = _scene("mcdropout", dev, K=K, seed=seed, p_drop=p)
+    sd.field.precision = "f16"
+    o, d = _rays(16, 24)
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    dens, rgb, _, _ = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR, ray_offset=1000)
+    R, S = sb.shape[0], sb.shape[1] - 1
+    sidx = ((np.arange(R)[:, None] + 1000) * S + np.arange(S)[None]).reshape(-1)
+    for k in range(max(K, 1)):
+        kt = kh = None
+        if K > 0:
+            kt = torch.from_numpy(O.mc_keep_mask(seed, k, sidx, 0, 64, p))
+            kh = torch.from_numpy(O.mc_keep_mask(seed, k, sidx, 1, 64, p))
+        for ac, dtol, ctol in ((None, 1e-2, 2e-4), (torch.float16, 2e-2, 4e-4)):
+            dr, cr = O.mcdropout_field(o, d, eb, sc.field, kt, kh, p, autocast=ac)
+            _close(dens[k], dr, dtol, 1e-7, f"density pass {k} vs autocast={ac}", max_bad_frac=1e-3)
+            _close(rgb[k], cr, 0, ctol, f"rgb pass {k} vs autocast={ac}")
+    # f16 needs the f16 operand blobs: a field whose weights leave the f16 range says so
+    sd.field.mfma16_blob = None
+    with pytest.raises(Exception, match="precision='f16' needs"):
+        ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
+
+
+def test_field_f16_single_product_mode_active_and_laplace(dev):
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    o, d = _rays(12, 16)
+    t, sc, sd = _scene("active", dev)
+    sd.field.precision = "f16"
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    dens, rgb, beta, _ = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
+    dr, cr, br = O.active_field(o, d, eb, sc.field)
+    _close(dens[0], dr, 1e-2, 1e-7, "density", max_bad_frac=1e-3)
+    _close(rgb[0], cr, 0, 2e-4, "rgb")
+    _close(beta, br, 1e-2, 1e-4, "beta", max_bad_frac=1e-3)
+    t, sc, _ = _scene("laplace", dev)
+    wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+    sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+    sd.field.precision = "f16"
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    mu_d, var_d, mu_rgb, var_rgb = O.laplace_field(o, d, eb, sc.field, wsd, wsr)
+    dens, rgb, dvar, rvar = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
+    _close(dens[0], mu_d, 1e-2, 1e-7, "mu_d", max_bad_frac=1e-3)
+    _close(rgb[0], mu_rgb, 0, 2e-4, "mu_rgb")
+    _close(dvar, var_d, 0, 2e-2 * float((mu_d ** 2).max()), "var_d")
+    _close(rvar, var_rgb, 0, 2e-5, "var_rgb")

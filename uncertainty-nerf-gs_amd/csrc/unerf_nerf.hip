@@ -617,17 +617,13 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
             for (int j = 0; j < HID / 2; ++j) h2[j] = __builtin_elementwise_fma(fk, w0p[k * (HID / 2) + j], h2[j]);
         }
         float o = a.net.b1[0];
-#if defined(UNERF_PROBE_NO_PROP_MLP)   // experiment build only: how much of this kernel is its MLP?  (wrong results)
-        (void)h2; (void)w1t;
-#pragma unroll
-        for (int k = 0; k < 2 * L; ++k) o += feat[k];
-#else
+        // [probe:prop-mlp-out begin]  (benchmarks/probe_source.py rewrites the marked span in COPIES of this file)
 #pragma unroll
         for (int j = 0; j < HID / 2; ++j) {
             o = fmaf(__int_as_float(max(__float_as_int(h2[j].x), 0)), w1t[2 * j], o);
             o = fmaf(__int_as_float(max(__float_as_int(h2[j].y), 0)), w1t[2 * j + 1], o);
         }
-#endif
+        // [probe:prop-mlp-out end]
         dens = a.avg * unerf_exp(o) * sel;
     }
     if (a.vec4) {  // uniform: n % 4 == 0 and a 16-byte aligned output: the ray's 4 densities leave as one store
@@ -1650,28 +1646,43 @@ __device__ __forceinline__ void mf16_split2(float x0, float x1, uint32_t& hi, ui
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
     lo = l;
 }
+// F1 (every helper below, and the kernels): the REFERENCE-PRECISION form, `precision = "f16"` / unerf_field_params.f16_single.
+// One f16 product per MAC with fp32 accumulation: operands rounded to f16 once (v_cvt_pk_f16_f32 for the activations,
+// the hi halves of the packed weights), no lo halves anywhere -- the arithmetic of torch.autocast(float16) Linear layers
+// (forced at eval by mcdropout_models.py:86-92) and at least that of tiny-cuda-nn's FullyFusedMLP (fp16 weights,
+// activations AND accumulators; the reference's default implementation="tcnn", activenerfacto_field.py:89).  A third of
+// the split form's MFMAs and none of its 1.5-instruction-per-element residual splits.
+template <bool F1 = false>
 __device__ __forceinline__ void mf16_split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
     u32x4 hv, lv;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        uint32_t hq, lq;
-        mf16_split2(x[2 * p], x[2 * p + 1], hq, lq);
-        hv[p] = hq;
-        lv[p] = lq;
+        if (F1) {
+            const f16x2 hh = {(_Float16)x[2 * p], (_Float16)x[2 * p + 1]};
+            hv[p] = lv[p] = __builtin_bit_cast(uint32_t, hh);   // lo is never read in this form
+        } else {
+            uint32_t hq, lq;
+            mf16_split2(x[2 * p], x[2 * p + 1], hq, lq);
+            hv[p] = hq;
+            lv[p] = lq;
+        }
     }
     hi = __builtin_bit_cast(f16x8, hv);
     lo = __builtin_bit_cast(f16x8, lv);
 }
+template <bool F1 = false>
 __device__ __forceinline__ void mf16_split(const f32x16& v, int s, f16x8& hi, f16x8& lo) {
     float x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = v[8 * s + e];
-    mf16_split8(x, hi, lo);
+    mf16_split8<F1>(x, hi, lo);
 }
 // acc += W(slab) x B: small terms first
+template <bool F1 = false>
 __device__ __forceinline__ f32x16 mf16_mac(const float* lds, int slab, int lane, const f16x8& bhi, const f16x8& blo,
                                            f32x16 acc) {
     const f16x8 ahi = *reinterpret_cast<const f16x8*>(lds + slab * 512 + lane * 4);
+    if (F1) return __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
     const f16x8 alo = *reinterpret_cast<const f16x8*>(lds + slab * 512 + 256 + lane * 4);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
@@ -1681,11 +1692,17 @@ __device__ __forceinline__ f32x16 mf16_mac(const float* lds, int slab, int lane,
 // two row blocks against one B operand, the two accumulator chains interleaved: an MFMA whose SrcC is the result of
 // the MFMA right before it issues 16 cycles late (benchmarks/mfma_data_probe.hip: 48 instead of 32 cycles per
 // instruction in a single dependent chain), an independent MFMA in between hides that
+template <bool F1 = false>
 __device__ __forceinline__ void mf16_mac2(const float* lds, int slab_a, int slab_b, int lane, const f16x8& bhi, const f16x8& blo,
                                           f32x16& o0, f32x16& o1) {
     const f16x8 ahi0 = *reinterpret_cast<const f16x8*>(lds + slab_a * 512 + lane * 4);
-    const f16x8 alo0 = *reinterpret_cast<const f16x8*>(lds + slab_a * 512 + 256 + lane * 4);
     const f16x8 ahi1 = *reinterpret_cast<const f16x8*>(lds + slab_b * 512 + lane * 4);
+    if (F1) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi0, bhi, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1, bhi, o1, 0, 0, 0);
+        return;
+    }
+    const f16x8 alo0 = *reinterpret_cast<const f16x8*>(lds + slab_a * 512 + 256 + lane * 4);
     const f16x8 alo1 = *reinterpret_cast<const f16x8*>(lds + slab_b * 512 + 256 + lane * 4);
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo0, bhi, o0, 0, 0, 0);
     o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo1, bhi, o1, 0, 0, 0);
@@ -1712,15 +1729,15 @@ __device__ __forceinline__ f32x16 mf16_fold_rows(f32x16 acc) {
 }
 // a 64-wide layer input held as two accumulator blocks (units 0..31 in v0, 32..63 in v1) against the
 // 4 k-steps x NB row blocks of slabs starting at `slab0` (slab = slab0 + NB*step + block)
-template <int NB>
+template <int NB, bool F1 = false>
 __device__ __forceinline__ void mf16_layer64(const float* lds, int slab0, int lane, const f32x16& v0, const f32x16& v1,
                                              f32x16& o0, f32x16& o1) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         f16x8 bhi, blo;
-        mf16_split(s < 2 ? v0 : v1, s & 1, bhi, blo);
-        if (NB == 2) mf16_mac2(lds, slab0 + NB * s, slab0 + NB * s + 1, lane, bhi, blo, o0, o1);
-        else o0 = mf16_mac(lds, slab0 + NB * s, lane, bhi, blo, o0);
+        mf16_split<F1>(s < 2 ? v0 : v1, s & 1, bhi, blo);
+        if (NB == 2) mf16_mac2<F1>(lds, slab0 + NB * s, slab0 + NB * s + 1, lane, bhi, blo, o0, o1);
+        else o0 = mf16_mac<F1>(lds, slab0 + NB * s, lane, bhi, blo, o0);
     }
 }
 
@@ -1729,12 +1746,13 @@ __device__ __forceinline__ void mf16_layer64(const float* lds, int slab0, int la
 #define mf16_bias mf_bias
 // and both operand quads of k-step `st` (accumulator registers 8 st .. 8 st + 7 = mask words 4 st .. 4 st + 3 of
 // the block's eight) with their keep masks
+template <bool F1 = false>
 __device__ __forceinline__ void mf16_apply_masks(f16x8& hi, f16x8& lo, const uint32_t (&words)[8], int st, uint32_t thr_pk) {
     u32x4 m;
 #pragma unroll
     for (int p = 0; p < 4; ++p) m[p] = mf16_keep_mask(words[4 * st + p], thr_pk);
     hi = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, hi) & m);
-    lo = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, lo) & m);
+    if (!F1) lo = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, lo) & m);
 }
 
 // SITES = false: the reference's default Dropout placement (trunk + last head layer), every site test a compile-time
@@ -1743,7 +1761,9 @@ __device__ __forceinline__ void mf16_apply_masks(f16x8& hi, f16x8& lo, const uin
 // they cost that kernel 50 VGPRs and 84 bytes of scratch (K = 8 field kernel 50 -> 55.6 ms).
 // DROP: masks are generated (MCDROPOUT with K > 0 and p > 0).  A compile-time flag: as a run-time (uniform) flag every
 // k-step of the masked layers carried a branch and the operand quads were copied to merge the two paths.
-template <int MODE, bool TCNN, bool SITES = false, bool DROP = false>
+template <int MODE, bool TCNN, bool SITES = false, bool DROP = false, bool F1 = false>
+// (the single-product K-pass kernel at 3 waves per SIMD -- 168 VGPRs, 96 B of scratch, trunk operands re-read from LDS --
+// was measured and lost: 4.84 vs 3.89 ms per launch, same box, profiles/r3_exp_f16_single_occ3.json)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && !TCNN) ? 3 : 2)))
 void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
@@ -1791,8 +1811,8 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             for (int q = 0; q < 8; ++q)
                 mine[q] = __uint_as_float((__float_as_uint(sh[8 + q]) & hm) | (__float_as_uint(sh[q]) & ~hm));
             f16x8 bhi, blo;
-            mf16_split8(mine, bhi, blo);
-            mf16_mac2(lds, 10, 11, lane, bhi, blo, csh0, csh1);
+            mf16_split8<F1>(mine, bhi, blo);
+            mf16_mac2<F1>(lds, 10, 11, lane, bhi, blo, csh0, csh1);
         }
 
         // layer 0: 32 -> 64 (this half's 16 features = two k-steps), ReLU; the 64 hidden units are the trunk
@@ -1803,26 +1823,27 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 f16x8 bhi, blo;
-                mf16_split(feat, st, bhi, blo);
-                mf16_mac2(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hid0, hid1);
+                mf16_split<F1>(feat, st, bhi, blo);
+                mf16_mac2<F1>(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hid0, hid1);
             }
             hid0 = mf_relu(hid0);
             hid1 = mf_relu(hid1);
 #pragma unroll
-            for (int st = 0; st < 4; ++st) mf16_split(st < 2 ? hid0 : hid1, st & 1, hhi[st], hlo[st]);
+            for (int st = 0; st < 4; ++st) mf16_split<F1>(st < 2 ? hid0 : hid1, st & 1, hhi[st], hlo[st]);
         }
 
         const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
         // variants: the trunk-out operands (4 k-steps x 2 quads = 32 VGPRs) kept in registers across the passes; the
         // 16-row trunk-out layer of MCDROPOUT folded into two MFMAs per k-step
         constexpr bool TRUNK_RESIDENT = UNERF_TRUNK_RESIDENT && MODE == UNERF_FIELD_MCDROPOUT && DROP && !SITES;
-        constexpr bool FOLD = UNERF_TRUNK_FOLD && MODE == UNERF_FIELD_MCDROPOUT;
+        // F1: the first operand of a (folded or plain) trunk slab is W_hi, which is all the single-product form reads
+        constexpr bool FOLD = UNERF_TRUNK_FOLD && MODE == UNERF_FIELD_MCDROPOUT && !F1;
         f16x8 ta0[4], ta1[4];   // first / second operand of trunk slab 4 + st
         if (TRUNK_RESIDENT) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 ta0[st] = *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + lane * 4);
-                ta1[st] = *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + 256 + lane * 4);
+                if (!F1) ta1[st] = *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + 256 + lane * 4);
             }
         }
         constexpr bool drop = DROP;   // host: a.drop_on
@@ -1847,22 +1868,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 mf_mask_step(mk2);
                 mf_mask_step(mk3);
             }
-#if defined(UNERF_PROBE_EXTRA_VALU)   // experiment builds only (benchmarks/exp_issue_model.sh): N independent VALU per pass
-            {
-                uint32_t dummy = (uint32_t)k;
-#pragma unroll
-                for (int q = 0; q < UNERF_PROBE_EXTRA_VALU; ++q) asm volatile("v_alignbit_b32 %0, %0, %0, 5" : "+v"(dummy));
-                asm volatile("" ::"v"(dummy));
-            }
-#endif
-#if defined(UNERF_PROBE_EXTRA_MFMA)   // ... or N independent MFMAs per pass
-            {
-                f32x16 junk = {0};
-#pragma unroll
-                for (int q = 0; q < UNERF_PROBE_EXTRA_MFMA; ++q) junk = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhi[0], hlo[0], junk, 0, 0, 0);
-                asm volatile("" ::"v"(junk));
-            }
-#endif
+            // [probe:kpass-pass-start]
             // Wave priority: low through the matrix layers of a pass, high from the rgb layer to the end of the pass --
             // and, after the last pass, through the next tile's gathers.  The tail (packed-fma chains, the half exchange,
             // exp / rcp, stores) and the gather prologue are short instruction streams that wait on latencies; letting
@@ -1875,16 +1881,18 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 f16x8 bhi = hhi[st], blo = hlo[st];
-                if (drop_trunk) mf16_apply_masks(bhi, blo, st < 2 ? mk0 : mk1, st & 1, a.keep_pk);
+                if (drop_trunk) mf16_apply_masks<F1>(bhi, blo, st < 2 ? mk0 : mk1, st & 1, a.keep_pk);
                 f16x8 a0, a1;
                 if (TRUNK_RESIDENT) {
                     a0 = ta0[st];
-                    a1 = ta1[st];
+                    a1 = F1 ? ta0[st] : ta1[st];
                 } else {
                     a0 = *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + lane * 4);
-                    a1 = *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + 256 + lane * 4);
+                    a1 = F1 ? a0 : *reinterpret_cast<const f16x8*>(lds + (4 + st) * 512 + 256 + lane * 4);
                 }
-                if (FOLD) {
+                if (F1) {
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bhi, t, 0, 0, 0);
+                } else if (FOLD) {
                     t = mf16_mac_fold_ops(a0, a1, bhi, blo, t);
                 } else {   // a0 = W_hi, a1 = W_lo: small terms first
                     t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bhi, t, 0, 0, 0);
@@ -1897,8 +1905,8 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             f32x16 c0 = csh0, c1 = csh1;
             {
                 f16x8 bhi, blo;
-                mf16_split(t, 0, bhi, blo);
-                mf16_mac2(lds, 8, 9, lane, bhi, blo, c0, c1);
+                mf16_split<F1>(t, 0, bhi, blo);
+                mf16_mac2<F1>(lds, 8, 9, lane, bhi, blo, c0, c1);
             }
             c0 = mf_relu(c0);
             c1 = mf_relu(c1);
@@ -1908,14 +1916,14 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     f16x8 bhi, blo;
-                    mf16_split(st < 2 ? c0 : c1, st & 1, bhi, blo);
+                    mf16_split<F1>(st < 2 ? c0 : c1, st & 1, bhi, blo);
                     uint32_t mw[8];
                     mf_mask_words_at(mw, st >> 1, h, base0_h0, 2u, k);
-                    mf16_apply_masks(bhi, blo, mw, st & 1, a.keep_pk);
-                    mf16_mac2(lds, 12 + 2 * st, 12 + 2 * st + 1, lane, bhi, blo, d0, d1);
+                    mf16_apply_masks<F1>(bhi, blo, mw, st & 1, a.keep_pk);
+                    mf16_mac2<F1>(lds, 12 + 2 * st, 12 + 2 * st + 1, lane, bhi, blo, d0, d1);
                 }
             } else {
-                mf16_layer64<2>(lds, 12, lane, c0, c1, d0, d1);
+                mf16_layer64<2, F1>(lds, 12, lane, c0, c1, d0, d1);
             }
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
@@ -2189,7 +2197,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
 // (ops.pack_laplace_heads16: density rows x log2 e, colour rows x -log2 e), so exp / sigmoid are the bare v_exp_f32
 // (+ v_rcp_f32); softplus rows are unscaled.  The running sums of p and p^2 are one packed fma per activation,
 // (s1, s2) += (p, p) * (1, p), instead of a multiply and a packed add.
-template <int ACT>
+template <int ACT, bool F1 = false>
 __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int q, int n_lap, int lane,
                                               const f16x8 (&bhi)[4], const f16x8 (&blo)[4], int h, float& sum1,
                                               float& sum2) {
@@ -2198,14 +2206,14 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
     {
         const float* f = lap + (size_t)((q * LAP_BLOCKS + 0) * 8) * 256 + lane * 4;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cur[i] = *reinterpret_cast<const f16x8*>(f + i * 256);
+        for (int i = 0; i < 8; i += (F1 ? 2 : 1)) cur[i] = *reinterpret_cast<const f16x8*>(f + i * 256);   // F1: hi quads only
     }
 #pragma unroll
     for (int b = 0; b < LAP_BLOCKS; ++b) {
         if (b + 1 < LAP_BLOCKS) {
             const float* f = lap + (size_t)((q * LAP_BLOCKS + b + 1) * 8) * 256 + lane * 4;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) nxt[i] = *reinterpret_cast<const f16x8*>(f + i * 256);
+            for (int i = 0; i < 8; i += (F1 ? 2 : 1)) nxt[i] = *reinterpret_cast<const f16x8*>(f + i * 256);
         }
         const float4* bp = reinterpret_cast<const float4*>(lap + LAP_BIAS_OFF + ((q * LAP_BLOCKS + b) * 2 + h) * 16);
         float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
@@ -2215,8 +2223,10 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < 4; ++st) {  // cur[2 st] = hi, cur[2 st + 1] = lo of k-step st
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st + 1], bhi[st], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st], blo[st], acc, 0, 0, 0);
+            if (!F1) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st + 1], bhi[st], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st], blo[st], acc, 0, 0, 0);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st], bhi[st], acc, 0, 0, 0);
         }
         // register quad qd holds rows 8 qd + 4 h + (0..3) of this block: skip quads that are padding in both halves
@@ -2245,14 +2255,14 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
         __builtin_amdgcn_sched_barrier(0);
         if (b + 1 < LAP_BLOCKS) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+            for (int i = 0; i < 8; i += (F1 ? 2 : 1)) cur[i] = nxt[i];
         }
     }
     sum1 = s12.x + __shfl_xor(s12.x, 32, 64);
     sum2 = s12.y + __shfl_xor(s12.y, 32, 64);
 }
 
-template <bool TCNN>
+template <bool TCNN, bool F1 = false>
 __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
@@ -2287,19 +2297,19 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             f16x8 bhi, blo;
-            mf16_split(feat, st, bhi, blo);
-            mf16_mac2(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hb0, hb1);
+            mf16_split<F1>(feat, st, bhi, blo);
+            mf16_mac2<F1>(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hb0, hb1);
         }
         // the 64 base outputs feed both mlp_hidden (geo) and the sampled density rows: split them once
         f16x8 xhi[4], xlo[4];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) mf16_split(st < 2 ? hb0 : hb1, st & 1, xhi[st], xlo[st]);
+        for (int st = 0; st < 4; ++st) mf16_split<F1>(st < 2 ? hb0 : hb1, st & 1, xhi[st], xlo[st]);
         f32x16 t = mf16_bias(lds, 2, h);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) t = mf16_mac(lds, 4 + st, lane, xhi[st], xlo[st], t);
+        for (int st = 0; st < 4; ++st) t = mf16_mac<F1>(lds, 4 + st, lane, xhi[st], xlo[st], t);
         float d1, d2;
-        if (a.p.lap_softplus) mf16_lap_head<2>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);   // uniform
-        else mf16_lap_head<0>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
+        if (a.p.lap_softplus) mf16_lap_head<2, F1>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);   // uniform
+        else mf16_lap_head<0, F1>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
         float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
         if (a.p.lap_mask_density) {  // use_deterministic_density: selector-masked mean, no variance
             mu_d *= sel;
@@ -2310,8 +2320,8 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
         f32x16 c0 = mf16_bias(lds, 3, h), c1 = mf16_bias(lds, 4, h);
         {
             f16x8 bhi, blo;
-            mf16_split(t, 0, bhi, blo);
-            mf16_mac2(lds, 8, 9, lane, bhi, blo, c0, c1);
+            mf16_split<F1>(t, 0, bhi, blo);
+            mf16_mac2<F1>(lds, 8, 9, lane, bhi, blo, c0, c1);
             float sh[16];
             float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
             if (a.p.sh_remap) {
@@ -2325,22 +2335,22 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 mine[q] = __uint_as_float((__float_as_uint(sh[8 + q]) & hm) | (__float_as_uint(sh[q]) & ~hm));
-            mf16_split8(mine, bhi, blo);
-            mf16_mac2(lds, 10, 11, lane, bhi, blo, c0, c1);
+            mf16_split8<F1>(mine, bhi, blo);
+            mf16_mac2<F1>(lds, 10, 11, lane, bhi, blo, c0, c1);
         }
         c0 = mf_relu(c0);
         c1 = mf_relu(c1);
         f32x16 x0 = mf16_bias(lds, 5, h), x1 = mf16_bias(lds, 6, h);
-        mf16_layer64<2>(lds, 12, lane, c0, c1, x0, x1);
+        mf16_layer64<2, F1>(lds, 12, lane, c0, c1, x0, x1);
         x0 = mf_relu(x0);
         x1 = mf_relu(x1);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) mf16_split(st < 2 ? x0 : x1, st & 1, xhi[st], xlo[st]);
+        for (int st = 0; st < 4; ++st) mf16_split<F1>(st < 2 ? x0 : x1, st & 1, xhi[st], xlo[st]);
         float mu_c[3], vsum = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float c1s, c2s;
-            mf16_lap_head<1>(a.p.lap16_blob, 1 + c, a.p.n_lap, lane, xhi, xlo, h, c1s, c2s);
+            mf16_lap_head<1, F1>(a.p.lap16_blob, 1 + c, a.p.n_lap, lane, xhi, xlo, h, c1s, c2s);
             mu_c[c] = c1s * inv_n;
             vsum += fmaxf(c2s * inv_n - mu_c[c] * mu_c[c], 0.f);
         }
@@ -2496,10 +2506,16 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     dim3 grid(blocks_for(R * (int64_t)S, 64)), block(64);
     hipStream_t st = (hipStream_t)stream;
     const bool tc = p->tcnn_levels != nullptr;
+    const bool f1 = p->f16_single != 0;
+    UNERF_REQUIRE(!f1 || (p->mfma16_blob && !features && (p->mode != UNERF_FIELD_LAPLACE || (p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS))),
+                  "field_fwd: f16_single needs mfma16_blob (and lap16_blob with n_lap <= 128 for LAPLACE), without pre-gathered features");
     switch (p->mode) {
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
-            if (p->mfma16_blob && !features) {
+            if (p->mfma16_blob && !features && f1) {
+                if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, true, false, false, true>, MF_LDS_F16, a, st);
+                else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, false, false, false, true>, MF_LDS_F16, a, st);
+            } else if (p->mfma16_blob && !features) {
                 if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, true>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob) {
@@ -2515,7 +2531,15 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
             UNERF_REQUIRE((p->drop_sites & ~(UNERF_DROP_TRUNK | UNERF_DROP_HEAD0 | UNERF_DROP_HEAD1)) == 0,
                           "field_fwd MCDROPOUT: unknown bits in drop_sites=%d", p->drop_sites);
-            if (p->mfma16_blob && !features) {
+            if (p->mfma16_blob && !features && f1) {
+                const bool head0 = a.drop_on && a.drop_sites != (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1);   // non-default sites
+                if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, true, true, true>, MF_LDS_F16, a, st);
+                else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true, true>, MF_LDS_F16, a, st);
+                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, false, true, true>, MF_LDS_F16, a, st);
+                else if (a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, true, true>, MF_LDS_F16, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, false, false, true>, MF_LDS_F16, a, st);
+                else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, false, true>, MF_LDS_F16, a, st);
+            } else if (p->mfma16_blob && !features) {
                 const bool head0 = a.drop_on && a.drop_sites != (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1);   // non-default sites
                 if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, true, true>, MF_LDS_F16, a, st);
                 else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true>, MF_LDS_F16, a, st);
@@ -2534,7 +2558,10 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_LAPLACE:
             UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
-            if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS) {
+            if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS && f1) {
+                if (tc) launch_matrix_kernel(field_kernel_mfma16_laplace<true, true>, MF_LDS_F16, a, st);
+                else launch_matrix_kernel(field_kernel_mfma16_laplace<false, true>, MF_LDS_F16, a, st);
+            } else if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS) {
                 if (tc) launch_matrix_kernel(field_kernel_mfma16_laplace<true>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16_laplace<false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
@@ -2754,6 +2781,7 @@ struct CompArgs {
     float* out;
     int bg_mode;      // UNERF_BG_*: what RGBRenderer blends behind the samples
     float bg[3];      // UNERF_BG_COLOR
+    int32_t* flag;    // nonfinite_flag (may be null): |= 1 when a density or colour read here is NaN
 };
 
 // one (pass b, ray r) composite, executed by a 16-lane group; g = b*R + r.  Results are replicated on all 16 lanes.
@@ -2800,6 +2828,16 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
 #pragma unroll
     for (int e = 0; e < SPL; ++e)
         col[e] = (!RAGGED || k0 + e < S) ? reinterpret_cast<const Rgb*>(a.rgb)[g * S + k0 + e] : Rgb{0.f, 0.f, 0.f};
+    if (a.flag) {   // uniform.  NaN inputs: the signature of an f16 operand overflow in the field kernel (|x| >= 65504 ->
+        // hi = inf, lo = -inf -> NaN), which the nan_to_num calls below would otherwise turn into a plausible pixel.
+        // One ballot per wave, one atomic per OFFENDING wave.
+        bool bad = false;
+#pragma unroll
+        for (int e = 0; e < SPL; ++e)
+            bad |= (dens[e] != dens[e]) | (col[e].r != col[e].r) | (col[e].g != col[e].g) | (col[e].b != col[e].b);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(bad);
+        if (m != 0 && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicOr(a.flag, 1);
+    }
     group_weights<SPL>(dens, delta, l16, w);
 
     float cr = 0.f, cg = 0.f, cb = 0.f, accw = 0.f, uvar = 0.f, lr = 0.f, lg = 0.f, lb = 0.f;
@@ -2971,7 +3009,7 @@ static inline int unerf_spl_for(int S) {
 extern "C" int unerf_composite_var(const float* density, const float* rgb, const float* beta, const float* weights_alt,
                                    const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane, int spacing,
                                    const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, int background,
-                                   const float* background_rgb, float* out, void* stream) {
+                                   const float* background_rgb, int32_t* nonfinite_flag, float* out, void* stream) {
     UNERF_REQUIRE(R == 0 || (density && rgb && sbins && out), "composite_var: null pointer");
     UNERF_REQUIRE(B >= 1 && R >= 0, "composite_var: bad B/R");
     UNERF_REQUIRE(S >= 1 && S <= 256, "composite_var: S=%d outside [1,256]", S);
@@ -2982,6 +3020,7 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
     UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing);
     a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays; a.out = out;
     if (int rc = unerf_set_background(a, background, background_rgb, "composite_var")) return rc;
+    a.flag = nonfinite_flag;
     dim3 grid(blocks_for((int64_t)B * R, 16)), block(256);
     hipStream_t st = (hipStream_t)stream;
     UNERF_DISPATCH_SPL(S, composite_kernel, grid, block, 0, st, a);
@@ -2990,8 +3029,8 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
 
 extern "C" int unerf_composite_moments(const float* density, const float* rgb, const float* sbins, int B, int64_t R, int S,
                                        float near_plane, float far_plane, int spacing, const float* clip_minmax, int64_t ray_offset,
-                                       int64_t chunk_rays, int background, const float* background_rgb, float* mean_out,
-                                       float* var_out, void* stream) {
+                                       int64_t chunk_rays, int background, const float* background_rgb,
+                                       int32_t* nonfinite_flag, float* mean_out, float* var_out, void* stream) {
     UNERF_REQUIRE(R == 0 || (density && rgb && sbins && mean_out && var_out), "composite_moments: null pointer");
     UNERF_REQUIRE(B >= 1 && B <= 16 && R >= 0, "composite_moments: B=%d outside [1,16] (use composite_var + moments)", B);
     UNERF_REQUIRE(S >= 1 && S <= 256, "composite_moments: S=%d outside [1,256]", S);
@@ -3002,6 +3041,7 @@ extern "C" int unerf_composite_moments(const float* density, const float* rgb, c
     UNERF_REQUIRE_SPACING(spacing); a.lin = spacing; a.s_near = unerf_spacing_of(near_plane, spacing); a.s_far = unerf_spacing_of(far_plane, spacing);
     a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays; a.out = nullptr;
     if (int rc = unerf_set_background(a, background, background_rgb, "composite_moments")) return rc;
+    a.flag = nonfinite_flag;
     dim3 grid(blocks_for(R, 16)), block(256);
     hipStream_t st = (hipStream_t)stream;
     UNERF_DISPATCH_SPL(S, composite_moments_kernel, grid, block, 0, st, a, mean_out, var_out);
@@ -3036,6 +3076,7 @@ struct CompSmArgs {
     float* var_out;   // [R,8]
     int bg_mode;      // as CompArgs
     float bg[3];
+    int32_t* flag;
 };
 
 #define CSM_G 4   // passes per walk
@@ -3053,6 +3094,7 @@ __global__ __launch_bounds__(256) void composite_sm_kernel(CompSmArgs a) {
         clip_lo = a.clip[chunk * 2 + 0];
         clip_hi = a.clip[chunk * 2 + 1];
     }
+    bool saw_nan = false;         // -> a.flag (see CompArgs)
     float x0[8], sd[8], sd2[8];   // moments over the passes, around pass 0
 #pragma unroll
     for (int c = 0; c < 8; ++c) x0[c] = sd[c] = sd2[c] = 0.f;
@@ -3085,6 +3127,7 @@ __global__ __launch_bounds__(256) void composite_sm_kernel(CompSmArgs a) {
                     const float dens = a.density[plane * R + r];
                     const float* cp = a.rgb + plane * 3 * R + r;
                     const float r0 = unerf_nan_to_num(cp[0]), g0 = unerf_nan_to_num(cp[R]), bl0 = unerf_nan_to_num(cp[2 * R]);
+                    saw_nan |= (dens != dens) | (cp[0] != cp[0]) | (cp[R] != cp[R]) | (cp[2 * R] != cp[2 * R]);
                     const float dd = delta * dens;
                     const float alpha = 1.f - unerf_exp(-dd);
                     const float T = unerf_exp(-cum[j]);
@@ -3145,6 +3188,7 @@ __global__ __launch_bounds__(256) void composite_sm_kernel(CompSmArgs a) {
             }
         }
     }
+    if (a.flag && saw_nan) atomicOr(a.flag, 1);
     if (MOMENTS) {
         const float invB = 1.f / (float)a.B, invB1 = 1.f / (float)(a.B - 1);
         float m8[8], v8[8];
@@ -3165,7 +3209,8 @@ __global__ __launch_bounds__(256) void composite_sm_kernel(CompSmArgs a) {
 static int composite_planes_launch(const float* density, const float* rgb, const float* beta, const float* sbins, int B,
                                    int64_t R, int S, float near_plane, float far_plane, int spacing, const float* clip_minmax,
                                    int64_t ray_offset, int64_t chunk_rays, int background, const float* background_rgb,
-                                   float* out, float* mean_out, float* var_out, void* stream, const char* what) {
+                                   int32_t* nonfinite_flag, float* out, float* mean_out, float* var_out, void* stream,
+                                   const char* what) {
     UNERF_REQUIRE(R == 0 || (density && rgb && sbins), "%s: null pointer", what);
     UNERF_REQUIRE(B >= 1 && R >= 0 && S >= 1, "%s: bad B/R/S", what);
     UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "%s: chunk_rays must be > 0 with clip_minmax", what);
@@ -3176,6 +3221,7 @@ static int composite_planes_launch(const float* density, const float* rgb, const
     a.clip = clip_minmax; a.ray_offset = ray_offset; a.chunk_rays = chunk_rays;
     a.out = out; a.mean_out = mean_out; a.var_out = var_out;
     if (int rc = unerf_set_background(a, background, background_rgb, what)) return rc;
+    a.flag = nonfinite_flag;
     dim3 grid(blocks_for(R, 256)), block(256);
     if (out) hipLaunchKernelGGL(composite_sm_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(composite_sm_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
@@ -3185,21 +3231,23 @@ static int composite_planes_launch(const float* density, const float* rgb, const
 extern "C" int unerf_composite_var_planes(const float* density, const float* rgb, const float* beta, const float* sbins,
                                           int B, int64_t R, int S, float near_plane, float far_plane, int spacing,
                                           const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, int background,
-                                          const float* background_rgb, float* out, void* stream) {
+                                          const float* background_rgb, int32_t* nonfinite_flag, float* out, void* stream) {
     UNERF_REQUIRE(R == 0 || out, "composite_var_planes: null pointer");
     return composite_planes_launch(density, rgb, beta, sbins, B, R, S, near_plane, far_plane, spacing, clip_minmax, ray_offset,
-                                   chunk_rays, background, background_rgb, out, nullptr, nullptr, stream, "composite_var_planes");
+                                   chunk_rays, background, background_rgb, nonfinite_flag, out, nullptr, nullptr, stream,
+                                   "composite_var_planes");
 }
 
 extern "C" int unerf_composite_moments_planes(const float* density, const float* rgb, const float* sbins, int B,
                                               int64_t R, int S, float near_plane, float far_plane, int spacing,
                                               const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays,
-                                              int background, const float* background_rgb, float* mean_out,
-                                              float* var_out, void* stream) {
+                                              int background, const float* background_rgb, int32_t* nonfinite_flag,
+                                              float* mean_out, float* var_out, void* stream) {
     UNERF_REQUIRE(R == 0 || (mean_out && var_out), "composite_moments_planes: null pointer");
     UNERF_REQUIRE(B >= 2, "composite_moments_planes: B=%d (the unbiased variance needs at least two passes)", B);
     return composite_planes_launch(density, rgb, nullptr, sbins, B, R, S, near_plane, far_plane, spacing, clip_minmax, ray_offset,
-                                   chunk_rays, background, background_rgb, nullptr, mean_out, var_out, stream, "composite_moments_planes");
+                                   chunk_rays, background, background_rgb, nonfinite_flag, nullptr, mean_out, var_out, stream,
+                                   "composite_moments_planes");
 }
 
 // ---- laplace depth draws --------------------------------------------------------------

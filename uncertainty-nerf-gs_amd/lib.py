@@ -106,7 +106,7 @@ class FieldParams(C.Structure):
         ("tcnn_levels", C.c_void_p),
         ("mfma16_blob", C.c_void_p), ("lap16_blob", C.c_void_p),
         ("image_width", C.c_int), ("sample_major", C.c_int), ("drop_sites", C.c_int), ("lap_softplus", C.c_int), ("use_aabb", C.c_int),
-        ("aabb", C.c_float * 6),
+        ("aabb", C.c_float * 6), ("f16_single", C.c_int),
     ]
 
 
@@ -141,11 +141,11 @@ SIGNATURES = {
     "unerf_laplace_ggn_workspace_bytes": (C.c_size_t, [_i64, _i]),
     "unerf_laplace_ggn_diag": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i, C.POINTER(FieldParams), _i, _fp, _vp, C.c_size_t,
                                     _vp, _vp, _vp]),
-    "unerf_composite_var": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp]),
-    "unerf_composite_moments": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp, _vp]),
-    "unerf_composite_var_planes": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp]),
+    "unerf_composite_var": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp, _vp]),
+    "unerf_composite_moments": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp, _vp, _vp]),
+    "unerf_composite_var_planes": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp, _vp]),
     "unerf_composite_moments_planes": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _f, _i, _vp, _i64, _i64, _i, _fp, _vp, _vp,
-                                            _vp]),
+                                            _vp, _vp]),
     "unerf_moments": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "unerf_splat_project": (_i, [_vp, _vp, _f, _vp, _fp, _f, _f, _f, _f, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp]),

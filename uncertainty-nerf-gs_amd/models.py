@@ -375,12 +375,21 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         from .ops import new_clip_buffer
         clip = new_clip_buffer(H * W, scene.chunk_rays, o.device)
         lists: Dict[str, List[torch.Tensor]] = {}
-        for s in range(0, H * W, rpl):
-            out = render.render_rays(scene, o[s:s + rpl], d[s:s + rpl], ray_offset=s, total_rays=H * W, clip=clip,
-                                     image_width=W, init_bins=None if init is None else init[s:s + rpl],
-                                     **self._render_kwargs())
-            for k, v in out.items():
+        starts = list(range(0, H * W, rpl))
+        guard = render.OverflowGuard(scene, len(starts))
+
+        def group(gi, flag=None):
+            s = starts[gi]
+            return render.render_rays(scene, o[s:s + rpl], d[s:s + rpl], ray_offset=s, total_rays=H * W, clip=clip,
+                                      image_width=W, init_bins=None if init is None else init[s:s + rpl],
+                                      nonfinite_flag=flag, **self._render_kwargs())
+
+        for gi in range(len(starts)):
+            for k, v in group(gi, guard.flag(gi)).items():
                 lists.setdefault(k, []).append(v)
+        for gi in guard.offenders():    # f16 operand overflow: that group again on the exact-fp32 kernels
+            for k, v in guard.redo(gi, lambda: group(gi)).items():
+                lists[k][gi] = v
         return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}
 
 
@@ -407,9 +416,12 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         R = o.shape[0]
         clip = new_clip_buffer(R, max(R, 1), o.device)                 # one chunk = the whole bundle
         saved, scene.chunk_rays = scene.chunk_rays, max(R, 1)
+        guard = render.OverflowGuard(scene, 1)
         try:
-            return render.render_rays(scene, o, d, ray_offset=0, total_rays=R, clip=clip, init_bins=init,
-                                      **self._render_kwargs())
+            run = lambda flag=None: render.render_rays(scene, o, d, ray_offset=0, total_rays=R, clip=clip, init_bins=init,
+                                                       nonfinite_flag=flag, **self._render_kwargs())
+            out = run(guard.flag(0))
+            return guard.redo(0, run) if guard.offenders() else out
         finally:
             scene.chunk_rays = saved
 

@@ -303,7 +303,10 @@ class FieldDev:
     tcnn_levels: Optional[torch.Tensor] = None   # device records: `table` is then a tcnn-layout parameter vector
     mfma16_blob: Optional[torch.Tensor] = None   # split-f16 operands of the dense layers (pack_field_mfma16)
     lap16_blob: Optional[torch.Tensor] = None
-    precision: str = "f16x2"                     # "f16x2": split-f16 matrix kernels (fp32-equivalent); "fp32": exact
+    # "f16x2": split-f16 matrix kernels (fp32-equivalent, default); "fp32": exact fp32-input MFMA; "f16": ONE f16 product
+    # per MAC with fp32 accumulation -- the reference's own eval precision (forced autocast, mcdropout_models.py:86-92;
+    # tcnn FullyFusedMLP, activenerfacto_field.py:89), unerf_field_params.f16_single
+    precision: str = "f16x2"
     packed_drop_scale: float = 1.0               # the inverted-dropout scale folded into mfma16_blob at pack time
     drop_sites: int = 0                          # UNERF_DROP_* bits (0 = reference default: trunk + last head layer)
     packed_drop_sites: int = 0                   # ... and the layers it was folded into
@@ -356,7 +359,13 @@ class FieldDev:
         return drop_sites if drop_sites else (_l.DROP_TRUNK | _l.DROP_HEAD1)
 
     def cstruct(self) -> _l.FieldParams:
-        use16 = self.use_mfma and self.precision == "f16x2" and self.mfma16_blob is not None
+        if self.precision not in ("f16x2", "fp32", "f16"):
+            raise _l.UnerfError(f"FieldDev.precision={self.precision!r}: expected 'f16x2', 'fp32' or 'f16'")
+        h16 = self.precision in ("f16x2", "f16")
+        use16 = self.use_mfma and h16 and self.mfma16_blob is not None
+        if self.precision == "f16" and (not use16 or (self.mode == _l.FIELD_LAPLACE and self.lap16_blob is None)):
+            raise _l.UnerfError("FieldDev.precision='f16' needs the f16 operand blobs (weights inside the f16 range, "
+                                "use_mfma=True, at most 128 Laplace samples); use 'f16x2' or 'fp32'")
         if use16 and (abs(self._drop_scale(self.mode, self.K, self.p_drop) - self.packed_drop_scale) > 1e-7
                       or (self.packed_drop_scale != 1.0 and self._sites(self.drop_sites) != self.packed_drop_sites)):
             # the split-f16 operands carry 1/(1-p) inside two weight matrices: K (0 <-> > 0) or p_drop changed since
@@ -379,9 +388,9 @@ class FieldDev:
             int(self.lap_mask_density),
             _p(self.mfma_blob) if self.use_mfma else None, _p(self.lap_blob) if self.use_mfma else None,
             _p(self.tcnn_levels, torch.int32),
-            _p(self.mfma16_blob) if (self.use_mfma and self.precision == "f16x2") else None,
-            _p(self.lap16_blob) if (self.use_mfma and self.precision == "f16x2") else None, 0, 0, int(self.drop_sites), int(self.lap_softplus),
-            0 if self.aabb is None else 1, _aabb6(self.aabb))
+            _p(self.mfma16_blob) if (self.use_mfma and h16) else None,
+            _p(self.lap16_blob) if (self.use_mfma and h16) else None, 0, 0, int(self.drop_sites), int(self.lap_softplus),
+            0 if self.aabb is None else 1, _aabb6(self.aabb), 1 if self.precision == "f16" else 0)
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------
@@ -775,21 +784,23 @@ def _background(background):
 
 
 def composite_var(density, rgb, sbins, near: float, far: float, beta=None, weights_alt=None, clip_minmax=None,
-                  ray_offset: int = 0, chunk_rays: int = 1 << 15, spacing: int = 0, background=None) -> torch.Tensor:
-    """density [B,R,S] -> out [B,R,8] = rgb3, accumulation, depth, expected_depth, rgb_var, depth_var"""
+                  ray_offset: int = 0, chunk_rays: int = 1 << 15, spacing: int = 0, background=None,
+                  nonfinite_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """density [B,R,S] -> out [B,R,8] = rgb3, accumulation, depth, expected_depth, rgb_var, depth_var.
+    nonfinite_flag: int32 device tensor (1 element) that receives |= 1 when a NaN density / colour is read"""
     lib = _l.load()
     B, R, S = density.shape
     out = torch.empty(B, R, 8, device=density.device, dtype=torch.float32)
     bg_mode, bg_rgb = _background(background)
     with _ctx(out.device):
         _run("composite_var", lambda: lib.unerf_composite_var(_p(density), _p(rgb), _p(beta), _p(weights_alt), _p(sbins), B, R, S, near,
-                                         far, spacing, _p(clip_minmax), ray_offset, chunk_rays, bg_mode, bg_rgb, _p(out),
-                                         _stream()))
+                                         far, spacing, _p(clip_minmax), ray_offset, chunk_rays, bg_mode, bg_rgb,
+                                         _p(nonfinite_flag, torch.int32), _p(out), _stream()))
     return out
 
 
 def composite_moments(density, rgb, sbins, near: float, far: float, clip_minmax=None, ray_offset: int = 0,
-                      chunk_rays: int = 1 << 15, spacing: int = 0, background=None):
+                      chunk_rays: int = 1 << 15, spacing: int = 0, background=None, nonfinite_flag=None):
     """density [B<=16,R,S], rgb [B,R,S,3] -> (mean [R,8], var [R,8]) over the B passes (fused composite + moments)"""
     lib = _l.load()
     B, R, S = density.shape
@@ -799,12 +810,14 @@ def composite_moments(density, rgb, sbins, near: float, far: float, clip_minmax=
     with _ctx(mean.device):
         _run("composite_moments", lambda: lib.unerf_composite_moments(_p(density), _p(rgb), _p(sbins), B, R, S, near, far,
                                                                       spacing, _p(clip_minmax), ray_offset, chunk_rays,
-                                                                      bg_mode, bg_rgb, _p(mean), _p(var), _stream()))
+                                                                      bg_mode, bg_rgb, _p(nonfinite_flag, torch.int32),
+                                                                      _p(mean), _p(var), _stream()))
     return mean, var
 
 
 def composite_var_planes(density, rgb, sbins, near: float, far: float, beta=None, clip_minmax=None,
-                         ray_offset: int = 0, chunk_rays: int = 1 << 15, spacing: int = 0, background=None) -> torch.Tensor:
+                         ray_offset: int = 0, chunk_rays: int = 1 << 15, spacing: int = 0, background=None,
+                         nonfinite_flag=None) -> torch.Tensor:
     """planes density [B,S,R], rgb [B,S,3,R], beta [S,R] -> out [B,R,8] (channels as composite_var)"""
     lib = _l.load()
     B, S, R = density.shape
@@ -813,12 +826,12 @@ def composite_var_planes(density, rgb, sbins, near: float, far: float, beta=None
     with _ctx(out.device):
         _run("composite_var", lambda: lib.unerf_composite_var_planes(_p(density), _p(rgb), _p(beta), _p(sbins), B, R, S, near, far,
                                                                     spacing, _p(clip_minmax), ray_offset, chunk_rays, bg_mode,
-                                                                    bg_rgb, _p(out), _stream()))
+                                                                    bg_rgb, _p(nonfinite_flag, torch.int32), _p(out), _stream()))
     return out
 
 
 def composite_moments_planes(density, rgb, sbins, near: float, far: float, clip_minmax=None, ray_offset: int = 0,
-                             chunk_rays: int = 1 << 15, spacing: int = 0, background=None):
+                             chunk_rays: int = 1 << 15, spacing: int = 0, background=None, nonfinite_flag=None):
     """planes density [B>=2,S,R], rgb [B,S,3,R] -> (mean [R,8], var [R,8]) over the B passes"""
     lib = _l.load()
     B, S, R = density.shape
@@ -828,7 +841,8 @@ def composite_moments_planes(density, rgb, sbins, near: float, far: float, clip_
     with _ctx(mean.device):
         _run("composite_moments", lambda: lib.unerf_composite_moments_planes(_p(density), _p(rgb), _p(sbins), B, R, S, near, far,
                                                                              spacing, _p(clip_minmax), ray_offset, chunk_rays,
-                                                                             bg_mode, bg_rgb, _p(mean), _p(var), _stream()))
+                                                                             bg_mode, bg_rgb, _p(nonfinite_flag, torch.int32),
+                                                                             _p(mean), _p(var), _stream()))
     return mean, var
 
 

@@ -63,6 +63,8 @@ class NerfSceneDev:
     # default: the plane stores cut the field kernel's write traffic to the algorithmic bytes, but the lane-per-ray
     # composite is latency-bound and costs more than the stores gain; UNERF_SAMPLE_MAJOR=1 turns it on
     sample_major: bool = field(default_factory=lambda: os.environ.get("UNERF_SAMPLE_MAJOR", "0") == "1")
+    overflow_guard: bool = True      # OverflowGuard: re-render launch groups whose f16 operands overflowed with fp32 kernels
+    overflow_rerenders: int = 0      # how many launch groups that has happened to (diagnostic)
     _const: Dict[str, torch.Tensor] = field(default_factory=dict)
 
     @property
@@ -75,6 +77,45 @@ class NerfSceneDev:
             t = _linspace_bins(n) if name == "bins" else _pdf_u(n)
             self._const[key] = t.to(self.device)
         return self._const[key]
+
+
+class OverflowGuard:
+    """The f16 matrix kernels (precision "f16x2" / "f16") carry activations as f16 operands: a hidden unit or logit at or
+    beyond 65504 becomes hi = inf, lo = -inf and poisons its sample with NaN -- which the renderers' nan_to_num would
+    turn into a plausible pixel.  Trained nerfacto fields sit orders of magnitude below that, so nothing is clamped in the
+    hot loops; instead every composite call ORs a "saw a NaN density / colour" bit into one device word per launch group
+    (unerf_composite_*: nonfinite_flag), the words of a frame are read back ONCE at its end, and a group whose word is
+    set is rendered again with the exact-fp32 kernels, which have no such limit.  A NaN the fp32 kernels produce too
+    (inf density x selector 0, as in the reference) survives the re-render unchanged."""
+
+    def __init__(self, scene: "NerfSceneDev", n_groups: int):
+        f = getattr(scene, "field", None)
+        on = (f is not None and f.use_mfma and f.precision != "fp32" and f.mfma16_blob is not None
+              and getattr(scene, "overflow_guard", True))
+        self.scene = scene
+        self.flags = torch.zeros(max(n_groups, 1), dtype=torch.int32, device=scene.device) if on else None
+        self.rerendered: List[int] = []
+
+    def flag(self, g: int) -> Optional[torch.Tensor]:
+        return None if self.flags is None else self.flags[g:g + 1]
+
+    def offenders(self) -> List[int]:
+        """launch groups that saw a NaN -- one device -> host read per frame"""
+        if self.flags is None:
+            return []
+        return [int(i) for i in torch.nonzero(self.flags).flatten().tolist()]
+
+    def redo(self, g: int, render_group):
+        """render_group() again with the exact-fp32 kernels"""
+        f = self.scene.field
+        saved, f.precision = f.precision, "fp32"
+        try:
+            out = render_group()
+        finally:
+            f.precision = saved
+        self.rerendered.append(g)
+        self.scene.overflow_rerenders += 1
+        return out
 
 
 def sample_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Tensor, clip: Optional[torch.Tensor],
@@ -137,7 +178,8 @@ def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: i
 
 def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, feats, clip, ray_offset: int = 0,
                   depth_noise: Optional[torch.Tensor] = None, depth_draws: int = 100, depth_seed: int = 0,
-                  keep_density: bool = False, image_width: int = 0) -> Dict[str, torch.Tensor]:
+                  keep_density: bool = False, image_width: int = 0,
+                  nonfinite_flag: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     f = scene.field
     # ACTIVE / MCDROPOUT: the field kernel writes sample-major planes (whole 32-byte sectors per store) and the
     # composite walks them with a lane per ray; LAPLACE keeps the ray-major layout its depth-draw kernel reads
@@ -145,7 +187,7 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
     density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset, features=feats,
                                             image_width=image_width, sample_major=planes, spacing=scene.spacing)
     kw = dict(clip_minmax=clip, ray_offset=ray_offset, chunk_rays=scene.chunk_rays, spacing=scene.spacing,
-              background=scene.background)
+              background=scene.background, nonfinite_flag=nonfinite_flag)
     res: Dict[str, torch.Tensor] = {}
     if f.mode == _l.FIELD_ACTIVE:
         if planes:
@@ -227,13 +269,25 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
     lists: Dict[str, List[torch.Tensor]] = {}
     with torch.cuda.device(dev):
         cur = torch.cuda.current_stream()
+        guard = OverflowGuard(scene, len(starts))
+
+        def group(gi: int, flag=None):
+            start = starts[gi]
+            o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start))
+            return render_rays(scene, o, d, ray_offset=start, total_rays=total, clip=clip, image_width=W,
+                               init_bins=crop_bins(scene, o, d, obb), nonfinite_flag=flag, **shade_kw)
+
         if not overlap or len(starts) == 1:
-            for start in starts:
-                o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start))
-                out = render_rays(scene, o, d, ray_offset=start, total_rays=total, clip=clip, image_width=W,
-                                  init_bins=crop_bins(scene, o, d, obb), **shade_kw)
+            for gi in range(len(starts)):
+                out = group(gi, guard.flag(gi))
                 for k, v in out.items():
                     lists.setdefault(k, []).append(v)
+            for gi in guard.offenders():
+                # (the sampling stage is fp32 in every precision: it reproduces the group's sample positions, so the
+                # per-chunk clip bounds it re-accumulates with atomic min / max do not move)
+                out = guard.redo(gi, lambda: group(gi))
+                for k, v in out.items():
+                    lists[k][gi] = v
         else:
             s_samp, s_shade = _streams(dev)
             s_samp.wait_stream(cur)

@@ -7,7 +7,7 @@ oracle (`oracle.nerf_oracle.scene_from_tensors`) are built from, so they see ide
 from __future__ import annotations
 
 import math
-from typing import Dict, List
+from typing import Dict, List, Tuple
 
 import numpy as np
 import torch
@@ -51,10 +51,17 @@ def _grid_tcnn(gen, num_levels, min_res, max_res, log2T, table_scale):
 def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, prop_log2T: int = 17,
                        max_res: int = 2048, table_scale: float = 0.5, density_gain: float = 16.0,
                        density_bias: float = -2.0, color_gain: float = 4.0, beta_gain: float = 12.0,
-                       grid: str = "torch") -> Dict:
+                       grid: str = "torch", sharp: bool = False, overflow_units: Tuple[int, ...] = ()) -> Dict:
     """Random-init nerfacto-shaped scene.  Tables U(-1,1)*table_scale; Linear layers
     Kaiming-uniform like nn.Linear; the density row is gained up so accumulation, depth and the
-    variances vary over the image instead of saturating."""
+    variances vary over the image instead of saturating.
+
+    sharp: magnitudes of a TRAINED field instead of a fresh one -- density logits spanning about +-12 (opaque surfaces
+    next to empty space: densities from e^-12 to e^12), colour-head activations of the order 1e3 (first hidden layer
+    scaled up, the next layer's weights scaled down to match), proposal logits likewise.
+    overflow_units: trunk hidden units whose pre-activations reach past 65504 -- beyond the f16 operand range of the
+    f16 matrix kernels -- on ~9 % of the samples (first-layer rows of +-5e4, inside the weight limit the packer checks);
+    their outgoing weights are 1e-6-small, so in fp32 arithmetic they move the outputs by less than 1."""
     assert kind in ("active", "mcdropout", "laplace") and grid in ("torch", "tcnn")
     gen = torch.Generator().manual_seed(seed)
     make_grid = _grid_tcnn if grid == "tcnn" else _grid
@@ -92,6 +99,24 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
         p["w1"][0] *= density_gain
         p["b1"][0] = density_bias + math.log(100.0)  # proposal nets carry average_init_density = 0.01
         props.append(p)
+    if sharp:
+        if kind == "laplace":
+            f["density_w"] = f["density_w"] * 8.0
+            f["density_b"] = f["density_b"] * 0.0
+        else:
+            f["w1"][0] *= 8.0
+            f["b1"][0] = 0.0
+        f["head_w"][0] = f["head_w"][0] * 4e3
+        f["head_b"][0] = f["head_b"][0] * 4e3
+        f["head_w"][1] = f["head_w"][1] * 2.5e-4
+        for p in props:
+            p["w1"][0] *= 3.0
+    for u in overflow_units:
+        f["w0"][u] = torch.sign(f["w0"][u]) * 5e4
+        f["b0"][u] = 0.0
+        f["w1"][:, u] = torch.sign(f["w1"][:, u]) * 1e-6
+        if kind == "laplace":
+            f["density_w"][:, u] = torch.sign(f["density_w"][:, u]) * 1e-6
     return {"kind": kind, "field": f, "props": props, "near": 0.05, "far": 1000.0, "num_prop": (256, 96),
             "num_nerf": 48, "prop_average_init_density": 0.01}
 
