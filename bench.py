@@ -63,6 +63,7 @@ def _alg(kind, K):
     }
 
 
+STALE_PROFILES = []            # issue / traffic profiles under profiles/ that were taken from other kernel sources
 ISSUE_PEAK_GCYC = 1024 * 2.4   # 256 CUs x 4 SIMDs x 2.4 GHz peak engine clock: issue cycles per nanosecond x 1e9
 
 
@@ -77,7 +78,15 @@ def _issue_profile(method, K):
     if not os.path.exists(f):
         return None
     j = json.load(open(f))
-    return j if j.get("K", 0) == K else None
+    if j.get("K", 0) != K:
+        return None
+    # the instruction counts describe ONE build of the kernels: a profile taken from other sources is not used (the
+    # roofline then falls back to the matrix-pipe / algorithmic-gather figures and says so)
+    from uncertainty_nerf_gs_amd import lib
+    if j.get("kernel_source_digest") not in (None, lib._source_digest()):
+        STALE_PROFILES.append(os.path.basename(f))
+        return None
+    return j
 
 
 def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check=True, want_cpu=True, precision=None):
@@ -219,12 +228,18 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     if os.path.exists(tfile):  # HBM-side bytes from committed rocprofv3 --pmc passes of this command
         tj = json.load(open(tfile))
         tk = tj.get("kernels", {}).get(dom)
+        from uncertainty_nerf_gs_amd import lib
+        if tj.get("kernel_source_digest") not in (None, lib._source_digest()):
+            STALE_PROFILES.append(os.path.basename(tfile))
+            tk = None
         if tk and K == tj.get("K", 0):
             scale = rays_per_launch / tj["rays_per_launch"]
             roof["traffic"] = (tk["fetch_bytes"] + tk["write_bytes"]) * scale
             roof["traffic_source"] = tj["source"]
             roof["other_roofs"]["hbm_traffic_GBps"] = roof["traffic"] / avg_s / 1e9
             roof["other_roofs"]["hbm_frac"] = roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS
+    if STALE_PROFILES:
+        roof["stale_profiles_ignored"] = sorted(set(STALE_PROFILES))
     roof["per_kernel_ms_per_frame"] = {k: round(v["total_ms"] / steps, 3) for k, v in sorted(ksum.items())}
     path_bytes = sum(alg[k]["bytes"] for k in ksum if k in alg)
     roof["path_bytes_per_ray"] = path_bytes
@@ -494,8 +509,21 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
         N = args.splats
         frame_bytes = N * 240 + 2 * N * 36 + n_isect * 96 + 2 * n_isect * 36 + H * W * 7 * 4
         sort_bytes = n_isect * 96
-        kbytes = {"splat_bin_sort": sort_bytes, "splat_rasterize": n_isect * 36 + H * W * 4 * 4}
+        kbytes = {"splat_bin_sort": sort_bytes, "splat_rasterize_c5": n_isect * 36 + H * W * 7 * 4,
+                  "splat_rasterize_c1": n_isect * 20 + H * W * 3 * 4}
         ach = kbytes.get(dom, 0) / (ksum[dom]["avg_ms"] * 1e-3) / 1e9 if dom in kbytes else None
+        # The rasteriser is bound by VALU issue per (pixel, splat) pair, not by bytes (its splat lists are staged through
+        # LDS once per tile): with a committed SQ counter pass of this command the roof is instruction issue, as for the
+        # field kernels -- achieved = 4 x VALU instructions of one 5-channel raster launch / its live duration.
+        iss = _issue_profile("splat", 0) if dom == "splat_rasterize_c5" else None
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_splat.json")
+        if os.path.exists(tfile):
+            from uncertainty_nerf_gs_amd import lib
+            tj = json.load(open(tfile))
+            if tj.get("kernel_source_digest") in (None, lib._source_digest()) and "field_fwd" in tj.get("kernels", {}):
+                tk = tj["kernels"]["field_fwd"]     # (summarize_pmc's slot name for a profile's dominant kernel)
+                traffic = tk["fetch_bytes"] + tk["write_bytes"]
         line = {
             "metric": "Mrays/s (+var) [pixels of an active-splatfacto frame], 1080p", "value": H * W * steps * world / elapsed / 1e6,
             "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -503,9 +531,19 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"active-splatfacto {W}x{H}, N={args.splats} splats, rgb+beta+depth+depth_var",
                        "parallelism": f"views x{world}" if world > 1 else "single"},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": None if ach is None else ach / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": ksum[dom]["avg_ms"], "num_intersects": n_isect,
+            "roofline": {"kernel": dom,
+                         **({"bound": "valu-issue", "unit": "Gcycle/s", "peak": ISSUE_PEAK_GCYC,
+                             "achieved": iss["issue_cycles_per_launch"] / (ksum[dom]["avg_ms"] * 1e-3) / 1e9,
+                             "frac": iss["issue_cycles_per_launch"] / (ksum[dom]["avg_ms"] * 1e-3) / 1e9 / ISSUE_PEAK_GCYC,
+                             "issue_source": iss["source"], "issue_kernel": iss["kernel_name"],
+                             "note": "issue cycles of the 5-channel raster launch (4 x VALU instructions, committed PMC pass) "
+                                     "over the mean live duration of the frame's raster launches"}
+                            if iss is not None else
+                            {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": None if ach is None else ach / HBM_PEAK_GBS,
+                             "note": "no PMC issue profile for these sources: algorithmic bytes (binds nothing; the kernel is "
+                                     "VALU-issue bound per pixel-splat pair)"}),
+                         "traffic": traffic, "avg_launch_ms": ksum[dom]["avg_ms"], "num_intersects": n_isect,
                          "frame_algorithmic_bytes": frame_bytes,
                          "frame_frac_of_hbm_peak": frame_bytes * steps * world / elapsed / 1e9 / HBM_PEAK_GBS,
                          "per_kernel_ms_per_frame": {k: round(v["total_ms"] / steps, 3) for k, v in sorted(ksum.items())}},

@@ -14,10 +14,17 @@ mkdir -p "$OUT" "$DST"
 export TMPDIR=/tmp
 cd /tmp
 
-stats() {  # method, extra bench args...
+margs() {  # profile id -> bench.py arguments
+    case $1 in
+        mcdropout_f16) echo "--method mcdropout --precision f16" ;;
+        *) echo "--method $1" ;;
+    esac
+}
+
+stats() {  # profile id
     local m=$1; shift
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${m}_stats" -- \
-        python3 "$ROOT/bench.py" --method "$m" --steps 4 --warmup 1 --no-cpu-baseline --no-exact-check "$@" > "$OUT/${m}_stats.log" 2>&1
+        python3 "$ROOT/bench.py" $(margs $m) --steps 4 --warmup 1 --no-cpu-baseline --no-exact-check "$@" > "$OUT/${m}_stats.log" 2>&1
     local f
     f=$(find "$OUT/${m}_stats" -name '*kernel_stats.csv' | head -1)
     [ -n "$f" ] && cp "$f" "$DST/${TAG}_${m}_kernel_stats.csv"
@@ -27,20 +34,22 @@ stats() {  # method, extra bench args...
 pmc() {  # method, set name, counters...
     local m=$1 name=$2; shift 2
     rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/${m}_pmc_$name" -- \
-        python3 "$ROOT/bench.py" --method "$m" --steps 1 --warmup 1 --no-cpu-baseline --no-exact-check > "$OUT/${m}_pmc_$name.log" 2>&1
+        python3 "$ROOT/bench.py" $(margs $m) --steps 1 --warmup 1 --no-cpu-baseline --no-exact-check > "$OUT/${m}_pmc_$name.log" 2>&1
     local f
     f=$(find "$OUT/${m}_pmc_$name" -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && python3 "$ROOT/benchmarks/summarize_pmc.py" reduce "$f" "$DST/${TAG}_${m}_pmc_$name.csv"
 }
 
-for m in active mcdropout laplace splat; do stats $m; done
-for m in active mcdropout; do
+ALL="active mcdropout mcdropout_f16 laplace splat"
+for m in $ALL; do stats $m; done
+for m in $ALL; do
     pmc $m fetch FETCH_SIZE
     pmc $m write WRITE_SIZE
 done
-for m in active mcdropout; do
+for m in $ALL; do
     pmc $m sq SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
 done
+pmc splat lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAVES
 pmc active ta TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
 pmc active tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
 python3 "$ROOT/benchmarks/summarize_pmc.py" summary "$DST" "$TAG"

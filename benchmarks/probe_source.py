@@ -7,6 +7,7 @@ inserted at (or substituted for the span of) a marker, for the measurement scrip
     python benchmarks/probe_source.py --extra-valu 32 -o /tmp/unerf_nerf_valu32.hip      # benchmarks/exp_issue_model.sh
     python benchmarks/probe_source.py --extra-mfma 8 -o /tmp/unerf_nerf_mfma8.hip
     python benchmarks/probe_source.py --no-prop-mlp -o /tmp/unerf_nerf_nomlp.hip         # benchmarks/exp_prop_mlp_bound.sh
+    python benchmarks/probe_source.py --no-prop-level0 -o /tmp/unerf_nerf_nol0.hip       # benchmarks/exp_prop_level0.sh
 
 The copies produce WRONG or slower results by design; nothing in the package builds or loads them."""
 import argparse
@@ -47,6 +48,8 @@ def main():
     ap.add_argument("--extra-valu", type=int, default=0)
     ap.add_argument("--extra-mfma", type=int, default=0)
     ap.add_argument("--no-prop-mlp", action="store_true")
+    ap.add_argument("--no-prop-level0", action="store_true",
+                    help="proposal kernels: level 0 of the grid without its gathers (upper bound of what LDS staging could save)")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
     s = open(SRC).read()
@@ -57,6 +60,11 @@ def main():
     if a.no_prop_mlp:
         s, n = re.subn(r"        // \[probe:prop-mlp-out begin\].*?// \[probe:prop-mlp-out end\]\n", NO_PROP_MLP, s, flags=re.S)
         assert n == 1
+    if a.no_prop_level0:
+        pat = re.compile(r"^( *)\} else if \(l < a\.net\.n_dense\) \{  // wave-uniform: coarse level with a dense, x-paired copy\n", re.M)
+        s, n = pat.subn(lambda m: f"{m.group(1)}}} else if (l == 0) {{  // probe: no gathers for level 0 (wrong results)\n"
+                                  f"{m.group(1)}    f = make_float2(px * py, pz);\n" + m.group(0), s)
+        assert n == 2      # prop_density_kernel and prop_patch_kernel
     # the copy lives outside csrc/: point its includes back at the product headers
     s = s.replace('#include "unerf_common.hpp"', f'#include "{os.path.join(os.path.dirname(SRC), "unerf_common.hpp")}"')
     with open(a.out, "w") as f:

@@ -39,11 +39,29 @@ def reduce(src, dst):
 # the dominant field kernel of a method = the first kernel name with one of these prefixes (template arguments after the
 # prefix -- tcnn / sites / drop flags -- vary with the round)
 FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false", "field_kernel_mfma<0, false"),
-                 "mcdropout": ("field_kernel_mfma16<1, false", "field_kernel_mfma<1, false")}
+                 "mcdropout": ("field_kernel_mfma16<1, false, false, true, false", "field_kernel_mfma16<1, false", "field_kernel_mfma<1, false"),
+                 "mcdropout_f16": ("field_kernel_mfma16<1, false, false, true, true",),
+                 "laplace": ("field_kernel_mfma16_laplace<false, false", "field_kernel_mfma16_laplace<false"),
+                 "splat": ("raster_kernel<5",)}
+# further kernels of a profile that get their own issue_<name>.json (same definition)
+EXTRA_ISSUE = {"laplace": {"lap_depth": ("lap_depth_kernel<3",)}, "splat": {"splat_raster1": ("raster_kernel<1",)}}
+K_OF = {"mcdropout": 8, "mcdropout_f16": 8}
+
+
+def _source_digest():
+    """sha256 of the kernel sources the counters were taken from (uncertainty_nerf_gs_amd.lib._source_digest): bench.py
+    uses an issue profile only while the sources it describes are the ones that are built"""
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in _sys.path:
+        _sys.path.insert(0, root)
+    from uncertainty_nerf_gs_amd import lib
+    return lib._source_digest()
 
 
 def summary(d, tag):
-    for method in ("active", "mcdropout"):
+    digest = _source_digest()
+    for method in ("active", "mcdropout", "mcdropout_f16", "laplace", "splat"):
         kernels = defaultdict(dict)
         for fn in sorted(os.listdir(d)):
             m = re.match(rf"{tag}_{method}_pmc_(\w+)\.csv$", fn)
@@ -53,6 +71,7 @@ def summary(d, tag):
                 for row in csv.DictReader(f):
                     kernels[row["kernel"]][row["counter"]] = float(row["mean_value"])
                     kernels[row["kernel"]].setdefault("avg_dur_us", float(row["mean_dur_us"]))
+                    kernels[row["kernel"]].setdefault("launches", int(row["launches"]))
         if not kernels:
             continue
         out = {"command": "benchmarks/collect_profiles.sh (one rocprofv3 --pmc pass per counter set, --kernel-trace only)",
@@ -63,7 +82,7 @@ def summary(d, tag):
             json.dump(out, f, indent=1)
         fk = next((k for pre in FIELD_KERNELS[method] for k in sorted(kernels) if k.startswith(pre)), None)
         if fk and "FETCH_SIZE" in kernels[fk] and "WRITE_SIZE" in kernels[fk]:
-            t = {"method": method, "K": 8 if method == "mcdropout" else 0, "rays_per_launch": 262144,
+            t = {"method": method, "K": K_OF.get(method, 0), "rays_per_launch": 2073600 if method == "splat" else 262144, "kernel_source_digest": digest,
                  "source": f"profiles/{tag}_{method}_pmc_fetch.csv + {tag}_{method}_pmc_write.csv "
                            "(separate rocprofv3 --pmc passes)",
                  "kernels": {"field_fwd": {
@@ -75,7 +94,11 @@ def summary(d, tag):
             with open(os.path.join(d, f"traffic_{method}.json"), "w") as f:
                 json.dump(t, f, indent=1)
         need = ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")
-        if fk and all(c in kernels[fk] for c in need):
+        targets = [(method, fk)]
+        for name, prefixes in EXTRA_ISSUE.get(method, {}).items():
+            targets.append((name, next((k for pre in prefixes for k in sorted(kernels) if k.startswith(pre)), None)))
+        for issue_name, fk in targets:
+          if fk and all(c in kernels[fk] for c in need):
             kk = kernels[fk]
             # Issue cycles a launch NEEDS: 4 per wave64 VALU instruction, 32 per v_mfma_f32_32x32x16_f16 (the costs
             # benchmarks/mfma_valu_overlap_probe.hip measures; the two classes share the SIMD's issue pipe and do not
@@ -89,7 +112,10 @@ def summary(d, tag):
             issue = 4.0 * valu_n + 32.0 * kk["SQ_INSTS_MFMA"]
             counters = 4.0 * kk["SQ_ACTIVE_INST_VALU"] + kk["SQ_VALU_MFMA_BUSY_CYCLES"]
             simd_cycles = kk["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-            j = {"method": method, "K": 8 if method == "mcdropout" else 0, "rays_per_launch": 262144, "kernel_name": fk,
+            j = {"method": issue_name, "K": K_OF.get(method, 0), "rays_per_launch": 2073600 if method == "splat" else 262144,
+                 "kernel_name": fk,
+                 "kernel_source_digest": digest, "launches_per_frame": kk.get("launches"),
+                 "wait_any_frac_of_wave_cycles": (kk["SQ_WAIT_ANY"] / kk["SQ_WAVE_CYCLES"]) if kk.get("SQ_WAVE_CYCLES") else None,
                  "source": f"profiles/{tag}_{method}_pmc_sq.csv (rocprofv3 --pmc, own pass)",
                  "issue_cycles_per_launch": issue,
                  "definition": "4 x (SQ_INSTS_VALU - SQ_INSTS_MFMA) + 32 x SQ_INSTS_MFMA",
@@ -98,7 +124,7 @@ def summary(d, tag):
                  "simd_cycles_per_launch": simd_cycles, "busy_frac": issue / simd_cycles,
                  "busy_frac_from_busy_counters": counters / simd_cycles,
                  "engine_clock_GHz_under_profiler": kk["GRBM_GUI_ACTIVE"] / 8.0 / (kk["avg_dur_us"] * 1e3)}
-            with open(os.path.join(d, f"issue_{method}.json"), "w") as f:
+            with open(os.path.join(d, f"issue_{issue_name}.json"), "w") as f:
                 json.dump(j, f, indent=1)
 
 

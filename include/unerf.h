@@ -279,6 +279,11 @@ typedef struct {
        models/activenerfacto/activenerfacto_field.py:89).  0: the split form above (fp32-equivalent).  Biases, the
        64 -> 3 colour layer and every activation function stay fp32 in both forms. */
     int f16_single;
+    /* f16_single only, DEVICE int32 (may be NULL): |= 1 when an output pre-activation (density logit, colour sums;
+       LAPLACE: a sampled-head mean) comes out inf / NaN -- the trace an activation beyond the f16 range (65504) leaves
+       in this form, which has no lo halves to turn it into a NaN sample.  Same word and same host protocol as the
+       composite entry points' nonfinite_flag (render.OverflowGuard: fp32 re-render of the launch group). */
+    int32_t* overflow_flag;
 } unerf_field_params;
 #define UNERF_DROP_TRUNK 1
 #define UNERF_DROP_HEAD0 2
@@ -422,11 +427,19 @@ int unerf_splat_bin_sort(const float* xys, const float* depths, const int32_t* r
 
 /* rasterize_forward / nd_rasterize_forward: C channels blended in one pass.
  * colors [N,C] (C<=8), opacities [N], background [C] DEVICE (NULL = zeros),
- * out_img [H,W,C], final_T [H,W], final_idx [H,W] i32 (may be NULL). */
+ * out_img [H,W,C], final_T [H,W], final_idx [H,W] i32 (may be NULL): index (into gaussian_ids_sorted) of the last splat
+ * blended into the pixel, 0 when there is none.
+ * stop_idx [H,W] i32 (may be NULL): the final_idx of an earlier pass over the SAME ids / bins / xys / conics / opacities
+ * (the reference's depth-variance pass, :343-356, after its rgb pass): each pixel then stops behind that index instead
+ * of re-deriving its end from the transmittance -- same blended terms, same result.
+ * flags: 0, or UNERF_RASTER_NO_CULL to walk every staged splat in every wave (gsplat's schedule).  By default a wave (a
+ * 4-row strip of the 16 x 16 tile) walks only the splats whose alpha >= 1/255 ellipse can reach its strip; the skipped
+ * (pixel, splat) pairs are pairs the blend loop would have skipped itself, so both settings give identical bits. */
+#define UNERF_RASTER_NO_CULL 1
 int unerf_splat_rasterize(const int32_t* gaussian_ids_sorted, const int32_t* tile_bins, const float* xys,
                           const float* conics, const float* colors, const float* opacities,
-                          const float* background, int C, int H, int W, int block_width, float* out_img,
-                          float* final_T, int32_t* final_idx, void* stream);
+                          const float* background, int C, int H, int W, int block_width, const int32_t* stop_idx,
+                          int flags, float* out_img, float* final_T, int32_t* final_idx, void* stream);
 
 /* :319 / :356  img = where(alpha>0, img/alpha, max(img)) with alpha = 1-final_T, applied IN PLACE
  * to channel `ch` of an interleaved image [HW, stride]; scratch_max = 1 device float. */

@@ -510,16 +510,26 @@ def mc_keep_mask(seed: int, pass_idx: int, sample_idx: np.ndarray, stream: int, 
     return np.stack([lo, hi], axis=-1).reshape(base.shape[0], n_units)
 
 
+def _xorshift32(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint32)
+    x = x ^ (x << np.uint32(13))
+    x = x ^ (x >> np.uint32(17))
+    x = x ^ (x << np.uint32(5))
+    return x
+
+
 def normal_noise(seed: int, draw: int, sample_idx: np.ndarray) -> np.ndarray:
-    """Box-Muller standard normal per (draw, sample), fp32 -- twin of the kernel's generator used when
-    no explicit noise tensor is supplied (laplace depth draws).  Draws come in pairs: the pair index
-    draw>>1 keys the two uniforms, the even draw takes the cosine branch, the odd one the sine."""
-    base = mc_base(seed, draw >> 1, sample_idx)
-    with np.errstate(over="ignore"):
-        r1 = base                      # the keyed sample hash is the first uniform's word ...
-        r2 = _hash32(base + GOLDEN)    # ... one more hash gives the second (two hashes per draw pair)
-    u1 = ((r1 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
-    u2 = ((r2 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    """Standard normal per (draw, sample), fp32 -- twin of the kernel's generator used when no explicit noise tensor is
+    supplied (laplace depth draws; csrc: unerf_depth_stream_seed / unerf_xorshift32 / unerf_normal_pair_from_state).
+    Every sample owns one xorshift32 stream seeded by the counter hash of its global index (0 -> GOLDEN) and stepped
+    once per draw PAIR; the 16-bit halves of the state are the two uniforms of a Box-Muller pair, the even draw takes
+    the cosine branch, the odd one the sine."""
+    x = mc_base(seed, 0, sample_idx)
+    x = np.where(x == 0, GOLDEN, x).astype(np.uint32)
+    for _ in range(draw >> 1):
+        x = _xorshift32(x)
+    u1 = ((x >> np.uint32(16)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 65536.0)
+    u2 = ((x & np.uint32(0xFFFF)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 65536.0)
     rad = np.sqrt(np.float32(-2.0) * np.log(u1)).astype(np.float32)
     ang = np.float32(2.0 * math.pi) * u2
     return (rad * (np.sin(ang) if (draw & 1) else np.cos(ang))).astype(np.float32)

@@ -58,7 +58,7 @@ def test_bad_shapes_are_rejected(lib):
     rc = h.unerf_weights_pdf_resample(1, 1, 0, 4, 300, 0.05, 1000.0, 0, 1, 96, 0.01, 1e-5, 1, None, None, None, 0, 32768,
                                       None)
     assert rc == -1 and b"outside" in h.unerf_last_error()
-    rc = h.unerf_splat_rasterize(None, 1, 1, 1, 1, 1, None, 9, 16, 16, 16, 1, 1, None, None)
+    rc = h.unerf_splat_rasterize(None, 1, 1, 1, 1, 1, None, 9, 16, 16, 16, None, 0, 1, 1, None, None)
     assert rc == -1 and b"C=9" in h.unerf_last_error()
 
 

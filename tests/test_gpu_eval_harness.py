@@ -80,7 +80,8 @@ def test_run_eval_on_hip_renders_matches_oracle_render_through_reference_metrics
         if kind == "active":
             ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d)
         else:
-            ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, K, seed, 0.2, ray_offset=off), o, d)
+            fs = models.frame_seed(seed, i)   # every render draws fresh masks: the i-th camera's stream
+            ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, K, fs, 0.2, ray_offset=off), o, d)
         gt = _gt(ref["rgb"], 100 + i)
         refs.append(_cpu_reference_metrics(ref, gt))
         eval_set.append((cam, gt))

@@ -268,3 +268,38 @@ def test_full_size_splat_frame_properties(dev):
     empty = out1["accumulation"][..., 0] == 0
     if empty.any():   # untouched pixels show the background exactly
         assert torch.equal(out1["rgb"][empty], bg.expand_as(out1["rgb"][empty]))
+
+
+@pytest.mark.parametrize("C", [1, 5])
+def test_wave_level_culling_and_bounded_pass_change_no_bit(dev, C):
+    """the default schedule (a wave walks only the splats whose alpha >= 1/255 ellipse reaches its 4 x 16 strip) against
+    gsplat's (every wave walks every staged splat): identical images, transmittances and final indices; and a second
+    pass bounded by the first pass's final indices (the depth-variance pass) equals the unbounded one.  Splats with
+    tiny opacity and huge / needle-shaped / degenerate / indefinite conics are in the set."""
+    from uncertainty_nerf_gs_amd import ops
+    N, H, W = 6000, 100, 150
+    gp = _scene(N)
+    gp["scales"][:50] += 2.0                     # a few very large splats
+    gp["scales"][50:100, 0] -= 3.0               # needles
+    gp["opacities"][100:400] = -7.0              # sigmoid -> 9e-4 < 1/255: never visible
+    ref, got, _ = _project_both(gp, _camera(2.2), 60.0, 60.0, W / 2, H / 2, H, W, dev)
+    xys, depths, radii, conics, comp, tiles, _ = got
+    # (xys / radii / tiles stay as projected: the binning derives its intersection counts from them)
+    conics = conics.clone()
+    conics[450:460] = 0.0                                    # det = 0: no ellipse -> must not be culled wrongly
+    conics[460:470, 1] = 5.0                                 # indefinite form (sigma can be negative)
+    I, cum, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W)
+    g = torch.Generator().manual_seed(C)
+    colors = torch.rand(N, C, generator=g).to(dev)
+    opac = torch.sigmoid(gp["opacities"]).reshape(-1).to(dev)
+    bg = torch.rand(C, generator=g).to(dev)
+    a = ops.splat_rasterize(gids, bins, xys, conics, colors, opac, H, W, bg, want_final_idx=True)
+    b = ops.splat_rasterize(gids, bins, xys, conics, colors, opac, H, W, bg, want_final_idx=True, cull=False)
+    for x, y, what in zip(a, b, ("image", "final_T", "final_idx")):
+        assert torch.equal(x, y), what
+    assert float((a[1] < 1).float().mean()) > 0.5            # the scene does cover the image
+    c = ops.splat_rasterize(gids, bins, xys, conics, colors, opac, H, W, bg, stop_idx=a[2])
+    assert torch.equal(c[0], a[0])
+    # final_T of a bounded pass: the transmittance behind the last BLENDED splat -- the unbounded pass may have multiplied
+    # one more (1 - alpha) in before its T <= 1e-4 stop... it does not: the stopping splat is not applied either
+    assert torch.equal(c[1], a[1])

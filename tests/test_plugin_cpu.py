@@ -126,7 +126,8 @@ def test_rendering_methods_take_nerfstudio_types_and_forward_to_the_mirror(monke
 
     monkeypatch.setattr(render, "render_rays", fake_render_rays)
     monkeypatch.setattr(models._NerfactoBase, "device_scene",
-                        lambda self, device=None: type("S", (), {"device": torch.device("cpu"), "chunk_rays": 1 << 15})())
+                        lambda self, device=None: type("S", (), {"device": torch.device("cpu"), "chunk_rays": 1 << 15,
+                                                                 "field": type("F", (), {"seed": 0, "use_mfma": False})()})())
     H, W = 6, 9
     bundle = RayBundle(origins=torch.zeros(H, W, 3), directions=torch.ones(H, W, 3))
     out = model.get_outputs_for_camera_ray_bundle(bundle)
@@ -186,3 +187,23 @@ def test_plugin_needs_nerfstudio_only_for_the_registry_objects():
     assert plugin.build_model("active-nerfacto").config.eval_num_rays_per_chunk == 1 << 15
     with pytest.raises(AttributeError):
         plugin.NoSuchThing
+
+
+def test_ns_config_annotations_are_resolved_types_not_strings():
+    """models.py uses postponed annotations; the dynamic nerfstudio ModelConfig classes must carry evaluated types (tyro /
+    typing.get_type_hints resolve a dynamic class's strings in plugin.py's namespace, where they resolved only by luck)"""
+    import dataclasses
+    import typing
+    from uncertainty_nerf_gs_amd import plugin
+    for name in ("NerfactoMCDropoutModelConfig", "ActiveNerfactoModelConfig", "NerfactoLaplaceModelConfig", "ActiveSplatfactoModelConfig"):
+        cls = getattr(plugin, name)
+        ann = {}
+        for k in reversed(cls.__mro__):
+            ann.update(getattr(k, "__annotations__", {}))
+        own = {f.name for f in dataclasses.fields(cls)}
+        for fname in ("background_color", "rasterize_mode", "proposal_net_args_list", "num_proposal_samples_per_ray", "mc_samples"):
+            if fname in own:
+                assert not isinstance(ann[fname], str), (name, fname, ann[fname])
+        typing.get_type_hints(cls)      # and the whole class resolves without this module's globals
+    nerf = plugin.NerfactoMCDropoutModelConfig
+    assert {"proposal_initial_sampler", "background_color"} <= {f.name for f in dataclasses.fields(nerf)}

@@ -1782,6 +1782,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const uint32_t tpx = (num_tiles + 7u) / 8u;
     const uint32_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
+    bool f1_bad = false;   // F1: an output pre-activation of this lane was inf / NaN (see the epilogue)
     for (uint32_t tile = xcd * tpx + (uint32_t)slot * 4u + (uint32_t)wv; tile < tile_end; tile += (uint32_t)bpx * 4u) {
         int lane = lane_c;  // opaque per iteration: keeps the (tile-invariant) LDS operand reads inside the loop
         asm volatile("" : "+v"(lane));
@@ -1966,6 +1967,11 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 const OutIndex q = out_index(a, k, ts);
                 const float x = h ? o[1] : o[0];
                 const float y = h ? -o[2] : t[0];                 // h = 1: exp(-blue) for its sigmoid; h = 0: exp(logit)
+                // F1 has no lo halves to turn an operand overflow into NaN: an activation beyond 65504 becomes an f16 inf,
+                // which reaches every unit of the next layer (inf w, or inf - inf = NaN) and from there the density logit
+                // (trunk units) or the three colour sums (head units) -- but sigmoid / exp map +-inf to 0, 1, inf: plausible
+                // pixels.  So the four PRE-activation values are tested here (two per lane): two compares per pass.
+                if (F1) f1_bad |= !(fabsf(x) < INFINITY) | !(fabsf(y) < INFINITY);
                 const float ey = __expf(y);
                 const float vy = h ? __builtin_amdgcn_rcpf(1.f + ey) : a.p.average_init_density * ey * sel;
                 a.rgb[q.rgb + (h ? q.rgb_stride : 0)] = mf_sigmoid_fast(x);
@@ -1974,6 +1980,10 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 if (MODE == UNERF_FIELD_ACTIVE && h == 0) a.aux[q.aux] = unerf_softplus(t[8]) + a.p.beta_min;
             }
         }
+    }
+    if (F1 && a.p.overflow_flag) {   // one atomic per offending wave and launch
+        const uint64_t m = __builtin_amdgcn_ballot_w64(f1_bad);
+        if (m != 0 && lane_c == (int)__builtin_ctzll(m)) atomicOr(a.p.overflow_flag, 1);
     }
 }
 
@@ -2280,6 +2290,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const uint32_t tpx = (num_tiles + 7u) / 8u;
     const uint32_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
+    bool f1_bad = false;   // F1: a sampled-head mean of this lane came out inf / NaN
     for (uint32_t tile = xcd * tpx + (uint32_t)slot * 4u + (uint32_t)wv; tile < tile_end; tile += (uint32_t)bpx * 4u) {
         int lane = lane_c;
         asm volatile("" : "+v"(lane));
@@ -2354,6 +2365,9 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
             mu_c[c] = c1s * inv_n;
             vsum += fmaxf(c2s * inv_n - mu_c[c] * mu_c[c], 0.f);
         }
+        // F1: an f16 operand beyond 65504 turns the sampled rows into +-inf / NaN; a density mean of +inf from a FINITE
+        // logit is not possible below e^88, so non-finite means are treated as operand overflow (see field_kernel_mfma16)
+        if (F1 && valid) f1_bad |= !(fabsf(mu_d) < INFINITY) | !(fabsf(mu_c[0] + mu_c[1] + mu_c[2]) < INFINITY);
         if (valid && h == 0) {
             a.density[n] = mu_d;
             a.aux[n] = mu2_d - mu_d * mu_d;
@@ -2362,6 +2376,10 @@ __global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, 
             a.rgb[n * 3 + 1] = mu_c[1];
             a.rgb[n * 3 + 2] = mu_c[2];
         }
+    }
+    if (F1 && a.p.overflow_flag) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(f1_bad);
+        if (m != 0 && lane_c == (int)__builtin_ctzll(m)) atomicOr(a.p.overflow_flag, 1);
     }
 }
 
@@ -3266,34 +3284,51 @@ struct LapDepthArgs {
     float* out;
 };
 
-// Box-Muller on two hashed uniforms; BOTH outputs are used (cos for even draws, sin for odd ones of
-// a draw pair), with the hardware log / sin / cos (twin: oracle normal_noise).  `base` = mc_base(key, sample)
-// is itself the first uniform's word; the second is one more hash of it (two hashes per draw PAIR).
-__device__ __forceinline__ void unerf_normal_pair_from_hash(uint32_t base, float& z0, float& z1) {
-    const uint32_t r1 = base, r2 = unerf_hash32(base + UNERF_GOLDEN);
-    float u1 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float u2 = ((float)(r2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float rad = sqrtf(-2.f * __logf(u1));
-    z0 = rad * __cosf(6.283185307179586f * u2);
-    z1 = rad * __sinf(6.283185307179586f * u2);
+// Built-in generator of the depth draws (noise == NULL; twin: oracle normal_noise).  The round-2 form spent two full
+// 32-bit hashes (four quarter-rate integer multiplies) per draw PAIR and sample -- more issue slots than the Box-Muller
+// transform they feed.  Now every (ray, sample) owns ONE xorshift32 stream, seeded by the counter hash of its global sample
+// index (so launch grouping still cannot change a draw) and stepped once per draw pair (six full-rate shift / xor
+// instructions); the two 16-bit halves of the state are the two uniforms of a Box-Muller pair, BOTH of whose outputs are
+// used (cos for the even draw, sin for the odd one).  v_log_f32 is log2, v_sin / v_cos take revolutions: no argument
+// scaling.  16-bit uniforms bound |z| by sqrt(34 ln 2) = 4.85 and quantise the radius to 65536 levels -- far below the
+// Monte-Carlo error of a 100-draw mean (tests: moments, independence between samples, draws and halves).
+__device__ __forceinline__ uint32_t unerf_xorshift32(uint32_t x) {
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    return x;
+}
+__device__ __forceinline__ uint32_t unerf_depth_stream_seed(uint32_t seed, uint32_t sample_idx) {
+    const uint32_t x = unerf_mc_base(unerf_mc_key(seed, 0u), sample_idx);
+    return x ? x : UNERF_GOLDEN;   // 0 is xorshift's fixed point
+}
+__device__ __forceinline__ void unerf_normal_pair_from_state(uint32_t x, float& z0, float& z1) {
+    const float u1 = fmaf((float)(x >> 16), 1.0f / 65536.0f, 0.5f / 65536.0f);
+    const float u2 = fmaf((float)(x & 0xFFFFu), 1.0f / 65536.0f, 0.5f / 65536.0f);
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+    z0 = rad * __builtin_amdgcn_cosf(u2);
+    z1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
-// get_weights for the Monte-Carlo depth draws on the hardware exp, ONE per sample: with e_i = exp(-delta_i
-// sigma_i) the weights are (1 - e_i) * prod_{j<i} e_j -- the transmittance as a running product (a 16-lane
-// multiplicative scan) instead of a second exp of the running sum.  The 100-draw mean absorbs the ~1e-6
-// difference from get_weights' exp(-cumsum) form (tests/test_gpu_nerf_kernels.py: explicit-noise parity).
-// nd2 = -delta * log2(e), formed once per sample outside the draw loop, makes the exponential the bare v_exp_f32.
-// (1 - e) * T is >= 0 or NaN here (e in [0, 1] unless a density is NaN), so nan_to_num is one v_max_f32 with 0 --
-// the general form costs three compares and three selects per weight, a sixth of this kernel's instructions.
+// get_weights for the Monte-Carlo depth draws.  With e_i = exp(-delta_i sigma_i) the weights are
+//   w_i = (1 - e_i) prod_{j<i} e_j = P_i - P_{i+1},   P_i = prod_{j<i} e_j,
+// the transmittance as a running product (a 16-lane multiplicative scan of the lanes' own products) instead of a second
+// exp of the running sum.  Per draw and sample: the exponent min(a_i z + b_i, 0) with a_i = -delta_i log2(e) sd_i and
+// b_i = -delta_i log2(e) mu_i formed once per sample (= -delta log2(e) relu(mu + sd z): -delta <= 0 turns the relu into a
+// min), one v_exp_f32, one multiply for the running product, one subtract, and one fma that adds carry * (P_i - P_{i+1})
+// to the sample's sum over the draws -- 7 issue slots + 5 DPP multiplies per lane and draw (round 2: 12 + 5).
+// NaN (a NaN mean or variance reaches every draw alike) poisons the sums it would zero in get_weights' nan_to_num: this
+// sample, the later ones of the lane and, through the carry, of the ray; the caller maps the final NaN to 0.
 template <int SPL>
-__device__ __forceinline__ void group_weights_fast(const float (&dens)[SPL], const float (&nd2)[SPL], int l16,
-                                                   float (&w)[SPL]) {
-    float em[SPL], lex[SPL], lp = 1.f;
+__device__ __forceinline__ void group_weights_accumulate(const float (&z)[SPL], const float (&a)[SPL], const float (&b)[SPL],
+                                                         float (&wsum)[SPL]) {
+    float dl[SPL], lp = 1.f;
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
-        em[e] = __builtin_amdgcn_exp2f(nd2[e] * dens[e]);
-        lex[e] = lp;      // product of this lane's earlier samples
-        lp *= em[e];
+        const float em = __builtin_amdgcn_exp2f(fminf(fmaf(a[e], z[e], b[e]), 0.f));
+        const float nx = lp * em;
+        dl[e] = lp - nx;     // this lane's share of w_e: (product before) - (product after)
+        lp = nx;
     }
     // exclusive multiplicative scan over the 16 lanes of the ray
     // (DPP row shifts; lanes without a source lane keep the `old` operand = 1)
@@ -3304,7 +3339,7 @@ __device__ __forceinline__ void group_weights_fast(const float (&dens)[SPL], con
     incl *= dpp_f_or<0x118>(incl, 1.f);
     const float carry = dpp_f_or<0x111>(incl, 1.f);
 #pragma unroll
-    for (int e = 0; e < SPL; ++e) w[e] = fmaxf((1.f - em[e]) * (carry * lex[e]), 0.f);
+    for (int e = 0; e < SPL; ++e) wsum[e] = fmaf(carry, dl[e], wsum[e]);
 }
 
 template <int SPL, bool RAGGED = false>
@@ -3315,18 +3350,21 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
     if (!ok) r = a.R - 1;
     const int S = a.S, k0 = l16 * SPL;
     const float* sb = a.sbins + r * (S + 1);
-    float eu[SPL + 1], delta[SPL], nd2[SPL], mu[SPL], sd[SPL], wsum[SPL], dens[SPL], w[SPL];
+    float eu[SPL + 1], ca[SPL], cb[SPL], wsum[SPL];
+    uint32_t st[SPL];
 #pragma unroll
     for (int e = 0; e <= SPL; ++e) eu[e] = unerf_s2e(sb[RAGGED ? min(k0 + e, S) : k0 + e], a.s_near, a.s_far, a.lin);
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
-        delta[e] = eu[e + 1] - eu[e];
-        nd2[e] = -delta[e] * 1.4426950408889634f;
-        const bool live = !RAGGED || k0 + e < S;   // masked slots: mu = sd = 0 -> density 0, delta 0
-        mu[e] = live ? a.mu[r * S + k0 + e] : 0.f;
-        float s = live ? sqrtf(a.var[r * S + k0 + e]) : 0.f;
-        sd[e] = !live ? 0.f : (s != s) ? 1e-10f : fmaxf(s, 1e-10f);
+        const float nd2 = -(eu[e + 1] - eu[e]) * 1.4426950408889634f;
+        const bool live = !RAGGED || k0 + e < S;   // masked slots: mu = sd = 0 -> exponent 0, e = 1, weight 0
+        const float mu = live ? a.mu[r * S + k0 + e] : 0.f;
+        const float s = live ? sqrtf(a.var[r * S + k0 + e]) : 0.f;
+        const float sd = !live ? 0.f : (s != s) ? 1e-10f : fmaxf(s, 1e-10f);
+        ca[e] = nd2 * sd;
+        cb[e] = nd2 * mu;
         wsum[e] = 0.f;
+        st[e] = a.noise ? 0u : unerf_depth_stream_seed(a.seed, (uint32_t)((a.ray_offset + r) * S + k0 + e));
     }
     for (int d0 = 0; d0 < a.D; d0 += 2) {
         float z[2][SPL];
@@ -3338,26 +3376,21 @@ __global__ __launch_bounds__(256) void lap_depth_kernel(LapDepthArgs a) {
                 z[1][e] = (live && d0 + 1 < a.D) ? a.noise[((int64_t)(d0 + 1) * a.R + r) * S + k0 + e] : 0.f;
             }
         } else {
-            const uint32_t key = unerf_mc_key(a.seed, (uint32_t)(d0 >> 1));
 #pragma unroll
-            for (int e = 0; e < SPL; ++e)
-                unerf_normal_pair_from_hash(unerf_mc_base(key, (uint32_t)((a.ray_offset + r) * S + k0 + e)), z[0][e], z[1][e]);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (d0 + q < a.D) {
-#pragma unroll
-                for (int e = 0; e < SPL; ++e) dens[e] = fmaxf(fmaf(sd[e], z[q][e], mu[e]), 0.f);
-                group_weights_fast<SPL>(dens, nd2, l16, w);
-#pragma unroll
-                for (int e = 0; e < SPL; ++e) wsum[e] += w[e];
+            for (int e = 0; e < SPL; ++e) {
+                unerf_normal_pair_from_state(st[e], z[0][e], z[1][e]);
+                st[e] = unerf_xorshift32(st[e]);
             }
         }
+        group_weights_accumulate<SPL>(z[0], ca, cb, wsum);
+        if (d0 + 1 < a.D) group_weights_accumulate<SPL>(z[1], ca, cb, wsum);
     }
     if (ok) {
 #pragma unroll
-        for (int e = 0; e < SPL; ++e)
-            if (!RAGGED || k0 + e < S) a.out[r * S + k0 + e] = wsum[e] / (float)a.D;
+        for (int e = 0; e < SPL; ++e) {
+            const float w = wsum[e] / (float)a.D;
+            if (!RAGGED || k0 + e < S) a.out[r * S + k0 + e] = (w != w) ? 0.f : w;
+        }
     }
 }
 

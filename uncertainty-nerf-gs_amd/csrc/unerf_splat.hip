@@ -488,6 +488,17 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
 // ======================================================================================
 // rasteriser: one 16x16 tile per workgroup, 256-splat LDS batches, C channels at once
 // ======================================================================================
+// gsplat's schedule (a tile per workgroup, a pixel per thread, the tile's depth-sorted splats staged through shared
+// memory in batches) with two MI355X-side changes that leave every blended term untouched:
+//  * WAVE-LEVEL CULLING.  A wave64 of a 16 x 16 tile is a strip of 4 rows x 16 pixels.  A splat contributes to a pixel
+//    only where alpha = min(0.999, o e^-sigma) >= 1/255, i.e. inside the ellipse sigma <= ln(255 o) -- usually a good
+//    deal smaller than the 3-sigma square the tile lists are built from (and empty when o < 1/255).  The thread that
+//    stages a splat tests the ellipse's bounding box against the tile's four strips (conservatively: a margin far above
+//    the rounding of the in-loop test) and leaves a 4-bit mask; every wave then compacts the batch into its own index
+//    list with ballots and walks only that.  A culled (pixel, splat) pair is one the loop body would have skipped with
+//    `continue`, so sums, transmittances and final indices are bit-identical to the uncull loop (test_gpu_splat.py).
+//  * BOUNDED second pass.  The depth-variance pass blends with the same alphas as the first, so each pixel stops at the
+//    final index the first pass recorded instead of re-deriving it from the transmittance (stop_idx).
 struct RasterArgs {
     const int32_t* ids;
     const int32_t* bins;
@@ -500,14 +511,41 @@ struct RasterArgs {
     float* out;
     float* finalT;
     int32_t* final_idx;
+    const int32_t* stop_idx;   // BOUNDED: per-pixel last index to visit (a previous pass's final_idx)
+    int cull;                  // 0: walk every staged splat (reference schedule; kept for the identity test)
 };
 
-template <int C>
+// which of the tile's four 4-row strips can see the splat?  Conservative: returns 0xF when in doubt.
+__device__ __forceinline__ uint32_t raster_strip_mask(float x, float y, float op, float ca, float cb, float cc, float tile_x0,
+                                                      float tile_y0) {
+    if (!(op >= 0.0039f)) return (op != op) ? 0xFu : 0u;      // alpha <= opacity < 1/255 (0.00392...) everywhere
+    const float det = ca * cc - cb * cb;
+    if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0xFu;   // not an ellipse (or NaN): no culling
+    // sigma <= tau bounds |dx| <= sqrt(2 tau cc / det), |dy| <= sqrt(2 tau ca / det); tau = ln(255 o) padded by 1 % + 0.01,
+    // the box by another 1 % + 0.05 px: orders of magnitude above the fp32 rounding of sigma and of __expf
+    const float tau = fmaf(__logf(255.f * op), 1.01f, 0.01f);
+    const float inv = 2.f * tau / det;
+    const float hx = fmaf(sqrtf(inv * cc), 1.01f, 0.05f), hy = fmaf(sqrtf(inv * ca), 1.01f, 0.05f);
+    if (!(hx == hx) || !(hy == hy)) return 0xFu;
+    // pixel centres of the tile: x in [x0 + 0.5, x0 + 15.5]; strip w: y in [y0 + 4 w + 0.5, y0 + 4 w + 3.5]
+    if (x + hx < tile_x0 + 0.5f || x - hx > tile_x0 + 15.5f) return 0u;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float ylo = tile_y0 + 4.f * (float)w + 0.5f;
+        if (!(y + hy < ylo || y - hy > ylo + 3.f)) m |= 1u << w;
+    }
+    return m;
+}
+
+template <int C, bool BOUNDED>
 __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
     // one 16-byte + one 8-byte broadcast read per splat instead of six 4-byte ones
     __shared__ float4 s_geo[256];  // x, y, opacity, conic a
     __shared__ float2 s_bc[256];   // conic b, c
     __shared__ float s_col[256 * C];
+    __shared__ uint8_t s_mask[256];
+    __shared__ uint16_t s_list[4][256];
     const int bw = a.bw;
     const int tbx = (a.W + bw - 1) / bw;
     const int tile = blockIdx.y * tbx + blockIdx.x;
@@ -516,28 +554,56 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
     const int i = blockIdx.y * bw + ly, j = blockIdx.x * bw + lx;
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const bool inside = (ly < bw) && (i < a.H) && (j < a.W);
+    const int64_t p = (int64_t)i * a.W + j;
     bool done = !inside;
     const int r0 = a.bins[tile * 2], r1 = a.bins[tile * 2 + 1];
     const int nbatch = (r1 - r0 + 255) / 256;
+    const int stop = (BOUNDED && inside) ? a.stop_idx[p] : 0;
+    const bool cull = a.cull && bw == 16;                       // uniform: the strip geometry below is the 16-wide tile's
+    const int wv = __builtin_amdgcn_readfirstlane(tr >> 6), lane = tr & 63;
+    const float tile_x0 = (float)(blockIdx.x * bw), tile_y0 = (float)(blockIdx.y * bw);
     float T = 1.f;
     int cur_idx = 0;
     float pix[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) pix[c] = 0.f;
     for (int b = 0; b < nbatch; ++b) {
-        if (__syncthreads_count(done ? 1 : 0) >= 256) break;
         const int start = r0 + 256 * b;
+        if (BOUNDED) done = done || start > stop;
+        if (__syncthreads_count(done ? 1 : 0) >= 256) break;
         const int idx = start + tr;
         if (idx < r1) {
             int g = a.ids[idx];
-            s_geo[tr] = make_float4(a.xys[g * 2], a.xys[g * 2 + 1], a.opac[g], a.conics[g * 3]);
-            s_bc[tr] = make_float2(a.conics[g * 3 + 1], a.conics[g * 3 + 2]);
+            const float x = a.xys[g * 2], y = a.xys[g * 2 + 1], op = a.opac[g];
+            const float ca = a.conics[g * 3], cb = a.conics[g * 3 + 1], cc = a.conics[g * 3 + 2];
+            s_geo[tr] = make_float4(x, y, op, ca);
+            s_bc[tr] = make_float2(cb, cc);
 #pragma unroll
             for (int c = 0; c < C; ++c) s_col[tr * C + c] = a.colors[(int64_t)g * C + c];
+            if (cull) s_mask[tr] = (uint8_t)raster_strip_mask(x, y, op, ca, cb, cc, tile_x0, tile_y0);
         }
         __syncthreads();
         const int bsz = min(256, r1 - start);
-        for (int t = 0; t < bsz && !done; ++t) {
+        int n_mine = bsz;
+        if (cull) {   // this wave's (order-preserving) list of the staged splats its strip can see
+            n_mine = 0;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const int t = ch * 64 + lane;
+                const bool need = t < bsz && ((s_mask[t] >> wv) & 1u);
+                const uint64_t m = __builtin_amdgcn_ballot_w64(need);
+                if (need) s_list[wv][n_mine + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
+                n_mine += __builtin_popcountll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is read back by this wave only
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int k = 0; k < n_mine && !done; ++k) {
+            const int t = cull ? (int)s_list[wv][k] : k;
+            if (BOUNDED && start + t > stop) {   // past this pixel's last blended splat of the first pass
+                done = true;
+                break;
+            }
             const float4 ge = s_geo[t];
             const float2 bc = s_bc[t];
             float dx = ge.x - px, dy = ge.y - py, op = ge.z;
@@ -546,7 +612,7 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
             float alpha = fminf(0.999f, op * __expf(-sigma));
             if (sigma < 0.f || alpha < 1.f / 255.f) continue;
             float nT = T * (1.f - alpha);
-            if (nT <= 1e-4f) {
+            if (!BOUNDED && nT <= 1e-4f) {
                 done = true;
                 break;
             }
@@ -558,7 +624,6 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
         }
     }
     if (inside) {
-        int64_t p = (int64_t)i * a.W + j;
         a.finalT[p] = T;
         if (a.final_idx) a.final_idx[p] = cur_idx;
 #pragma unroll
@@ -568,28 +633,39 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
 
 extern "C" int unerf_splat_rasterize(const int32_t* gaussian_ids_sorted, const int32_t* tile_bins, const float* xys,
                                      const float* conics, const float* colors, const float* opacities,
-                                     const float* background, int C, int H, int W, int block_width, float* out_img,
-                                     float* final_T, int32_t* final_idx, void* stream) {
+                                     const float* background, int C, int H, int W, int block_width,
+                                     const int32_t* stop_idx, int flags, float* out_img, float* final_T, int32_t* final_idx,
+                                     void* stream) {
     UNERF_REQUIRE(tile_bins && xys && conics && colors && opacities && out_img && final_T,
                   "splat_rasterize: null pointer");
     UNERF_REQUIRE(C >= 1 && C <= 8, "splat_rasterize: C=%d outside [1,8]", C);
     UNERF_REQUIRE(block_width >= 1 && block_width <= 16 && H > 0 && W > 0, "splat_rasterize: bad block_width/H/W");
+    UNERF_REQUIRE((flags & ~UNERF_RASTER_NO_CULL) == 0, "splat_rasterize: unknown flags %d", flags);
     RasterArgs a;
     a.ids = gaussian_ids_sorted; a.bins = tile_bins; a.xys = xys; a.conics = conics; a.colors = colors;
     a.opac = opacities; a.bg = background; a.H = H; a.W = W; a.bw = block_width; a.out = out_img; a.finalT = final_T;
-    a.final_idx = final_idx;
+    a.final_idx = final_idx; a.stop_idx = stop_idx; a.cull = (flags & UNERF_RASTER_NO_CULL) ? 0 : 1;
     dim3 grid((W + block_width - 1) / block_width, (H + block_width - 1) / block_width), block(256);
     hipStream_t st = (hipStream_t)stream;
+#define UNERF_RASTER_CASE(N)                                                                       \
+    case N:                                                                                        \
+        if (stop_idx) hipLaunchKernelGGL((raster_kernel<N, true>), grid, block, 0, st, a);         \
+        else hipLaunchKernelGGL((raster_kernel<N, false>), grid, block, 0, st, a);                 \
+        break;
     switch (C) {
-        case 1: hipLaunchKernelGGL((raster_kernel<1>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((raster_kernel<2>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((raster_kernel<3>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((raster_kernel<4>), grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((raster_kernel<5>), grid, block, 0, st, a); break;
-        case 6: hipLaunchKernelGGL((raster_kernel<6>), grid, block, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((raster_kernel<7>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((raster_kernel<8>), grid, block, 0, st, a); break;
+        UNERF_RASTER_CASE(1)
+        UNERF_RASTER_CASE(2)
+        UNERF_RASTER_CASE(3)
+        UNERF_RASTER_CASE(4)
+        UNERF_RASTER_CASE(5)
+        UNERF_RASTER_CASE(6)
+        UNERF_RASTER_CASE(7)
+        default:
+            if (stop_idx) hipLaunchKernelGGL((raster_kernel<8, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((raster_kernel<8, false>), grid, block, 0, st, a);
+            break;
     }
+#undef UNERF_RASTER_CASE
     return unerf_check_launch("splat_rasterize");
 }
 

@@ -106,7 +106,7 @@ class FieldParams(C.Structure):
         ("tcnn_levels", C.c_void_p),
         ("mfma16_blob", C.c_void_p), ("lap16_blob", C.c_void_p),
         ("image_width", C.c_int), ("sample_major", C.c_int), ("drop_sites", C.c_int), ("lap_softplus", C.c_int), ("use_aabb", C.c_int),
-        ("aabb", C.c_float * 6), ("f16_single", C.c_int),
+        ("aabb", C.c_float * 6), ("f16_single", C.c_int), ("overflow_flag", C.c_void_p),
     ]
 
 
@@ -114,6 +114,7 @@ ABI_VERSION = 1200                                # include/unerf.h: UNERF_ABI_V
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
 SPACING_PIECEWISE, SPACING_UNIFORM = 0, 1         # include/unerf.h: UNERF_SPACING_*
 BG_LAST_SAMPLE, BG_NONE, BG_COLOR = 0, 1, 2       # include/unerf.h: UNERF_BG_*
+RASTER_NO_CULL = 1                                # include/unerf.h: UNERF_RASTER_NO_CULL
 BUILD_TRUNK_FOLD, BUILD_LAP_EXP2 = 1, 2   # include/unerf.h: UNERF_BUILD_*
 DROP_TRUNK, DROP_HEAD0, DROP_HEAD1 = 1, 2, 4     # include/unerf.h: UNERF_DROP_*
 
@@ -154,7 +155,7 @@ SIGNATURES = {
     "unerf_splat_sort_workspace_bytes": (_i64, [_i64, _i64]),
     "unerf_splat_count_intersects": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "unerf_splat_bin_sort": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "unerf_splat_rasterize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "unerf_splat_rasterize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "unerf_splat_alpha_normalize": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp]),
     "unerf_splat_depth_sqdiff": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _vp, _vp]),
 }

@@ -335,6 +335,9 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         """call after changing weights or eval-time knobs (mc_samples, GGN, ...)"""
         self._dev_scene = None
 
+    def _begin_render(self, scene: NerfSceneDev) -> None:
+        """once per get_outputs_for_camera / get_outputs_for_camera_ray_bundle / get_outputs call"""
+
     # -- rendering ----------------------------------------------------------------------------
     def _render_kwargs(self) -> Dict[str, Any]:
         return {}
@@ -346,7 +349,9 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         OrientedBox); rays get their planes from the box (render.crop_bins), rays that miss it render empty."""
         c2w, cam = _camera_args(camera)
         obb = None if obb_box is None else (ops.world_to_box(obb_box.R, obb_box.T), torch.as_tensor(obb_box.S).detach().cpu())
-        return render.render_camera(self.device_scene(), c2w, rays_per_launch=self.rays_per_launch, obb=obb,
+        scene = self.device_scene()
+        self._begin_render(scene)
+        return render.render_camera(scene, c2w, rays_per_launch=self.rays_per_launch, obb=obb,
                                     **cam, **self._render_kwargs())
 
     @torch.no_grad()
@@ -366,6 +371,7 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         origins = origins.to(device=scene0.device, dtype=torch.float32)
         directions = directions.to(device=scene0.device, dtype=torch.float32)
         scene = self.device_scene(origins.device)
+        self._begin_render(scene)
         o, d = origins.reshape(-1, 3).contiguous(), directions.reshape(-1, 3).contiguous()
         init = None
         if nears is not None and fars is not None:
@@ -406,6 +412,7 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
             o, d = ray_bundle.origins, ray_bundle.directions
             nears, fars = getattr(ray_bundle, "nears", None), getattr(ray_bundle, "fars", None)
         scene = self.device_scene(o.device if o.is_cuda else None)
+        self._begin_render(scene)
         o = o.reshape(-1, 3).to(device=scene.device, dtype=torch.float32).contiguous()
         d = d.reshape(-1, 3).to(device=scene.device, dtype=torch.float32).contiguous()
         init = None
@@ -449,9 +456,35 @@ class ActiveNerfactoModel(_NerfactoBase):
         return {"keep_density": True}  # the reference returns the raw [H,W,48] density too (:115,:122)
 
 
+def frame_seed(base_seed: int, frame: int) -> int:
+    """Mask-stream seed of the `frame`-th render of a model: the reference draws fresh dropout masks in every forward
+    (torch's global generator moves on, mcdropout_models.py:116-119), so two cameras never share their masks.  Frame 0
+    uses the base seed itself; later frames a hash of (base seed, frame) -- the counter-RNG twin of "the generator has
+    advanced" (same unerf_hash32 as the kernels' mask words)."""
+    if frame == 0:
+        return base_seed & 0xFFFFFFFF
+
+    def h32(x):
+        x &= 0xFFFFFFFF
+        x ^= x >> 16
+        x = (x * 0x21F0AAAD) & 0xFFFFFFFF
+        x ^= x >> 15
+        x = (x * 0x735A2D97) & 0xFFFFFFFF
+        x ^= x >> 15
+        return x
+
+    return h32((base_seed & 0xFFFFFFFF) ^ h32(frame + 0x9E3779B9))
+
+
 class NerfactoMCDropoutModel(_NerfactoBase):
     config: NerfactoMCDropoutModelConfig
-    seed: int = 0
+    seed: int = 0                    # base seed of the dropout-mask stream
+    frame_counter: int = 0           # renders made so far: every render draws fresh masks (frame_seed)
+    fresh_masks_per_render: bool = True
+
+    def _begin_render(self, scene: NerfSceneDev) -> None:
+        scene.field.seed = frame_seed(self.seed, self.frame_counter if self.fresh_masks_per_render else 0)
+        self.frame_counter += 1
 
     def _make_field(self):
         c = self.config

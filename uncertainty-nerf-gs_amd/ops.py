@@ -390,7 +390,7 @@ class FieldDev:
             _p(self.tcnn_levels, torch.int32),
             _p(self.mfma16_blob) if (self.use_mfma and h16) else None,
             _p(self.lap16_blob) if (self.use_mfma and h16) else None, 0, 0, int(self.drop_sites), int(self.lap_softplus),
-            0 if self.aabb is None else 1, _aabb6(self.aabb), 1 if self.precision == "f16" else 0)
+            0 if self.aabb is None else 1, _aabb6(self.aabb), 1 if self.precision == "f16" else 0, None)
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------
@@ -688,7 +688,7 @@ def supports_planes(field: FieldDev) -> bool:
 
 def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0,
               features: Optional[torch.Tensor] = None, image_width: int = 0, euclidean_bins: bool = False,
-              sample_major: bool = False, spacing: int = 0):
+              sample_major: bool = False, spacing: int = 0, nonfinite_flag: Optional[torch.Tensor] = None):
     """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h).  image_width > 0 tells the kernel that
     rays [ray_offset, ray_offset+R) are consecutive pixels of a row-major image (8x4-pixel tiles: same results).
     euclidean_bins: `sbins` holds Euclidean bin edges (a caller-made RaySamples) instead of spacing-domain bins.
@@ -711,6 +711,7 @@ def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: flo
     cs = field.cstruct()
     cs.image_width = int(image_width)
     cs.sample_major = 1 if sample_major else 0
+    cs.overflow_flag = _p(nonfinite_flag, torch.int32)      # read by the single-product (precision "f16") kernels only
     with _ctx(dev):
         _run("field_fwd", lambda: lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, spacing, ray_offset,
                                      C.byref(cs), _p(features), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()))
@@ -932,8 +933,11 @@ def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_widt
 
 
 def splat_rasterize(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, H: int, W: int,
-                    background: Optional[torch.Tensor] = None, block_width: int = 16, want_final_idx: bool = False):
-    """colors [N,C] -> (out_img [H,W,C], final_T [H,W], final_idx | None)"""
+                    background: Optional[torch.Tensor] = None, block_width: int = 16, want_final_idx: bool = False,
+                    stop_idx: Optional[torch.Tensor] = None, cull: bool = True):
+    """colors [N,C] -> (out_img [H,W,C], final_T [H,W], final_idx | None).  stop_idx [H,W] int32: the final_idx of an
+    earlier pass with the same geometry (bounded second pass); cull=False: gsplat's schedule without wave-level culling
+    (same bits either way)."""
     lib = _l.load()
     dev, Cn = xys.device, colors.shape[1]
     out = torch.empty(H, W, Cn, device=dev)
@@ -942,9 +946,10 @@ def splat_rasterize(gaussian_ids_sorted, tile_bins, xys, conics, colors, opaciti
     if gaussian_ids_sorted.numel() == 0:
         gaussian_ids_sorted = torch.zeros(1, device=dev, dtype=torch.int32)
     with _ctx(dev):
-        _run("splat_rasterize", lambda: lib.unerf_splat_rasterize(_p(gaussian_ids_sorted, torch.int32), _p(tile_bins, torch.int32), _p(xys),
+        _run(f"splat_rasterize_c{Cn}", lambda: lib.unerf_splat_rasterize(_p(gaussian_ids_sorted, torch.int32), _p(tile_bins, torch.int32), _p(xys),
                                            _p(conics), _p(colors), _p(opacities), _p(background), Cn, H, W,
-                                           block_width, _p(out), _p(fT), _p(fidx, torch.int32), _stream()))
+                                           block_width, _p(stop_idx, torch.int32), 0 if cull else _l.RASTER_NO_CULL, _p(out),
+                                           _p(fT), _p(fidx, torch.int32), _stream()))
     return out, fT, fidx
 
 

@@ -250,11 +250,16 @@ def _build() -> Dict[str, Any]:
     def _ns_config(name: str, mirror_cfg_cls, target):
         """dataclass(ModelConfig) carrying every field of the mirror config (same names and defaults as the
         reference's config for the fields that shape eval rendering) plus `camera_optimizer` for the NeRF methods"""
+        # models.py uses `from __future__ import annotations`: Field.type holds STRINGS there.  tyro / dataclasses resolve a
+        # dynamic class's string annotations in the namespace of the module that CREATED the class (this one), where
+        # they would only resolve by luck -- hand over the evaluated types instead
+        import typing
+        hints = typing.get_type_hints(mirror_cfg_cls)
         ann, ns = {}, {}
         for f in dataclasses.fields(mirror_cfg_cls):
             if f.name == "_target":
                 continue
-            ann[f.name] = f.type
+            ann[f.name] = hints[f.name]
             ns[f.name] = (field(default_factory=f.default_factory) if f.default_factory is not dataclasses.MISSING
                           else f.default)
         ann["_target"] = type

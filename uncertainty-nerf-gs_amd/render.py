@@ -185,7 +185,8 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
     # composite walks them with a lane per ray; LAPLACE keeps the ray-major layout its depth-draw kernel reads
     planes = scene.sample_major and feats is None and ops.supports_planes(f)
     density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset, features=feats,
-                                            image_width=image_width, sample_major=planes, spacing=scene.spacing)
+                                            image_width=image_width, sample_major=planes, spacing=scene.spacing,
+                                            nonfinite_flag=nonfinite_flag)
     kw = dict(clip_minmax=clip, ray_offset=ray_offset, chunk_rays=scene.chunk_rays, spacing=scene.spacing,
               background=scene.background, nonfinite_flag=nonfinite_flag)
     res: Dict[str, torch.Tensor] = {}

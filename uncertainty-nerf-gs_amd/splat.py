@@ -107,11 +107,13 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
                 "background": background}
     cols = torch.cat([rgbs, beta[:, None], depths[:, None]], dim=1).contiguous()
     bg5 = torch.cat([background.to(dev, torch.float32), torch.zeros(2, device=dev)])
-    img, fT, _ = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg5, block_width)
+    img, fT, fidx = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg5, block_width, want_final_idx=True)
     alpha = (1.0 - fT)[..., None]
     ops.splat_alpha_normalize(img, 4, fT)           # depth = where(alpha>0, d/alpha, max(d))   (:319)
     sq = ops.splat_depth_sqdiff(xys, depths, img, 4)  # (z_i - depth[floor(xy_i)])^2            (:325-341)
-    dv, fT2, _ = ops.splat_rasterize(gids, bins, xys, conics, sq[:, None].contiguous(), opac, H, W, None, block_width)
+    # same ids / bins / geometry / opacities as the first pass: every pixel stops at the index that pass ended on
+    dv, fT2, _ = ops.splat_rasterize(gids, bins, xys, conics, sq[:, None].contiguous(), opac, H, W, None, block_width,
+                                     stop_idx=fidx)
     ops.splat_alpha_normalize(dv, 0, fT2)           # (:356)
     unc = img[..., 3:4]
     return {"rgb": torch.clamp(img[..., 0:3], max=1.0), "depth": img[..., 4:5], "accumulation": alpha,
