@@ -339,6 +339,7 @@ def main():
         if default_run and not args.no_sub_records and args.members % world == 0:
             # BASELINE.json configs[3] at every N: the M-member nerfacto ensemble sharded over the ranks (strong scaling)
             ens = bench_ensemble(args, rank, world, dev, dist, 3, 1)
+            torch.cuda.synchronize()
             if rank == 0:
                 subs = {"ensemble": {k: ens[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config")}}
         if default_run and not args.no_sub_records and world == 1:
@@ -347,8 +348,8 @@ def main():
             # the headline's workload with the dense layers at the REFERENCE's own eval precision (opt-in, --precision f16):
             # one f16 product per MAC, fp32 accumulate = torch.autocast(float16), forced by mcdropout_models.py:86-92
             for name, m, kk, prec in (("mcdropout_f16", "mcdropout", K, "f16"), ("active", "active", 0, None), ("laplace", "laplace", 0, None)):
-                r = run_nerf(args, m, kk, 3, 1, rank, world, dev, dist, exact_check=False, want_cpu=False, precision=prec)
-                subs[name] = {"value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
+                r = run_nerf(args, m, kk, 3, 2, rank, world, dev, dist, exact_check=False, want_cpu=False, precision=prec)
+                subs[name] = {"value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 2,
                               "workload": r["workload"], "per_kernel_ms_per_frame": r["roofline"]["per_kernel_ms_per_frame"],
                               "dtype": "f16 operands, f32 accumulate" if prec == "f16" else "f32 (split-f16 operands, f32-equivalent)",
                               "dense_layers": r["dense_layers"],

@@ -1677,6 +1677,23 @@ __device__ __forceinline__ void mf16_split(const f32x16& v, int s, f16x8& hi, f1
     for (int e = 0; e < 8; ++e) x[e] = v[8 * s + e];
     mf16_split8<F1>(x, hi, lo);
 }
+// F1: ReLU AFTER the conversion, on the packed halves: v_pk_max_i16(bits, 0) maps every negative f16 (sign bit = negative
+// int16, -0 included) to +0 and leaves the others alone -- relu(cvt(x)) = cvt(relu(x)) exactly, at one instruction per
+// TWO units instead of one v_max_i32 per unit on the fp32 accumulators.
+__device__ __forceinline__ void mf16_split_relu(const f32x16& v, int s, f16x8& hi) {
+    u32x4 hv;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        // (a VECTOR fptrunc: from two scalar conversions behind an integer max the compiler converts the halves one by one
+        // and packs them with a v_perm -- three instructions where v_cvt_pk_f16_f32 is one.  Not inline asm: the
+        // compiler has to see this read of MFMA results to place the wait states between the two.)
+        const unerf_v2f pr = {v[8 * s + 2 * p], v[8 * s + 2 * p + 1]};
+        const uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, f16x2));
+        const i16x2 z = {0, 0};
+        hv[p] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), z));
+    }
+    hi = __builtin_bit_cast(f16x8, hv);
+}
 // acc += W(slab) x B: small terms first
 template <bool F1 = false>
 __device__ __forceinline__ f32x16 mf16_mac(const float* lds, int slab, int lane, const f16x8& bhi, const f16x8& blo,
@@ -1729,13 +1746,18 @@ __device__ __forceinline__ f32x16 mf16_fold_rows(f32x16 acc) {
 }
 // a 64-wide layer input held as two accumulator blocks (units 0..31 in v0, 32..63 in v1) against the
 // 4 k-steps x NB row blocks of slabs starting at `slab0` (slab = slab0 + NB*step + block)
-template <int NB, bool F1 = false>
+template <int NB, bool F1 = false, bool RELU_PACKED = false>
 __device__ __forceinline__ void mf16_layer64(const float* lds, int slab0, int lane, const f32x16& v0, const f32x16& v1,
                                              f32x16& o0, f32x16& o1) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         f16x8 bhi, blo;
-        mf16_split<F1>(s < 2 ? v0 : v1, s & 1, bhi, blo);
+        if (RELU_PACKED) {   // (F1 only) the input's ReLU rides on the converted operands
+            mf16_split_relu(s < 2 ? v0 : v1, s & 1, bhi);
+            blo = bhi;
+        } else {
+            mf16_split<F1>(s < 2 ? v0 : v1, s & 1, bhi, blo);
+        }
         if (NB == 2) mf16_mac2<F1>(lds, slab0 + NB * s, slab0 + NB * s + 1, lane, bhi, blo, o0, o1);
         else o0 = mf16_mac<F1>(lds, slab0 + NB * s, lane, bhi, blo, o0);
     }
@@ -1909,23 +1931,32 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 mf16_split<F1>(t, 0, bhi, blo);
                 mf16_mac2<F1>(lds, 8, 9, lane, bhi, blo, c0, c1);
             }
-            c0 = mf_relu(c0);
-            c1 = mf_relu(c1);
+            if (!F1) {   // F1: ReLU on the packed f16 operands instead (mf16_split_relu: half the instructions)
+                c0 = mf_relu(c0);
+                c1 = mf_relu(c1);
+            }
             // colour 1: 64 -> 64, ReLU
             f32x16 d0 = mf16_bias(lds, 5, h), d1 = mf16_bias(lds, 6, h);
             if (SITES && drop && (a.drop_sites & UNERF_DROP_HEAD0)) {   // rgb_dropout_layers contains 1 (non-default): masks on c
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     f16x8 bhi, blo;
-                    mf16_split<F1>(st < 2 ? c0 : c1, st & 1, bhi, blo);
+                    if (F1) mf16_split_relu(st < 2 ? c0 : c1, st & 1, bhi);
+                    else mf16_split<F1>(st < 2 ? c0 : c1, st & 1, bhi, blo);
                     uint32_t mw[8];
                     mf_mask_words_at(mw, st >> 1, h, base0_h0, 2u, k);
                     mf16_apply_masks<F1>(bhi, blo, mw, st & 1, a.keep_pk);
                     mf16_mac2<F1>(lds, 12 + 2 * st, 12 + 2 * st + 1, lane, bhi, blo, d0, d1);
                 }
             } else {
-                mf16_layer64<2, F1>(lds, 12, lane, c0, c1, d0, d1);
+                mf16_layer64<2, F1, F1>(lds, 12, lane, c0, c1, d0, d1);
             }
+            // (F1 with this layer as four more k-steps on the matrix pipe -- 16 conversions + 16 packed ReLUs + 48 packed-mask
+            // instructions + 4 MFMAs instead of the 154 instructions below -- was built and measured: 3.68 vs 3.89 ms per
+            // launch, but the f16 rounding of the last layer's operands moved one MC-dropout AUSE figure past its 1e-3
+            // gate; profiles/r3_exp_f16_rgb_on_mfma.json, DESIGN.md 4.5.  The colour layer stays fp32 in every form.)
+            float o[3];
+            {
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
             if (drop_head1) {   // masks on the fp32 accumulators: one half-word compare + one select per unit
@@ -1939,7 +1970,6 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             // every occupancy and instruction order), so a layer belongs where it costs fewer of those cycles: as four
             // more k-steps on the matrix pipe this one took 12 MFMAs + 48 split instructions (576 cycles, 29 of 32
             // output rows wasted), as packed fp32 FMAs it takes 48 + the half-to-half exchange (~240 cycles).
-            float o[3];
             {
                 const float4* wq = reinterpret_cast<const float4*>(lds + MF_H2_OFF + h * 48);
 #pragma unroll
@@ -1959,6 +1989,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(half_sum), __float_as_uint(half_sum), false, false);
                     o[c] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + lds[MF_H2_OFF + 192 + c];
                 }
+            }
             }
             // Epilogue split over the two lane halves (both hold the three colour sums after the exchange; the density
             // logit, row 0, lives in the h = 0 half): h = 0 finishes (density, red), h = 1 (green, blue) -- two

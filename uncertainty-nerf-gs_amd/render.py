@@ -63,7 +63,8 @@ class NerfSceneDev:
     # default: the plane stores cut the field kernel's write traffic to the algorithmic bytes, but the lane-per-ray
     # composite is latency-bound and costs more than the stores gain; UNERF_SAMPLE_MAJOR=1 turns it on
     sample_major: bool = field(default_factory=lambda: os.environ.get("UNERF_SAMPLE_MAJOR", "0") == "1")
-    overflow_guard: bool = True      # OverflowGuard: re-render launch groups whose f16 operands overflowed with fp32 kernels
+    # OverflowGuard: re-render launch groups whose f16 operands overflowed with fp32 kernels (UNERF_OVERFLOW_GUARD=0: off)
+    overflow_guard: bool = field(default_factory=lambda: os.environ.get("UNERF_OVERFLOW_GUARD", "1") != "0")
     overflow_rerenders: int = 0      # how many launch groups that has happened to (diagnostic)
     _const: Dict[str, torch.Tensor] = field(default_factory=dict)
 
