@@ -360,7 +360,7 @@ def main():
                              "workload": sp["config"]["workload"],
                              "per_kernel_ms_per_frame": sp["roofline"]["per_kernel_ms_per_frame"],
                              "roofline": {k: sp["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
-                                                                             "avg_launch_ms", "traffic")}}
+                                                                             "avg_launch_ms", "traffic", "raster_roofline")}}
         if rank == 0:
             H, W = args.height, args.width
             line = {
@@ -516,15 +516,25 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
         # The rasteriser is bound by VALU issue per (pixel, splat) pair, not by bytes (its splat lists are staged through
         # LDS once per tile): with a committed SQ counter pass of this command the roof is instruction issue, as for the
         # field kernels -- achieved = 4 x VALU instructions of one 5-channel raster launch / its live duration.
-        iss = _issue_profile("splat", 0) if dom == "splat_rasterize_c5" else None
+        iss_r = _issue_profile("splat", 0)                       # raster_kernel<5>: issue profile of the 5-channel pass
+        iss = iss_r if dom == "splat_rasterize_c5" else None
+        raster = None
+        if iss_r is not None and "splat_rasterize_c5" in ksum:
+            g = iss_r["issue_cycles_per_launch"] / (ksum["splat_rasterize_c5"]["avg_ms"] * 1e-3) / 1e9
+            raster = {"kernel": "splat_rasterize_c5", "bound": "valu-issue", "achieved": g, "peak": ISSUE_PEAK_GCYC, "unit": "Gcycle/s",
+                      "frac": g / ISSUE_PEAK_GCYC, "avg_launch_ms": ksum["splat_rasterize_c5"]["avg_ms"],
+                      "valu_insts_per_launch": iss_r["valu_insts_per_launch"], "issue_source": iss_r["source"]}
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_splat.json")
         if os.path.exists(tfile):
             from uncertainty_nerf_gs_amd import lib
             tj = json.load(open(tfile))
             if tj.get("kernel_source_digest") in (None, lib._source_digest()) and "field_fwd" in tj.get("kernels", {}):
-                tk = tj["kernels"]["field_fwd"]     # (summarize_pmc's slot name for a profile's dominant kernel)
-                traffic = tk["fetch_bytes"] + tk["write_bytes"]
+                tk = tj["kernels"]["field_fwd"]     # (summarize_pmc's slot name for the profile's raster_kernel<5>)
+                if raster is not None:
+                    raster["traffic"] = tk["fetch_bytes"] + tk["write_bytes"]
+                if dom == "splat_rasterize_c5":
+                    traffic = tk["fetch_bytes"] + tk["write_bytes"]
         line = {
             "metric": "Mrays/s (+var) [pixels of an active-splatfacto frame], 1080p", "value": H * W * steps * world / elapsed / 1e6,
             "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -542,8 +552,10 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
                             if iss is not None else
                             {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": None if ach is None else ach / HBM_PEAK_GBS,
-                             "note": "no PMC issue profile for these sources: algorithmic bytes (binds nothing; the kernel is "
-                                     "VALU-issue bound per pixel-splat pair)"}),
+                             "note": ("bin-and-sort (rocprim scan / merge sort / two one-sweep radix passes + three own kernels): bytes "
+                                      "gsplat's 64-bit-key sort of the same intersections would move, I x 96 B, over this call's time"
+                                      if dom == "splat_bin_sort" else "algorithmic bytes of the dominant kernel")}),
+                         "raster_roofline": raster,
                          "traffic": traffic, "avg_launch_ms": ksum[dom]["avg_ms"], "num_intersects": n_isect,
                          "frame_algorithmic_bytes": frame_bytes,
                          "frame_frac_of_hbm_peak": frame_bytes * steps * world / elapsed / 1e9 / HBM_PEAK_GBS,

@@ -40,10 +40,23 @@ def test_committed_bench_line_has_every_contract_field():
     assert abs(want - r["achieved"]) < 1e-6 * want
     assert os.path.exists(os.path.join(ROOT, iss["source"].split(" ")[0]))
     subs = d["sub_records"]
-    assert {"active", "laplace", "splat"} <= set(subs)
+    assert set(subs) == {"ensemble", "mcdropout_f16", "active", "laplace", "splat"}
     for k, v in subs.items():
-        assert v["value"] > 0 and v["ms_per_step"] > 0 and v["per_kernel_ms_per_frame"], k
+        assert v["value"] > 0 and v["ms_per_step"] > 0, k
+        if k != "ensemble":
+            assert v["per_kernel_ms_per_frame"], k
     assert "density [H,W,48] kept" in subs["active"]["workload"]
+    # the reference-precision form of the headline's workload, with its arithmetic spelled out
+    f16 = subs["mcdropout_f16"]
+    assert "K=8" in f16["workload"] and f16["dtype"] == "f16 operands, f32 accumulate" and f16["value"] > d["value"]
+    assert f16["roofline"]["bound"] == "valu-issue" and 0 < f16["roofline"]["frac"] <= 1 and f16["roofline"]["traffic"] > 0
+    # every sub-record's roofline uses the same issue definition as the headline (committed PMC passes of this round)
+    for k in ("active", "laplace"):
+        assert subs[k]["roofline"]["bound"] == "valu-issue" and subs[k]["roofline"]["traffic"] > 0, k
+    # BASELINE.json configs[3]: the 8-member ensemble, strong scaling over --gpus N
+    ens = subs["ensemble"]
+    assert ens["scaling"] == "strong" and ens["config"]["members"] == 8 and ens["config"]["members_per_gpu"] == 8 // d["n_gpus"]
+    assert d["world_size"] == d["n_gpus"] and (d["backend"] is None) == (d["n_gpus"] == 1)
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -907,21 +907,58 @@ def splat_sh_colors_split(degree: int, means3d, cam_pos: torch.Tensor, features_
     return colors, beta
 
 
+class SplatCount:
+    """The asynchronous half of gsplat's compute_cumulative_intersects: the inclusive scan of num_tiles_hit is launched
+    on the caller's stream, and its last element (the number of intersections, which sizes every later buffer) travels to
+    pinned host memory on a SIDE stream.  `wait()` blocks on that copy only -- kernels the caller queued on its own stream
+    in between (SH colours: independent of the count) keep the GPU busy while the host learns the number, instead of the
+    device idling through a full stream synchronisation and the launch latency of everything behind it."""
+
+    _side: Dict = {}
+
+    def __init__(self, num_tiles_hit: torch.Tensor):
+        lib = _l.load()
+        self.N, self.dev = num_tiles_hit.shape[0], num_tiles_hit.device
+        self.cum = torch.empty(self.N, device=self.dev, dtype=torch.int32)
+        with _ctx(self.dev):
+            ws0 = torch.empty(int(lib.unerf_splat_sort_workspace_bytes(self.N, 0)), device=self.dev, dtype=torch.uint8)
+            _run("splat_count", lambda: lib.unerf_splat_count_intersects(_p(num_tiles_hit, torch.int32), self.N,
+                                                                         _p(self.cum, torch.int32), _p(ws0, torch.uint8),
+                                                                         ws0.numel(), _stream()))
+            key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+            if key not in SplatCount._side:
+                SplatCount._side[key] = torch.cuda.Stream(device=self.dev)
+            side = SplatCount._side[key]
+            self._host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                self._host.copy_(self.cum[-1:], non_blocking=True)
+                self._done = torch.cuda.Event()
+                self._done.record(side)
+            self.cum.record_stream(side)
+            self._ws0 = ws0     # keeps the scan's scratch alive until the count is known
+
+    def wait(self) -> int:
+        self._done.synchronize()
+        return int(self._host[0])
+
+
 def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_width: int = 16,
-                   want_isect_ids: bool = True):
+                   want_isect_ids: bool = True, count: Optional[SplatCount] = None):
     """-> (num_intersects, cum_tiles_hit, isect_ids_sorted | None, gaussian_ids_sorted, tile_bins [tiles,2])
-    One host read-back (num_intersects) sizes the buffers, as gsplat's compute_cumulative_intersects does.
+    One host read-back (num_intersects) sizes the buffers, as gsplat's compute_cumulative_intersects does; `count`: a
+    SplatCount started earlier (so that the read-back overlaps other work), else it is made and awaited here.
     The 64-bit isect ids are gsplat's by-product; the rasteriser does not read them (want_isect_ids=False
     skips their gather + 8-byte store per intersection)."""
     lib = _l.load()
     N, dev = xys.shape[0], xys.device
     tbx, tby = (W + block_width - 1) // block_width, (H + block_width - 1) // block_width
-    cum = torch.empty(N, device=dev, dtype=torch.int32)
+    count = SplatCount(num_tiles_hit) if count is None else count
+    cum = count.cum
+    I = count.wait()
     with _ctx(dev):
-        ws0 = torch.empty(int(lib.unerf_splat_sort_workspace_bytes(N, 0)), device=dev, dtype=torch.uint8)
-        _run("splat_count", lambda: lib.unerf_splat_count_intersects(_p(num_tiles_hit, torch.int32), N, _p(cum, torch.int32),
-                                                  _p(ws0, torch.uint8), ws0.numel(), _stream()))
-        I = int(cum[-1].item())
         ws = torch.empty(int(lib.unerf_splat_sort_workspace_bytes(N, I)), device=dev, dtype=torch.uint8)
         ids = torch.empty(max(I, 1), device=dev, dtype=torch.int64) if want_isect_ids else None
         gids = torch.empty(max(I, 1), device=dev, dtype=torch.int32)

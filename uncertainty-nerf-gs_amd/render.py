@@ -294,7 +294,7 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
             s_samp, s_shade = _streams(dev)
             s_samp.wait_stream(cur)
             s_shade.wait_stream(cur)
-            for start in starts:
+            for gi, start in enumerate(starts):
                 with torch.cuda.stream(s_samp):
                     o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start))
                     sb, pds, feats = sampling_stage(scene, o, d, clip, start, image_width=W,
@@ -306,13 +306,17 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
                             t.record_stream(s_shade)
                 with torch.cuda.stream(s_shade):
                     s_shade.wait_event(ev)
-                    out = shading_stage(scene, o, d, sb, pds, feats, clip, start, image_width=W, **shade_kw)
+                    out = shading_stage(scene, o, d, sb, pds, feats, clip, start, image_width=W,
+                                        nonfinite_flag=guard.flag(gi), **shade_kw)
                     for v in out.values():
                         v.record_stream(cur)
                 for k, v in out.items():
                     lists.setdefault(k, []).append(v)
             cur.wait_stream(s_shade)
             cur.wait_stream(s_samp)
+            for gi in guard.offenders():
+                for k, v in guard.redo(gi, lambda: group(gi)).items():
+                    lists[k][gi] = v
         return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}
 
 

@@ -80,11 +80,9 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     quats = gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True)
     xys, depths, radii, conics, comp, tiles, _cov = ops.splat_project(
         means, torch.exp(gp["scales"]), 1.0, quats.contiguous(), V[:3], fx, fy, cx, cy, H, W, block_width)
-    # (self.radii).sum() == 0 -> get_empty_outputs (:239-240).  A splat has a non-zero radius exactly when it hits at
-    # least one tile, so "no intersections" is the same test and rides on the one host read-back of the frame
-    I, _cum, _keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, block_width, want_isect_ids=False)
-    if I == 0:
-        return empty_outputs(W, H, background)
+    # the intersection count (the frame's one host read-back) starts its way to the host now and is awaited inside
+    # splat_bin_sort; the SH colours do not depend on it and keep the GPU busy meanwhile
+    count = ops.SplatCount(tiles)
     if config_sh_degree is not None and config_sh_degree <= 0:
         sh_degree = -1                                     # kernel: colours = sigmoid(features_dc)
     # the reference concatenates features_dc and features_rest first (:242-243); the kernel reads them in place
@@ -92,6 +90,12 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     rgbs, beta = ops.splat_sh_colors_split(sh_degree, means, c2w[:3, 3], gp["features_dc"].contiguous(),
                                            gp["features_rest"].contiguous(),
                                            None if plain else gp["log_uncertainties"].reshape(-1).contiguous(), beta_min)
+    # (self.radii).sum() == 0 -> get_empty_outputs (:239-240).  A splat has a non-zero radius exactly when it hits at
+    # least one tile, so "no intersections" is the same test and rides on the one host read-back of the frame
+    I, _cum, _keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, block_width, want_isect_ids=False,
+                                                    count=count)
+    if I == 0:
+        return empty_outputs(W, H, background)
     opac = torch.sigmoid(gp["opacities"]).reshape(-1)
     if rasterize_mode == "antialiased":
         opac = opac * comp
