@@ -41,7 +41,21 @@ def _scalar(v) -> float:
 
 
 def _camera_args(camera) -> Tuple[torch.Tensor, Dict[str, Any]]:
+    """[UPSTREAM Cameras.generate_rays] is restated (unerf_generate_rays) for ONE distortion-free perspective camera, which
+    is what the reference's eval loops hand over (one eval image at a time, undistorted datasets).  Anything else a
+    nerfstudio `Cameras` can describe would silently render the wrong rays, so it is refused here."""
     c2w = camera.camera_to_worlds
+    if c2w.dim() == 3 and c2w.shape[0] != 1:
+        raise ValueError(f"get_outputs_for_camera takes one camera, got a batch of {c2w.shape[0]}")
+    dist_params = getattr(camera, "distortion_params", None)
+    if dist_params is not None and bool(torch.as_tensor(dist_params).abs().max() > 0):
+        raise NotImplementedError("cameras with lens distortion parameters are not built (generate_rays would bend the rays); "
+                                  "undistort the dataset")
+    ctype = getattr(camera, "camera_type", None)
+    if ctype is not None:
+        v = int(torch.as_tensor(ctype).reshape(-1)[0]) if torch.is_tensor(ctype) else int(getattr(ctype, "value", ctype))
+        if v != 1:      # nerfstudio CameraType.PERSPECTIVE = 1
+            raise NotImplementedError(f"camera_type {v}: only perspective cameras (CameraType.PERSPECTIVE = 1) are built")
     c2w = c2w[0] if c2w.dim() == 3 else c2w
     return c2w[:3, :4], dict(fx=_scalar(camera.fx), fy=_scalar(camera.fy), cx=_scalar(camera.cx), cy=_scalar(camera.cy),
                              H=int(_scalar(camera.height)), W=int(_scalar(camera.width)))
