@@ -281,7 +281,7 @@ def main():
     ap.add_argument("--mc-samples", type=int, default=8)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--rays-per-launch", type=int, default=1 << 18)
+    ap.add_argument("--rays-per-launch", type=int, default=1 << 20)
     ap.add_argument("--overlap", action="store_true", help="sampling / shading stages on two HIP streams (experiment)")
     ap.add_argument("--split-gather", action="store_true", help="level-major gather kernel + feature planes (experiment)")
     ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f16", "fp32"],

@@ -46,6 +46,16 @@ FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false", "field_kernel_mfma<0
 # further kernels of a profile that get their own issue_<name>.json (same definition)
 EXTRA_ISSUE = {"laplace": {"lap_depth": ("lap_depth_kernel<3",)}, "splat": {"splat_raster1": ("raster_kernel<1",)}}
 K_OF = {"mcdropout": 8, "mcdropout_f16": 8}
+FRAME_RAYS = 1920 * 1080      # bench.py's frame
+PMC_FRAMES = 2                # collect_profiles.sh pmc(): --steps 1 --warmup 1
+
+
+def _rays_per_launch(method, launches):
+    """mean rays of one launch of a per-launch-group kernel (the last group of a frame is a partial one); the splat
+    kernels see the whole frame"""
+    if method == "splat" or not launches:
+        return FRAME_RAYS
+    return FRAME_RAYS * PMC_FRAMES / launches
 
 
 def _source_digest():
@@ -82,7 +92,7 @@ def summary(d, tag):
             json.dump(out, f, indent=1)
         fk = next((k for pre in FIELD_KERNELS[method] for k in sorted(kernels) if k.startswith(pre)), None)
         if fk and "FETCH_SIZE" in kernels[fk] and "WRITE_SIZE" in kernels[fk]:
-            t = {"method": method, "K": K_OF.get(method, 0), "rays_per_launch": 2073600 if method == "splat" else 262144, "kernel_source_digest": digest,
+            t = {"method": method, "K": K_OF.get(method, 0), "rays_per_launch": _rays_per_launch(method, kernels[fk].get("launches")), "kernel_source_digest": digest,
                  "source": f"profiles/{tag}_{method}_pmc_fetch.csv + {tag}_{method}_pmc_write.csv "
                            "(separate rocprofv3 --pmc passes)",
                  "kernels": {"field_fwd": {
@@ -112,9 +122,9 @@ def summary(d, tag):
             issue = 4.0 * valu_n + 32.0 * kk["SQ_INSTS_MFMA"]
             counters = 4.0 * kk["SQ_ACTIVE_INST_VALU"] + kk["SQ_VALU_MFMA_BUSY_CYCLES"]
             simd_cycles = kk["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-            j = {"method": issue_name, "K": K_OF.get(method, 0), "rays_per_launch": 2073600 if method == "splat" else 262144,
+            j = {"method": issue_name, "K": K_OF.get(method, 0), "rays_per_launch": _rays_per_launch(method, kk.get("launches")),
                  "kernel_name": fk,
-                 "kernel_source_digest": digest, "launches_per_frame": kk.get("launches"),
+                 "kernel_source_digest": digest, "launches_per_frame": (kk.get("launches") or 0) / PMC_FRAMES,
                  "wait_any_frac_of_wave_cycles": (kk["SQ_WAIT_ANY"] / kk["SQ_WAVE_CYCLES"]) if kk.get("SQ_WAVE_CYCLES") else None,
                  "source": f"profiles/{tag}_{method}_pmc_sq.csv (rocprofv3 --pmc, own pass)",
                  "issue_cycles_per_launch": issue,

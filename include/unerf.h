@@ -38,7 +38,7 @@ extern "C" {
 const char* unerf_last_error(void);
 /* Library/ABI version (major*1000+minor).  A binding built against this header must find exactly UNERF_ABI_VERSION
  * (struct layouts and argument lists change with it; uncertainty-nerf-gs_amd/lib.py::load checks). */
-#define UNERF_ABI_VERSION 1200
+#define UNERF_ABI_VERSION 1210
 int unerf_version(void);
 
 /* Spacing function of the proposal sampler's initial sampler, passed behind every (near_plane, far_plane) pair:
@@ -394,6 +394,14 @@ int unerf_splat_project(const float* means3d, const float* scales, float glob_sc
                         int block_width, float clip_thresh, int64_t N, float* xys, float* depths, int32_t* radii,
                         float* conics, float* compensation, int32_t* num_tiles_hit, float* cov3d, void* stream);
 
+/* The same projection fed with the model's parameters as stored: log_scales [N,3] (gauss_params.scales) and raw_quats
+ * [N,4] (gauss_params.quats, unnormalised).  Replaces torch.exp(scales_crop) and quats_crop / quats_crop.norm(dim=-1,
+ * keepdim=True) (:221-223) + project_gaussians: three elementwise launches less per frame. */
+int unerf_splat_project_raw(const float* means3d, const float* log_scales, float glob_scale, const float* raw_quats,
+                            const float* viewmat_host, float fx, float fy, float cx, float cy, int H, int W,
+                            int block_width, float clip_thresh, int64_t N, float* xys, float* depths, int32_t* radii,
+                            float* conics, float* compensation, int32_t* num_tiles_hit, float* cov3d, void* stream);
+
 /* :245-246 spherical_harmonics(degree, viewdirs, coeffs[N,16,3]) then clamp(+0.5, min 0);
  * and :286 softplus(log_unc)+beta_min.  cam_pos_host: 3 floats.  colors_out [N,3], beta_out [N].
  * degree = -1: the config.sh_degree == 0 branch (:247-248), colors = sigmoid(DC coefficients), no SH, no +0.5.
@@ -408,6 +416,16 @@ int unerf_splat_sh_colors(int degree, const float* means3d, const float* cam_pos
 int unerf_splat_sh_colors_split(int degree, const float* means3d, const float* cam_pos_host, const float* features_dc,
                                 const float* features_rest, const float* log_unc, float beta_min, int64_t N,
                                 float* colors_out, float* beta_out, void* stream);
+
+/* Everything the rasteriser reads per splat, in one launch and in its final layout: SH colours (as
+ * unerf_splat_sh_colors_split), beta = softplus(log_unc) + beta_min (:286), the depth channel, and
+ * opacities = sigmoid(opacity_logits) [* compensation] (:252-256).  Replaces the torch.cat([rgbs, beta, depths]) and
+ * torch.sigmoid launches of the frame.  rows_out [N,C]: C = 5 -> [r, g, b, beta, depth]; C = 4 -> [r, g, b, depth]
+ * (plain splatfacto; log_unc may be NULL).  compensation may be NULL ("classic").  opacities_out [N]. */
+int unerf_splat_shade_inputs(int degree, const float* means3d, const float* cam_pos_host, const float* features_dc,
+                             const float* features_rest, const float* log_unc, float beta_min,
+                             const float* opacity_logits, const float* compensation, const float* depths, int64_t N,
+                             int C, float* rows_out, float* opacities_out, void* stream);
 
 /* bin-and-sort done ONCE per frame (the reference repeats it inside each of its four
  * rasterize_gaussians calls :260,:289,:306,:343).  cum_tiles_hit [N] i32 (inclusive scan,
@@ -434,17 +452,23 @@ int unerf_splat_bin_sort(const float* xys, const float* depths, const int32_t* r
  * of re-deriving its end from the transmittance -- same blended terms, same result.
  * flags: 0, or UNERF_RASTER_NO_CULL to walk every staged splat in every wave (gsplat's schedule).  By default a wave (a
  * 4-row strip of the 16 x 16 tile) walks only the splats whose alpha >= 1/255 ellipse can reach its strip; the skipped
- * (pixel, splat) pairs are pairs the blend loop would have skipped itself, so both settings give identical bits. */
+ * (pixel, splat) pairs are pairs the blend loop would have skipped itself, so both settings give identical bits.
+ * chan_max (may be NULL): 1 DEVICE float the caller zeroed; on return it holds max(chan_max, max over the image of
+ * out_img[..., max_channel]) -- the `img.max()` that unerf_splat_alpha_normalize(max_ready = 1) then needs not
+ * compute.  Values of that channel must be >= 0 (depths, squared differences). */
 #define UNERF_RASTER_NO_CULL 1
 int unerf_splat_rasterize(const int32_t* gaussian_ids_sorted, const int32_t* tile_bins, const float* xys,
                           const float* conics, const float* colors, const float* opacities,
                           const float* background, int C, int H, int W, int block_width, const int32_t* stop_idx,
-                          int flags, float* out_img, float* final_T, int32_t* final_idx, void* stream);
+                          int flags, int max_channel, float* chan_max, float* out_img, float* final_T,
+                          int32_t* final_idx, void* stream);
 
 /* :319 / :356  img = where(alpha>0, img/alpha, max(img)) with alpha = 1-final_T, applied IN PLACE
- * to channel `ch` of an interleaved image [HW, stride]; scratch_max = 1 device float. */
+ * to channel `ch` of an interleaved image [HW, stride]; scratch_max = 1 device float.
+ * max_ready = 0: max(img[..., ch]) is computed here into scratch_max;  1: scratch_max already holds it (the chan_max
+ * of the unerf_splat_rasterize call that produced img). */
 int unerf_splat_alpha_normalize(float* img, int stride, int ch, const float* final_T, int64_t HW,
-                                float* scratch_max, void* stream);
+                                float* scratch_max, int max_ready, void* stream);
 /* :325-341 per-splat (z_i - depth[floor(xy_i)])^2, bounds test with the reference's strict ">0";
  * depth image = channel `ch` of [H,W,stride].  sq_diff_out [N]. */
 int unerf_splat_depth_sqdiff(const float* xys, const float* depths, const float* depth_img, int stride, int ch,

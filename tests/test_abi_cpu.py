@@ -26,7 +26,7 @@ def test_header_symbols_all_bound_and_exported(lib):
 
 def test_version_and_error_string(lib):
     h = lib.load()
-    assert h.unerf_version() == lib.ABI_VERSION == 1200
+    assert h.unerf_version() == lib.ABI_VERSION == 1210
     assert h.unerf_build_flags() & lib.BUILD_TRUNK_FOLD          # the shipped build folds the K-pass trunk-out slabs
     assert isinstance(h.unerf_last_error(), bytes)
 
@@ -58,8 +58,15 @@ def test_bad_shapes_are_rejected(lib):
     rc = h.unerf_weights_pdf_resample(1, 1, 0, 4, 300, 0.05, 1000.0, 0, 1, 96, 0.01, 1e-5, 1, None, None, None, 0, 32768,
                                       None)
     assert rc == -1 and b"outside" in h.unerf_last_error()
-    rc = h.unerf_splat_rasterize(None, 1, 1, 1, 1, 1, None, 9, 16, 16, 16, None, 0, 1, 1, None, None)
+    rc = h.unerf_splat_rasterize(None, 1, 1, 1, 1, 1, None, 9, 16, 16, 16, None, 0, -1, None, 1, 1, None, None)
     assert rc == -1 and b"C=9" in h.unerf_last_error()
+    rc = h.unerf_splat_rasterize(None, 1, 1, 1, 1, 1, None, 5, 16, 16, 16, None, 0, 5, 1, 1, 1, None, None)
+    assert rc == -1 and b"max_channel 5" in h.unerf_last_error()
+    cam = (C.c_float * 3)(0.0, 0.0, 0.0)
+    rc = h.unerf_splat_shade_inputs(3, 1, cam, 1, 1, None, 0.01, 1, None, 1, 4, 5, 1, 1, None)
+    assert rc == -1 and b"needs log_unc" in h.unerf_last_error()
+    rc = h.unerf_splat_shade_inputs(3, 1, cam, 1, 1, 1, 0.01, 1, None, 1, 4, 3, 1, 1, None)
+    assert rc == -1 and b"C=3" in h.unerf_last_error()
 
 
 def test_zero_counts_are_no_ops_and_oversized_inputs_are_refused(lib):
@@ -80,6 +87,10 @@ def test_zero_counts_are_no_ops_and_oversized_inputs_are_refused(lib):
     vm = (C.c_float * 12)(*([0.0] * 12))
     assert h.unerf_splat_project(None, None, 1.0, None, vm, 1.0, 1.0, 0.0, 0.0, 16, 16, 16, 0.01, 0, None, None, None, None,
                                  None, None, None, None) == 0
+    assert h.unerf_splat_project_raw(None, None, 1.0, None, vm, 1.0, 1.0, 0.0, 0.0, 16, 16, 16, 0.01, 0, None, None, None,
+                                     None, None, None, None, None) == 0
+    assert h.unerf_splat_shade_inputs(3, None, (C.c_float * 3)(0.0, 0.0, 0.0), None, None, None, 0.01, None, None, None, 0, 5,
+                                      None, None, None) == 0
     assert h.unerf_splat_depth_sqdiff(None, None, None, 1, 0, 16, 16, 0, None, None) == 0
     # ... but a non-zero count still needs its pointers
     assert h.unerf_ray_planes_bins(None, None, 5, 0.05, 1000.0, 0, None, 256, None, None) == -1

@@ -303,3 +303,76 @@ def test_wave_level_culling_and_bounded_pass_change_no_bit(dev, C):
     # final_T of a bounded pass: the transmittance behind the last BLENDED splat -- the unbounded pass may have multiplied
     # one more (1 - alpha) in before its T <= 1e-4 stop... it does not: the stopping splat is not applied either
     assert torch.equal(c[1], a[1])
+
+
+def test_frame_prologue_fused_into_the_kernels(dev):
+    """the per-frame torch launches of the reference's get_outputs that the frame now leaves to its kernels:
+    exp(scales) and quats / quats.norm() inside the projection (unerf_splat_project_raw); the SH colours, beta, the
+    [rgb, beta, depth] concatenation and sigmoid(opacities) [* compensation] in one launch (unerf_splat_shade_inputs)"""
+    from uncertainty_nerf_gs_amd import ops, splat
+    N, H, W = 20000, 120, 160
+    gp = {k: v.to(dev) for k, v in _scene(N).items()}
+    gp["quats"] = gp["quats"] * (0.25 + 3.0 * torch.rand(N, 1, device=dev))      # far from unit length
+    c2w = _camera()
+    V = splat.viewmat_from_c2w(c2w)
+    K = (0.9 * W, 0.9 * W, W / 2, H / 2, H, W)
+    want = ops.splat_project(gp["means"], torch.exp(gp["scales"]), 1.0,
+                             (gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True)).contiguous(), V[:3], *K)
+    got = ops.splat_project(gp["means"], gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], *K, raw=True)
+    # the same operations; only the summation order inside torch's norm() is not pinned, so: equal up to an ulp of the
+    # quaternion, which can move a radius across an integer for a handful of splats at most
+    same_r = (got[2] == want[2])
+    assert float(same_r.float().mean()) > 0.999
+    for name, g, w_, tol in (("xys", got[0], want[0], 1e-3), ("depths", got[1], want[1], 1e-6), ("conics", got[3], want[3], 1e-4),
+                             ("compensation", got[4], want[4], 1e-5)):
+        g, w_ = g[same_r], w_[same_r]
+        assert float((g - w_).abs().max()) <= tol * max(1.0, float(w_.abs().max())), name
+    assert int((got[5][same_r] != want[5][same_r]).sum()) == 0
+    assert int((want[2] > 0).sum()) > N // 4
+
+    xys, depths, radii, conics, comp, tiles, _ = want
+    lu = gp["log_uncertainties"].reshape(-1).contiguous()
+    for degree in (3, 1, -1):
+        col, beta = ops.splat_sh_colors_split(degree, gp["means"], c2w[:3, 3], gp["features_dc"].contiguous(),
+                                              gp["features_rest"].contiguous(), lu, 0.01)
+        for compensation in (None, comp):
+            rows, opac = ops.splat_shade_inputs(degree, gp["means"], c2w[:3, 3], gp["features_dc"].contiguous(),
+                                                gp["features_rest"].contiguous(), lu, 0.01,
+                                                gp["opacities"].reshape(-1).contiguous(), compensation, depths)
+            assert torch.equal(rows, torch.cat([col, beta[:, None], depths[:, None]], dim=1))
+            o = torch.sigmoid(gp["opacities"]).reshape(-1)
+            o = o * comp if compensation is not None else o
+            torch.testing.assert_close(opac, o, rtol=3e-7, atol=0)
+        rows4, _ = ops.splat_shade_inputs(degree, gp["means"], c2w[:3, 3], gp["features_dc"].contiguous(),
+                                          gp["features_rest"].contiguous(), None, 0.01,
+                                          gp["opacities"].reshape(-1).contiguous(), None, depths)
+        assert torch.equal(rows4, torch.cat([col, depths[:, None]], dim=1))
+
+
+@pytest.mark.parametrize("C,ch", [(5, 4), (4, 3), (1, 0)])
+def test_channel_maximum_taken_inside_the_rasteriser(dev, C, ch):
+    """`depth_im.max()` of the alpha normalisation (:319, :356) comes out of the raster pass: the same float as a
+    reduction over the written image, and the normalised image is the one the stand-alone path gives"""
+    from uncertainty_nerf_gs_amd import ops
+    N, H, W = 6000, 100, 150
+    gp = _scene(N)
+    ref, got, _ = _project_both(gp, _camera(2.2), 60.0, 60.0, W / 2, H / 2, H, W, dev)
+    xys, depths, radii, conics, comp, tiles, _ = got
+    I, cum, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W)
+    g = torch.Generator().manual_seed(C)
+    colors = (torch.rand(N, C, generator=g) * 7.0).to(dev)
+    opac = torch.sigmoid(gp["opacities"]).reshape(-1).to(dev)
+    bg = torch.zeros(C, device=dev)
+    mx = torch.zeros(1, device=dev)
+    img, fT, fidx = ops.splat_rasterize(gids, bins, xys, conics, colors, opac, H, W, bg, want_final_idx=True, chan_max=(ch, mx))
+    plain, fT0, _ = ops.splat_rasterize(gids, bins, xys, conics, colors, opac, H, W, bg)
+    assert torch.equal(img, plain) and torch.equal(fT, fT0)
+    assert float(mx) == float(img[..., ch].max()) > 0
+    a, b = img.clone(), img.clone()
+    ops.splat_alpha_normalize(a, ch, fT, max_ready=mx)
+    ops.splat_alpha_normalize(b, ch, fT)
+    assert torch.equal(a, b)
+    # a bounded pass reports its maximum as well
+    mx2 = torch.zeros(1, device=dev)
+    img2, _, _ = ops.splat_rasterize(gids, bins, xys, conics, colors, opac, H, W, bg, stop_idx=fidx, chan_max=(ch, mx2))
+    assert torch.equal(img2, img) and float(mx2) == float(mx)

@@ -6,6 +6,7 @@
 #include "unerf_common.hpp"
 
 #include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
@@ -40,6 +41,10 @@ __device__ __forceinline__ void tile_bbox(float cx, float cy, float radius, int 
     y1 = min(max(0, (int)(tcy + tr + 1.f)), tby);
 }
 
+// RAW: `scales` / `quats` are the model's parameters as stored -- log-scales and unnormalised quaternions -- and the
+// reference's per-frame torch prologue (activesplatfacto_model.py:221-223: torch.exp(scales_crop),
+// quats_crop / quats_crop.norm(dim=-1, keepdim=True)) happens here instead of in three elementwise launches.
+template <bool RAW>
 __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.N) return;
@@ -65,13 +70,18 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
 
     // scale_rot_to_cov3d
     float qw = a.quats[i * 4], qx = a.quats[i * 4 + 1], qy = a.quats[i * 4 + 2], qz = a.quats[i * 4 + 3];
+    if (RAW) {   // the model's normalisation (a true division, as torch's), then gsplat's own below
+        const float qn = sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
+        qw = qw / qn; qx = qx / qn; qy = qy / qn; qz = qz / qn;
+    }
     float qs = 1.f / sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
     float w = qw * qs, x = qx * qs, y = qy * qs, z = qz * qs;
     float Rm[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - w * z),       2.f * (x * z + w * y),
                    2.f * (x * y + w * z),       1.f - 2.f * (x * x + z * z), 2.f * (y * z - w * x),
                    2.f * (x * z - w * y),       2.f * (y * z + w * x),       1.f - 2.f * (x * x + y * y)};
-    float s0 = a.glob_scale * a.scales[i * 3], s1 = a.glob_scale * a.scales[i * 3 + 1],
-          s2 = a.glob_scale * a.scales[i * 3 + 2];
+    float sc0 = a.scales[i * 3], sc1 = a.scales[i * 3 + 1], sc2 = a.scales[i * 3 + 2];
+    if (RAW) { sc0 = expf(sc0); sc1 = expf(sc1); sc2 = expf(sc2); }
+    float s0 = a.glob_scale * sc0, s1 = a.glob_scale * sc1, s2 = a.glob_scale * sc2;
     float M[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -146,11 +156,11 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
     a.comp[i] = comp;
 }
 
-extern "C" int unerf_splat_project(const float* means3d, const float* scales, float glob_scale, const float* quats,
-                                   const float* viewmat, float fx, float fy, float cx, float cy, int H, int W,
-                                   int block_width, float clip_thresh, int64_t N, float* xys, float* depths,
-                                   int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit,
-                                   float* cov3d, void* stream) {
+static int splat_project_impl(bool raw, const float* means3d, const float* scales, float glob_scale, const float* quats,
+                              const float* viewmat, float fx, float fy, float cx, float cy, int H, int W,
+                              int block_width, float clip_thresh, int64_t N, float* xys, float* depths,
+                              int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit,
+                              float* cov3d, void* stream) {
     UNERF_REQUIRE(viewmat && (N == 0 || (means3d && scales && quats && xys && depths && radii && conics && compensation &&
                                        num_tiles_hit && cov3d)),
                   "splat_project: null pointer");
@@ -162,8 +172,27 @@ extern "C" int unerf_splat_project(const float* means3d, const float* scales, fl
     a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.H = H; a.W = W; a.bw = block_width; a.clip = clip_thresh; a.N = N;
     a.xys = xys; a.depths = depths; a.radii = radii; a.conics = conics; a.comp = compensation;
     a.tiles = num_tiles_hit; a.cov3d = cov3d;
-    hipLaunchKernelGGL(project_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    if (raw) hipLaunchKernelGGL(project_kernel<true>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(project_kernel<false>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return unerf_check_launch("splat_project");
+}
+
+extern "C" int unerf_splat_project(const float* means3d, const float* scales, float glob_scale, const float* quats,
+                                   const float* viewmat, float fx, float fy, float cx, float cy, int H, int W,
+                                   int block_width, float clip_thresh, int64_t N, float* xys, float* depths,
+                                   int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit,
+                                   float* cov3d, void* stream) {
+    return splat_project_impl(false, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block_width,
+                              clip_thresh, N, xys, depths, radii, conics, compensation, num_tiles_hit, cov3d, stream);
+}
+
+extern "C" int unerf_splat_project_raw(const float* means3d, const float* log_scales, float glob_scale,
+                                       const float* raw_quats, const float* viewmat, float fx, float fy, float cx,
+                                       float cy, int H, int W, int block_width, float clip_thresh, int64_t N, float* xys,
+                                       float* depths, int32_t* radii, float* conics, float* compensation,
+                                       int32_t* num_tiles_hit, float* cov3d, void* stream) {
+    return splat_project_impl(true, means3d, log_scales, glob_scale, raw_quats, viewmat, fx, fy, cx, cy, H, W, block_width,
+                              clip_thresh, N, xys, depths, radii, conics, compensation, num_tiles_hit, cov3d, stream);
 }
 
 // ======================================================================================
@@ -172,12 +201,24 @@ extern "C" int unerf_splat_project(const float* means3d, const float* scales, fl
 // SPLIT: the coefficients arrive as the model stores them -- features_dc [N,3] and features_rest [N,15,3]
 // (`coeffs` = dc, `rest` = the 45-float rows) -- which saves the per-frame torch.cat of 192 B per splat that the
 // reference performs (activesplatfacto_model.py:242-243) and this kernel would only read back once.
-template <bool SPLIT>
+// PACK (unerf_splat_shade_inputs): everything the rasteriser reads per splat leaves this kernel in its final layout --
+// one interleaved row [rgb, (beta), depth] per splat and the activated opacity -- instead of through the reference's
+// torch.cat / torch.sigmoid launches (activesplatfacto_model.py:256, 286-305).
+struct ShadePack {
+    const float* opacity_logits;   // [N]
+    const float* compensation;     // [N] or NULL (rasterize_mode == "antialiased": opacities * comp, :252-254)
+    const float* depths;           // [N]
+    float* opacities;              // [N] out
+    int C;                         // row length: 4 = rgb + depth, 5 = rgb + beta + depth
+};
+
+template <bool SPLIT, bool PACK>
 __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float* __restrict__ means, float cxp,
                                                         float cyp, float czp, const float* __restrict__ coeffs,
                                                         const float* __restrict__ rest,
                                                         const float* __restrict__ log_unc, float beta_min, int64_t N,
-                                                        float* __restrict__ colors, float* __restrict__ beta) {
+                                                        float* __restrict__ colors, float* __restrict__ beta,
+                                                        ShadePack pk) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
@@ -236,14 +277,22 @@ __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float*
             }
         }
     }
+    const int64_t row = PACK ? i * pk.C : i * 3;
     if (degree < 0) {  // config.sh_degree == 0: rgbs = sigmoid(features_dc) (activesplatfacto_model.py:247-248)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) colors[i * 3 + c] = unerf_sigmoid(k[c]);
+        for (int c = 0; c < 3; ++c) colors[row + c] = unerf_sigmoid(k[c]);
     } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) colors[i * 3 + c] = fmaxf(col[c] + 0.5f, 0.f);
+        for (int c = 0; c < 3; ++c) colors[row + c] = fmaxf(col[c] + 0.5f, 0.f);
     }
-    if (beta) beta[i] = unerf_softplus(log_unc[i]) + beta_min;
+    if (PACK) {
+        if (pk.C == 5) colors[row + 3] = unerf_softplus(log_unc[i]) + beta_min;
+        colors[row + pk.C - 1] = pk.depths[i];
+        const float o = unerf_sigmoid(pk.opacity_logits[i]);
+        pk.opacities[i] = pk.compensation ? o * pk.compensation[i] : o;
+    } else if (beta) {
+        beta[i] = unerf_softplus(log_unc[i]) + beta_min;
+    }
 }
 
 extern "C" int unerf_splat_sh_colors(int degree, const float* means3d, const float* cam_pos, const float* sh_coeffs,
@@ -254,9 +303,9 @@ extern "C" int unerf_splat_sh_colors(int degree, const float* means3d, const flo
     UNERF_REQUIRE(!beta_out || log_unc || N <= 0, "splat_sh_colors: beta_out without log_unc");
     UNERF_REQUIRE(((uintptr_t)sh_coeffs & 15u) == 0, "splat_sh_colors: sh_coeffs must be 16-byte aligned");
     if (N <= 0) return UNERF_OK;
-    hipLaunchKernelGGL(sh_colors_kernel<false>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
-                       means3d, cam_pos[0], cam_pos[1], cam_pos[2], sh_coeffs, nullptr, log_unc, beta_min, N, colors_out,
-                       beta_out);
+    hipLaunchKernelGGL((sh_colors_kernel<false, false>), dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       degree, means3d, cam_pos[0], cam_pos[1], cam_pos[2], sh_coeffs, nullptr, log_unc, beta_min, N,
+                       colors_out, beta_out, ShadePack{});
     return unerf_check_launch("splat_sh_colors");
 }
 
@@ -268,10 +317,30 @@ extern "C" int unerf_splat_sh_colors_split(int degree, const float* means3d, con
     UNERF_REQUIRE(degree <= 0 || N <= 0 || features_rest, "splat_sh_colors_split: degree %d needs features_rest", degree);
     UNERF_REQUIRE(!beta_out || log_unc || N <= 0, "splat_sh_colors_split: beta_out without log_unc");
     if (N <= 0) return UNERF_OK;
-    hipLaunchKernelGGL(sh_colors_kernel<true>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
-                       means3d, cam_pos[0], cam_pos[1], cam_pos[2], features_dc, features_rest, log_unc, beta_min, N,
-                       colors_out, beta_out);
+    hipLaunchKernelGGL((sh_colors_kernel<true, false>), dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       degree, means3d, cam_pos[0], cam_pos[1], cam_pos[2], features_dc, features_rest, log_unc, beta_min,
+                       N, colors_out, beta_out, ShadePack{});
     return unerf_check_launch("splat_sh_colors_split");
+}
+
+extern "C" int unerf_splat_shade_inputs(int degree, const float* means3d, const float* cam_pos, const float* features_dc,
+                                        const float* features_rest, const float* log_unc, float beta_min,
+                                        const float* opacity_logits, const float* compensation, const float* depths,
+                                        int64_t N, int C, float* rows_out, float* opacities_out, void* stream) {
+    UNERF_REQUIRE(cam_pos && (N <= 0 || (means3d && features_dc && opacity_logits && depths && rows_out && opacities_out)),
+                  "splat_shade_inputs: null pointer");
+    UNERF_REQUIRE(degree >= -1 && degree <= 3, "splat_shade_inputs: degree %d outside [-1,3]", degree);
+    UNERF_REQUIRE(degree <= 0 || N <= 0 || features_rest, "splat_shade_inputs: degree %d needs features_rest", degree);
+    UNERF_REQUIRE(C == 4 || C == 5, "splat_shade_inputs: C=%d, rows are [rgb, depth] (4) or [rgb, beta, depth] (5)", C);
+    UNERF_REQUIRE(C == 4 || log_unc || N <= 0, "splat_shade_inputs: C=5 needs log_unc");
+    if (N <= 0) return UNERF_OK;
+    ShadePack pk;
+    pk.opacity_logits = opacity_logits; pk.compensation = compensation; pk.depths = depths; pk.opacities = opacities_out;
+    pk.C = C;
+    hipLaunchKernelGGL((sh_colors_kernel<true, true>), dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
+                       means3d, cam_pos[0], cam_pos[1], cam_pos[2], features_dc, features_rest, log_unc, beta_min, N,
+                       rows_out, nullptr, pk);
+    return unerf_check_launch("splat_shade_inputs");
 }
 
 // ======================================================================================
@@ -291,14 +360,23 @@ static int tile_bits(int H, int W, int bw) {
 // tile id (13 bits at 1080p, 16-bit keys): two 6-byte-per-entry radix passes over the I intersections
 // instead of six 12-byte passes over 64-bit (tile | depth) keys.  Same final order, bit for bit: ties in
 // depth keep the splat-index order in both schemes.
+// rocprim's default radix-sort config takes a merge-sort path up to 2^20 items -- exactly where a 1 M-splat scene sits
+// (20 launches, 162 us); Onesweep does the same stable sort in 137 us there and is what the default picks above 2^20
+// anyway (benchmarks/exp_depth_sort.hip).  Small scenes keep the default's choice.
+using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                   rocprim::default_config, (size_t)1 << 18>;
+static hipError_t depth_sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const int32_t* vin,
+                                   int32_t* vout, int64_t n, hipStream_t st) {
+    return rocprim::radix_sort_pairs<DepthSortConfig>(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, 32u, st);
+}
+
 struct SortWs {
     int64_t tmp, dkey_in, dkey_out, id_in, order, counts, cum, tkey_in, tkey_out, val_in, total;
 };
 static SortWs sort_ws_layout(int64_t N, int64_t I) {
     size_t scan_tmp = 0, sortN_tmp = 0, sortI_tmp = 0;
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, (const int32_t*)nullptr, (int32_t*)nullptr, (int)N);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sortN_tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                             (const int32_t*)nullptr, (int32_t*)nullptr, (int)N, 0, 32);
+    (void)depth_sort_pairs(nullptr, sortN_tmp, nullptr, nullptr, nullptr, nullptr, N, 0);
     if (I > 0)
         (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sortI_tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                                  (const int32_t*)nullptr, (int32_t*)nullptr, (int)I, 0, 32);
@@ -460,8 +538,7 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
     int32_t* cum_sorted = reinterpret_cast<int32_t*>(ws + L.cum);
     // 1. splats in depth order (stable: equal depths keep their index order)
     hipLaunchKernelGGL(depth_keys_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, depths, radii, N, dk_in, id_in);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(ws + L.tmp, tmp_bytes, dk_in, dk_out, id_in,
-                                                      order, (int)N, 0, 32, st);
+    hipError_t e = depth_sort_pairs(ws + L.tmp, tmp_bytes, dk_in, dk_out, id_in, order, N, st);
     if (e != hipSuccess) {
         unerf_set_error("splat_bin_sort: depth sort: %s", hipGetErrorString(e));
         return UNERF_ERR_HIP;
@@ -513,6 +590,8 @@ struct RasterArgs {
     int32_t* final_idx;
     const int32_t* stop_idx;   // BOUNDED: per-pixel last index to visit (a previous pass's final_idx)
     int cull;                  // 0: walk every staged splat (reference schedule; kept for the identity test)
+    unsigned int* chan_max;    // NULL, or the running max (float bits, values >= 0) of out[..., max_ch] over the image
+    int max_ch;
 };
 
 // which of the tile's four 4-row strips can see the splat?  Conservative: returns 0xF when in doubt.
@@ -623,28 +702,47 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
             cur_idx = start + t;
         }
     }
+    float vmax = 0.f;
     if (inside) {
         a.finalT[p] = T;
         if (a.final_idx) a.final_idx[p] = cur_idx;
 #pragma unroll
-        for (int c = 0; c < C; ++c) a.out[p * C + c] = pix[c] + T * (a.bg ? a.bg[c] : 0.f);
+        for (int c = 0; c < C; ++c) {
+            const float v = pix[c] + T * (a.bg ? a.bg[c] : 0.f);
+            a.out[p * C + c] = v;
+            if (c == a.max_ch) vmax = v;
+        }
+    }
+    // The `img.max()` that the alpha normalisation of this channel needs (depth_im.detach().max(), :319 / :356) is
+    // taken here, where the values are in registers: one compare per wave, and an atomic only from a wave that raises
+    // the maximum (a separate reduction kernel cost 28 us per pass).
+    if (a.chan_max) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m, 64));
+        if (lane == 0) {
+            const unsigned int bits = __float_as_uint(fmaxf(vmax, 0.f));   // >= 0: bit patterns order like the values
+            if (bits > __hip_atomic_load(a.chan_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.chan_max, bits);
+        }
     }
 }
 
 extern "C" int unerf_splat_rasterize(const int32_t* gaussian_ids_sorted, const int32_t* tile_bins, const float* xys,
                                      const float* conics, const float* colors, const float* opacities,
                                      const float* background, int C, int H, int W, int block_width,
-                                     const int32_t* stop_idx, int flags, float* out_img, float* final_T, int32_t* final_idx,
-                                     void* stream) {
+                                     const int32_t* stop_idx, int flags, int max_channel, float* chan_max, float* out_img,
+                                     float* final_T, int32_t* final_idx, void* stream) {
     UNERF_REQUIRE(tile_bins && xys && conics && colors && opacities && out_img && final_T,
                   "splat_rasterize: null pointer");
     UNERF_REQUIRE(C >= 1 && C <= 8, "splat_rasterize: C=%d outside [1,8]", C);
     UNERF_REQUIRE(block_width >= 1 && block_width <= 16 && H > 0 && W > 0, "splat_rasterize: bad block_width/H/W");
     UNERF_REQUIRE((flags & ~UNERF_RASTER_NO_CULL) == 0, "splat_rasterize: unknown flags %d", flags);
+    UNERF_REQUIRE(!chan_max || (max_channel >= 0 && max_channel < C), "splat_rasterize: max_channel %d outside [0,%d)",
+                  max_channel, C);
     RasterArgs a;
     a.ids = gaussian_ids_sorted; a.bins = tile_bins; a.xys = xys; a.conics = conics; a.colors = colors;
     a.opac = opacities; a.bg = background; a.H = H; a.W = W; a.bw = block_width; a.out = out_img; a.finalT = final_T;
     a.final_idx = final_idx; a.stop_idx = stop_idx; a.cull = (flags & UNERF_RASTER_NO_CULL) ? 0 : 1;
+    a.chan_max = reinterpret_cast<unsigned int*>(chan_max); a.max_ch = chan_max ? max_channel : -1;
     dim3 grid((W + block_width - 1) / block_width, (H + block_width - 1) / block_width), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define UNERF_RASTER_CASE(N)                                                                       \
@@ -702,17 +800,19 @@ __global__ __launch_bounds__(256) void alpha_norm_kernel(float* __restrict__ img
 }
 
 extern "C" int unerf_splat_alpha_normalize(float* img, int stride, int ch, const float* final_T, int64_t HW,
-                                           float* scratch_max, void* stream) {
+                                           float* scratch_max, int max_ready, void* stream) {
     UNERF_REQUIRE(img && final_T && scratch_max, "splat_alpha_normalize: null pointer");
     UNERF_REQUIRE(stride >= 1 && ch >= 0 && ch < stride && HW >= 0, "splat_alpha_normalize: bad stride/ch");
     if (HW == 0) return UNERF_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(scratch_max, 0, sizeof(float), st) != hipSuccess)
-        return unerf_check_launch("splat_alpha_normalize memset");
-    const unsigned max_blocks = 2048;  // 8 workgroups per CU
-    const unsigned nblk = blocks_for(HW, 256) < max_blocks ? blocks_for(HW, 256) : max_blocks;
-    hipLaunchKernelGGL(chan_max_kernel, dim3(nblk), dim3(256), 0, st, img, stride, ch, HW,
-                       reinterpret_cast<unsigned int*>(scratch_max));
+    if (!max_ready) {   // otherwise the rasteriser that produced img left the channel's maximum in scratch_max
+        if (hipMemsetAsync(scratch_max, 0, sizeof(float), st) != hipSuccess)
+            return unerf_check_launch("splat_alpha_normalize memset");
+        const unsigned max_blocks = 2048;  // 8 workgroups per CU
+        const unsigned nblk = blocks_for(HW, 256) < max_blocks ? blocks_for(HW, 256) : max_blocks;
+        hipLaunchKernelGGL(chan_max_kernel, dim3(nblk), dim3(256), 0, st, img, stride, ch, HW,
+                           reinterpret_cast<unsigned int*>(scratch_max));
+    }
     hipLaunchKernelGGL(alpha_norm_kernel, dim3(blocks_for(HW, 256)), dim3(256), 0, st, img, stride, ch, final_T, HW,
                        scratch_max);
     return unerf_check_launch("splat_alpha_normalize");

@@ -271,7 +271,7 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         self.scene_box = scene_box
         self.num_train_data = num_train_data
         self._dev_scene: Optional[NerfSceneDev] = None
-        self.rays_per_launch = 1 << 18
+        self.rays_per_launch = 1 << 20
         self.populate_modules()
 
     # -- construction -------------------------------------------------------------------------

@@ -861,9 +861,12 @@ def moments(x: torch.Tensor, want_var: bool = True):
 # ---------------------------------------------------------------- splats ---------------
 
 def splat_project(means3d, scales, glob_scale: float, quats, viewmat: torch.Tensor, fx, fy, cx, cy, H: int, W: int,
-                  block_width: int = 16, clip_thresh: float = 0.01):
-    """gsplat.project_gaussians signature -> (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)"""
+                  block_width: int = 16, clip_thresh: float = 0.01, raw: bool = False):
+    """gsplat.project_gaussians signature -> (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d).
+    raw=True: `scales` are the model's log-scales and `quats` its unnormalised quaternions; torch.exp and the division by
+    quats.norm() of activesplatfacto_model.py:221-223 happen inside the kernel (unerf_splat_project_raw)."""
     lib = _l.load()
+    entry = lib.unerf_splat_project_raw if raw else lib.unerf_splat_project
     N, dev = means3d.shape[0], means3d.device
     xys = torch.empty(N, 2, device=dev)
     depths = torch.empty(N, device=dev)
@@ -873,7 +876,7 @@ def splat_project(means3d, scales, glob_scale: float, quats, viewmat: torch.Tens
     tiles = torch.empty(N, device=dev, dtype=torch.int32)
     cov3d = torch.empty(N, 6, device=dev)
     with _ctx(dev):
-        _run("splat_project", lambda: lib.unerf_splat_project(_p(means3d), _p(scales), glob_scale, _p(quats), _host12(viewmat), fx, fy, cx,
+        _run("splat_project", lambda: entry(_p(means3d), _p(scales), glob_scale, _p(quats), _host12(viewmat), fx, fy, cx,
                                          cy, H, W, block_width, clip_thresh, N, _p(xys), _p(depths),
                                          _p(radii, torch.int32), _p(conics), _p(comp), _p(tiles, torch.int32),
                                          _p(cov3d), _stream()))
@@ -905,6 +908,24 @@ def splat_sh_colors_split(degree: int, means3d, cam_pos: torch.Tensor, features_
             degree, _p(means3d), cp, _p(features_dc), _p(features_rest), _p(log_unc), beta_min, N, _p(colors), _p(beta),
             _stream()))
     return colors, beta
+
+
+def splat_shade_inputs(degree: int, means3d, cam_pos: torch.Tensor, features_dc, features_rest, log_unc, beta_min: float,
+                       opacity_logits, compensation, depths):
+    """-> (rows [N,C], opacities [N]): rows = [rgb, beta, depth] (C = 5) with `log_unc`, [rgb, depth] (C = 4) without;
+    opacities = sigmoid(opacity_logits) [* compensation].  One launch for the SH colours, beta, the channel
+    concatenation and the opacity activation of one frame (unerf_splat_shade_inputs)."""
+    lib = _l.load()
+    N, dev = means3d.shape[0], means3d.device
+    Cn = 5 if log_unc is not None else 4
+    rows = torch.empty(N, Cn, device=dev)
+    opac = torch.empty(N, device=dev)
+    cp = (C.c_float * 3)(*[float(v) for v in cam_pos.detach().cpu().reshape(-1)[:3]])
+    with _ctx(dev):
+        _run("splat_sh_colors", lambda: lib.unerf_splat_shade_inputs(
+            degree, _p(means3d), cp, _p(features_dc), _p(features_rest), _p(log_unc), beta_min, _p(opacity_logits),
+            _p(compensation), _p(depths), N, Cn, _p(rows), _p(opac), _stream()))
+    return rows, opac
 
 
 class SplatCount:
@@ -971,10 +992,12 @@ def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_widt
 
 def splat_rasterize(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, H: int, W: int,
                     background: Optional[torch.Tensor] = None, block_width: int = 16, want_final_idx: bool = False,
-                    stop_idx: Optional[torch.Tensor] = None, cull: bool = True):
+                    stop_idx: Optional[torch.Tensor] = None, cull: bool = True,
+                    chan_max: Optional[Tuple[int, torch.Tensor]] = None):
     """colors [N,C] -> (out_img [H,W,C], final_T [H,W], final_idx | None).  stop_idx [H,W] int32: the final_idx of an
     earlier pass with the same geometry (bounded second pass); cull=False: gsplat's schedule without wave-level culling
-    (same bits either way)."""
+    (same bits either way).  chan_max = (channel, one zeroed device float): receives max(out_img[..., channel]) for
+    splat_alpha_normalize(..., max_ready=that float)."""
     lib = _l.load()
     dev, Cn = xys.device, colors.shape[1]
     out = torch.empty(H, W, Cn, device=dev)
@@ -985,18 +1008,21 @@ def splat_rasterize(gaussian_ids_sorted, tile_bins, xys, conics, colors, opaciti
     with _ctx(dev):
         _run(f"splat_rasterize_c{Cn}", lambda: lib.unerf_splat_rasterize(_p(gaussian_ids_sorted, torch.int32), _p(tile_bins, torch.int32), _p(xys),
                                            _p(conics), _p(colors), _p(opacities), _p(background), Cn, H, W,
-                                           block_width, _p(stop_idx, torch.int32), 0 if cull else _l.RASTER_NO_CULL, _p(out),
-                                           _p(fT), _p(fidx, torch.int32), _stream()))
+                                           block_width, _p(stop_idx, torch.int32), 0 if cull else _l.RASTER_NO_CULL,
+                                           chan_max[0] if chan_max else -1, _p(chan_max[1]) if chan_max else None,
+                                           _p(out), _p(fT), _p(fidx, torch.int32), _stream()))
     return out, fT, fidx
 
 
-def splat_alpha_normalize(img: torch.Tensor, ch: int, final_T: torch.Tensor) -> None:
-    """in place on channel `ch` of img [H,W,C]"""
+def splat_alpha_normalize(img: torch.Tensor, ch: int, final_T: torch.Tensor, max_ready: Optional[torch.Tensor] = None) -> None:
+    """in place on channel `ch` of img [H,W,C].  max_ready: the device float a splat_rasterize(chan_max=(ch, float)) call
+    that produced img left the channel's maximum in; None: the maximum is computed here."""
     lib = _l.load()
     H, W, Cn = img.shape
-    scratch = torch.empty(1, device=img.device)
+    scratch = torch.empty(1, device=img.device) if max_ready is None else max_ready
     with _ctx(img.device):
-        _run("splat_alpha_normalize", lambda: lib.unerf_splat_alpha_normalize(_p(img), Cn, ch, _p(final_T), H * W, _p(scratch), _stream()))
+        _run("splat_alpha_normalize", lambda: lib.unerf_splat_alpha_normalize(_p(img), Cn, ch, _p(final_T), H * W, _p(scratch),
+                                                                              0 if max_ready is None else 1, _stream()))
 
 
 def splat_depth_sqdiff(xys, depths, depth_img: torch.Tensor, ch: int) -> torch.Tensor:

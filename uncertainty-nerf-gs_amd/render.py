@@ -2,8 +2,10 @@
 
 One call renders a batch of rays the way the reference renders one eval chunk
 (`Model.get_outputs_for_camera_ray_bundle` -> `forward` -> `get_outputs`), but with a launch
-granularity chosen for MI355X: `rays_per_launch` (default 2^18) rays go through the seven
-kernels at once -- 288 GB of HBM make the reference's 32768-ray chunking unnecessary; the only
+granularity chosen for MI355X: `rays_per_launch` (default 2^20: a 1080p frame is two launch groups; the K = 8 sample
+buffers of one group are 6.4 GB) rays go through the seven kernels at once -- 288 GB of HBM make the reference's
+32768-ray chunking unnecessary (2^18 -> 2^20 is worth 1.5-2 % of a frame: fewer partially filled last rounds; measured
+in profiles/r3_12_exp_rays_per_launch.json); the only
 place the reference chunk size is observable (DepthRenderer("expected") clips to the chunk's
 min/max sample position) is reproduced exactly through `chunk_rays`.
 
@@ -257,7 +259,7 @@ def render_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Te
 
 
 def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int,
-                  rays_per_launch: int = 1 << 18, overlap: bool = False, obb=None, **shade_kw) -> Dict[str, torch.Tensor]:
+                  rays_per_launch: int = 1 << 20, overlap: bool = False, obb=None, **shade_kw) -> Dict[str, torch.Tensor]:
     """get_outputs_for_camera: generate the H*W rays on device, render them in row-major launch
     groups, return images [H,W,C].  With `overlap`, sampling (group g+1) and shading (group g) run on
     two streams.  obb = (world_to_box [3,4], S [3]): the oriented crop box of `obb_box` (see crop_bins)."""

@@ -77,9 +77,9 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     means = gp["means"].contiguous()
     dev = means.device
     V = viewmat_from_c2w(c2w)
-    quats = gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True)
+    # exp(scales) and quats / quats.norm() (:221-223) are taken inside the projection kernel
     xys, depths, radii, conics, comp, tiles, _cov = ops.splat_project(
-        means, torch.exp(gp["scales"]), 1.0, quats.contiguous(), V[:3], fx, fy, cx, cy, H, W, block_width)
+        means, gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], fx, fy, cx, cy, H, W, block_width, raw=True)
     # the intersection count (the frame's one host read-back) starts its way to the host now and is awaited inside
     # splat_bin_sort; the SH colours do not depend on it and keep the GPU busy meanwhile
     count = ops.SplatCount(tiles)
@@ -87,38 +87,40 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
         sh_degree = -1                                     # kernel: colours = sigmoid(features_dc)
     # the reference concatenates features_dc and features_rest first (:242-243); the kernel reads them in place
     plain = "log_uncertainties" not in gp
-    rgbs, beta = ops.splat_sh_colors_split(sh_degree, means, c2w[:3, 3], gp["features_dc"].contiguous(),
-                                           gp["features_rest"].contiguous(),
-                                           None if plain else gp["log_uncertainties"].reshape(-1).contiguous(), beta_min)
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
+    # one launch leaves the rasteriser's per-splat rows [rgb, (beta), depth] and sigmoid(opacities) [* comp] (:252-256)
+    cols, opac = ops.splat_shade_inputs(sh_degree, means, c2w[:3, 3], gp["features_dc"].contiguous(),
+                                        gp["features_rest"].contiguous(),
+                                        None if plain else gp["log_uncertainties"].reshape(-1).contiguous(), beta_min,
+                                        gp["opacities"].reshape(-1).contiguous(),
+                                        comp if rasterize_mode == "antialiased" else None, depths)
     # (self.radii).sum() == 0 -> get_empty_outputs (:239-240).  A splat has a non-zero radius exactly when it hits at
     # least one tile, so "no intersections" is the same test and rides on the one host read-back of the frame
     I, _cum, _keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, block_width, want_isect_ids=False,
                                                     count=count)
     if I == 0:
         return empty_outputs(W, H, background)
-    opac = torch.sigmoid(gp["opacities"]).reshape(-1)
-    if rasterize_mode == "antialiased":
-        opac = opac * comp
-    elif rasterize_mode != "classic":
-        raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
-    opac = opac.contiguous()
+    # frame scratch: the background padded to the row length, and the two channel maxima the rasteriser passes leave for
+    # their alpha normalisations
+    Cn = cols.shape[1]
+    scratch = torch.zeros(Cn + 2, device=dev)
+    scratch[:3] = background
+    bg, mx1, mx2 = scratch[:Cn], scratch[Cn:Cn + 1], scratch[Cn + 1:Cn + 2]
     if plain:
-        cols = torch.cat([rgbs, depths[:, None]], dim=1).contiguous()
-        bg4 = torch.cat([background.to(dev, torch.float32), torch.zeros(1, device=dev)])
-        img, fT, _ = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg4, block_width)
-        ops.splat_alpha_normalize(img, 3, fT)       # depth = where(alpha > 0, d / alpha, max(d))
+        img, fT, _ = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg, block_width, chan_max=(3, mx1))
+        ops.splat_alpha_normalize(img, 3, fT, max_ready=mx1)       # depth = where(alpha > 0, d / alpha, max(d))
         return {"rgb": torch.clamp(img[..., 0:3], max=1.0), "depth": img[..., 3:4], "accumulation": (1.0 - fT)[..., None],
                 "background": background}
-    cols = torch.cat([rgbs, beta[:, None], depths[:, None]], dim=1).contiguous()
-    bg5 = torch.cat([background.to(dev, torch.float32), torch.zeros(2, device=dev)])
-    img, fT, fidx = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg5, block_width, want_final_idx=True)
+    img, fT, fidx = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg, block_width, want_final_idx=True,
+                                        chan_max=(4, mx1))
     alpha = (1.0 - fT)[..., None]
-    ops.splat_alpha_normalize(img, 4, fT)           # depth = where(alpha>0, d/alpha, max(d))   (:319)
-    sq = ops.splat_depth_sqdiff(xys, depths, img, 4)  # (z_i - depth[floor(xy_i)])^2            (:325-341)
+    ops.splat_alpha_normalize(img, 4, fT, max_ready=mx1)   # depth = where(alpha>0, d/alpha, max(d))   (:319)
+    sq = ops.splat_depth_sqdiff(xys, depths, img, 4)       # (z_i - depth[floor(xy_i)])^2            (:325-341)
     # same ids / bins / geometry / opacities as the first pass: every pixel stops at the index that pass ended on
-    dv, fT2, _ = ops.splat_rasterize(gids, bins, xys, conics, sq[:, None].contiguous(), opac, H, W, None, block_width,
-                                     stop_idx=fidx)
-    ops.splat_alpha_normalize(dv, 0, fT2)           # (:356)
+    dv, fT2, _ = ops.splat_rasterize(gids, bins, xys, conics, sq[:, None], opac, H, W, None, block_width,
+                                     stop_idx=fidx, chan_max=(0, mx2))
+    ops.splat_alpha_normalize(dv, 0, fT2, max_ready=mx2)   # (:356)
     unc = img[..., 3:4]
     return {"rgb": torch.clamp(img[..., 0:3], max=1.0), "depth": img[..., 4:5], "accumulation": alpha,
             "background": background, "uncertainty": unc, "rgb_var": unc ** 2, "rgb_std": unc,
