@@ -38,7 +38,7 @@ extern "C" {
 const char* unerf_last_error(void);
 /* Library/ABI version (major*1000+minor).  A binding built against this header must find exactly UNERF_ABI_VERSION
  * (struct layouts and argument lists change with it; uncertainty-nerf-gs_amd/lib.py::load checks). */
-#define UNERF_ABI_VERSION 1210
+#define UNERF_ABI_VERSION 1220
 int unerf_version(void);
 
 /* Spacing function of the proposal sampler's initial sampler, passed behind every (near_plane, far_plane) pair:
@@ -396,11 +396,19 @@ int unerf_splat_project(const float* means3d, const float* scales, float glob_sc
 
 /* The same projection fed with the model's parameters as stored: log_scales [N,3] (gauss_params.scales) and raw_quats
  * [N,4] (gauss_params.quats, unnormalised).  Replaces torch.exp(scales_crop) and quats_crop / quats_crop.norm(dim=-1,
- * keepdim=True) (:221-223) + project_gaussians: three elementwise launches less per frame. */
+ * keepdim=True) (:221-223) + project_gaussians: three elementwise launches less per frame.
+ * opacity_logits [N] (may be NULL): gauss_params.opacities.  When given, opacities_out [N] receives
+ * sigmoid(opacity_logits) (:256), times the compensation when antialiased != 0 (:252-254), and num_tiles_hit becomes
+ * TIGHT: it counts only the tiles of gsplat's box in which some pixel centre can have alpha >= 1/255 for that opacity
+ * (the ellipse sigma <= ln(255 o); about half of the box for the bench scene).  The pairs left out are pairs the blend
+ * loop skips by itself, so every rasterised output is bit-identical -- with shorter lists to sort and stage.  A tight
+ * count must be binned by unerf_splat_bin_sort with tight_conics / tight_opacities = these conics / opacities_out.
+ * radii, xys, ... stay gsplat's (radii > 0 is still "visible"). */
 int unerf_splat_project_raw(const float* means3d, const float* log_scales, float glob_scale, const float* raw_quats,
                             const float* viewmat_host, float fx, float fy, float cx, float cy, int H, int W,
-                            int block_width, float clip_thresh, int64_t N, float* xys, float* depths, int32_t* radii,
-                            float* conics, float* compensation, int32_t* num_tiles_hit, float* cov3d, void* stream);
+                            int block_width, float clip_thresh, int64_t N, const float* opacity_logits, int antialiased,
+                            float* opacities_out, float* xys, float* depths, int32_t* radii, float* conics,
+                            float* compensation, int32_t* num_tiles_hit, float* cov3d, void* stream);
 
 /* :245-246 spherical_harmonics(degree, viewdirs, coeffs[N,16,3]) then clamp(+0.5, min 0);
  * and :286 softplus(log_unc)+beta_min.  cam_pos_host: 3 floats.  colors_out [N,3], beta_out [N].
@@ -421,7 +429,8 @@ int unerf_splat_sh_colors_split(int degree, const float* means3d, const float* c
  * unerf_splat_sh_colors_split), beta = softplus(log_unc) + beta_min (:286), the depth channel, and
  * opacities = sigmoid(opacity_logits) [* compensation] (:252-256).  Replaces the torch.cat([rgbs, beta, depths]) and
  * torch.sigmoid launches of the frame.  rows_out [N,C]: C = 5 -> [r, g, b, beta, depth]; C = 4 -> [r, g, b, depth]
- * (plain splatfacto; log_unc may be NULL).  compensation may be NULL ("classic").  opacities_out [N]. */
+ * (plain splatfacto; log_unc may be NULL).  compensation may be NULL ("classic").  opacities_out [N].
+ * opacity_logits may be NULL (the opacities were made by unerf_splat_project_raw): opacities_out is then not written. */
 int unerf_splat_shade_inputs(int degree, const float* means3d, const float* cam_pos_host, const float* features_dc,
                              const float* features_rest, const float* log_unc, float beta_min,
                              const float* opacity_logits, const float* compensation, const float* depths, int64_t N,
@@ -434,13 +443,17 @@ int unerf_splat_shade_inputs(int degree, const float* means3d, const float* cam_
  * on device), read it back, size the buffers, then unerf_splat_bin_sort.
  * The sorted order is that of gsplat's stable sort of (tile << 32 | depth bits) keys; it is produced by
  * ordering the N splats by depth first and then sorting the intersections by tile id only (stable).
- * isect_ids_sorted may be NULL (the rasteriser needs only gaussian_ids_sorted and tile_bins). */
+ * isect_ids_sorted may be NULL (the rasteriser needs only gaussian_ids_sorted and tile_bins).
+ * tight_conics [N,3] + tight_opacities [N] (both or neither): cum_tiles_hit is the scan of a TIGHT num_tiles_hit
+ * (unerf_splat_project_raw with opacity logits) -- each splat then emits exactly the tiles that count was made of.
+ * NULL, NULL: gsplat's lists (every tile of the radius box). */
 int64_t unerf_splat_sort_workspace_bytes(int64_t N, int64_t num_intersects);
 int unerf_splat_count_intersects(const int32_t* num_tiles_hit, int64_t N, int32_t* cum_tiles_hit,
                                  void* workspace, int64_t workspace_bytes, void* stream);
 int unerf_splat_bin_sort(const float* xys, const float* depths, const int32_t* radii,
                          const int32_t* cum_tiles_hit, int64_t N, int64_t num_intersects, int H, int W,
-                         int block_width, int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted,
+                         int block_width, const float* tight_conics, const float* tight_opacities,
+                         int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted,
                          int32_t* tile_bins, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* rasterize_forward / nd_rasterize_forward: C channels blended in one pass.

@@ -26,7 +26,7 @@ def test_header_symbols_all_bound_and_exported(lib):
 
 def test_version_and_error_string(lib):
     h = lib.load()
-    assert h.unerf_version() == lib.ABI_VERSION == 1210
+    assert h.unerf_version() == lib.ABI_VERSION == 1220
     assert h.unerf_build_flags() & lib.BUILD_TRUNK_FOLD          # the shipped build folds the K-pass trunk-out slabs
     assert isinstance(h.unerf_last_error(), bytes)
 
@@ -87,8 +87,14 @@ def test_zero_counts_are_no_ops_and_oversized_inputs_are_refused(lib):
     vm = (C.c_float * 12)(*([0.0] * 12))
     assert h.unerf_splat_project(None, None, 1.0, None, vm, 1.0, 1.0, 0.0, 0.0, 16, 16, 16, 0.01, 0, None, None, None, None,
                                  None, None, None, None) == 0
-    assert h.unerf_splat_project_raw(None, None, 1.0, None, vm, 1.0, 1.0, 0.0, 0.0, 16, 16, 16, 0.01, 0, None, None, None,
-                                     None, None, None, None, None) == 0
+    assert h.unerf_splat_project_raw(None, None, 1.0, None, vm, 1.0, 1.0, 0.0, 0.0, 16, 16, 16, 0.01, 0, None, 0, None, None,
+                                     None, None, None, None, None, None, None) == 0
+    # tight tile counts need somewhere to put the opacities they were made with; tight binning needs both arrays
+    assert h.unerf_splat_project_raw(1, 1, 1.0, 1, vm, 1.0, 1.0, 0.0, 0.0, 16, 16, 16, 0.01, 4, 1, 0, None, 1, 1, 1, 1, 1, 1,
+                                     1, None) == -1
+    assert b"opacities_out" in h.unerf_last_error()
+    assert h.unerf_splat_bin_sort(1, 1, 1, 1, 4, 4, 16, 16, 16, 1, None, None, 1, 1, 1, 1024, None) == -1
+    assert b"tight lists need both" in h.unerf_last_error()
     assert h.unerf_splat_shade_inputs(3, None, (C.c_float * 3)(0.0, 0.0, 0.0), None, None, None, 0.01, None, None, None, 0, 5,
                                       None, None, None) == 0
     assert h.unerf_splat_depth_sqdiff(None, None, None, 1, 0, 16, 16, 0, None, None) == 0

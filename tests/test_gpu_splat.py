@@ -376,3 +376,114 @@ def test_channel_maximum_taken_inside_the_rasteriser(dev, C, ch):
     mx2 = torch.zeros(1, device=dev)
     img2, _, _ = ops.splat_rasterize(gids, bins, xys, conics, colors, opac, H, W, bg, stop_idx=fidx, chan_max=(ch, mx2))
     assert torch.equal(img2, img) and float(mx2) == float(mx)
+
+
+def _hard_scene(N, dev, seed=11):
+    """needles, pancakes, huge and faint splats, opacities on both sides of 1/255"""
+    gp = _scene(N, seed=seed)
+    gp["scales"][:N // 20] += 2.0
+    gp["scales"][N // 20:N // 8, 0] -= 3.0
+    gp["scales"][N // 8:N // 5, 1] += 1.5
+    gp["opacities"][N // 5:N // 3] = -5.6 + 0.4 * torch.randn(N // 3 - N // 5, 1)     # sigmoid ~ 1/255 +- a factor
+    gp["opacities"][N // 3:N // 2] = 6.0                                             # nearly opaque: ellipse beyond 3 sigma
+    return {k: v.to(dev) for k, v in gp.items()}
+
+
+@pytest.mark.parametrize("mode", ["classic", "antialiased"])
+def test_tight_tile_lists_change_no_output_bit(dev, mode):
+    """binning a splat only into the tiles its alpha >= 1/255 ellipse reaches (instead of gsplat's radius box) removes only
+    pairs the blend loop skips: every output of the frame keeps its bits, with fewer intersections to sort"""
+    from uncertainty_nerf_gs_amd import ops, splat
+    N, H, W = 30000, 200, 296
+    gp = _hard_scene(N, dev)
+    c2w = _camera(0.9, 2.3)
+    K = (0.8 * W, 0.8 * W, W / 2, H / 2, H, W)
+    bg = torch.tensor([0.2, 0.5, 0.7])
+    a = splat.active_splatfacto_outputs(gp, c2w, *K, bg, rasterize_mode=mode, tight=True)
+    b = splat.active_splatfacto_outputs(gp, c2w, *K, bg, rasterize_mode=mode, tight=False)
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    assert float(b["accumulation"].mean()) > 0.3
+    plain = {k: v for k, v in gp.items() if k != "log_uncertainties"}
+    a = splat.active_splatfacto_outputs(plain, c2w, *K, bg, rasterize_mode=mode, tight=True)
+    b = splat.active_splatfacto_outputs(plain, c2w, *K, bg, rasterize_mode=mode, tight=False)
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    # how much shorter the lists are
+    V = splat.viewmat_from_c2w(c2w)
+    logits = gp["opacities"].reshape(-1).contiguous()
+    full = ops.splat_project(gp["means"], gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], *K, raw=True)
+    tight = ops.splat_project(gp["means"], gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], *K, raw=True,
+                              opacity_logits=logits, antialiased=mode == "antialiased")
+    for x, y in zip(full[:5], tight[:5]):
+        assert torch.equal(x, y)                       # xys, depths, radii, conics, compensation: gsplat's, untouched
+    assert bool((tight[5] <= full[5]).all()) and int(tight[5].sum()) < 0.75 * int(full[5].sum())
+    o = torch.sigmoid(logits) * (full[4] if mode == "antialiased" else 1.0)
+    vis = full[2] > 0
+    torch.testing.assert_close(tight[7][vis], o[vis], rtol=3e-7, atol=0)
+
+
+def test_tight_tile_lists_are_conservative(dev):
+    """brute force: every (tile, splat) pair with a pixel that the blend loop would NOT skip (sigma >= 0 and
+    alpha = min(0.999, o exp(-sigma)) >= 1/255) is in the tight lists, the tight lists are a subset of gsplat's, and
+    both keep the depth order"""
+    from uncertainty_nerf_gs_amd import ops, splat
+    N, H, W = 4000, 112, 176
+    gp = _hard_scene(N, dev, seed=5)
+    c2w = _camera(0.3, 2.4)
+    V = splat.viewmat_from_c2w(c2w)
+    K = (0.8 * W, 0.8 * W, W / 2, H / 2, H, W)
+    logits = gp["opacities"].reshape(-1).contiguous()
+    args = (gp["means"], gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3]) + K
+    xys, depths, radii, conics, comp, tiles_t, _, opac = ops.splat_project(*args, raw=True, opacity_logits=logits)
+    tiles_f = ops.splat_project(*args, raw=True)[5]
+    It, _, _, gids_t, bins_t = ops.splat_bin_sort(xys, depths, radii, tiles_t, H, W, want_isect_ids=False, tight=(conics, opac))
+    If, _, _, gids_f, bins_f = ops.splat_bin_sort(xys, depths, radii, tiles_f, H, W, want_isect_ids=False)
+    assert 0 < It < If
+    tbx, tby = (W + 15) // 16, (H + 15) // 16
+
+    def member(gids, bins):
+        m = torch.zeros(tbx * tby, N, dtype=torch.bool, device=dev)
+        b = bins.cpu()
+        for t in range(tbx * tby):
+            ids = gids[int(b[t, 0]):int(b[t, 1])].long()
+            assert bool((depths[ids][1:] >= depths[ids][:-1]).all())           # depth order inside a tile
+            assert ids.unique().numel() == ids.numel()
+            m[t, ids] = True
+        return m
+
+    mt, mf = member(gids_t, bins_t), member(gids_f, bins_f)
+    assert not bool((mt & ~mf).any())                                          # subset of gsplat's lists
+    # pixels that blend: per splat chunk, alpha at every pixel centre
+    py, px = torch.meshgrid(torch.arange(H, device=dev) + 0.5, torch.arange(W, device=dev) + 0.5, indexing="ij")
+    tile_of = ((py - 0.5).long() // 16) * tbx + (px - 0.5).long() // 16       # [H,W]
+    need = torch.zeros_like(mt)
+    vis = torch.nonzero(radii > 0).reshape(-1)
+    for chunk in vis.split(256):
+        dx = xys[chunk, 0, None, None] - px[None]
+        dy = xys[chunk, 1, None, None] - py[None]
+        ca, cb, cc = conics[chunk, 0, None, None], conics[chunk, 1, None, None], conics[chunk, 2, None, None]
+        sigma = 0.5 * (ca * dx * dx + cc * dy * dy) + cb * dx * dy
+        alpha = torch.clamp(opac[chunk, None, None] * torch.exp(-sigma), max=0.999)
+        hit = (sigma >= 0) & (alpha >= (1.0 / 255.0) * (1 - 1e-4))             # a hair more than the loop keeps
+        for k, g in enumerate(chunk.tolist()):
+            need[tile_of[hit[k]].unique(), g] = True
+    need &= mf                                                                 # gsplat never blends outside its box
+    missing = need & ~mt
+    assert not bool(missing.any()), f"{int(missing.sum())} blending (tile, splat) pairs are not in the tight lists"
+    assert int(need.sum()) > 0.5 * int(mt.sum())                               # and the tight lists are tight
+
+
+def test_tight_lists_all_faint_frame_is_the_references_not_the_empty_one(dev):
+    """radii.sum() > 0 with every opacity under 1/255: the reference rasterises (nothing blends: depth 0, rgb =
+    background), it does not return get_empty_outputs (depth 10)"""
+    from uncertainty_nerf_gs_amd import splat
+    gp = {k: v.to(dev) for k, v in _scene(2000).items()}
+    gp["opacities"][:] = -9.0
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    K = (50.0, 50.0, 32.0, 24.0, 48, 64)
+    a = splat.active_splatfacto_outputs(gp, _camera(), *K, bg, tight=True)
+    b = splat.active_splatfacto_outputs(gp, _camera(), *K, bg, tight=False)
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["depth"].abs().max()) == 0.0 and float(a["accumulation"].max()) == 0.0

@@ -30,6 +30,11 @@ struct ProjArgs {
     float* comp;
     int32_t* tiles;
     float* cov3d;
+    // tight binning (unerf_splat_project_raw with opacity logits): the activated opacity leaves this kernel and
+    // num_tiles_hit counts only the tiles the splat's alpha >= 1/255 ellipse can reach
+    const float* opl;
+    float* opac_out;
+    int antialiased;
 };
 
 __device__ __forceinline__ void tile_bbox(float cx, float cy, float radius, int bw, int tbx, int tby, int& x0, int& y0,
@@ -39,6 +44,82 @@ __device__ __forceinline__ void tile_bbox(float cx, float cy, float radius, int 
     x1 = min(max(0, (int)(tcx + tr + 1.f)), tbx);
     y0 = min(max(0, (int)(tcy - tr)), tby);
     y1 = min(max(0, (int)(tcy + tr + 1.f)), tby);
+}
+
+// ---- tight tile lists ------------------------------------------------------------------------------------------------
+// gsplat bins a splat into every tile of the square [xy -+ radius] with radius = ceil(3 sqrt(lambda_max)).  The blend
+// loop then skips each (pixel, splat) pair with alpha = min(0.999, o exp(-sigma)) < 1/255, i.e. everything outside the
+// ellipse sigma <= ln(255 o): for an anisotropic or faint splat most tiles of the square hold no such pixel (49 % of
+// the 37 M pairs of the 1 M-splat bench frame), yet each costs a sort entry and a staging slot in the rasteriser.
+// TightSplat describes that ellipse (padded far above fp32 rounding, as raster_strip_mask); tight_row gives, for one
+// tile row, the range of tiles whose pixel centres it can reach -- always a subset of gsplat's box, so the lists
+// lose only pairs the blend loop would have skipped: images, transmittances and orders of the blended terms are
+// bit-identical (tests/test_gpu_splat.py::test_tight_tile_lists_*).
+struct TightSplat {
+    float x, y, b;          // centre, conic b
+    float k, det, inv_a, hy, ry;   // k = 2 tau a; ry = -(b / c) hx: dy of the ellipse's rightmost point (leftmost: -ry)
+    float pad;
+    int valid;              // 0: keep gsplat's box (not an ellipse / non-finite numbers); -1: never visible
+};
+// (hardware sqrt / rcp, ~1 ulp: the pad is orders of magnitude above that, and both kernels that walk a splat's rows --
+// the count in project_kernel, the emission in map_intersects_kernel -- run this same code on the same stored numbers)
+
+__device__ __forceinline__ TightSplat tight_splat(float x, float y, float op, float a, float b, float c) {
+    TightSplat t;
+    t.x = x; t.y = y; t.b = b;
+    t.valid = 0; t.k = 0.f; t.det = 0.f; t.inv_a = 0.f; t.hy = 0.f; t.ry = 0.f; t.pad = 0.f;
+    if (!(op >= 0.0039f)) {            // alpha <= opacity < 1/255 (0.00392...) at every pixel
+        t.valid = (op != op) ? 0 : -1;
+        return t;
+    }
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return t;
+    const float two_tau = 2.f * fmaf(__logf(255.f * op), 1.01f, 0.01f);
+    const float inv_det = __builtin_amdgcn_rcpf(det);
+    const float hx = __builtin_amdgcn_sqrtf(two_tau * c * inv_det);
+    t.k = two_tau * a;
+    t.det = det;
+    t.inv_a = __builtin_amdgcn_rcpf(a);
+    t.hy = __builtin_amdgcn_sqrtf(t.k * inv_det);
+    t.ry = -(b * __builtin_amdgcn_rcpf(c)) * hx;
+    t.pad = fmaf(fmaxf(hx, t.hy), 0.01f, 0.05f);
+    const bool fin = fabsf(hx) < INFINITY && fabsf(t.hy) < INFINITY && fabsf(t.ry) < INFINITY && fabsf(t.inv_a) < INFINITY;   // false for NaN too
+    t.valid = fin ? 1 : 0;
+    return t;
+}
+
+// tiles [tx0, tx1) of tile row ty (inside gsplat's [x0, x1)) holding a pixel centre with sigma <= tau
+__device__ __forceinline__ void tight_row(const TightSplat& t, int ty, int bw, int x0, int x1, int& tx0, int& tx1) {
+    tx0 = x0; tx1 = x1;
+    if (t.valid == 0) return;
+    if (t.valid < 0) { tx1 = x0; return; }
+    const float fbw = (float)bw, inv_bw = 1.f / fbw;   // (bw is uniform: one scalar division; exact for 16)
+    // pixel-centre rows of the tile row, relative to the splat, widened by the pad
+    float d0 = ((float)ty * fbw + 0.5f) - t.y - t.pad, d1 = ((float)ty * fbw + (fbw - 0.5f)) - t.y + t.pad;
+    if (d0 > t.hy || d1 < -t.hy) { tx1 = x0; return; }
+    d0 = fmaxf(d0, -t.hy); d1 = fminf(d1, t.hy);
+    // right end (-b dy + sqrt(2 tau a - det dy^2)) / a is concave in dy: its maximum over the rows is at the rightmost
+    // point's dy clamped into them; the left end is the mirror image
+    const float dr = fminf(fmaxf(t.ry, d0), d1), dl = fminf(fmaxf(-t.ry, d0), d1);
+    const float sr = __builtin_amdgcn_sqrtf(fmaxf(t.k - t.det * dr * dr, 0.f));
+    const float sl = __builtin_amdgcn_sqrtf(fmaxf(t.k - t.det * dl * dl, 0.f));
+    const float xr = (-t.b * dr + sr) * t.inv_a + t.pad, xl = (-t.b * dl - sl) * t.inv_a - t.pad;
+    if (!(xr >= xl)) return;   // NaN: keep the box
+    // a pixel centre c = j + 0.5 lies in tile floor((c - 0.5) / bw); the pad covers the rounding of the product
+    const float fl = floorf((t.x + xl - 0.5f) * inv_bw), fr = floorf((t.x + xr - 0.5f) * inv_bw);
+    tx0 = max(x0, (int)fmaxf(fl, -1e6f));
+    tx1 = min(x1, (int)fminf(fr, 1e6f) + 1);
+    if (tx1 < tx0) tx1 = tx0;
+}
+
+__device__ __forceinline__ int tight_count(const TightSplat& t, int bw, int x0, int y0, int x1, int y1) {
+    int n = 0;
+    for (int ty = y0; ty < y1; ++ty) {
+        int a0, a1;
+        tight_row(t, ty, bw, x0, x1, a0, a1);
+        n += a1 - a0;
+    }
+    return n;
 }
 
 // RAW: `scales` / `quats` are the model's parameters as stored -- log-scales and unnormalised quaternions -- and the
@@ -60,6 +141,11 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
     a.conics[i * 3 + 2] = 0.f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) a.cov3d[i * 6 + k] = 0.f;
+    float opac = 0.f;
+    if (a.opl) {   // uniform.  sigmoid(opacities) (:256); "antialiased" multiplies the compensation in below (:252-254)
+        opac = unerf_sigmoid(a.opl[i]);
+        a.opac_out[i] = a.antialiased ? 0.f : opac;
+    }
 
     const float p0 = a.means[i * 3], p1 = a.means[i * 3 + 1], p2 = a.means[i * 3 + 2];
     const float* V = a.V;
@@ -148,6 +234,13 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
     tile_bbox(u, v, radius, a.bw, tbx, tby, x0, y0, x1, y1);
     int area = (x1 - x0) * (y1 - y0);
     if (area <= 0) return;
+    if (a.opl) {
+        if (a.antialiased) {
+            opac = opac * comp;
+            a.opac_out[i] = opac;
+        }
+        area = tight_count(tight_splat(u, v, opac, cc * inv_det, -cb * inv_det, ca * inv_det), a.bw, x0, y0, x1, y1);
+    }
     a.tiles[i] = area;
     a.depths[i] = tz;
     a.radii[i] = (int)radius;
@@ -156,7 +249,8 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
     a.comp[i] = comp;
 }
 
-static int splat_project_impl(bool raw, const float* means3d, const float* scales, float glob_scale, const float* quats,
+static int splat_project_impl(bool raw, const float* opacity_logits, int antialiased, float* opacities_out,
+                              const float* means3d, const float* scales, float glob_scale, const float* quats,
                               const float* viewmat, float fx, float fy, float cx, float cy, int H, int W,
                               int block_width, float clip_thresh, int64_t N, float* xys, float* depths,
                               int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit,
@@ -172,6 +266,7 @@ static int splat_project_impl(bool raw, const float* means3d, const float* scale
     a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.H = H; a.W = W; a.bw = block_width; a.clip = clip_thresh; a.N = N;
     a.xys = xys; a.depths = depths; a.radii = radii; a.conics = conics; a.comp = compensation;
     a.tiles = num_tiles_hit; a.cov3d = cov3d;
+    a.opl = opacity_logits; a.opac_out = opacities_out; a.antialiased = antialiased;
     if (raw) hipLaunchKernelGGL(project_kernel<true>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(project_kernel<false>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return unerf_check_launch("splat_project");
@@ -182,16 +277,18 @@ extern "C" int unerf_splat_project(const float* means3d, const float* scales, fl
                                    int block_width, float clip_thresh, int64_t N, float* xys, float* depths,
                                    int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit,
                                    float* cov3d, void* stream) {
-    return splat_project_impl(false, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block_width,
+    return splat_project_impl(false, nullptr, 0, nullptr, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block_width,
                               clip_thresh, N, xys, depths, radii, conics, compensation, num_tiles_hit, cov3d, stream);
 }
 
 extern "C" int unerf_splat_project_raw(const float* means3d, const float* log_scales, float glob_scale,
                                        const float* raw_quats, const float* viewmat, float fx, float fy, float cx,
-                                       float cy, int H, int W, int block_width, float clip_thresh, int64_t N, float* xys,
+                                       float cy, int H, int W, int block_width, float clip_thresh, int64_t N,
+                                       const float* opacity_logits, int antialiased, float* opacities_out, float* xys,
                                        float* depths, int32_t* radii, float* conics, float* compensation,
                                        int32_t* num_tiles_hit, float* cov3d, void* stream) {
-    return splat_project_impl(true, means3d, log_scales, glob_scale, raw_quats, viewmat, fx, fy, cx, cy, H, W, block_width,
+    UNERF_REQUIRE(!opacity_logits || opacities_out || N <= 0, "splat_project_raw: opacity_logits without opacities_out");
+    return splat_project_impl(true, opacity_logits, antialiased, opacities_out, means3d, log_scales, glob_scale, raw_quats, viewmat, fx, fy, cx, cy, H, W, block_width,
                               clip_thresh, N, xys, depths, radii, conics, compensation, num_tiles_hit, cov3d, stream);
 }
 
@@ -288,8 +385,10 @@ __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float*
     if (PACK) {
         if (pk.C == 5) colors[row + 3] = unerf_softplus(log_unc[i]) + beta_min;
         colors[row + pk.C - 1] = pk.depths[i];
-        const float o = unerf_sigmoid(pk.opacity_logits[i]);
-        pk.opacities[i] = pk.compensation ? o * pk.compensation[i] : o;
+        if (pk.opacity_logits) {   // uniform
+            const float o = unerf_sigmoid(pk.opacity_logits[i]);
+            pk.opacities[i] = pk.compensation ? o * pk.compensation[i] : o;
+        }
     } else if (beta) {
         beta[i] = unerf_softplus(log_unc[i]) + beta_min;
     }
@@ -327,8 +426,8 @@ extern "C" int unerf_splat_shade_inputs(int degree, const float* means3d, const 
                                         const float* features_rest, const float* log_unc, float beta_min,
                                         const float* opacity_logits, const float* compensation, const float* depths,
                                         int64_t N, int C, float* rows_out, float* opacities_out, void* stream) {
-    UNERF_REQUIRE(cam_pos && (N <= 0 || (means3d && features_dc && opacity_logits && depths && rows_out && opacities_out)),
-                  "splat_shade_inputs: null pointer");
+    UNERF_REQUIRE(cam_pos && (N <= 0 || (means3d && features_dc && depths && rows_out)), "splat_shade_inputs: null pointer");
+    UNERF_REQUIRE(!opacity_logits || opacities_out || N <= 0, "splat_shade_inputs: opacity_logits without opacities_out");
     UNERF_REQUIRE(degree >= -1 && degree <= 3, "splat_shade_inputs: degree %d outside [-1,3]", degree);
     UNERF_REQUIRE(degree <= 0 || N <= 0 || features_rest, "splat_shade_inputs: degree %d needs features_rest", degree);
     UNERF_REQUIRE(C == 4 || C == 5, "splat_shade_inputs: C=%d, rows are [rgb, depth] (4) or [rgb, beta, depth] (5)", C);
@@ -444,7 +543,8 @@ __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __rest
                                                              const int32_t* __restrict__ radii,
                                                              const int32_t* __restrict__ order,
                                                              const int32_t* __restrict__ cum_sorted, int64_t N, int bw,
-                                                             int tbx, int tby, TKey* __restrict__ tkeys,
+                                                             int tbx, int tby, const float* __restrict__ conics,
+                                                             const float* __restrict__ opac, TKey* __restrict__ tkeys,
                                                              int32_t* __restrict__ vals) {
     const int l16 = threadIdx.x & 15;
     const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -452,10 +552,49 @@ __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __rest
     const int32_t i = order[j];
     if (radii[i] <= 0) return;
     int x0, y0, x1, y1;
-    tile_bbox(xys[(int64_t)i * 2], xys[(int64_t)i * 2 + 1], (float)radii[i], bw, tbx, tby, x0, y0, x1, y1);
+    const float sx = xys[(int64_t)i * 2], sy = xys[(int64_t)i * 2 + 1];
+    tile_bbox(sx, sy, (float)radii[i], bw, tbx, tby, x0, y0, x1, y1);
     const int w = x1 - x0, count = w * (y1 - y0);
     if (count <= 0) return;
     const int64_t first = (j == 0) ? 0 : cum_sorted[j - 1];
+    if (conics) {   // uniform: tight lists -- the rows project_kernel counted, in the same order
+        const TightSplat t = tight_splat(sx, sy, opac[i], conics[(int64_t)i * 3], conics[(int64_t)i * 3 + 1],
+                                         conics[(int64_t)i * 3 + 2]);
+        // 16 tile rows at a time, one per lane of the splat's 16-lane group; their widths are scanned inside the group and
+        // the round's entries go out striped over the lanes like the box form below (a row is only ~5 tiles wide: a
+        // lane-per-row or row-by-row emission leaves most lanes of every store idle -- 2.5 x the kernel time)
+        const int nrows = y1 - y0;
+        int64_t at = first;
+        for (int rb = 0; rb < nrows; rb += 16) {
+            int a0 = 0, a1 = 0;
+            if (rb + l16 < nrows) tight_row(t, y0 + rb + l16, bw, x0, x1, a0, a1);
+            const int wd = a1 - a0;
+            int incl = wd;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int v = __shfl_up(incl, d, 16);
+                if (l16 >= d) incl += v;
+            }
+            const int total = __shfl(incl, 15, 16), excl = incl - wd;
+            for (int e0 = 0; e0 < total; e0 += 16) {          // (uniform inside the group: every lane takes every shuffle)
+                const int e = e0 + l16;
+                int r = 0;                                    // row of entry e: first lane whose inclusive sum exceeds e
+#pragma unroll
+                for (int step = 8; step >= 1; step >>= 1) {
+                    const int probe = __shfl(incl, r + step - 1, 16);
+                    if (probe <= e) r += step;
+                }
+                r = min(r, 15);
+                const int rex = __shfl(excl, r, 16), ra0 = __shfl(a0, r, 16);
+                if (e < total) {
+                    tkeys[at + e] = (TKey)((y0 + rb + r) * tbx + ra0 + (e - rex));
+                    vals[at + e] = i;
+                }
+            }
+            at += total;
+        }
+        return;
+    }
     // row = floor(t / w) through the reciprocal, then made exact by one step either way (the estimate is within 1
     // for any box that fits an image)
     const float rw = 1.f / (float)w;
@@ -492,14 +631,15 @@ __global__ __launch_bounds__(256) void tile_edges_kernel(const TKey* __restrict_
 
 template <typename TKey>
 static int bin_sort_impl(const float* xys, const float* depths, const int32_t* radii, const int32_t* order,
-                         const int32_t* cum_sorted, int64_t N, int64_t I, int bw, int tbx, int tby, int bits,
+                         const int32_t* cum_sorted, const float* conics, const float* opac, int64_t N, int64_t I, int bw,
+                         int tbx, int tby, int bits,
                          int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted, int32_t* tile_bins, char* ws,
                          const SortWs& L, size_t tmp_bytes, hipStream_t st) {
     TKey* tk_in = reinterpret_cast<TKey*>(ws + L.tkey_in);
     TKey* tk_out = reinterpret_cast<TKey*>(ws + L.tkey_out);
     int32_t* v_in = reinterpret_cast<int32_t*>(ws + L.val_in);
     hipLaunchKernelGGL((map_intersects_kernel<TKey>), dim3(blocks_for(N, 16)), dim3(256), 0, st, xys, radii, order,
-                       cum_sorted, N, bw, tbx, tby, tk_in, v_in);
+                       cum_sorted, N, bw, tbx, tby, conics, opac, tk_in, v_in);
     int rc = unerf_check_launch("splat_bin_sort map");
     if (rc) return rc;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(ws + L.tmp, tmp_bytes, tk_in, tk_out, v_in, gaussian_ids_sorted,
@@ -515,9 +655,12 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
 
 extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const int32_t* radii,
                                     const int32_t* cum_tiles_hit, int64_t N, int64_t I, int H, int W, int block_width,
+                                    const float* tight_conics, const float* tight_opacities,
                                     int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted, int32_t* tile_bins,
                                     void* workspace, int64_t workspace_bytes, void* stream) {
     UNERF_REQUIRE(xys && depths && radii && cum_tiles_hit && tile_bins && workspace, "splat_bin_sort: null pointer");
+    UNERF_REQUIRE((tight_conics == nullptr) == (tight_opacities == nullptr),
+                  "splat_bin_sort: tight lists need both the conics and the opacities the tile counts were made with");
     UNERF_REQUIRE(N >= 1 && N < (1ll << 31) && I >= 0 && I < (1ll << 31), "splat_bin_sort: bad N/I");
     hipStream_t st = (hipStream_t)stream;
     int tbx = (W + block_width - 1) / block_width, tby = (H + block_width - 1) / block_width;
@@ -556,9 +699,9 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
     const int bits = tile_bits(H, W, block_width);
     tmp_bytes = (size_t)(L.dkey_in - L.tmp);
     if (bits <= 16)
-        return bin_sort_impl<uint16_t>(xys, depths, radii, order, cum_sorted, N, I, block_width, tbx, tby, bits,
+        return bin_sort_impl<uint16_t>(xys, depths, radii, order, cum_sorted, tight_conics, tight_opacities, N, I, block_width, tbx, tby, bits,
                                        isect_ids_sorted, gaussian_ids_sorted, tile_bins, ws, L, tmp_bytes, st);
-    return bin_sort_impl<uint32_t>(xys, depths, radii, order, cum_sorted, N, I, block_width, tbx, tby, bits,
+    return bin_sort_impl<uint32_t>(xys, depths, radii, order, cum_sorted, tight_conics, tight_opacities, N, I, block_width, tbx, tby, bits,
                                    isect_ids_sorted, gaussian_ids_sorted, tile_bins, ws, L, tmp_bytes, st);
 }
 

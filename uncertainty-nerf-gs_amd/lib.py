@@ -110,7 +110,7 @@ class FieldParams(C.Structure):
     ]
 
 
-ABI_VERSION = 1210                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
+ABI_VERSION = 1220                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
 SPACING_PIECEWISE, SPACING_UNIFORM = 0, 1         # include/unerf.h: UNERF_SPACING_*
 BG_LAST_SAMPLE, BG_NONE, BG_COLOR = 0, 1, 2       # include/unerf.h: UNERF_BG_*
@@ -150,14 +150,14 @@ SIGNATURES = {
     "unerf_moments": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "unerf_splat_project": (_i, [_vp, _vp, _f, _vp, _fp, _f, _f, _f, _f, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp]),
-    "unerf_splat_project_raw": (_i, [_vp, _vp, _f, _vp, _fp, _f, _f, _f, _f, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp,
-                                 _vp, _vp, _vp, _vp]),
+    "unerf_splat_project_raw": (_i, [_vp, _vp, _f, _vp, _fp, _f, _f, _f, _f, _i, _i, _i, _f, _i64, _vp, _i, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, _vp, _vp]),
     "unerf_splat_sh_colors": (_i, [_i, _vp, _fp, _vp, _vp, _f, _i64, _vp, _vp, _vp]),
     "unerf_splat_sh_colors_split": (_i, [_i, _vp, _fp, _vp, _vp, _vp, _f, _i64, _vp, _vp, _vp]),
     "unerf_splat_shade_inputs": (_i, [_i, _vp, _fp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "unerf_splat_sort_workspace_bytes": (_i64, [_i64, _i64]),
     "unerf_splat_count_intersects": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
-    "unerf_splat_bin_sort": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "unerf_splat_bin_sort": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "unerf_splat_rasterize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
                                    _vp]),
     "unerf_splat_alpha_normalize": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i, _vp]),

@@ -861,12 +861,17 @@ def moments(x: torch.Tensor, want_var: bool = True):
 # ---------------------------------------------------------------- splats ---------------
 
 def splat_project(means3d, scales, glob_scale: float, quats, viewmat: torch.Tensor, fx, fy, cx, cy, H: int, W: int,
-                  block_width: int = 16, clip_thresh: float = 0.01, raw: bool = False):
+                  block_width: int = 16, clip_thresh: float = 0.01, raw: bool = False, opacity_logits=None,
+                  antialiased: bool = False):
     """gsplat.project_gaussians signature -> (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d).
     raw=True: `scales` are the model's log-scales and `quats` its unnormalised quaternions; torch.exp and the division by
-    quats.norm() of activesplatfacto_model.py:221-223 happen inside the kernel (unerf_splat_project_raw)."""
+    quats.norm() of activesplatfacto_model.py:221-223 happen inside the kernel (unerf_splat_project_raw).
+    opacity_logits [N] (raw only): the tuple gains an 8th entry, opacities = sigmoid(logits) [* compensation if
+    antialiased], and num_tiles_hit is the TIGHT count (tiles the alpha >= 1/255 ellipse reaches); bin it with
+    splat_bin_sort(..., tight=(conics, opacities))."""
     lib = _l.load()
-    entry = lib.unerf_splat_project_raw if raw else lib.unerf_splat_project
+    if opacity_logits is not None and not raw:
+        raise ValueError("opacity_logits (tight tile counts) go with raw=True")
     N, dev = means3d.shape[0], means3d.device
     xys = torch.empty(N, 2, device=dev)
     depths = torch.empty(N, device=dev)
@@ -875,11 +880,20 @@ def splat_project(means3d, scales, glob_scale: float, quats, viewmat: torch.Tens
     comp = torch.empty(N, device=dev)
     tiles = torch.empty(N, device=dev, dtype=torch.int32)
     cov3d = torch.empty(N, 6, device=dev)
+    opac = torch.empty(N, device=dev) if opacity_logits is not None else None
+    outs = lambda: (_p(xys), _p(depths), _p(radii, torch.int32), _p(conics), _p(comp), _p(tiles, torch.int32), _p(cov3d),
+                    _stream())
     with _ctx(dev):
-        _run("splat_project", lambda: entry(_p(means3d), _p(scales), glob_scale, _p(quats), _host12(viewmat), fx, fy, cx,
-                                         cy, H, W, block_width, clip_thresh, N, _p(xys), _p(depths),
-                                         _p(radii, torch.int32), _p(conics), _p(comp), _p(tiles, torch.int32),
-                                         _p(cov3d), _stream()))
+        if raw:
+            _run("splat_project", lambda: lib.unerf_splat_project_raw(
+                _p(means3d), _p(scales), glob_scale, _p(quats), _host12(viewmat), fx, fy, cx, cy, H, W, block_width,
+                clip_thresh, N, _p(opacity_logits), 1 if antialiased else 0, _p(opac), *outs()))
+        else:
+            _run("splat_project", lambda: lib.unerf_splat_project(
+                _p(means3d), _p(scales), glob_scale, _p(quats), _host12(viewmat), fx, fy, cx, cy, H, W, block_width,
+                clip_thresh, N, *outs()))
+    if opac is not None:
+        return xys, depths, radii, conics, comp, tiles, cov3d, opac
     return xys, depths, radii, conics, comp, tiles, cov3d
 
 
@@ -912,14 +926,15 @@ def splat_sh_colors_split(degree: int, means3d, cam_pos: torch.Tensor, features_
 
 def splat_shade_inputs(degree: int, means3d, cam_pos: torch.Tensor, features_dc, features_rest, log_unc, beta_min: float,
                        opacity_logits, compensation, depths):
-    """-> (rows [N,C], opacities [N]): rows = [rgb, beta, depth] (C = 5) with `log_unc`, [rgb, depth] (C = 4) without;
-    opacities = sigmoid(opacity_logits) [* compensation].  One launch for the SH colours, beta, the channel
-    concatenation and the opacity activation of one frame (unerf_splat_shade_inputs)."""
+    """-> (rows [N,C], opacities [N] | None): rows = [rgb, beta, depth] (C = 5) with `log_unc`, [rgb, depth] (C = 4)
+    without; opacities = sigmoid(opacity_logits) [* compensation] (None when opacity_logits is None: the projection
+    made them).  One launch for the SH colours, beta, the channel concatenation and the opacity activation of one frame
+    (unerf_splat_shade_inputs)."""
     lib = _l.load()
     N, dev = means3d.shape[0], means3d.device
     Cn = 5 if log_unc is not None else 4
     rows = torch.empty(N, Cn, device=dev)
-    opac = torch.empty(N, device=dev)
+    opac = torch.empty(N, device=dev) if opacity_logits is not None else None
     cp = (C.c_float * 3)(*[float(v) for v in cam_pos.detach().cpu().reshape(-1)[:3]])
     with _ctx(dev):
         _run("splat_sh_colors", lambda: lib.unerf_splat_shade_inputs(
@@ -967,12 +982,14 @@ class SplatCount:
 
 
 def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_width: int = 16,
-                   want_isect_ids: bool = True, count: Optional[SplatCount] = None):
+                   want_isect_ids: bool = True, count: Optional[SplatCount] = None,
+                   tight: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """-> (num_intersects, cum_tiles_hit, isect_ids_sorted | None, gaussian_ids_sorted, tile_bins [tiles,2])
     One host read-back (num_intersects) sizes the buffers, as gsplat's compute_cumulative_intersects does; `count`: a
     SplatCount started earlier (so that the read-back overlaps other work), else it is made and awaited here.
     The 64-bit isect ids are gsplat's by-product; the rasteriser does not read them (want_isect_ids=False
-    skips their gather + 8-byte store per intersection)."""
+    skips their gather + 8-byte store per intersection).
+    tight = (conics, opacities): num_tiles_hit is a tight count of splat_project(..., opacity_logits=...)."""
     lib = _l.load()
     N, dev = xys.shape[0], xys.device
     tbx, tby = (W + block_width - 1) // block_width, (H + block_width - 1) // block_width
@@ -985,7 +1002,8 @@ def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_widt
         gids = torch.empty(max(I, 1), device=dev, dtype=torch.int32)
         bins = torch.empty(tbx * tby, 2, device=dev, dtype=torch.int32)
         _run("splat_bin_sort", lambda: lib.unerf_splat_bin_sort(_p(xys), _p(depths), _p(radii, torch.int32), _p(cum, torch.int32), N, I, H,
-                                          W, block_width, _p(ids, torch.int64), _p(gids, torch.int32),
+                                          W, block_width, _p(tight[0]) if tight else None, _p(tight[1]) if tight else None,
+                                          _p(ids, torch.int64), _p(gids, torch.int32),
                                           _p(bins, torch.int32), _p(ws, torch.uint8), ws.numel(), _stream()))
     return I, cum, (ids[:I] if ids is not None else None), gids[:I], bins
 

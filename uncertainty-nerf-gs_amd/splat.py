@@ -56,7 +56,7 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
                               cy: float, H: int, W: int, background: torch.Tensor, beta_min: float = 0.01,
                               sh_degree: int = 3, rasterize_mode: str = "classic",
                               block_width: int = 16, crop_ids: Optional[torch.Tensor] = None,
-                              config_sh_degree: Optional[int] = None) -> Dict[str, Optional[torch.Tensor]]:
+                              config_sh_degree: Optional[int] = None, tight: bool = True) -> Dict[str, Optional[torch.Tensor]]:
     """gp: gauss_params on the device (means, scales, quats, features_dc, features_rest, opacities,
     log_uncertainties).  Returns the reference's output dict (:359-367) as [H,W,C] tensors.
     Without `log_uncertainties` in gp: plain splatfacto [UPSTREAM nerfstudio 1.1.0 SplatfactoModel.get_outputs, the
@@ -64,7 +64,10 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     pass, outputs rgb / depth / accumulation / background only.
     crop_ids: bool [N] from `crop_box.within(means)` (:174-180, 202-217) -- only those splats are rendered.
     sh_degree: the active degree n = min(step // interval, config.sh_degree) (:244);
-    config_sh_degree == 0 selects the sigmoid(features_dc) colours of :247-248."""
+    config_sh_degree == 0 selects the sigmoid(features_dc) colours of :247-248.
+    tight: bin each splat into the tiles its alpha >= 1/255 ellipse reaches instead of gsplat's whole radius box (the
+    left-out pairs are ones the blend loop skips itself: same output bits, about half the sort and staging work);
+    False: gsplat's lists."""
     _l.require_gpu()
     background = background.to(gp["means"].device, torch.float32)
     if gp["means"].shape[0] == 0:          # no splats at all: the same picture as "nothing visible" (:239-240)
@@ -77,9 +80,16 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     means = gp["means"].contiguous()
     dev = means.device
     V = viewmat_from_c2w(c2w)
-    # exp(scales) and quats / quats.norm() (:221-223) are taken inside the projection kernel
-    xys, depths, radii, conics, comp, tiles, _cov = ops.splat_project(
-        means, gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], fx, fy, cx, cy, H, W, block_width, raw=True)
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
+    # exp(scales) and quats / quats.norm() (:221-223) are taken inside the projection kernel; with `tight` also
+    # sigmoid(opacities) [* comp] (:252-256), which the tight tile counts depend on
+    logits = gp["opacities"].reshape(-1).contiguous()
+    proj = ops.splat_project(means, gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], fx, fy, cx, cy, H, W,
+                             block_width, raw=True, opacity_logits=logits if tight else None,
+                             antialiased=rasterize_mode == "antialiased")
+    xys, depths, radii, conics, comp, tiles, _cov = proj[:7]
+    opac = proj[7] if tight else None
     # the intersection count (the frame's one host read-back) starts its way to the host now and is awaited inside
     # splat_bin_sort; the SH colours do not depend on it and keep the GPU busy meanwhile
     count = ops.SplatCount(tiles)
@@ -87,20 +97,22 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
         sh_degree = -1                                     # kernel: colours = sigmoid(features_dc)
     # the reference concatenates features_dc and features_rest first (:242-243); the kernel reads them in place
     plain = "log_uncertainties" not in gp
-    if rasterize_mode not in ("classic", "antialiased"):
-        raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
-    # one launch leaves the rasteriser's per-splat rows [rgb, (beta), depth] and sigmoid(opacities) [* comp] (:252-256)
-    cols, opac = ops.splat_shade_inputs(sh_degree, means, c2w[:3, 3], gp["features_dc"].contiguous(),
-                                        gp["features_rest"].contiguous(),
-                                        None if plain else gp["log_uncertainties"].reshape(-1).contiguous(), beta_min,
-                                        gp["opacities"].reshape(-1).contiguous(),
-                                        comp if rasterize_mode == "antialiased" else None, depths)
+    # one launch leaves the rasteriser's per-splat rows [rgb, (beta), depth] (and the opacities unless made above)
+    cols, opac2 = ops.splat_shade_inputs(sh_degree, means, c2w[:3, 3], gp["features_dc"].contiguous(),
+                                         gp["features_rest"].contiguous(),
+                                         None if plain else gp["log_uncertainties"].reshape(-1).contiguous(), beta_min,
+                                         None if tight else logits,
+                                         comp if rasterize_mode == "antialiased" else None, depths)
+    opac = opac if tight else opac2
     # (self.radii).sum() == 0 -> get_empty_outputs (:239-240).  A splat has a non-zero radius exactly when it hits at
     # least one tile, so "no intersections" is the same test and rides on the one host read-back of the frame
     I, _cum, _keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, block_width, want_isect_ids=False,
-                                                    count=count)
-    if I == 0:
+                                                    count=count, tight=(conics, opac) if tight else None)
+    if I == 0 and not (tight and bool((radii > 0).any())):
         return empty_outputs(W, H, background)
+    # (tight lists can be empty while splats are "visible" by radius -- every opacity below 1/255: the reference then
+    # rasterises a frame in which nothing blends, which the empty lists give as well; the extra read-back is on that path
+    # only)
     # frame scratch: the background padded to the row length, and the two channel maxima the rasteriser passes leave for
     # their alpha normalisations
     Cn = cols.shape[1]
