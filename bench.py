@@ -201,7 +201,10 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
                      "note": "VALU and MFMA instructions share one issue pipe per SIMD on gfx950 and do not overlap "
                              "(benchmarks/mfma_valu_overlap_probe.hip); achieved = (4 x VALU instructions + 32 x f16 MFMAs) of one "
                              "launch, exact counts from the committed PMC pass, over the live launch time; peak = 1024 SIMDs x "
-                             "2.4 GHz.  The engine clock under this load is 1.9-2.1 GHz, so ~0.85 is the practical ceiling; what "
+                             "2.4 GHz.  The flat price of 4 cycles per VALU instruction is what packed / converting / integer-multiply "
+                             "/ SGPR-operand forms cost; plain fp32 add / mul / fma, and / xor / add_u32 and moves on VGPR operands "
+                             "issue in ~2.7 (profiles/r3_13_probe_valu_cost.jsonl), so for the part of the stream made of those the "
+                             "cycles needed -- and this fraction -- are an upper bound.  The engine clock under this load is 1.9-2.1 GHz, so ~0.85 is the practical ceiling; what "
                              "the kernel leaves of it is latency of its dependent MFMA -> split -> MFMA chain at two waves per "
                              "SIMD (DESIGN.md 4.5: removing 32 independent VALU instructions per pass changed nothing, keeping "
                              "32 operand registers resident bought 2.5 %)",

@@ -70,6 +70,27 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float sx, un
     if (KIND == 47) BODY("v_mul_hi_u32 %0, %0, %1", "+v"(u[q]) : "v"(uy))
     if (KIND == 48) BODY("v_cmp_lt_f32 vcc, %0, %1", "+v"(v[q]) : "v"(x) : "vcc")
     if (KIND == 49) BODY("v_ldexp_f32 %0, %0, %1", "+v"(v[q]) : "v"(ux))
+    if (KIND == 50) { unsigned long long m = 0x5555aaaa5555aaaaull ^ su; BODY("v_cndmask_b32_e64 %0, %0, %1, %2", "+v"(u[q]) : "v"(uy), "s"(m)) }
+    if (KIND == 51) BODY("v_ceil_f32 %0, %0", "+v"(v[q]) : )
+    if (KIND == 52) BODY("v_trunc_f32 %0, %0", "+v"(v[q]) : )
+    if (KIND == 53) BODY("v_cmp_ne_u32 vcc, %0, %1", "+v"(u[q]) : "v"(uy) : "vcc")
+    if (KIND == 54) BODY("v_or_b32 %0, %0, %1", "+v"(u[q]) : "v"(uy))
+    if (KIND == 55) BODY("v_sub_u32 %0, %0, %1", "+v"(u[q]) : "v"(uy))
+    if (KIND == 56) BODY("v_lshrrev_b32 %0, 5, %0", "+v"(u[q]) : )
+    if (KIND == 57) BODY("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96", "+v"(u[q]) : "v"(uy), "v"(ux))
+    if (KIND == 58) BODY("v_add_f32 %0, %0, %1", "+v"(v[q]) : "s"(sx))
+    if (KIND == 59) BODY("v_min_u32 %0, %0, %1", "+v"(u[q]) : "v"(uy))
+    if (KIND == 60) BODY("v_add_lshl_u32 %0, %0, %1, 3", "+v"(u[q]) : "v"(uy))
+    if (KIND == 61) BODY("v_med3_f32 %0, %0, %1, %2", "+v"(v[q]) : "v"(x), "v"(y))
+    if (KIND == 62) BODY("v_and_b32 %0, %0, %1", "+v"(u[q]) : "s"(su))
+    if (KIND == 63) { asm volatile("s_mov_b64 vcc, 0x5555aaaa" ::: "vcc"); BODY("v_cndmask_b32_e32 %0, %0, %1, vcc", "+v"(u[q]) : "v"(uy)) }
+    if (KIND == 64) { asm volatile("s_mov_b64 vcc, 0x5555aaaa" ::: "vcc"); BODY("v_cndmask_b32_e64 %0, %0, %1, vcc", "+v"(u[q]) : "v"(uy)) }
+    if (KIND == 65) { asm volatile("s_mov_b64 vcc, 0x5555aaaa" ::: "vcc"); BODY("v_cndmask_b32_e32 %0, %1, %2, vcc", "=v"(u[q]) : "v"(uy), "v"(ux)) }
+    if (KIND == 66) BODY("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %1, %2, vcc", "=v"(v[q]) : "v"(x), "v"(y) : "vcc")
+    if (KIND == 68) BODY("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %1, %2, vcc\n\tv_cndmask_b32_e32 %0, %2, %1, vcc\n\tv_cndmask_b32_e32 %0, %1, %2, vcc", "=v"(v[q]) : "v"(x), "v"(y) : "vcc")
+    if (KIND == 69) { unsigned long long m; BODY("v_cmp_lt_f32_e64 %1, %2, %3\n\tv_cndmask_b32_e64 %0, %2, %3, %1\n\tv_cndmask_b32_e64 %0, %3, %2, %1\n\tv_cndmask_b32_e64 %0, %2, %3, %1", "=v"(v[q]), "=s"(m) : "v"(x), "v"(y)) }
+    if (KIND == 70) BODY("v_cmp_lt_f32 vcc, %1, %2\n\tv_add_f32 %0, %1, %2\n\tv_cndmask_b32_e32 %0, %1, %2, vcc\n\tv_mul_f32 %0, %1, %2\n\tv_cndmask_b32_e32 %0, %2, %1, vcc", "=v"(v[q]) : "v"(x), "v"(y) : "vcc")
+    if (KIND == 67) { unsigned long long m; BODY("v_cmp_lt_f32_e64 %1, %2, %3\n\tv_cndmask_b32_e64 %0, %2, %3, %1", "=v"(v[q]), "=s"(m) : "v"(x), "v"(y)) }
     float r = 0.f;
     for (int q = 0; q < 16; ++q) r += v[q] + w[q][0] + w[q][1] + (float)u[q];
     out[blockIdx.x * 256 + threadIdx.x] = r;
@@ -107,5 +128,9 @@ int main() {
     RUN(23, "v_pk_sub_i16 clamp"); RUN(24, "v_pk_ashrrev_i16"); RUN(25, "v_pk_max_i16"); RUN(26, "v_pk_mul_f16"); RUN(27, "v_pk_fma_f16");
     RUN(28, "v_cvt_f16_f32"); RUN(29, "v_cvt_pk_f16_f32"); RUN(30, "v_fma_mix_f32"); RUN(31, "v_perm_b32"); RUN(32, "v_cndmask_b32"); RUN(33, "v_mov_b32");
     RUN(34, "v_mov_b32_dpp row_shr"); RUN(35, "v_floor_f32"); RUN(36, "v_fract_f32"); RUN(37, "v_cvt_i32_f32"); RUN(38, "v_cvt_f32_u32"); RUN(48, "v_cmp_lt_f32"); RUN(49, "v_ldexp_f32");
+    RUN(50, "v_cndmask_b32_e64 sgpr mask"); RUN(51, "v_ceil_f32"); RUN(52, "v_trunc_f32"); RUN(53, "v_cmp_ne_u32"); RUN(54, "v_or_b32"); RUN(55, "v_sub_u32");
+    RUN(56, "v_lshrrev_b32 imm"); RUN(57, "v_bitop3_b32"); RUN(58, "v_add_f32 v,s"); RUN(59, "v_min_u32"); RUN(60, "v_add_lshl_u32"); RUN(61, "v_med3_f32"); RUN(62, "v_and_b32 v,s");
+    RUN(63, "v_cndmask_b32_e32 vcc (set)"); RUN(64, "v_cndmask_b32_e64 vcc (set)"); RUN(65, "v_cndmask_b32_e32 vcc, dst != src"); RUN(66, "v_cmp_lt_f32 vcc + v_cndmask e32 (pair)"); RUN(67, "v_cmp_lt_f32 sgpr + v_cndmask e64 (pair)");
+    RUN(68, "v_cmp vcc + 3 x v_cndmask e32 (4 insts)"); RUN(69, "v_cmp sgpr + 3 x v_cndmask e64 (4 insts)"); RUN(70, "v_cmp vcc, add, cndmask e32, mul, cndmask e32 (5 insts)");
     return 0;
 }

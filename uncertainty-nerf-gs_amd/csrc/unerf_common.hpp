@@ -152,22 +152,40 @@ __device__ __forceinline__ float unerf_normalize_position(float& x, float& y, fl
 // (v * prime) << 3 == v * (prime << 3) mod 2^32, so the shift is folded into the constants and a
 // corner costs one v_bitop3; the loads then take a uniform (SGPR) level base + this 32-bit VGPR
 // offset, with no 64-bit address arithmetic per corner.  Needs log2T <= 28.
-template <bool WITH_BASE = false>
+//
+// EXACT_CEIL = false (the fused kernels): the "ceil" corner of an axis is taken as floor + 1 always.  It differs from
+// ceil only where the scaled coordinate is an exact integer (masked samples sit at 0) -- and there the offset is 0, so
+// the ceil-side row is multiplied by exactly 0 in the blend whichever row it is: the feature comes out the same (table
+// entries are finite).  Per axis that is one truncating convert + one v_fract_f32 + adds instead of floor, ceil, three
+// converts, a subtract, a compare and a select (positions are >= 0 here, so truncation is floor).  All of those are
+// 4-cycle-class VALU instructions (profiles/r3_13_probe_valu_cost.jsonl): ~50 issue cycles less per level and sample.
+// EXACT_CEIL = true: ceilf itself -- unerf_hashgrid_fwd, whose corner indices are an output and match the reference's.
+template <bool WITH_BASE = false, bool EXACT_CEIL = false>
 __device__ __forceinline__ void unerf_hash_corners(float px, float py, float pz, float scale, uint32_t mask,
                                                    uint32_t (&off)[8], float& ox, float& oy, float& oz,
                                                    uint32_t base = 0u) {
     float sx = px * scale, sy = py * scale, sz = pz * scale;
-    int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
-    int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
-    ox = sx - (float)fx;
-    oy = sy - (float)fy;
-    oz = sz - (float)fz;
     const uint32_t P1 = 2654435761u << 3, P2 = 805459861u << 3, m8 = mask << 3;
-    uint32_t hfx = (uint32_t)fx << 3, hcx = (uint32_t)cx << 3;
-    // ceil = floor + 1 unless the coordinate is an exact integer, so the ceil products are the floor
-    // products plus the prime (mod 2^32): two quarter-rate v_mul_lo_u32 per level instead of four
-    uint32_t hfy = (uint32_t)fy * P1, hfz = (uint32_t)fz * P2;
-    uint32_t hcy = hfy + (cy != fy ? P1 : 0u), hcz = hfz + (cz != fz ? P2 : 0u);
+    uint32_t hfx, hcx, hfy, hfz, hcy, hcz;
+    if (EXACT_CEIL) {
+        int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
+        int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
+        ox = sx - (float)fx;
+        oy = sy - (float)fy;
+        oz = sz - (float)fz;
+        hfx = (uint32_t)fx << 3; hcx = (uint32_t)cx << 3;
+        // ceil = floor + 1 unless the coordinate is an exact integer, so the ceil products are the floor
+        // products plus the prime (mod 2^32): two quarter-rate v_mul_lo_u32 per level instead of four
+        hfy = (uint32_t)fy * P1; hfz = (uint32_t)fz * P2;
+        hcy = hfy + (cy != fy ? P1 : 0u); hcz = hfz + (cz != fz ? P2 : 0u);
+    } else {
+        ox = __builtin_amdgcn_fractf(sx);     // = sx - floor(sx), exact for these magnitudes
+        oy = __builtin_amdgcn_fractf(sy);
+        oz = __builtin_amdgcn_fractf(sz);
+        hfx = (uint32_t)(int)sx << 3; hcx = hfx + 8u;
+        hfy = (uint32_t)(int)sy * P1; hfz = (uint32_t)(int)sz * P2;
+        hcy = hfy + P1; hcz = hfz + P2;
+    }
     if (!WITH_BASE) {  // 4 pair xors + one v_bitop3 ((t ^ z) & m8) per corner
         off[0] = (hcx ^ hcy ^ hcz) & m8;
         off[1] = (hcx ^ hfy ^ hcz) & m8;
@@ -252,11 +270,12 @@ __device__ __forceinline__ void unerf_fetch_corners(const float2* __restrict__ l
     for (int k = 0; k < 8; ++k) f[k] = *reinterpret_cast<const float2*>(base + off[k]);
 }
 
+template <bool EXACT_CEIL = false>
 __device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lvl, float px, float py, float pz,
                                                    float scale, uint32_t mask) {
     uint32_t off[8];
     float ox, oy, oz;
-    unerf_hash_corners(px, py, pz, scale, mask, off, ox, oy, oz);
+    unerf_hash_corners<false, EXACT_CEIL>(px, py, pz, scale, mask, off, ox, oy, oz);
     float2 f[8];
     unerf_fetch_corners(lvl, off, f);
     return unerf_blend8(f, ox, oy, oz);
@@ -268,9 +287,10 @@ __device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lv
 __device__ __forceinline__ float2 unerf_dense_level(const float4* __restrict__ cells, int dim, float px, float py,
                                                     float pz, float scale) {
     float sx = px * scale, sy = py * scale, sz = pz * scale;
-    int cx = (int)ceilf(sx), cy = (int)ceilf(sy), cz = (int)ceilf(sz);
-    int fx = (int)floorf(sx), fy = (int)floorf(sy), fz = (int)floorf(sz);
-    float ox = sx - (float)fx, oy = sy - (float)fy, oz = sz - (float)fz;
+    // floor + 1 for the "ceil" corners (see unerf_hash_corners): at an exact integer the ceil-side value is weighted 0
+    const int fx = (int)sx, fy = (int)sy, fz = (int)sz;
+    const int cy = fy + 1, cz = fz + 1;
+    const float ox = __builtin_amdgcn_fractf(sx), oy = __builtin_amdgcn_fractf(sy), oz = __builtin_amdgcn_fractf(sz);
     // 32-bit byte offsets off a uniform base.  dim <= 640 (checked by the caller): every OPERAND below stays under
     // 2^24 (v_mad_u32_u24 multiplies the low 24 bits of its operands exactly into 32), and the cell index dim^3 under
     // 2^28, so its byte offset (x 16) fits 32 bits.
@@ -292,15 +312,6 @@ __device__ __forceinline__ float2 unerf_dense_level(const float4* __restrict__ c
     f[4] = make_float2(pcf.z, pcf.w);
     f[6] = make_float2(pff.x, pff.y);
     f[5] = make_float2(pff.z, pff.w);
-    // scaled x an exact integer (ceil == floor: masked samples sit at 0): the ceil-x corner IS the floor-x corner.
-    // Rare, so the eight selects are skipped unless some lane of the wave needs them.
-    if (__any(cx == fx)) {
-        const bool step = cx != fx;
-        f[0] = step ? f[0] : f[3];
-        f[1] = step ? f[1] : f[2];
-        f[4] = step ? f[4] : f[7];
-        f[5] = step ? f[5] : f[6];
-    }
     return unerf_blend8(f, ox, oy, oz);
 }
 

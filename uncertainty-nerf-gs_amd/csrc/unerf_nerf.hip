@@ -361,13 +361,13 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(const float* __restrict__
     const uint32_t mask = (1u << log2T) - 1u;
     for (int l = 0; l < L; ++l) {
         const float2* lvl = reinterpret_cast<const float2*>(table) + ((size_t)l << log2T);
-        float2 f = unerf_hash_level(lvl, px, py, pz, scalings[l], mask);
+        float2 f = unerf_hash_level<true>(lvl, px, py, pz, scalings[l], mask);   // the reference's ceil / floor, any sign
         out[n * (2 * L) + 2 * l + 0] = f.x;
         out[n * (2 * L) + 2 * l + 1] = f.y;
         if (out_idx) {
             uint32_t idx[8];
             float ox, oy, oz;
-            unerf_hash_corners(px, py, pz, scalings[l], mask, idx, ox, oy, oz);
+            unerf_hash_corners<false, true>(px, py, pz, scalings[l], mask, idx, ox, oy, oz);
 #pragma unroll
             for (int k = 0; k < 8; ++k) out_idx[(n * L + l) * 8 + k] = (int32_t)((idx[k] >> 3) + ((uint32_t)l << log2T));
         }
