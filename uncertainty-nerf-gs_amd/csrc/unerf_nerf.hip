@@ -2304,7 +2304,7 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
 }
 
 template <bool TCNN, bool F1 = false>
-__global__ __launch_bounds__(256) void field_kernel_mfma16_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCNN) ? 3 : 2))) void field_kernel_mfma16_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
         const float4* src = reinterpret_cast<const float4*>(a.p.mfma16_blob);

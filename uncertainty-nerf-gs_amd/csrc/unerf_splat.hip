@@ -6,7 +6,6 @@
 #include "unerf_common.hpp"
 
 #include <hipcub/hipcub.hpp>
-#include <rocprim/device/device_radix_sort.hpp>
 
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
@@ -459,14 +458,12 @@ static int tile_bits(int H, int W, int bw) {
 // tile id (13 bits at 1080p, 16-bit keys): two 6-byte-per-entry radix passes over the I intersections
 // instead of six 12-byte passes over 64-bit (tile | depth) keys.  Same final order, bit for bit: ties in
 // depth keep the splat-index order in both schemes.
-// rocprim's default radix-sort config takes a merge-sort path up to 2^20 items -- exactly where a 1 M-splat scene sits
-// (20 launches, 162 us); Onesweep does the same stable sort in 137 us there and is what the default picks above 2^20
-// anyway (benchmarks/exp_depth_sort.hip).  Small scenes keep the default's choice.
-using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                   rocprim::default_config, (size_t)1 << 18>;
+// (The depth sort stays on rocprim's default dispatch -- a merge sort up to 2^20 items, where a 1 M-splat scene sits.
+// Forcing Onesweep there is 137 us against 162 for the sort alone (benchmarks/exp_depth_sort.hip), and its histogram
+// kernel and per-pass hipMemsetAsync calls give the difference back inside the frame: measured net zero twice.)
 static hipError_t depth_sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const int32_t* vin,
                                    int32_t* vout, int64_t n, hipStream_t st) {
-    return rocprim::radix_sort_pairs<DepthSortConfig>(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, 32u, st);
+    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, st);
 }
 
 struct SortWs {
