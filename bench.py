@@ -510,6 +510,11 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
         pr = ops.splat_project(gp["means"].contiguous(), torch.exp(gp["scales"]), 1.0, q.contiguous(),
                                viewmat_from_c2w(poses[0])[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)
         n_isect = int(pr[5].sum().item())
+        # what the frame actually sorts: the tight lists (tiles each splat's alpha >= 1/255 ellipse reaches)
+        pt = ops.splat_project(gp["means"].contiguous(), gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(),
+                               viewmat_from_c2w(poses[0])[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16, raw=True,
+                               opacity_logits=gp["opacities"].reshape(-1).contiguous())
+        n_isect_tight = int(pt[5].sum().item())
         N = args.splats
         frame_bytes = N * 240 + 2 * N * 36 + n_isect * 96 + 2 * n_isect * 36 + H * W * 7 * 4
         sort_bytes = n_isect * 96
@@ -556,10 +561,13 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
                             {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": None if ach is None else ach / HBM_PEAK_GBS,
                              "note": ("bin-and-sort (rocprim scan / merge sort / two one-sweep radix passes + three own kernels): bytes "
-                                      "gsplat's 64-bit-key sort of the same intersections would move, I x 96 B, over this call's time"
+                                      "gsplat's 64-bit-key sort of the reference's intersections would move, I x 96 B (I = num_intersects, gsplat's "
+                                      "radius boxes), over this call's time; the call itself sorts num_intersects_sorted (tile, id) pairs "
+                                      "with 16-bit keys -- the tight lists, same rasterised bits"
                                       if dom == "splat_bin_sort" else "algorithmic bytes of the dominant kernel")}),
                          "raster_roofline": raster,
                          "traffic": traffic, "avg_launch_ms": ksum[dom]["avg_ms"], "num_intersects": n_isect,
+                         "num_intersects_sorted": n_isect_tight,
                          "frame_algorithmic_bytes": frame_bytes,
                          "frame_frac_of_hbm_peak": frame_bytes * steps * world / elapsed / 1e9 / HBM_PEAK_GBS,
                          "per_kernel_ms_per_frame": {k: round(v["total_ms"] / steps, 3) for k, v in sorted(ksum.items())}},
