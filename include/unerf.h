@@ -38,7 +38,7 @@ extern "C" {
 const char* unerf_last_error(void);
 /* Library/ABI version (major*1000+minor).  A binding built against this header must find exactly UNERF_ABI_VERSION
  * (struct layouts and argument lists change with it; uncertainty-nerf-gs_amd/lib.py::load checks). */
-#define UNERF_ABI_VERSION 1220
+#define UNERF_ABI_VERSION 1230
 int unerf_version(void);
 
 /* Spacing function of the proposal sampler's initial sampler, passed behind every (near_plane, far_plane) pair:
@@ -263,7 +263,11 @@ typedef struct {
        UNERF_DROP_TRUNK: after the trunk's hidden ReLU (density_dropout_layers); UNERF_DROP_HEAD0: in front of the
        colour head's Linear 1 (rgb_dropout_layers contains 1); UNERF_DROP_HEAD1: in front of its last Linear (contains
        2 or -1).  Mask streams 0 / 2 / 1 of the counter RNG.  With mfma16_blob the scale 1/(1-p) is expected folded
-       into the layer behind each active site (ops.pack_field_mfma16). */
+       into the layer behind each active site (ops.pack_field_mfma16).
+       UNERF_DROP_HEADIN: in front of the colour head's Linear 0 (rgb_dropout_layers contains 0), i.e. on its 63 INPUTS
+       [SH16 | geo15 | appearance32] -- mask stream 3.  The appearance block can then no longer ride in the bias, so this
+       site needs h0_full_t / hb0_raw / app_embed below, and it is served by the VALU kernel only (any precision setting;
+       roughly 10 x the time of the matrix kernels -- a rarely used configuration kept correct rather than fast). */
     int drop_sites;
     /* LAPLACE: 1 = density_activation "softplus" (laplace_model.py:151, laplace_field.py:323) instead of trunc_exp on
        the (sampled) density head (unerf_laplace_ggn_diag: dsigma/dpre = 1 - exp(-sigma) instead of sigma). */
@@ -284,10 +288,17 @@ typedef struct {
        in this form, which has no lo halves to turn it into a NaN sample.  Same word and same host protocol as the
        composite entry points' nonfinite_flag (render.OverflowGuard: fp32 re-render of the launch group). */
     int32_t* overflow_flag;
+    /* UNERF_DROP_HEADIN only (else may be NULL): the colour head's first layer unfolded -- weights transposed
+       [63][64] over the inputs [SH16 | geo15 | appearance32], its bias [64] WITHOUT the appearance term, and the eval
+       appearance embedding [32] (zeros or the mean embedding, [UPSTREAM NerfactoField.get_outputs]). */
+    const float* h0_full_t;
+    const float* hb0_raw;
+    const float* app_embed;
 } unerf_field_params;
 #define UNERF_DROP_TRUNK 1
 #define UNERF_DROP_HEAD0 2
 #define UNERF_DROP_HEAD1 4
+#define UNERF_DROP_HEADIN 8
 #define UNERF_MFMA_BLOB_FLOATS 10660
 #define UNERF_LAP_BLOB_FLOATS 33280
 

@@ -603,12 +603,13 @@ def _linear(x, w, b, autocast: Optional[torch.dtype] = None):
 
 def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trunk: Optional[torch.Tensor],
                     keep_head: Optional[torch.Tensor], p_drop: float, keep_head0: Optional[torch.Tensor] = None,
-                    autocast: Optional[torch.dtype] = None):
+                    autocast: Optional[torch.dtype] = None, keep_in: Optional[torch.Tensor] = None):
     """[REF mcdropout_fields.py:110-174 + utils.py:6-43]
     trunk = Linear(32,64),ReLU,Dropout,Linear(64,16); head = Linear(63,64),ReLU,[Dropout,]Linear(64,64),ReLU,
     Dropout,Linear(64,3),Sigmoid.  keep_* are bool masks [R*S,64] (None = no Dropout module at that site):
     keep_trunk -- density_dropout_layers; keep_head0 -- rgb_dropout_layers contains 1 (in front of Linear 1);
-    keep_head -- rgb_dropout_layers contains -1 / 2 (in front of the last Linear)."""
+    keep_head -- rgb_dropout_layers contains -1 / 2 (in front of the last Linear); keep_in [R*S,63] --
+    rgb_dropout_layers contains 0 (in front of Linear 0: on the head's inputs [SH16 | geo15 | appearance32])."""
     R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
     scale = 1.0 / (1.0 - p_drop)
     pos = sample_positions(origins, directions, euclid_bins)
@@ -622,6 +623,8 @@ def mcdropout_field(origins, directions, euclid_bins, fp: FieldParams, keep_trun
     density = fp.average_init_density * torch.exp(out[..., 0]) * sel
     geo = out[..., 1:1 + g]
     x = _color_inputs(directions, S, geo, fp.appearance, fp.sh_remap)
+    if keep_in is not None:
+        x = x * keep_in.to(x.dtype) * scale
     x = F.relu(_linear(x, fp.head_w[0], fp.head_b[0], autocast))
     if keep_head0 is not None:
         x = x * keep_head0.to(x.dtype) * scale
@@ -836,11 +839,14 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
     sidx = (rid[:, None] * S + np.arange(S)[None, :]).reshape(-1)
     outs = []
     for k in range(K):
-        # drop_sites bits: 1 trunk (mask stream 0), 2 head hidden-0 (stream 2), 4 head hidden-1 (stream 1)
+        # drop_sites bits: 1 trunk (mask stream 0), 2 head hidden-0 (stream 2), 4 head hidden-1 (stream 1),
+        # 8 head inputs (stream 3, 63 of its 64 units)
         kt = torch.from_numpy(mc_keep_mask(seed, k, sidx, 0, 64, p_drop)) if drop_sites & 1 else None
         kh0 = torch.from_numpy(mc_keep_mask(seed, k, sidx, 2, 64, p_drop)) if drop_sites & 2 else None
         kh = torch.from_numpy(mc_keep_mask(seed, k, sidx, 1, 64, p_drop)) if drop_sites & 4 else None
-        density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop, keep_head0=kh0, autocast=autocast)
+        kin = torch.from_numpy(mc_keep_mask(seed, k, sidx, 3, 64, p_drop)[:, :63]) if drop_sites & 8 else None
+        density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop, keep_head0=kh0, autocast=autocast,
+                                       keep_in=kin)
         outs.append(nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb, nears, fars))
     res = {}
     for key in outs[0].keys():

@@ -423,3 +423,38 @@ def test_model_loaded_from_a_run_directory_renders_like_its_source(dev, tmp_path
         a, b = src.get_outputs_for_camera(cam), dst.get_outputs_for_camera(cam)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_mcdropout_model_with_dropout_on_the_colour_heads_inputs(dev):
+    """`rgb_dropout_layers=[0, -1]` (mcdropout_models.py:35, create_mlp utils.py:24-25): a Dropout in front of the colour
+    head's first Linear.  The checkpoint's Sequential indices shift by one (Dropout, Linear, ReLU, Linear, ReLU, Dropout,
+    Linear), the render goes through UNERF_DROP_HEADIN, and the frame matches the oracle with the same mask streams."""
+    from uncertainty_nerf_gs_amd import plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=3, kind="mcdropout", log2T=14, prop_log2T=12)
+    t["field"]["appearance"] = torch.linspace(-0.5, 0.7, 32)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["nerfacto-mcdropout"]())
+    cfg.rgb_dropout_layers = [0, -1]
+    cfg.mc_samples = 4
+    cfg.use_average_appearance_embedding = True
+    model = cfg._target(cfg, num_train_data=4)
+    sd = _state_dict_from_tensors(t, "mcdropout")
+    for i, (old, new) in enumerate(((0, 1), (2, 3), (5, 6))):          # Linear modules of the shifted Sequential
+        for leaf in ("weight", "bias"):
+            sd[f"_model.field.mlp_head.{new}.{leaf}"] = {"weight": t["field"]["head_w"], "bias": t["field"]["head_b"]}[leaf][i]
+    for k in [k for k in sd if k.startswith("_model.field.mlp_head.") and int(k.split(".")[3]) in (0, 2, 5)]:
+        del sd[k]
+    model.load_state_dict(sd, strict=True)
+    model.seed = 77
+    model.invalidate()
+    H, W = 24, 32
+    cam = _camera(H, W)
+    with torch.cuda.device(dev):
+        out = model.get_outputs_for_camera(cam)
+    sc = O.scene_from_tensors(t)
+    o, d, _ = O.generate_rays(cam.camera_to_worlds[0], 0.9 * W, 0.9 * W, W / 2, H / 2, H, W)
+    ref = O.mcdropout_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), 4, 77, 0.2, drop_sites=1 | 8 | 4)
+    for k, atol in (("rgb", 5e-5), ("rgb_std", 5e-5), ("accumulation", 3e-4)):
+        got, want = out[k].cpu().double().reshape(-1), ref[k].double().reshape(-1)
+        assert float((got - want).abs().max()) <= atol, (k, float((got - want).abs().max()))
+    plain = O.mcdropout_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), 4, 77, 0.2, drop_sites=1 | 4)
+    assert float((plain["rgb"] - ref["rgb"]).abs().max()) > 1e-3      # the input masks do change the picture

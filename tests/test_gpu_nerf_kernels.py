@@ -273,6 +273,38 @@ def test_field_mcdropout_dropout_sites_match_oracle(dev, sites, use_mfma, precis
             ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR)
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "f16", "fp32"])
+@pytest.mark.parametrize("sites", [8, 13, 15])
+def test_field_mcdropout_dropout_on_the_head_inputs(dev, sites, precision):
+    """rgb_dropout_layers containing 0 (create_mlp, utils.py:24-25): a Dropout in front of the colour head's Linear 0,
+    i.e. on its 63 inputs [SH16 | geo15 | appearance32] -- UNERF_DROP_HEADIN, mask stream 3.  The appearance block then
+    cannot ride in the bias; the site is served by the VALU kernel whatever precision is configured.  A non-zero eval
+    embedding (use_average_appearance_embedding) makes the appearance masks matter."""
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    K, seed, p = 3, 41, 0.25
+    t = synthetic.make_scene_tensors(seed=0, kind="mcdropout", log2T=14, prop_log2T=12)
+    t["field"]["appearance"] = torch.linspace(-0.6, 0.9, 32)         # a mean embedding that is far from zero
+    sc = O.scene_from_tensors(t)
+    sd = synthetic.scene_to_device(t, dev, K=K, seed=seed, p_drop=p, drop_sites=sites)
+    sd.field.precision = precision
+    o, d = _rays(12, 20)
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    dens, rgb, _, _ = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR, ray_offset=64)
+    R, S = sb.shape[0], sb.shape[1] - 1
+    sidx = ((np.arange(R)[:, None] + 64) * S + np.arange(S)[None]).reshape(-1)
+    for k in range(K):
+        m = lambda stream, bit: torch.from_numpy(O.mc_keep_mask(seed, k, sidx, stream, 64, p)) if sites & bit else None
+        kin = m(3, 8)
+        dr, cr = O.mcdropout_field(o, d, eb, sc.field, m(0, 1), m(1, 4), p, keep_head0=m(2, 2), keep_in=kin[:, :63])
+        _close(dens[k], dr, 2e-4, 1e-7, f"density pass {k}")
+        _close(rgb[k], cr, 0, 2e-5, f"rgb pass {k}")
+        # and the masks do act: without them the colours differ
+        _, c0 = O.mcdropout_field(o, d, eb, sc.field, m(0, 1), m(1, 4), p, keep_head0=m(2, 2))
+        assert float((c0 - cr).abs().max()) > 1e-3
+    assert not torch.equal(rgb[0], rgb[1])
+
+
 @pytest.mark.parametrize("use_mfma,precision,n_samples",
                          [(True, "f16x2", 100), (True, "fp32", 100), (False, "fp32", 100), (True, "f16x2", 37),
                           (True, "fp32", 37), (True, "f16x2", 128), (True, "f16x2", 4)],

@@ -145,7 +145,7 @@ def test_models_expose_the_eval_scripts_image_metrics():
 
 def test_mcdropout_field_dropout_layer_options():
     """density_dropout_layers / rgb_dropout_layers (mcdropout_fields.py:80-81, 112-144): module layout follows
-    create_mlp, the kernel's site bits follow the layout, index 0 (dropout on the head's input) is refused"""
+    create_mlp, the kernel's site bits follow the layout -- index 0 (dropout on the head's inputs) included"""
     from torch import nn
     from uncertainty_nerf_gs_amd import fields as F
     from uncertainty_nerf_gs_amd import lib as L
@@ -160,9 +160,12 @@ def test_mcdropout_field_dropout_layer_options():
     assert [type(m).__name__ for m in f.mlp_head] == ["Linear", "ReLU", "Dropout", "Linear", "ReLU", "Dropout", "Linear", "Sigmoid"]
     f = F.NerfactoMCDropoutField(density_dropout_layers=False, rgb_dropout_layers=[], **kw)
     assert f.drop_sites == 0 and not any(isinstance(m, nn.Dropout) for m in f.modules())
+    f = F.NerfactoMCDropoutField(rgb_dropout_layers=[0, -1], **kw)
+    assert f.drop_sites == (L.DROP_TRUNK | L.DROP_HEADIN | L.DROP_HEAD1)
+    assert [type(m).__name__ for m in f.mlp_head] == ["Dropout", "Linear", "ReLU", "Linear", "ReLU", "Dropout", "Linear", "Sigmoid"]
     import pytest
-    with pytest.raises(NotImplementedError):
-        F.NerfactoMCDropoutField(rgb_dropout_layers=[0], **kw)
+    with pytest.raises(ValueError, match="Linear layers 0, 1, 2"):
+        F.NerfactoMCDropoutField(rgb_dropout_layers=[3], **kw)
 
 
 def test_oracle_intersect_obb_known_answers_and_per_ray_planes():

@@ -1066,24 +1066,27 @@ __device__ __forceinline__ void dense_lds(const float* __restrict__ Wt, const fl
     }
 }
 
-// same, with an inverted-dropout mask on the 64 inputs (mask words: unerf_mask_word0 / unerf_mask_step)
-template <int OUT>
+// same, with an inverted-dropout mask on the IN inputs (mask words: unerf_mask_word0 / unerf_mask_step; unit 2j is the
+// low half of word j, unit 2j + 1 the high half)
+template <int OUT, int IN = 64>
 __device__ __forceinline__ void dense_lds_dropout(const float* __restrict__ Wt, const float* __restrict__ b,
                                                   const float* act, int lane, uint32_t base0, int pass,
                                                   uint32_t stream_id, int32_t thr_hi, float scale, float (&acc)[OUT]) {
 #pragma unroll
     for (int o = 0; o < OUT; ++o) acc[o] = b[o];
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < (IN + 1) / 2; ++j) {
         uint32_t rnd = unerf_mask_word0(base0, stream_id, (uint32_t)j);
         for (int q = 0; q < pass; ++q) rnd = unerf_mask_step(rnd);
         float x0 = act[(2 * j) * 64 + lane];
-        float x1 = act[(2 * j + 1) * 64 + lane];
         x0 = unerf_keep_lo(rnd, thr_hi) ? x0 * scale : 0.f;
-        x1 = unerf_keep_hi(rnd, thr_hi) ? x1 * scale : 0.f;
 #pragma unroll
         for (int o = 0; o < OUT; ++o) acc[o] = fmaf(x0, Wt[(2 * j) * OUT + o], acc[o]);
+        if (2 * j + 1 < IN) {
+            float x1 = act[(2 * j + 1) * 64 + lane];
+            x1 = unerf_keep_hi(rnd, thr_hi) ? x1 * scale : 0.f;
 #pragma unroll
-        for (int o = 0; o < OUT; ++o) acc[o] = fmaf(x1, Wt[(2 * j + 1) * OUT + o], acc[o]);
+            for (int o = 0; o < OUT; ++o) acc[o] = fmaf(x1, Wt[(2 * j + 1) * OUT + o], acc[o]);
+        }
     }
 }
 
@@ -1179,7 +1182,12 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
             store_act<16>(Bf, lane, sh, 0, false);
 #pragma unroll
             for (int g = 0; g < 15; ++g) Bf[(16 + g) * 64 + lane] = o1[1 + g];
-            dense_lds<31, 64>(a.p.h0t, a.p.hb0, Bf, lane, acc);
+            if (a.drop_sites & UNERF_DROP_HEADIN) {   // rgb_dropout_layers contains 0: Dropout on the head's 63 inputs
+                for (int e = 0; e < 32; ++e) Bf[(31 + e) * 64 + lane] = a.p.app_embed[e];
+                dense_lds_dropout<64, 63>(a.p.h0_full_t, a.p.hb0_raw, Bf, lane, base, k, 3u, a.keep_hi, a.drop_scale, acc);
+            } else {
+                dense_lds<31, 64>(a.p.h0t, a.p.hb0, Bf, lane, acc);
+            }
             store_act<64>(Bf, lane, acc, 0, true);
             if (a.drop_sites & UNERF_DROP_HEAD0) {
                 float acc2[64];
@@ -2578,9 +2586,15 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_MCDROPOUT:
             UNERF_REQUIRE(p->out1 == 16, "field_fwd MCDROPOUT: out1 must be 16");
             UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
-            UNERF_REQUIRE((p->drop_sites & ~(UNERF_DROP_TRUNK | UNERF_DROP_HEAD0 | UNERF_DROP_HEAD1)) == 0,
+            UNERF_REQUIRE((p->drop_sites & ~(UNERF_DROP_TRUNK | UNERF_DROP_HEAD0 | UNERF_DROP_HEAD1 | UNERF_DROP_HEADIN)) == 0,
                           "field_fwd MCDROPOUT: unknown bits in drop_sites=%d", p->drop_sites);
-            if (p->mfma16_blob && !features && f1) {
+            if (a.drop_sites & UNERF_DROP_HEADIN) {   // dropout on the head's inputs: the VALU kernel (include/unerf.h)
+                UNERF_REQUIRE(p->h0_full_t && p->hb0_raw && p->app_embed,
+                              "field_fwd MCDROPOUT: UNERF_DROP_HEADIN needs h0_full_t / hb0_raw / app_embed");
+                UNERF_REQUIRE(!features && !p->sample_major,
+                              "field_fwd MCDROPOUT: UNERF_DROP_HEADIN has no feature-plane / sample-major form");
+                hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
+            } else if (p->mfma16_blob && !features && f1) {
                 const bool head0 = a.drop_on && a.drop_sites != (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1);   // non-default sites
                 if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, true, true, true>, MF_LDS_F16, a, st);
                 else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true, true>, MF_LDS_F16, a, st);

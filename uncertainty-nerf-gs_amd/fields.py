@@ -380,16 +380,17 @@ class NerfactoMCDropoutField(_NerfactoFieldBase):
         assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
         rgb_dropout_layers = [-1] if rgb_dropout_layers is None else list(rgb_dropout_layers)
         # create_mlp (utils.py:6-43) puts a Dropout in front of Linear i for every i in dropout_layers; -1 and
-        # num_layers - 1 both mean "in front of the last Linear".  Built: the trunk's hidden layer
-        # (density_dropout_layers) and the colour head's two hidden layers; index 0 would drop the head's INPUT
-        # (direction encoding / appearance embedding), which is folded into constants here.
-        bad = [i for i in rgb_dropout_layers if i not in (-1, 1, 2)]
+        # num_layers - 1 both mean "in front of the last Linear".  The trunk's hidden layer (density_dropout_layers) and
+        # the colour head's two hidden layers run in the matrix kernels; index 0 drops the head's INPUTS (direction
+        # encoding, geo features, appearance embedding) and is served by the VALU kernel (DROP_HEADIN: correct, slow).
+        bad = [i for i in rgb_dropout_layers if i not in (-1, 0, 1, 2)]
         if bad:
-            raise NotImplementedError(f"rgb_dropout_layers={rgb_dropout_layers}: dropout on the colour head's input (index 0) is not built")
+            raise ValueError(f"rgb_dropout_layers={rgb_dropout_layers}: the colour head has Linear layers 0, 1, 2 (-1 = 2)")
         self.density_dropout_layers = bool(density_dropout_layers)
         self.rgb_dropout_layers = rgb_dropout_layers
         self.drop_sites = ((_l.DROP_TRUNK if density_dropout_layers else 0) | (_l.DROP_HEAD0 if 1 in rgb_dropout_layers else 0)
-                           | (_l.DROP_HEAD1 if (-1 in rgb_dropout_layers or 2 in rgb_dropout_layers) else 0))
+                           | (_l.DROP_HEAD1 if (-1 in rgb_dropout_layers or 2 in rgb_dropout_layers) else 0)
+                           | (_l.DROP_HEADIN if 0 in rgb_dropout_layers else 0))
         self.dropout_rate = dropout_rate
         self._register_field_buffers(aabb, max_res, num_levels, log2_hashmap_size)
         if density_dropout_layers:

@@ -107,16 +107,17 @@ class FieldParams(C.Structure):
         ("mfma16_blob", C.c_void_p), ("lap16_blob", C.c_void_p),
         ("image_width", C.c_int), ("sample_major", C.c_int), ("drop_sites", C.c_int), ("lap_softplus", C.c_int), ("use_aabb", C.c_int),
         ("aabb", C.c_float * 6), ("f16_single", C.c_int), ("overflow_flag", C.c_void_p),
+        ("h0_full_t", C.c_void_p), ("hb0_raw", C.c_void_p), ("app_embed", C.c_void_p),
     ]
 
 
-ABI_VERSION = 1220                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
+ABI_VERSION = 1230                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
 SPACING_PIECEWISE, SPACING_UNIFORM = 0, 1         # include/unerf.h: UNERF_SPACING_*
 BG_LAST_SAMPLE, BG_NONE, BG_COLOR = 0, 1, 2       # include/unerf.h: UNERF_BG_*
 RASTER_NO_CULL = 1                                # include/unerf.h: UNERF_RASTER_NO_CULL
 BUILD_TRUNK_FOLD, BUILD_LAP_EXP2 = 1, 2   # include/unerf.h: UNERF_BUILD_*
-DROP_TRUNK, DROP_HEAD0, DROP_HEAD1 = 1, 2, 4     # include/unerf.h: UNERF_DROP_*
+DROP_TRUNK, DROP_HEAD0, DROP_HEAD1, DROP_HEADIN = 1, 2, 4, 8     # include/unerf.h: UNERF_DROP_*
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 _fp = C.POINTER(C.c_float)

@@ -314,6 +314,11 @@ class FieldDev:
     packed_mode: int = -1                        # the mode mfma16_blob was laid out for (MCDROPOUT: folded trunk-out slabs)
     lap_softplus: int = 0                        # LAPLACE: density_activation "softplus" instead of trunc_exp
     aabb: Optional[Tuple[float, ...]] = None     # 6 floats: scene-box normalisation instead of the contraction
+    # the first colour layer UNFOLDED -- [63][64] transposed weights, bias without the appearance term, the eval embedding:
+    # read only when drop_sites contains DROP_HEADIN (dropout on the head's inputs; VALU kernel, include/unerf.h)
+    h0_full_t: Optional[torch.Tensor] = None
+    hb0_raw: Optional[torch.Tensor] = None
+    app_embed: Optional[torch.Tensor] = None
 
     @classmethod
     def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device,
@@ -347,7 +352,8 @@ class FieldDev:
             kw["packed_lap_softplus"] = int(bool(kw.get("lap_softplus", 0)))
         return cls(mode, f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
                    f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
-                   mfma_blob=blob, lap_blob=lap_blob, **kw)
+                   mfma_blob=blob, lap_blob=lap_blob, h0_full_t=f(h0.t()), hb0_raw=f(head_b[0]), app_embed=f(appearance),
+                   **kw)
 
     @staticmethod
     def _drop_scale(mode: int, K: int, p_drop: float) -> float:
@@ -390,7 +396,8 @@ class FieldDev:
             _p(self.tcnn_levels, torch.int32),
             _p(self.mfma16_blob) if (self.use_mfma and h16) else None,
             _p(self.lap16_blob) if (self.use_mfma and h16) else None, 0, 0, int(self.drop_sites), int(self.lap_softplus),
-            0 if self.aabb is None else 1, _aabb6(self.aabb), 1 if self.precision == "f16" else 0, None)
+            0 if self.aabb is None else 1, _aabb6(self.aabb), 1 if self.precision == "f16" else 0, None,
+            _p(self.h0_full_t), _p(self.hb0_raw), _p(self.app_embed))
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------
