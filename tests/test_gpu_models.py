@@ -458,3 +458,37 @@ def test_mcdropout_model_with_dropout_on_the_colour_heads_inputs(dev):
         assert float((got - want).abs().max()) <= atol, (k, float((got - want).abs().max()))
     plain = O.mcdropout_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), 4, 77, 0.2, drop_sites=1 | 4)
     assert float((plain["rgb"] - ref["rgb"]).abs().max()) > 1e-3      # the input masks do change the picture
+
+
+@pytest.mark.parametrize("method", ["nerfacto-mcdropout", "active-splatfacto"])
+def test_repeated_renders_do_not_grow_device_memory(dev, method):
+    """a render leaves nothing behind on the device: after a warm-up the allocator's live bytes are the same after 1 and
+    after 25 more frames (side streams, pinned count buffers, overflow flags, per-frame scratch all return)"""
+    from uncertainty_nerf_gs_amd import plugin, synthetic
+    from uncertainty_nerf_gs_amd import models
+    cfg = plugin.MODEL_CONFIGS[method]()
+    if method == "active-splatfacto":
+        gp = synthetic.make_splat_tensors(3, 3000)
+        gp["scales"] = gp["scales"] + 1.5
+        model = models.ActiveSplatfactoModel(models.ActiveSplatfactoModelConfig(), num_points=10)
+        model.load_state_dict({f"gauss_params.{k}": v for k, v in gp.items()})
+        model.to(dev)
+    else:
+        cfg = _small_cfg(cfg)
+        cfg.mc_samples = 3
+        model = cfg._target(cfg, num_train_data=4)
+        t = synthetic.make_scene_tensors(seed=3, kind="mcdropout", log2T=14, prop_log2T=12)
+        model.load_state_dict(_state_dict_from_tensors(t, "mcdropout"))
+    cam = _camera(48, 64)
+    with torch.cuda.device(dev):
+        for _ in range(3):
+            out = model.get_outputs_for_camera(cam)
+        del out
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        for i in range(25):
+            out = model.get_outputs_for_camera(_camera(48, 64, theta=0.1 * i))
+            assert torch.isfinite(out["rgb"]).all()
+            del out
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() <= base + (1 << 16), (base, torch.cuda.memory_allocated())
