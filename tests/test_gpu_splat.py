@@ -268,6 +268,15 @@ def test_full_size_splat_frame_properties(dev):
     empty = out1["accumulation"][..., 0] == 0
     if empty.any():   # untouched pixels show the background exactly
         assert torch.equal(out1["rgb"][empty], bg.expand_as(out1["rgb"][empty]))
+    # the frame above ran on the tight tile lists (the default); on gsplat's own lists -- every tile of each splat's radius
+    # box, the bookkeeping checked in the first half of this test -- every output has the same bits, at full size too
+    out3 = splat.active_splatfacto_outputs(gp, c2w, fx, fy, W / 2, H / 2, H, W, bg, tight=False)
+    for k in out3:
+        assert torch.equal(out1[k], out3[k]), f"{k}: tight and gsplat tile lists disagree"
+    logits = gp["opacities"].reshape(-1).contiguous()
+    tight = ops.splat_project(gp["means"], gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], fx, fy, W / 2, H / 2,
+                              H, W, raw=True, opacity_logits=logits)
+    assert bool((tight[5] <= tiles).all()) and 0.4 * I < int(tight[5].sum()) < 0.7 * I
 
 
 @pytest.mark.parametrize("C", [1, 5])
