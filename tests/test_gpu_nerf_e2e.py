@@ -352,6 +352,33 @@ def test_full_size_mcdropout_and_laplace_degenerate_to_the_deterministic_render(
     assert (lap["accumulation"] - lap_exact["accumulation"]).abs().max() <= 2e-4
 
 
+def test_full_size_reference_precision_frame_against_the_fp32_equivalent_frame(dev):
+    """BASELINE size (full tables, 1080p, K = 8): the frame at the reference's eval precision (`precision="f16"`, one f16
+    product per MAC) against the fp32-equivalent split-f16 frame with the SAME dropout masks.  The oracle cannot run at
+    this size; what can be checked is that the two precisions give the same picture to within what fp16 operand
+    rounding explains, with the gates' quantities measured between them: PSNR of either against a common target differs
+    by < 1e-4 dB, the per-pixel spread (rgb_std) by ~1e-4, and nothing tripped the overflow guard."""
+    from uncertainty_nerf_gs_amd import render, synthetic
+    cam, c2w = dict(synthetic.CAMERA_1080P), synthetic.orbit_c2w(0.4)
+    t = synthetic.make_scene_tensors(seed=1, kind="mcdropout")
+    sd = synthetic.scene_to_device(t, dev, K=8, seed=9, p_drop=0.2)
+    a = render.render_camera(sd, c2w, **cam)
+    sd.field.precision = "f16"
+    b = render.render_camera(sd, c2w, **cam)
+    assert sd.overflow_rerenders == 0
+    for k in ("rgb", "rgb_std", "accumulation", "depth"):
+        assert torch.isfinite(b[k]).all(), k
+    d = (a["rgb"] - b["rgb"]).abs()
+    assert float(d.max()) < 2e-3 and float(d.mean()) < 3e-5, (float(d.max()), float(d.mean()))
+    assert float((a["rgb_std"] - b["rgb_std"]).abs().mean()) < 3e-5
+    assert torch.equal(a["depth"], b["depth"]) or float((a["depth"] - b["depth"]).abs().mean()) < 1e-3 * float(a["depth"].mean())
+    # PSNR against a common target (the split frame plus fixed noise, ~27 dB like the parity scenes)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    target = (a["rgb"].cpu() + 0.045 * torch.randn(a["rgb"].shape, generator=g)).clamp(0, 1)
+    psnr = lambda x: float(-10.0 * torch.log10(((x.cpu().double() - target.double()) ** 2).mean()))
+    assert abs(psnr(a["rgb"]) - psnr(b["rgb"])) < 1e-4, (psnr(a["rgb"]), psnr(b["rgb"]))
+
+
 def _rot(axis, th):
     a = torch.tensor(axis, dtype=torch.float64)
     a = a / a.norm()
