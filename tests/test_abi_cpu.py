@@ -172,3 +172,12 @@ def test_ctypes_structs_match_the_header_layout(lib, tmp_path):
             assert getattr(ct, what).offset == int(val), (cname, what, getattr(ct, what).offset, val)
         seen += 1
     assert seen == sum(len(ct._fields_) + 1 for ct in structs.values())
+
+
+def test_tight_tile_counts_are_only_offered_with_the_raw_projection(lib):
+    """ops.splat_project: the tight counts depend on the activated opacity, which only the raw-parameter entry point makes"""
+    import torch
+    from uncertainty_nerf_gs_amd import ops
+    z = torch.zeros(4, 3)
+    with pytest.raises(ValueError, match="raw=True"):
+        ops.splat_project(z, z, 1.0, torch.zeros(4, 4), torch.eye(4)[:3], 1.0, 1.0, 0.0, 0.0, 16, 16, opacity_logits=torch.zeros(4))
