@@ -63,6 +63,12 @@ def _alg(kind, K):
     }
 
 
+# The arithmetic the REFERENCE runs each method's Linear layers in at eval: MC-dropout forces torch.autocast(float16)
+# (mcdropout_models.py:86-92); active-nerfacto's MLPs are tiny-cuda-nn FullyFusedMLPs, fp16 throughout
+# (activenerfacto_field.py:89, upstream's default implementation="tcnn"); the Laplace field calls `.float()` in front of
+# every Linear (laplace_field.py:305, :460).  "f16" = one f16 product per MAC, fp32 accumulate -- no narrower than either.
+REFERENCE_PRECISION = {"mcdropout": "f16", "active": "f16", "laplace": "f16x2"}
+DTYPE_OF = {"f16": "f16 operands, f32 accumulate", "f16x2": "f32 (split-f16 operands, f32-equivalent)", "fp32": "f32"}
 STALE_PROFILES = []            # issue / traffic profiles under profiles/ that were taken from other kernel sources
 ISSUE_PEAK_GCYC = 1024 * 2.4   # 256 CUs x 4 SIMDs x 2.4 GHz peak engine clock: issue cycles per nanosecond x 1e9
 
@@ -100,7 +106,8 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
         kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
     scene = synthetic.scene_to_device(t, dev, **kw)
-    scene.field.precision = precision or ("fp32" if (args.exact_fp32 or args.split_gather) else args.precision)
+    scene.field.precision = precision or ("fp32" if (args.exact_fp32 or args.split_gather) else
+                                          (args.precision or REFERENCE_PRECISION[method]))
     scene.split_gather = args.split_gather
     H, W = args.height, args.width
     cam = dict(synthetic.CAMERA_1080P)
@@ -139,13 +146,15 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     assert torch.isfinite(out["rgb"]).all()
     mrays = H * W * steps * world / elapsed / 1e6
 
-    # Reported next to the headline, outside its timed region: the same frames with the dense layers on the
-    # exact fp32-input MFMA kernels, and how far the split-f16 image is from that exact-fp32 image.
+    # Reported next to the headline, outside its timed region: the same frames with the dense layers in the next WIDER
+    # arithmetic (f16 -> split-f16, split-f16 -> exact fp32-input MFMA), and how far the headline image is from that one.
     exact = None
-    if scene.field.precision == "f16x2" and exact_check:
-        scene.field.precision = "fp32"
+    head_prec = scene.field.precision
+    if head_prec in ("f16x2", "f16") and exact_check:
+        wider = "fp32" if head_prec == "f16x2" else "f16x2"
+        scene.field.precision = wider
         n_alt = max(1, min(steps, 3))
-        ref = frame(warmup + steps - 1)          # also warms the exact kernels up
+        ref = frame(warmup + steps - 1)          # also warms those kernels up
         sync_all()
         t1 = time.perf_counter()
         for i in range(n_alt):
@@ -156,12 +165,14 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
             tt = torch.tensor([alt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             alt = float(tt.item())
-        scene.field.precision = "f16x2"
-        exact = {"value": H * W * n_alt * world / alt / 1e6, "unit": "Mrays/s", "ms_per_step": alt / n_alt * 1e3,
-                 "steps": n_alt, "max_abs_rgb_diff_vs_split_f16": float((ref["rgb"] - out["rgb"]).abs().max()),
-                 "max_abs_rgb_std_diff_vs_split_f16": float((ref["rgb_std"] - out["rgb_std"]).abs().max())}
+        scene.field.precision = head_prec
+        exact = {"precision": wider, "value": H * W * n_alt * world / alt / 1e6, "unit": "Mrays/s", "ms_per_step": alt / n_alt * 1e3,
+                 "steps": n_alt, "max_abs_rgb_diff_vs_headline": float((ref["rgb"] - out["rgb"]).abs().max()),
+                 "mean_abs_rgb_diff_vs_headline": float((ref["rgb"] - out["rgb"]).abs().mean()),
+                 "max_abs_rgb_std_diff_vs_headline": float((ref["rgb_std"] - out["rgb_std"]).abs().max())}
+        del ref
 
-    rec = {"value": mrays, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "exact_fp32_kernels": exact}
+    rec = {"value": mrays, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "wider_arithmetic": exact}
     split = scene.field.precision == "f16x2"
     single = scene.field.precision == "f16"
     rec["workload"] = (f"{method}-nerfacto {W}x{H} render with variance" + (f", K={K} MC-dropout passes" if K else "")
@@ -256,8 +267,13 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     roof["path_bytes_per_ray"] = path_bytes
     rec["roofline"] = roof
     rec["cpu_baseline"] = None
+    rec["parity_at_bench_size"] = None
     if want_cpu and not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
-        rec["cpu_baseline"] = cpu_baseline(t, args, method, poses[0], cam, K)
+        # the oracle's outputs for its strided chunks are KEPT and compared with the same rays of a GPU frame of the same
+        # pose (rendered here, outside every timed region)
+        rec["cpu_baseline"], ids, ref = cpu_baseline(t, args, method, poses[0], cam, K)
+        got = render.render_camera(scene, poses[0], rays_per_launch=args.rays_per_launch, depth_seed=7, **cam, **shade_kw)
+        rec["parity_at_bench_size"] = parity_record(got, ids, ref, scene.field.precision)
     return rec
 
 
@@ -265,16 +281,14 @@ def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run (one rank
     per GPU, rendezvous on 127.0.0.1) as a CHILD process -- never an exec of this one, and before anything here has
     initialised the GPU -- stream its output through, and return its exit code.  Rank 0 prints the JSON line."""
-    import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d store on a port IT binds (localhost:0) -- no port probed here and taken by someone
+    # else before the store binds it; --local-addr: the ranks' MASTER_ADDR (the container hostname may not resolve)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n_gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: launching " + " ".join(cmd), file=sys.stderr)
     return subprocess.run(cmd, env=env).returncode
 
@@ -295,9 +309,11 @@ def main():
     ap.add_argument("--rays-per-launch", type=int, default=1 << 20)
     ap.add_argument("--overlap", action="store_true", help="sampling / shading stages on two HIP streams (experiment)")
     ap.add_argument("--split-gather", action="store_true", help="level-major gather kernel + feature planes (experiment)")
-    ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f16", "fp32"],
-                    help="dense layers: f16x2 = split-f16 (fp32-equivalent, default); f16 = one f16 product per MAC, fp32 "
-                         "accumulate (the reference's autocast / tcnn precision); fp32 = exact fp32-input MFMA")
+    ap.add_argument("--precision", default=None, choices=["f16x2", "f16", "fp32"],
+                    help="dense layers: f16 = one f16 product per MAC, fp32 accumulate (the reference's autocast / tcnn "
+                         "precision); f16x2 = split-f16 (fp32-equivalent); fp32 = exact fp32-input MFMA.  Default: what the "
+                         "reference computes the method in -- f16 for mcdropout (forced autocast) and active (tcnn), f16x2 for "
+                         "laplace (`.float()` Linears)")
     ap.add_argument("--exact-fp32", action="store_true",
                     help="dense layers on the exact fp32-input MFMA kernels instead of the split-f16 ones")
     ap.add_argument("--no-exact-check", action="store_true",
@@ -358,12 +374,14 @@ def main():
             # default run must stay within minutes); the headline above is the north-star target config
             # the headline's workload with the dense layers at the REFERENCE's own eval precision (opt-in, --precision f16):
             # one f16 product per MAC, fp32 accumulate = torch.autocast(float16), forced by mcdropout_models.py:86-92
-            for name, m, kk, prec in (("mcdropout_f16", "mcdropout", K, "f16"), ("active", "active", 0, None), ("laplace", "laplace", 0, None)):
+            # (mcdropout_f32eq: the headline's workload in the fp32-equivalent split-f16 form, round 3's headline)
+            other = "f16x2" if rec["precision"] == "f16" else "f16"
+            for name, m, kk, prec in ((f"mcdropout_{'f32eq' if other == 'f16x2' else 'f16'}", "mcdropout", K, other),
+                                      ("active", "active", 0, None), ("laplace", "laplace", 0, None)):
                 r = run_nerf(args, m, kk, 3, 2, rank, world, dev, dist, exact_check=False, want_cpu=False, precision=prec)
                 subs[name] = {"value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 2,
                               "workload": r["workload"], "per_kernel_ms_per_frame": r["roofline"]["per_kernel_ms_per_frame"],
-                              "dtype": "f16 operands, f32 accumulate" if prec == "f16" else "f32 (split-f16 operands, f32-equivalent)",
-                              "dense_layers": r["dense_layers"],
+                              "dtype": DTYPE_OF[r["precision"]], "dense_layers": r["dense_layers"],
                               "roofline": {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
                                                                              "avg_launch_ms", "traffic", "issue_roofline")}}
             sp = bench_splat(args, rank, world, dev, dist, 5, 2)
@@ -377,11 +395,13 @@ def main():
             line = {
                 "metric": "Mrays/s (+var), Mip-NeRF360-garden-shaped 1080p", "value": rec["value"], "unit": "Mrays/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF[rec["precision"]],
+                "data": "synthetic",
                 "config": {"workload": rec["workload"], "rays_per_step": H * W, "samples_per_ray": [256, 96, 48],
                            "hash_grid": "16x2^19x2 fp32", "dense_layers": rec["dense_layers"],
                            "parallelism": f"views x{world}" if world > 1 else "single"},
-                "roofline": rec["roofline"], "cpu_baseline": rec["cpu_baseline"], "exact_fp32_kernels": rec["exact_fp32_kernels"],
+                "roofline": rec["roofline"], "cpu_baseline": rec["cpu_baseline"],
+                "parity_at_bench_size": rec["parity_at_bench_size"], "wider_arithmetic": rec["wider_arithmetic"],
             }
             line.update(comm)
             if subs is not None:
@@ -587,8 +607,10 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
 
 def cpu_baseline(t, args, method, c2w, cam, K):
     """The CPU oracle (a port: the reference's own stack is not installable here) on a bounded,
-    strided sample of the same frame's rays, all host cores."""
+    strided sample of the same frame's rays, all host cores.  -> (record, ray ids [n], oracle outputs {key: [n, C]})"""
+    import numpy as np
     from oracle import nerf_oracle as O
+    from oracle import sampled_frame as SF
     # torch-CPU oversubscribes badly on many-core hosts for these small tensors (256 threads were
     # 40x slower than 16 on the MI355X host): cap the pool and report the threads actually used.
     cores = min(os.cpu_count() or 1, 16)
@@ -598,25 +620,52 @@ def cpu_baseline(t, args, method, c2w, cam, K):
     o, d = o.reshape(-1, 3), d.reshape(-1, 3)
     chunk = 1024
     stride = max(1, o.shape[0] // 64 // chunk) * chunk
-    done, t0, i = 0, time.perf_counter(), 0
-    wsd = wsr = None
+    kw = {}
+    if method == "mcdropout":
+        kw = dict(K=K, mc_seed=1234, p_drop=0.2)
     if method == "laplace":
         from uncertainty_nerf_gs_amd import synthetic
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
-    while time.perf_counter() - t0 < args.cpu_seconds and i * stride + chunk <= o.shape[0]:
-        oo, dd = o[i * stride:i * stride + chunk], d[i * stride:i * stride + chunk]
-        if method == "active":
-            O.active_outputs(sc, oo, dd)
-        elif method == "mcdropout":
-            O.mcdropout_outputs(sc, oo, dd, K, 1234, 0.2, ray_offset=i * stride)
-        else:
-            O.laplace_outputs(sc, oo, dd, wsd, wsr, torch.randn(100, chunk, 48))
-        done += chunk
-        i += 1
+        kw = dict(ws_density=wsd, ws_rgb=wsr, depth_seed=7, depth_draws=100)   # the frame's own depth draws (depth_seed=7)
+    ids_all = (np.arange(o.shape[0] // stride, dtype=np.int64)[:, None] * stride + np.arange(chunk, dtype=np.int64)[None]).reshape(-1)
+    ids, lists, t0 = [], {}, time.perf_counter()
+    for part, out in SF.reference_chunks(method, sc, o, d, ids_all, step=chunk, **kw):
+        ids.append(part)
+        for k, v in out.items():
+            lists.setdefault(k, []).append(v)
+        if time.perf_counter() - t0 >= args.cpu_seconds:
+            break
     dt = time.perf_counter() - t0
-    return {"value": done / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{done} rays ({done // chunk} strided 1024-ray chunks of the same 1080p camera), {dt:.1f} s, "
-                      f"torch-CPU fp32 oracle, {cores} threads"}
+    ids = np.concatenate(ids)
+    done = len(ids)
+    rec = {"value": done / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "sample": f"{done} rays ({done // chunk} strided 1024-ray chunks of the same 1080p camera), {dt:.1f} s, "
+                     f"torch-CPU fp32 oracle, {cores} threads"}
+    return rec, ids, {k: torch.cat(v) for k, v in lists.items()}
+
+
+def parity_record(got, ids, ref, precision):
+    """`parity_at_bench_size`: the GPU frame (full tables, 1080p, the bench's launch groups) against the oracle outputs the
+    cpu_baseline leg produced for `ids` -- the north-star gate quantities (|dPSNR| against a common synthetic target, |dAUSE|)
+    and the worst per-pixel differences."""
+    from uncertainty_nerf_gs_amd import metrics
+    sel = torch.from_numpy(ids).to(got["rgb"].device)
+    pick = lambda k: got[k].reshape(-1, got[k].shape[-1])[sel].cpu()
+    rgb, std, rrgb, rstd = pick("rgb"), pick("rgb_std"), ref["rgb"], ref["rgb_std"]
+    g = torch.Generator().manual_seed(123)
+    gt = torch.clamp(rrgb + torch.randn(rrgb.shape, generator=g) * 0.05 * (0.3 + torch.rand(rrgb.shape[:1] + (1,), generator=g)), 0, 1)
+    ause = lambda c, s: metrics.ause((s ** 2).flatten(), torch.sum((c - gt) ** 2, -1).flatten(), "mse")[3]
+    rec = {"rays": int(len(ids)), "oracle": "torch-CPU fp32 (oracle/sampled_frame.py), same pose, same mask / depth-draw counters",
+           "precision": precision,
+           "max_abs_rgb": float((rgb - rrgb).abs().max()), "max_abs_rgb_std": float((std - rstd).abs().max()),
+           "max_abs_accumulation": float((pick("accumulation") - ref["accumulation"]).abs().max()),
+           "psnr_vs_target": metrics.psnr(rrgb, gt), "d_psnr": abs(metrics.psnr(rgb, gt) - metrics.psnr(rrgb, gt)),
+           "d_ause_mse": abs(ause(rgb, std) - ause(rrgb, rstd))}
+    dd = (pick("depth") - ref["depth"]).abs() > 1e-3 * ref["depth"].abs()
+    rec["median_depth_pixels_off_1e-3"] = float(dd.double().mean())
+    rec["gates"] = "|dPSNR| <= 1e-4 dB, |dAUSE| <= 1e-3"
+    rec["inside_gates"] = bool(rec["d_psnr"] <= 1e-4 and rec["d_ause_mse"] <= 1e-3)
+    return rec
 
 
 if __name__ == "__main__":

@@ -38,7 +38,7 @@ extern "C" {
 const char* unerf_last_error(void);
 /* Library/ABI version (major*1000+minor).  A binding built against this header must find exactly UNERF_ABI_VERSION
  * (struct layouts and argument lists change with it; uncertainty-nerf-gs_amd/lib.py::load checks). */
-#define UNERF_ABI_VERSION 1230
+#define UNERF_ABI_VERSION 1300
 int unerf_version(void);
 
 /* Spacing function of the proposal sampler's initial sampler, passed behind every (near_plane, far_plane) pair:
@@ -73,9 +73,21 @@ int unerf_device_count(void);
  * slicing used by get_outputs_for_camera (scripts/eval_uncertainty.py:1097,1127;
  * models/laplace/laplace_model.py:269-297, 403-415).
  * c2w: HOST pointer to 12 floats (3x4 row-major).  Rays [ray_start, ray_start+count)
- * of the H*W row-major image.  pixel_area may be NULL. */
-int unerf_generate_rays(const float* c2w_host, float fx, float fy, float cx, float cy, int H, int W,
-                        int64_t ray_start, int64_t count, float* origins, float* directions,
+ * of the H*W row-major image.  pixel_area may be NULL.
+ * distortion: HOST pointer to the camera's 6 OPENCV lens parameters in nerfstudio's order (k1, k2, k3, k4, p1, p2 --
+ * camera_utils.get_distortion_params, as the reference's dataparsers hand them to `Cameras`:
+ * dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:113-125, 248-274; every `ns-process-data images` scene
+ * of /root/reference/README.md:52-56 carries them), or NULL.  Non-zero parameters bend the rays the way
+ * Cameras._generate_rays_from_coords does for a perspective camera: the image-plane coordinate ((x - cx) / fx,
+ * -(y - cy) / fy) of the pixel centre AND of its +1-pixel x / y neighbours (which feed pixel_area) goes through
+ * camera_utils.radial_and_tangential_undistort -- UNERF_UNDISTORT_ITERATIONS Newton steps on the 2x2 Jacobian of the
+ * forward model, a step taken only where |det| > UNERF_UNDISTORT_EPS -- before it is rotated into the world.  NULL or
+ * six zeros: no iteration runs (upstream's `(distortion_params != 0).any()` guard) and the rays are bit-for-bit those
+ * of the distortion-free camera. */
+#define UNERF_UNDISTORT_ITERATIONS 10
+#define UNERF_UNDISTORT_EPS 1e-3f
+int unerf_generate_rays(const float* c2w_host, float fx, float fy, float cx, float cy, const float* distortion_host,
+                        int H, int W, int64_t ray_start, int64_t count, float* origins, float* directions,
                         float* pixel_area, void* stream);
 
 /* Oriented crop box (`obb_box` of Model.get_outputs_for_camera / get_outputs_for_camera_unc,
@@ -219,7 +231,7 @@ typedef struct {
     int K; uint32_t seed; float p_drop;
     /* LAPLACE */
     const float* ws_density;  /* [n_lap][65]  */
-    const float* ws_rgb;      /* [n_lap][195] */
+    const float* ws_rgb;      /* [n_lap_rgb (n_lap when that is 0)][195] */
     int n_lap;
     int lap_mask_density;     /* 1: multiply the density mean by the box selector (the use_deterministic_density=True
                                  path, laplace_field.py:501-506 / :317-345, fed with n_lap copies of the mean row) */
@@ -283,10 +295,13 @@ typedef struct {
        models/activenerfacto/activenerfacto_field.py:89).  0: the split form above (fp32-equivalent).  Biases, the
        64 -> 3 colour layer and every activation function stay fp32 in both forms. */
     int f16_single;
-    /* f16_single only, DEVICE int32 (may be NULL): |= 1 when an output pre-activation (density logit, colour sums;
-       LAPLACE: a sampled-head mean) comes out inf / NaN -- the trace an activation beyond the f16 range (65504) leaves
-       in this form, which has no lo halves to turn it into a NaN sample.  Same word and same host protocol as the
-       composite entry points' nonfinite_flag (render.OverflowGuard: fp32 re-render of the launch group). */
+    /* With mfma16_blob, DEVICE int32 (may be NULL): |= 1 when an f16 OPERAND of the dense layers overflowed (an activation
+       beyond 65504).  f16_single: an output pre-activation (density logit, colour sums; LAPLACE: a sampled-head mean)
+       comes out inf / NaN -- the trace such an activation leaves in this form, which has no lo halves to turn it into a
+       NaN sample.  Split form: the pre-activations of a colour layer are NaN (hi = inf, lo = -inf make every unit of the
+       next layer NaN, which the ReLU behind it could otherwise zero; trunk overflows reach the density as NaN and are
+       flagged by the composite entry points).  Same word and same host protocol as the composite entry points'
+       nonfinite_flag (render.OverflowGuard: fp32 re-render of the launch group). */
     int32_t* overflow_flag;
     /* UNERF_DROP_HEADIN only (else may be NULL): the colour head's first layer unfolded -- weights transposed
        [63][64] over the inputs [SH16 | geo15 | appearance32], its bias [64] WITHOUT the appearance term, and the eval
@@ -294,6 +309,20 @@ typedef struct {
     const float* h0_full_t;
     const float* hb0_raw;
     const float* app_embed;
+    /* LAPLACE: the reference draws a fresh set of last-layer samples in EVERY eval chunk of a frame -- sample_laplace
+       runs inside get_outputs_unc, which get_outputs_for_camera_ray_bundle_unc calls per 32,768-ray chunk
+       (models/laplace/laplace_model.py:432-443 -> laplace_field.py:331-339, 468-476, 545).  lap_chunk_rays > 0:
+       ws_density [lap_sets][n_lap][65], ws_rgb [lap_sets][n_lap][195], lap_blob / lap16_blob
+       [lap_sets][UNERF_LAP_BLOB_FLOATS] are STACKS of sets and ray g = ray_offset + r is evaluated with set
+       g / lap_chunk_rays (every ray of the call must map below lap_sets).  lap_chunk_rays and ray_offset must be
+       multiples of 32: the matrix kernels then take 32 consecutive rays as a tile (image_width is not used), so no tile
+       straddles two sets.  0: one set for every ray (lap_sets ignored). */
+    int lap_chunk_rays;
+    int lap_sets;
+    /* LAPLACE: rows of ws_rgb (and of the colour heads in the blobs) when it differs from n_lap; <= 0: n_lap.  The
+       reference's forward_unc does not pass n_samples on to the colour head (laplace_field.py:516-520), which therefore
+       always draws its default 100 whatever the density head was asked for. */
+    int n_lap_rgb;
 } unerf_field_params;
 #define UNERF_DROP_TRUNK 1
 #define UNERF_DROP_HEAD0 2

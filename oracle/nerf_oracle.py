@@ -10,9 +10,10 @@ Two kinds of functions live here, tagged in their docstrings:
                           "parity unpinned" for these.
 
 Everything is written as plain functions over tensors so that each HIP kernel
-has a same-shaped counterpart.  fp32 throughout (the canonical precision of
-this build; the reference's autocast fp16/bf16 for MC-dropout,
-mcdropout_models.py:86-92, is documented as a divergence in DESIGN.md).
+has a same-shaped counterpart.  fp32 by default; `autocast=torch.float16 / bfloat16`
+on the Linear layers (`_linear`) emulates the autocast the reference forces at
+eval for MC-dropout (mcdropout_models.py:86-92) -- the arithmetic the kernels'
+`precision="f16"` form follows ("Precision").
 """
 from __future__ import annotations
 
@@ -229,8 +230,52 @@ def normalized_positions(positions: torch.Tensor, aabb: Optional[torch.Tensor] =
 # L0.9 camera rays                                        [UPSTREAM nerfstudio]
 # --------------------------------------------------------------------------
 
-def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int):
-    """Cameras.generate_rays(keep_shape=True) for a distortion-free perspective camera.
+# [UPSTREAM-RECALL] the two constants of camera_utils.radial_and_tangential_undistort's signature (nerfstudio 1.1.0:
+# `eps: float = 1e-3, max_iterations: int = 10`); include/unerf.h carries the same pair as UNERF_UNDISTORT_*
+UNDISTORT_EPS = 1e-3
+UNDISTORT_MAX_ITERATIONS = 10
+
+
+def radial_and_tangential_undistort(coords: torch.Tensor, distortion_params: torch.Tensor,
+                                    eps: float = UNDISTORT_EPS, max_iterations: int = UNDISTORT_MAX_ITERATIONS) -> torch.Tensor:
+    """[UPSTREAM-RECALL nerfstudio 1.1.0 cameras/camera_utils.py: radial_and_tangential_undistort +
+    _compute_residual_and_jacobian, adapted there from MultiNeRF] -- the WHOLE of upstream's undistortion lives in
+    this one function, so a diff against a real install is one function.
+    coords [..., 2] distorted image-plane coordinates; distortion_params [6] = (k1, k2, k3, k4, p1, p2).
+    Newton's method from the distorted point on the forward OPENCV model
+        xd = x d + 2 p1 x y + p2 (r + 2 x^2),  yd = y d + 2 p2 x y + p1 (r + 2 y^2),
+        r = x^2 + y^2,  d = 1 + r (k1 + r (k2 + r (k3 + r k4)));
+    a fixed `max_iterations` steps, each taken only where |det J| > eps."""
+    k1, k2, k3, k4, p1, p2 = (distortion_params[..., i] for i in range(6))
+    xd, yd = coords[..., 0], coords[..., 1]
+    x, y = xd, yd
+    for _ in range(max_iterations):
+        r = x * x + y * y
+        d = 1.0 + r * (k1 + r * (k2 + r * (k3 + r * k4)))
+        fx = d * x + 2 * p1 * x * y + p2 * (r + 2 * x * x) - xd
+        fy = d * y + 2 * p2 * x * y + p1 * (r + 2 * y * y) - yd
+        d_r = k1 + r * (2.0 * k2 + r * (3.0 * k3 + r * 4.0 * k4))
+        d_x = 2.0 * x * d_r
+        d_y = 2.0 * y * d_r
+        fx_x = d + d_x * x + 2.0 * p1 * y + 6.0 * p2 * x
+        fx_y = d_y * x + 2.0 * p1 * x + 2.0 * p2 * y
+        fy_x = d_x * y + 2.0 * p2 * y + 2.0 * p1 * x
+        fy_y = d + d_y * y + 2.0 * p2 * x + 6.0 * p1 * y
+        denominator = fy_x * fx_y - fx_x * fy_y
+        x_numerator = fx * fy_y - fy * fx_y
+        y_numerator = fy * fx_x - fx * fy_x
+        ok = torch.abs(denominator) > eps
+        x = x + torch.where(ok, x_numerator / denominator, torch.zeros_like(denominator))
+        y = y + torch.where(ok, y_numerator / denominator, torch.zeros_like(denominator))
+    return torch.stack([x, y], dim=-1)
+
+
+def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int, distortion=None):
+    """Cameras.generate_rays(keep_shape=True) for ONE perspective camera [UPSTREAM nerfstudio 1.1.0
+    Cameras._generate_rays_from_coords].  distortion: the camera's `distortion_params` (k1, k2, k3, k4, p1, p2) as the
+    reference's dataparsers pass them (dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:113-125, 248-274),
+    or None; when any is non-zero the coordinate stack (pixel centre and its +1 x / y neighbours, y already negated) is
+    undistorted before the rotation, as upstream does under `mask.any() and (distortion_params != 0).any()`.
     Returns origins [H,W,3], directions [H,W,3], pixel_area [H,W,1]."""
     c2w = c2w.to(torch.float32)
     ii, jj = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
@@ -241,6 +286,10 @@ def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
     coord_x = torch.stack([(x - cx + 1) / fx, -(y - cy) / fy], -1)
     coord_y = torch.stack([(x - cx) / fx, -(y - cy + 1) / fy], -1)
     cs = torch.stack([coord, coord_x, coord_y], dim=0)
+    if distortion is not None:
+        dp = torch.as_tensor(distortion, dtype=torch.float32).reshape(6)
+        if bool((dp != 0).any()):
+            cs = radial_and_tangential_undistort(cs, dp)
     ds = torch.cat([cs, -torch.ones_like(cs[..., :1])], dim=-1)  # [3,H,W,3]
     rot = c2w[:3, :3]
     ds = torch.sum(ds[..., None, :] * rot, dim=-1)
@@ -443,6 +492,19 @@ def render_depth_median(weights: torch.Tensor, steps: torch.Tensor) -> torch.Ten
     idx = torch.searchsorted(cw, split, side="left")
     idx = torch.clamp(idx, 0, steps.shape[-1] - 1)
     return torch.gather(steps, dim=-1, index=idx)
+
+
+def median_margin(weights: torch.Tensor) -> torch.Tensor:
+    """Test diagnostic, not part of any output: how far the weight CDF of each ray stays from the 0.5 that
+    render_depth_median searches for, min_j |cumsum(w)_j - 0.5| -> [R,1].  A ray whose margin is within the rounding of
+    the CDF is a TIE: which of two neighbouring samples becomes the median depends on summation order, so two correct
+    implementations may differ there by a whole sample step (the tests allow depth differences on such rays only)."""
+    return (torch.cumsum(weights, dim=-1) - 0.5).abs().min(dim=-1, keepdim=True).values
+
+
+def _note_margin(diagnostics: Optional[dict], weights: torch.Tensor) -> None:
+    if diagnostics is not None:
+        diagnostics.setdefault("median_margin", []).append(median_margin(weights))
 
 
 def render_depth_expected(weights: torch.Tensor, steps: torch.Tensor) -> torch.Tensor:
@@ -768,13 +830,14 @@ def _prop_depths(scene, wl, bl, nears=None, fars=None):
     return out
 
 
-def active_compose(eb, density, rgb, beta, background="last_sample") -> Dict[str, torch.Tensor]:
+def active_compose(eb, density, rgb, beta, background="last_sample", diagnostics: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """[REF activenerfacto_model.py:94-127] everything get_outputs does after the field call: eb [R,S+1] Euclidean
     bin edges, density / beta [R,S], rgb [R,S,3].  Pinned to the reference's own code by
     tests/golden/nerf_model_glue.npz (fake-self run of ActiveNerfactoModel.get_outputs)."""
     deltas = eb[..., 1:] - eb[..., :-1]
     steps = (eb[..., :-1] + eb[..., 1:]) / 2
     w = get_weights(density, deltas)
+    _note_margin(diagnostics, w)
     out = {
         "rgb": render_rgb(rgb, w, background),
         "accumulation": render_accumulation(w),
@@ -791,22 +854,24 @@ def active_compose(eb, density, rgb, beta, background="last_sample") -> Dict[str
 
 
 def active_outputs(scene: NerfScene, origins, directions, nears=None, fars=None,
-                   autocast: Optional[torch.dtype] = None) -> Dict[str, torch.Tensor]:
+                   autocast: Optional[torch.dtype] = None, diagnostics: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """[REF activenerfacto_model.py:83-152] one chunk of rays [R,3]; nears / fars [R,1]: per-ray planes of the bundle
     (obb_box), else the collider's constants.  autocast: the MAIN field's Linear layers in low precision (the proposal
     networks stay fp32 here as they do in the kernels)."""
     eb, wl, bl = _sample(scene, origins, directions, nears, fars)
     density, rgb, beta = active_field(origins, directions, eb, scene.field, autocast)
-    out = active_compose(eb, density, rgb, beta, scene.background)
+    out = active_compose(eb, density, rgb, beta, scene.background, diagnostics)
     out.update(_prop_depths(scene, wl, bl, nears, fars))
     return out
 
 
-def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, density, rgb, nears=None, fars=None):
+def nerfacto_pass_outputs(scene: NerfScene, origins, directions, eb, wl, bl, density, rgb, nears=None, fars=None,
+                          diagnostics: Optional[dict] = None):
     """[UPSTREAM NerfactoModel.get_outputs] rgb/accumulation/depth/expected_depth/prop_depth_i."""
     deltas = eb[..., 1:] - eb[..., :-1]
     steps = (eb[..., :-1] + eb[..., 1:]) / 2
     w = get_weights(density, deltas)
+    _note_margin(diagnostics, w)
     out = {
         "rgb": render_rgb(rgb, w, scene.background),
         "accumulation": render_accumulation(w),
@@ -827,7 +892,8 @@ def nerfacto_outputs(scene: NerfScene, origins, directions, nears=None, fars=Non
 
 def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, p_drop: float,
                       ray_offset: int = 0, drop_sites: int = 5, autocast: Optional[torch.dtype] = None,
-                      nears=None, fars=None, ray_ids: Optional[np.ndarray] = None) -> Dict[str, torch.Tensor]:
+                      nears=None, fars=None, ray_ids: Optional[np.ndarray] = None,
+                      diagnostics: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """[REF mcdropout_models.py:94-131] K stochastic passes of one chunk + mean / unbiased std.
     Masks come from the shared counter RNG keyed by the global sample index
     (ray_offset+r)*S+s, so chunking does not change them (ray_ids [R]: the rays' global indices when they are not
@@ -838,6 +904,7 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
     rid = np.arange(R, dtype=np.int64) + ray_offset if ray_ids is None else np.asarray(ray_ids, dtype=np.int64)
     sidx = (rid[:, None] * S + np.arange(S)[None, :]).reshape(-1)
     outs = []
+    passes: Optional[dict] = {} if diagnostics is not None else None
     for k in range(K):
         # drop_sites bits: 1 trunk (mask stream 0), 2 head hidden-0 (stream 2), 4 head hidden-1 (stream 1),
         # 8 head inputs (stream 3, 63 of its 64 units)
@@ -847,7 +914,9 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
         kin = torch.from_numpy(mc_keep_mask(seed, k, sidx, 3, 64, p_drop)[:, :63]) if drop_sites & 8 else None
         density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop, keep_head0=kh0, autocast=autocast,
                                        keep_in=kin)
-        outs.append(nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb, nears, fars))
+        outs.append(nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb, nears, fars, passes))
+    if diagnostics is not None:   # the smallest margin of the K passes: a tie in ANY pass moves the mean of the medians
+        diagnostics.setdefault("median_margin", []).append(torch.stack(passes["median_margin"]).min(dim=0).values)
     res = {}
     for key in outs[0].keys():
         el = torch.stack([o[key] for o in outs], dim=0)
@@ -858,7 +927,8 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
 
 
 def laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise: Optional[torch.Tensor],
-                    use_deterministic_density: bool = False, background="last_sample") -> Dict[str, torch.Tensor]:
+                    use_deterministic_density: bool = False, background="last_sample",
+                    diagnostics: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """[REF laplace_model.py:471-530] everything get_outputs_unc does after the field call: weights from mu_d,
     rgb / rgb_var from those weights, then (unless use_deterministic_density) D density draws
     relu(mu_d + max(sqrt(var_d), 1e-10) * noise), their mean weights, and depth / expected depth / accumulation
@@ -876,6 +946,7 @@ def laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise: Optional[torc
         sampled = F.relu(mu_d[None] + sd[None] * depth_noise)
         sw = torch.stack([get_weights(sampled[i], deltas) for i in range(sampled.shape[0])], dim=0)
         wm = sw.mean(dim=0)
+    _note_margin(diagnostics, wm)
     depth = render_depth_median(wm, steps)
     depth_var = torch.sum(wm * (steps - depth) ** 2, dim=-1, keepdim=True) + 1e-5
     return {
@@ -886,7 +957,8 @@ def laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise: Optional[torc
 
 def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
                     depth_noise: Optional[torch.Tensor], use_deterministic_density: bool = False,
-                    nears=None, fars=None, autocast: Optional[torch.dtype] = None) -> Dict[str, torch.Tensor]:
+                    nears=None, fars=None, autocast: Optional[torch.dtype] = None,
+                    diagnostics: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """[REF laplace_model.py:456-556] is_inference=True.
     use_deterministic_density=False: density = sampled-head mean (NOT selector-masked), depth from the mean of the
     weights of D Normal(mu_d, sigma_d) density draws; depth_noise [D,R,S] = the standard-normal draw behind them.
@@ -896,7 +968,8 @@ def laplace_outputs(scene: NerfScene, origins, directions, ws_density, ws_rgb,
     mu_d, var_d, mu_rgb, var_rgb = laplace_field(origins, directions, eb, scene.field, ws_density, ws_rgb, autocast)
     if use_deterministic_density:
         mu_d, _ = laplace_field_deterministic(origins, directions, eb, scene.field)
-    out = laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise, use_deterministic_density, scene.background)
+    out = laplace_compose(eb, mu_d, var_d, mu_rgb, var_rgb, depth_noise, use_deterministic_density, scene.background,
+                          diagnostics)
     out.update(_prop_depths(scene, wl, bl, nears, fars))
     return out
 

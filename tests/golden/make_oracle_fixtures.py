@@ -33,8 +33,12 @@ def lego200():
     cam = dict(synthetic.CAMERA_LEGO200)
     c2w = synthetic.orbit_c2w(c["theta"], radius=c["radius"], height=c["height"])
     o, d, _ = O.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["H"], cam["W"])
-    ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, c["K"], c["mc_seed"], c["p_drop"], ray_offset=off),
-                          o, d, chunk=32768)
+    diag = {}
+    ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, c["K"], c["mc_seed"], c["p_drop"], ray_offset=off,
+                                                                  diagnostics=diag), o, d, chunk=32768)
+    # test diagnostic, not an output: the smallest |cdf - 0.5| of the K passes per ray (oracle.median_margin) -- the depth
+    # gate treats rays whose median differs as ties only when this is within rounding
+    ref["median_margin"] = torch.cat(diag["median_margin"]).view(cam["H"], cam["W"], 1)
     np.savez_compressed(os.path.join(HERE, "lego200_mcdropout.npz"), **{k: v.numpy().astype(np.float32) for k, v in ref.items()})
     print({k: tuple(v.shape) for k, v in ref.items()})
 

@@ -73,6 +73,10 @@ def test_model_from_checkpoint_equals_direct_pipeline(dev, kind, method):
     with torch.cuda.device(dev):
         out = model.get_outputs_for_camera(cam)
     sd = synthetic.scene_to_device(t, dev, **kw)
+    # the model renders in the REFERENCE's arithmetic: mc-dropout under its forced fp16 autocast (mcdropout_models.py:86-92),
+    # an implementation="torch" active-nerfacto in fp32 (the split-f16 kernels)
+    assert model.device_scene().field.precision == sd.field.precision.replace("f16x2", "f16" if kind == "mcdropout" else "f16x2")
+    sd.field.precision = model.device_scene().field.precision
     ref = render.render_camera(sd, cam.camera_to_worlds[0], fx=0.9 * W, fy=0.9 * W, cx=W / 2, cy=H / 2, H=H, W=W,
                                keep_density=(kind == "active"))
     assert set(out) == set(ref)
@@ -142,6 +146,52 @@ def test_laplace_model_unc_render_matches_oracle(dev):
         got, want = out[k].cpu().reshape(H * W, -1).double(), ref[k].double()
         bad = (got - want).abs() > atol + rtol * want.abs()
         assert bad.double().mean() <= 5e-3, (k, (got - want).abs().max().item())
+
+
+def test_laplace_model_draws_fresh_last_layer_samples_in_every_eval_chunk(dev):
+    """NerfactoLaplaceModel.resample = "chunk" (default): get_outputs_for_camera_unc renders every chunk of
+    config.eval_num_rays_per_chunk rays with its own sample_laplace draw, consuming the generator as the reference's chunk
+    loop does (laplace_model.py:432-443: chunk 0 density, chunk 0 colour, chunk 1 density, ...); "camera": one draw."""
+    from oracle import sampled_frame as SF
+    from uncertainty_nerf_gs_amd import plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=4, kind="laplace", log2T=14, prop_log2T=12)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["nerfacto-laplace"]())
+    cfg.eval_num_rays_per_chunk = 128
+    model = cfg._target(cfg, num_train_data=4)
+    model.load_state_dict(_state_dict_from_tensors(t, "laplace"))
+    g = torch.Generator().manual_seed(5)
+    model.field.mlp_density_ggn = torch.rand(65, generator=g) * 1e3
+    model.field.mlp_rgb_ggn = torch.rand(195, generator=g) * 1e3
+    assert model.resample == "chunk"
+    H, W = 16, 24                                  # 384 rays = 3 chunks
+    cam = _camera(H, W, 2.0)
+    with torch.cuda.device(dev):
+        out = model.get_outputs_for_camera_unc(cam, n_samples=50, generator=torch.Generator().manual_seed(9))
+    g2 = torch.Generator().manual_seed(9)
+    f = t["field"]
+    mu_d = torch.cat([f["density_w"].reshape(-1), f["density_b"].reshape(-1)])
+    mu_r = torch.cat([f["head_w"][2].reshape(-1), f["head_b"][2].reshape(-1)])
+    sets = []
+    for _ in range(3):     # quirk kept: the colour head always draws 100 samples (laplace_field.py:516-520)
+        sets.append((O.laplace_weight_samples(mu_d, model.field.mlp_density_ggn, 1.0, 1e-9, torch.randn(50, 65, generator=g2)),
+                     O.laplace_weight_samples(mu_r, model.field.mlp_rgb_ggn, 1.0, 1e-9, torch.randn(100, 195, generator=g2))))
+    sc = O.scene_from_tensors(t)
+    o, d, _ = O.generate_rays(cam.camera_to_worlds[0], 0.9 * W, 0.9 * W, W / 2, H / 2, H, W)
+
+    def chunk_fn(oo, dd, off):
+        ids = np.arange(off, off + oo.shape[0], dtype=np.int64)
+        return O.laplace_outputs(sc, oo, dd, sets[off // 128][0], sets[off // 128][1], SF.depth_noise_for(ids, 48, 0, 100))
+
+    ref = O.render_camera(chunk_fn, o, d, chunk=128)
+    for k, atol, rtol in (("rgb", 5e-5, 0), ("rgb_std", 2e-5, 5e-3), ("accumulation", 3e-4, 0), ("expected_depth", 0, 2e-3)):
+        got, want = out[k].cpu().reshape(H * W, -1).double(), ref[k].reshape(H * W, -1).double()
+        bad = (got - want).abs() > atol + rtol * want.abs()
+        assert bad.double().mean() <= 5e-3, (k, (got - want).abs().max().item())
+    model.resample = "camera"
+    with torch.cuda.device(dev):
+        one = model.get_outputs_for_camera_unc(cam, n_samples=50, generator=torch.Generator().manual_seed(9))
+    assert torch.allclose(one["rgb"].reshape(-1, 3)[:128], out["rgb"].reshape(-1, 3)[:128], atol=1e-6)   # chunk 0: the same draw
+    assert float((one["rgb_std"] - out["rgb_std"]).abs().max()) > 1e-4
 
 
 def test_laplace_model_deterministic_density_matches_oracle(dev):

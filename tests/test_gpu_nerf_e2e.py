@@ -17,7 +17,8 @@ def _cam(H, W):
 
 
 def _oracle_rays(c2w, cam):
-    o, d, _ = O.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["H"], cam["W"])
+    o, d, _ = O.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["H"], cam["W"],
+                              distortion=cam.get("distortion"))
     return o, d
 
 
@@ -38,8 +39,68 @@ def _report(name, rec):
             f.write(json.dumps({"test": name, **rec}) + "\n")
 
 
-def _gates(name, out_rgb, out_std, ref_rgb, ref_std):
-    """The north-star parity gates: |dPSNR| <= 1e-4 dB and |dAUSE| <= 1e-3 against the same GT."""
+def _depth_gt(ref_depth):
+    """Synthetic ground-truth depth for the depth gates: the oracle's median depth with seeded multiplicative noise
+    (sigma 8 %, spatially varying) and 5 % invalid pixels (GT = 0, which get_unc_metrics_depth masks out)."""
+    g = torch.Generator().manual_seed(321)
+    flat = ref_depth.reshape(-1).double()
+    noise = torch.randn(flat.shape, generator=g, dtype=torch.float64) * 0.08 * (0.3 + torch.rand(flat.shape, generator=g, dtype=torch.float64))
+    gt = (flat * (1.0 + noise)).clamp_min(1e-3)
+    gt[torch.rand(flat.shape, generator=g) < 0.05] = 0.0
+    return gt.float()
+
+
+# A median depth is a DISCRETE pick -- the first sample whose weight CDF reaches 0.5 -- so where the CDF passes within
+# rounding of 0.5 two correct implementations choose neighbouring samples, a whole step apart (far from the camera a step
+# is large, and AUSE normalises by the largest error: ONE such pixel in 4,096 moves depth AUSE by 2.6e-2, measured at the
+# BASELINE size).  The oracle reports the margin min_j |cdf_j - 0.5| of every ray (oracle.median_margin; mc-dropout: the
+# smallest of the K passes, since the output is the mean of the K medians); rays whose median differs must have a margin
+# below what the arithmetic explains, and are then compared as ties (the oracle's value on both sides).
+# What the arithmetic explains: scan order and the ~1e-6 sample-position differences between the two pipelines
+# (test_active_nerfacto_camera_parity) move a weight by delta x density x that difference -- measured worst margins of
+# differing medians over the whole suite (profiles/r4_*_parity_report.jsonl): 2e-5 single-pass methods, 4e-4 mc-dropout
+# (8 chances per ray), 1.3e-4 at precision "f16".  TIE_MARGIN is that with a factor of two; the trained-like stress scene
+# (densities up to e^12: the same position difference moves a weight a thousand times further) passes its own.
+TIE_MARGIN = {"f16x2": 1e-3, "fp32": 1e-3, "f16": 1e-3}
+
+
+def _margin_of(diag):
+    if diag is None:
+        return None
+    m = diag["median_margin"] if isinstance(diag, dict) else diag
+    return (torch.cat(list(m)) if isinstance(m, (list, tuple)) else m).reshape(-1)
+
+
+def _depth_gates(rec, out, ref, margin=None, precision="f16x2", tie_margin=None):
+    """The depth half of the reference's per-image evaluation (scripts/eval_uncertainty.py:415-644 get_unc_metrics_depth:
+    depth AUSE mse / mae / rmse, NLL, AUCE on the masked, clipped prediction) computed for the rendered and the oracle
+    (depth, depth_std) against the same synthetic depth map: |dAUSE| <= 1e-3 like the RGB gate; NLL / AUCE deltas are
+    recorded.  margin: the oracle's median margins [pixels] -- differing medians must be ties (see TIE_MARGIN) and are
+    then taken out of the comparison."""
+    from uncertainty_nerf_gs_amd import eval as E
+    rd, rs = ref["depth"].reshape(-1).float(), ref["depth_std"].reshape(-1).float()
+    od, os_ = out["depth"].reshape(-1).float().cpu(), out["depth_std"].reshape(-1).float().cpu()
+    flip = (od - rd).abs() > 1e-3 * rd.abs()
+    rec["depth_pixels_off_1e-3"] = float(flip.double().mean())
+    if margin is not None:
+        tie = TIE_MARGIN[precision] if tie_margin is None else tie_margin
+        rec["depth_flips"] = int(flip.sum())
+        rec["depth_flip_worst_margin"] = float(margin[flip].max()) if bool(flip.any()) else 0.0
+        rec["tie_margin"] = tie
+        rec["pixels_within_tie_margin"] = float((margin <= tie).double().mean())
+        od, os_ = torch.where(flip, rd, od), torch.where(flip, rs, os_)
+    gt = _depth_gt(rd)
+    mo, _ = E.depth_metrics_unc({"depth": od.view(1, -1, 1), "depth_std": os_.view(1, -1, 1)}, gt.view(1, -1), 1.0)
+    mr, _ = E.depth_metrics_unc({"depth": rd.view(1, -1, 1), "depth_std": rs.view(1, -1, 1)}, gt.view(1, -1), 1.0)
+    for k in ("depth_ause_mse", "depth_ause_mae", "depth_ause_rmse", "depth_nll", "depth_auc_abs_error"):
+        rec[k + "_ref"] = float(mr[k])
+        rec["d_" + k] = abs(float(mo[k]) - float(mr[k]))
+
+
+def _gates(name, out_rgb, out_std, ref_rgb, ref_std, out=None, ref=None, diag=None, precision="f16x2", tie_margin=None):
+    """The north-star parity gates: |dPSNR| <= 1e-4 dB and |dAUSE| <= 1e-3 against the same GT -- for the RGB image and,
+    when the method returns `depth_std` (out / ref = the two output dicts), for the depth map too.  diag: the oracle's
+    diagnostics dict (median margins) of the same render."""
     from uncertainty_nerf_gs_amd import metrics
     gt = _gt_image(ref_rgb)
     rec = {"psnr_ref": metrics.psnr(ref_rgb, gt), "d_psnr": abs(metrics.psnr(out_rgb, gt) - metrics.psnr(ref_rgb, gt)),
@@ -51,10 +112,20 @@ def _gates(name, out_rgb, out_std, ref_rgb, ref_std):
             return metrics.ause((std ** 2).flatten(), err, et)[3]
         rec[f"ause_{et}_ref"] = a(ref_rgb, ref_std)
         rec[f"d_ause_{et}"] = abs(a(out_rgb, out_std) - rec[f"ause_{et}_ref"])
+    depth = out is not None and ref is not None and "depth_std" in out and "depth_std" in ref
+    if depth:
+        _depth_gates(rec, out, ref, _margin_of(diag), precision, tie_margin)
     _report(name, rec)
     assert rec["d_psnr"] <= 1e-4, f"|dPSNR| = {rec['d_psnr']:.2e} dB"
     for et in ("mse", "mae", "rmse"):
         assert rec[f"d_ause_{et}"] <= 1e-3, f"|dAUSE_{et}| = {rec[f'd_ause_{et}']:.2e}"
+    if depth:
+        if "depth_flips" in rec:
+            assert rec["depth_flip_worst_margin"] <= rec["tie_margin"], \
+                f"{rec['depth_flips']} median depths differ, one with CDF margin {rec['depth_flip_worst_margin']:.2e}: not a tie"
+            assert rec["depth_pixels_off_1e-3"] <= 2e-2
+        for et in ("mse", "mae", "rmse"):
+            assert rec[f"d_depth_ause_{et}"] <= 1e-3, f"|d depth AUSE_{et}| = {rec[f'd_depth_ause_{et}']:.2e}"
 
 
 def _img_close(got, ref, atol, rtol, what, max_bad_frac=0.0):
@@ -66,6 +137,7 @@ def _img_close(got, ref, atol, rtol, what, max_bad_frac=0.0):
 
 
 def test_active_nerfacto_camera_parity(dev):
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import render, synthetic
     t = synthetic.make_scene_tensors(seed=0, kind="active", log2T=15, prop_log2T=13)
     sc = O.scene_from_tensors(t)
@@ -75,9 +147,9 @@ def test_active_nerfacto_camera_parity(dev):
     cam, c2w = _cam(H, W), synthetic.orbit_c2w(0.7)
     out = render.render_camera(sd, c2w, rays_per_launch=2048, keep_density=True, **cam)
     o, d = _oracle_rays(c2w, cam)
-    ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=1024)
+    ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd, diagnostics=diag), o, d, chunk=1024)
     assert set(ref) <= set(out), set(ref) - set(out)
-    _gates("active", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _gates("active", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"], out=out, ref=ref, diag=diag)
     # Image-level tolerances.  The whole chain runs in fp32 on both sides, but the sample positions
     # pass through cumsum -> searchsorted -> the spacing->euclidean map (d euclid / d s = 2 euclid^2),
     # so a 1e-6 difference in a CDF (sequential vs parallel scan order) moves far samples by ~1e-3.
@@ -96,6 +168,7 @@ def test_active_nerfacto_camera_parity(dev):
 @pytest.mark.parametrize("K", [4, 8, 17])
 def test_mcdropout_camera_parity(dev, K):
     """K = 8: the BASELINE config; K = 17: beyond the fused 16-pass composite (composite_var + moments fallback)."""
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import render, synthetic
     seed, p = 1234, 0.2
     t = synthetic.make_scene_tensors(seed=1, kind="mcdropout", log2T=14, prop_log2T=12)
@@ -106,9 +179,9 @@ def test_mcdropout_camera_parity(dev, K):
     cam, c2w = _cam(H, W), synthetic.orbit_c2w(2.1)
     out = render.render_camera(sd, c2w, rays_per_launch=1024, **cam)
     o, d = _oracle_rays(c2w, cam)
-    ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, K, seed, p, ray_offset=off), o, d, chunk=512)
+    ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, K, seed, p, ray_offset=off, diagnostics=diag), o, d, chunk=512)
     assert set(ref) == set(out), set(ref) ^ set(out)
-    _gates(f"mcdropout-K{K}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _gates(f"mcdropout-K{K}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"], out=out, ref=ref, diag=diag)
     _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb (mean over K)")
     _img_close(out["rgb_std"], ref["rgb_std"], 1e-5, 5e-3, "rgb_std")
     _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
@@ -121,6 +194,7 @@ def test_mcdropout_camera_parity(dev, K):
 def test_sample_major_plane_path_meets_the_same_gates(dev, kind):
     """scene.sample_major = True (plane stores + lane-per-ray composite, the measured alternative of DESIGN.md 4.5):
     same parity gates as the default path"""
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import render, synthetic
     t = synthetic.make_scene_tensors(seed=4, kind=kind, log2T=14, prop_log2T=12)
     sc = O.scene_from_tensors(t)
@@ -129,14 +203,14 @@ def test_sample_major_plane_path_meets_the_same_gates(dev, kind):
     o, d = _oracle_rays(c2w, cam)
     if kind == "active":
         sd = synthetic.scene_to_device(t, dev)
-        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=512)
+        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd, diagnostics=diag), o, d, chunk=512)
     else:
         sd = synthetic.scene_to_device(t, dev, K=8, seed=3, p_drop=0.2)
-        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 3, 0.2, ray_offset=off), o, d, chunk=512)
+        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 3, 0.2, ray_offset=off, diagnostics=diag), o, d, chunk=512)
     sd.chunk_rays, sd.sample_major = 512, True
     out = render.render_camera(sd, c2w, rays_per_launch=1024, keep_density=(kind == "active"), **cam)
     assert set(ref) <= set(out)
-    _gates(f"planes-{kind}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _gates(f"planes-{kind}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"], out=out, ref=ref, diag=diag)
     _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb")
     _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
     _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=5e-3)
@@ -150,6 +224,7 @@ def test_sample_major_plane_path_meets_the_same_gates(dev, kind):
 def test_disable_scene_contraction_uses_the_scene_box(dev, kind):
     """disable_scene_contraction (mcdropout_models.py:60-63): spatial_distortion = None, positions normalised with the
     scene box in the main field AND both proposal networks; samples outside the box get selector 0"""
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import ops, render, synthetic
     t = synthetic.make_scene_tensors(seed=8, kind=kind, log2T=14, prop_log2T=12)
     t["aabb"] = torch.tensor([[-1.0, -1.2, -0.8], [1.0, 0.9, 1.1]])
@@ -161,21 +236,21 @@ def test_disable_scene_contraction_uses_the_scene_box(dev, kind):
     o, d = o.reshape(-1, 3), d.reshape(-1, 3)
     if kind == "active":
         sd = synthetic.scene_to_device(t, dev)
-        ref = O.active_outputs(sc, o, d)
+        ref = O.active_outputs(sc, o, d, diagnostics=diag)
         out = render.render_rays(sd, o.to(dev), d.to(dev), keep_density=True)
     elif kind == "mcdropout":
         sd = synthetic.scene_to_device(t, dev, K=8, seed=2, p_drop=0.2)
-        ref = O.mcdropout_outputs(sc, o, d, 8, 2, 0.2)
+        ref = O.mcdropout_outputs(sc, o, d, 8, 2, 0.2, diagnostics=diag)
         out = render.render_rays(sd, o.to(dev), d.to(dev))
     else:
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=5, n_samples=30)
         sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
         noise = torch.randn(20, H * W, 48, generator=torch.Generator().manual_seed(8))
-        ref = O.laplace_outputs(sc, o, d, wsd, wsr, noise)
+        ref = O.laplace_outputs(sc, o, d, wsd, wsr, noise, diagnostics=diag)
         out = render.render_rays(sd, o.to(dev), d.to(dev), depth_noise=noise.to(dev), depth_draws=20)
     assert sd.field.aabb is not None and sd.props[1].aabb is not None
     v = lambda x: x.view(H, W, -1)
-    _gates(f"aabb-{kind}", v(out["rgb"].cpu()), v(out["rgb_std"].cpu()), v(ref["rgb"]), v(ref["rgb_std"]))
+    _gates(f"aabb-{kind}", v(out["rgb"].cpu()), v(out["rgb_std"].cpu()), v(ref["rgb"]), v(ref["rgb_std"]), out=out, ref=ref, diag=diag)
     # the box has a HARD edge: a sample within an ulp of a face can fall on different sides in the two pipelines (their
     # sample positions differ by ~1e-6, see test_active_nerfacto_camera_parity) and take or lose its whole density
     _img_close(v(out["rgb"]), v(ref["rgb"]), 5e-5, 0, "rgb", max_bad_frac=2e-2)
@@ -192,6 +267,7 @@ def test_disable_scene_contraction_uses_the_scene_box(dev, kind):
 
 
 def test_laplace_camera_parity(dev):
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import render, synthetic
     t = synthetic.make_scene_tensors(seed=2, kind="laplace", log2T=14, prop_log2T=12)
     wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
@@ -205,10 +281,10 @@ def test_laplace_camera_parity(dev):
     o, d, _ = ops.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, dev)
     out = render.render_rays(sd, o, d, depth_noise=noise.to(dev))
     oo, dd = _oracle_rays(c2w, cam)
-    ref = O.laplace_outputs(sc, oo.reshape(-1, 3), dd.reshape(-1, 3), wsd, wsr, noise)
+    ref = O.laplace_outputs(sc, oo.reshape(-1, 3), dd.reshape(-1, 3), wsd, wsr, noise, diagnostics=diag)
     assert set(ref) == set(out), set(ref) ^ set(out)
     _gates("laplace", out["rgb"].cpu().view(H, W, 3), out["rgb_std"].cpu().view(H, W, 1), ref["rgb"].view(H, W, 3),
-           ref["rgb_std"].view(H, W, 1))
+           ref["rgb_std"].view(H, W, 1), out=out, ref=ref, diag=diag)
     _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb")
     _img_close(out["rgb_std"], ref["rgb_std"], 2e-5, 5e-3, "rgb_std")
     _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
@@ -217,28 +293,115 @@ def test_laplace_camera_parity(dev):
     _img_close(out["depth_std"], ref["depth_std"], 0, 5e-3, "depth_std", max_bad_frac=2e-2)
 
 
+@pytest.mark.parametrize("kind", ["active", "mcdropout", "laplace"])
+def test_camera_parity_with_lens_distortion(dev, kind):
+    """The three camera-parity tests again with the camera the reference's datasets actually carry: a COLMAP OPENCV
+    camera from `ns-process-data images` (/root/reference/README.md:52-56; k1, k2, p1, p2 handed to `Cameras` at
+    dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:248-274), whose rays Cameras.generate_rays bends.
+    Same gates as the distortion-free renders; the frame must differ from the distortion-free one."""
+    diag = {}   # the oracle's median margins of the render the gates compare with
+    from uncertainty_nerf_gs_amd import ops, render, synthetic
+    t = synthetic.make_scene_tensors(seed=6, kind=kind, log2T=14, prop_log2T=12)
+    sc = O.scene_from_tensors(t)
+    H, W = 36, 64
+    cam = dict(fx=0.58 * W, fy=0.58 * W, cx=W / 2, cy=H / 2, H=H, W=W, distortion=[-0.05, 0.02, 0.0, 0.0, 1e-3, -1e-3])
+    c2w = synthetic.orbit_c2w(2.6)
+    o, d = _oracle_rays(c2w, cam)
+    plain = {k: v for k, v in cam.items() if k != "distortion"}
+    if kind == "active":
+        sd = synthetic.scene_to_device(t, dev)
+        sd.chunk_rays = 512
+        out = render.render_camera(sd, c2w, rays_per_launch=1024, keep_density=True, **cam)
+        flat = render.render_camera(sd, c2w, rays_per_launch=1024, **plain)
+        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd, diagnostics=diag), o, d, chunk=512)
+    elif kind == "mcdropout":
+        sd = synthetic.scene_to_device(t, dev, K=8, seed=77, p_drop=0.2)
+        sd.chunk_rays = 512
+        out = render.render_camera(sd, c2w, rays_per_launch=1024, **cam)
+        flat = render.render_camera(sd, c2w, rays_per_launch=1024, **plain)
+        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 77, 0.2, ray_offset=off, diagnostics=diag), o, d, chunk=512)
+    else:
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
+        sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+        noise = torch.randn(20, H * W, 48, generator=torch.Generator().manual_seed(8))
+        out = render.render_camera(sd, c2w, depth_noise=noise.to(dev), depth_draws=20, **cam)
+        flat = render.render_camera(sd, c2w, depth_noise=noise.to(dev), depth_draws=20, **plain)
+        ref = {k: v.view(H, W, -1) for k, v in O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise, diagnostics=diag).items()}
+    assert set(ref) <= set(out), set(ref) - set(out)
+    assert (out["rgb"] - flat["rgb"]).abs().max().item() > 1e-3, "the lens parameters did not reach the rays"
+    _gates(f"lens-{kind}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"], out=out, ref=ref, diag=diag)
+    _img_close(out["rgb"], ref["rgb"], 1e-4, 0, "rgb")
+    _img_close(out["rgb_std"], ref["rgb_std"], 2e-5, 5e-3, "rgb_std", max_bad_frac=2e-3)
+    _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=5e-3)
+    _img_close(out["depth"], ref["depth"], 0, 1e-3, "depth", max_bad_frac=2e-2)
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "f16"])
+def test_laplace_camera_parity_with_per_chunk_weight_samples(dev, precision):
+    """The reference's frame (get_outputs_for_camera_ray_bundle_unc, laplace_model.py:432-443): every 'eval chunk' of rays
+    is rendered with its OWN draw of the last-layer samples.  5 chunks of 512 rays (the last one ragged), launch groups of
+    two chunks, distinct sets per chunk; the oracle renders chunk by chunk with the same sets."""
+    diag = {}
+    from uncertainty_nerf_gs_amd import render, synthetic
+    t = synthetic.make_scene_tensors(seed=12, kind="laplace", log2T=14, prop_log2T=12)
+    sc = O.scene_from_tensors(t)
+    H, W, chunk, D = 36, 64, 512, 20
+    n_chunks = -(-(H * W) // chunk)
+    ws = [synthetic.laplace_weight_samples(t, seed=40 + i, n_samples=100) for i in range(n_chunks)]
+    wsd, wsr = torch.stack([w[0] for w in ws]), torch.stack([w[1] for w in ws])
+    sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev), lap_chunk_rays=chunk)
+    sd.chunk_rays, sd.field.precision = chunk, precision
+    cam, c2w = _cam(H, W), synthetic.orbit_c2w(3.3)
+    out = render.render_camera(sd, c2w, rays_per_launch=2 * chunk, depth_seed=11, depth_draws=D, **cam)
+    o, d = _oracle_rays(c2w, cam)
+    from oracle import sampled_frame as SF
+
+    def chunk_fn(oo, dd, off):
+        ids = np.arange(off, off + oo.shape[0], dtype=np.int64)
+        return O.laplace_outputs(sc, oo, dd, wsd[off // chunk], wsr[off // chunk], SF.depth_noise_for(ids, 48, 11, D), diagnostics=diag)
+
+    ref = O.render_camera(chunk_fn, o, d, chunk=chunk)
+    assert set(ref) <= set(out)
+    _gates(f"laplace-per-chunk-{precision}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"], out=out, ref=ref,
+           diag=diag, precision=precision)
+    f16 = precision == "f16"
+    _img_close(out["rgb"], ref["rgb"], 1e-4 if f16 else 5e-5, 0, "rgb")
+    _img_close(out["rgb_std"], ref["rgb_std"], 3e-4 if f16 else 2e-5, 5e-3, "rgb_std", max_bad_frac=2e-3)
+    _img_close(out["accumulation"], ref["accumulation"], 6e-4 if f16 else 2e-4, 0, "accumulation")
+    _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=5e-3)
+    # one set for the whole frame is a different picture: the chunks' Monte-Carlo errors are independent in the reference
+    one = synthetic.scene_to_device(t, dev, ws_density=wsd[0].to(dev), ws_rgb=wsr[0].to(dev))
+    one.chunk_rays, one.field.precision = chunk, precision
+    same = render.render_camera(one, c2w, rays_per_launch=2 * chunk, depth_seed=11, depth_draws=D, **cam)
+    first = slice(0, chunk // W)          # whole image rows inside chunk 0
+    assert torch.allclose(same["rgb"][first], out["rgb"][first], atol=1e-6)
+    assert float((same["rgb_std"] - out["rgb_std"]).abs().max()) > 1e-3
+
+
 @pytest.mark.parametrize("kind,num_prop,num_nerf", [("active", (128, 60), 40), ("active", (100, 50), 25),
                                                     ("mcdropout", (200, 72), 50), ("laplace", (256, 96), 21), ("laplace", (128, 64), 37)])
 def test_non_default_sampler_counts(dev, kind, num_prop, num_nerf):
     """num_proposal_samples_per_ray / num_nerf_samples_per_ray other than (256, 96) / 48 -- including counts
     that are not multiples of 16 (ragged composite kernels): same gates as the default-count tests."""
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import render, synthetic
     t = synthetic.make_scene_tensors(seed=11, kind=kind, log2T=14, prop_log2T=12)
     t["num_prop"], t["num_nerf"] = num_prop, num_nerf
     sc = O.scene_from_tensors(t)
-    H, W = 36, 56   # AUSE is a rank statistic: ~2000 pixels keep one near-tie swap below the gate
+    H, W = 48, 72   # AUSE is a rank statistic: ~3500 pixels keep one near-tie swap below the gate (rgb and depth)
     cam, c2w = _cam(H, W), synthetic.orbit_c2w(1.3)
     o, d = _oracle_rays(c2w, cam)
     if kind == "active":
         sd = synthetic.scene_to_device(t, dev)
         sd.chunk_rays = 256
         out = render.render_camera(sd, c2w, rays_per_launch=512, keep_density=True, **cam)
-        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=256)
+        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd, diagnostics=diag), o, d, chunk=256)
     elif kind == "mcdropout":
         sd = synthetic.scene_to_device(t, dev, K=4, seed=9, p_drop=0.2)
         sd.chunk_rays = 256
         out = render.render_camera(sd, c2w, rays_per_launch=512, **cam)
-        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 4, 9, 0.2, ray_offset=off), o, d, chunk=256)
+        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 4, 9, 0.2, ray_offset=off, diagnostics=diag), o, d, chunk=256)
     else:
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=5, n_samples=20)
         sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
@@ -246,10 +409,10 @@ def test_non_default_sampler_counts(dev, kind, num_prop, num_nerf):
         from uncertainty_nerf_gs_amd import ops
         od, dd_, _ = ops.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, dev)
         out = {k: v.view(H, W, -1) for k, v in render.render_rays(sd, od, dd_, depth_noise=noise.to(dev), depth_draws=10).items()}
-        ref = {k: v.view(H, W, -1) for k, v in O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise).items()}
+        ref = {k: v.view(H, W, -1) for k, v in O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise, diagnostics=diag).items()}
     assert sd.num_nerf == num_nerf and sd.num_prop == num_prop
     assert set(ref) <= set(out), set(ref) - set(out)
-    _gates(f"{kind}-{num_prop}-{num_nerf}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _gates(f"{kind}-{num_prop}-{num_nerf}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"], out=out, ref=ref, diag=diag)
     # this scene/camera puts the dropout field's rgb at 4e-5 from the oracle with the DEFAULT counts and the exact
     # fp32 kernels too (sample-position amplification, see test_active_nerfacto_camera_parity): 1e-4 for that method
     # and very coarse proposal counts amplify more (measured: (64, 32)/16, all aligned, 1 % of pixels at 1e-4..3e-4)
@@ -267,6 +430,7 @@ def test_blender_lego_200x200_mcdropout_plumbing_config(dev):
     """BASELINE.json configs[0]: Blender-lego-shaped 200x200 single view, nerfacto-mcdropout with the torch-layout
     field, reference chunking (32768 + 7232 rays).  The oracle needs ~80 s of host time for this frame, so its
     outputs are a stored fixture (tests/golden/lego200_mcdropout.npz, made by tests/golden/make_oracle_fixtures.py)."""
+    diag = {}   # the oracle's median margins of the render the gates compare with
     import importlib.util, os
     from conftest import golden
     from uncertainty_nerf_gs_amd import render, synthetic
@@ -283,8 +447,9 @@ def test_blender_lego_200x200_mcdropout_plumbing_config(dev):
     out = render.render_camera(sd, c2w, **cam)
     g = golden("lego200_mcdropout.npz")
     ref = {k: torch.from_numpy(g[k]) for k in g.files}
+    diag["median_margin"] = ref.pop("median_margin")
     assert set(ref) == set(out) and out["rgb"].shape == (200, 200, 3)
-    _gates("lego200-mcdropout", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _gates("lego200-mcdropout", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"], out=out, ref=ref, diag=diag)
     _img_close(out["rgb"], ref["rgb"], 1e-4, 0, "rgb (mean over K)")
     _img_close(out["rgb_std"], ref["rgb_std"], 2e-5, 5e-3, "rgb_std", max_bad_frac=2e-3)
     _img_close(out["accumulation"], ref["accumulation"], 2e-4, 0, "accumulation")
@@ -491,6 +656,7 @@ def _fewview_tensors(kind, background, seed=21, half=128.0):
 def test_fewview_configuration_uniform_sampler_backgrounds_scene_box(dev, kind, background):
     """uniform initial sampler x every background x near 1 / far 100 x max_res 4096 x scene box, all three methods,
     full camera path: same north-star gates as the default configuration"""
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import lib as L, ops, render, synthetic
     t = _fewview_tensors(kind, background)
     sc = O.scene_from_tensors(t)
@@ -503,22 +669,22 @@ def test_fewview_configuration_uniform_sampler_backgrounds_scene_box(dev, kind, 
         sd = synthetic.scene_to_device(t, dev)
         sd.chunk_rays = 512
         out = render.render_camera(sd, c2w, rays_per_launch=1024, keep_density=True, **cam)
-        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=512)
+        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd, diagnostics=diag), o, d, chunk=512)
     elif kind == "mcdropout":
         sd = synthetic.scene_to_device(t, dev, K=8, seed=5, p_drop=0.2)
         sd.chunk_rays = 512
         out = render.render_camera(sd, c2w, rays_per_launch=1024, **cam)
-        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 5, 0.2, ray_offset=off), o, d, chunk=512)
+        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 5, 0.2, ray_offset=off, diagnostics=diag), o, d, chunk=512)
     else:
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=5, n_samples=30)
         sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
         noise = torch.randn(20, H * W, 48, generator=torch.Generator().manual_seed(8))
         od, dd_, _ = ops.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, dev)
         out = {k: v.view(H, W, -1) for k, v in render.render_rays(sd, od, dd_, depth_noise=noise.to(dev), depth_draws=20).items()}
-        ref = {k: v.view(H, W, -1) for k, v in O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise).items()}
+        ref = {k: v.view(H, W, -1) for k, v in O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise, diagnostics=diag).items()}
     assert sd.spacing == L.SPACING_UNIFORM and sd.field.aabb is not None
     assert set(ref) <= set(out), set(ref) - set(out)
-    _gates(f"fewview-{kind}-{background}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _gates(f"fewview-{kind}-{background}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"], out=out, ref=ref, diag=diag)
     _img_close(out["rgb"], ref["rgb"], 1e-4, 0, "rgb")
     _img_close(out["accumulation"], ref["accumulation"], 3e-4, 0, "accumulation")
     _img_close(out["expected_depth"], ref["expected_depth"], 0, 1e-3, "expected_depth", max_bad_frac=1e-2)
@@ -603,6 +769,7 @@ def test_reference_precision_f16_mode_meets_the_gates(dev, kind):
     Gates: (1) the north-star tolerances against the FP32 oracle -- |dPSNR| <= 1e-4 dB, |dAUSE| <= 1e-3; (2) a tight
     image tolerance against the oracle's autocast(float16)-emulating mode; (3) no further from that mode than the fp32
     oracle itself is (measured on MI355X, profiles/r3_exp_f16_single.json: max |d rgb| 1.4e-5 .. 3e-5)."""
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import render, synthetic
     t = synthetic.make_scene_tensors(seed=1, kind=kind, log2T=14, prop_log2T=12)
     sc = O.scene_from_tensors(t)
@@ -613,20 +780,21 @@ def test_reference_precision_f16_mode_meets_the_gates(dev, kind):
     kw, shade = {}, {}
     if kind == "mcdropout":
         kw = dict(K=8, seed=1234, p_drop=0.2)
-        ref = {ac: O.mcdropout_outputs(sc, o, d, 8, 1234, 0.2, autocast=ac) for ac in (None, torch.float16)}
+        ref = {ac: O.mcdropout_outputs(sc, o, d, 8, 1234, 0.2, autocast=ac, diagnostics=None if ac else diag) for ac in (None, torch.float16)}
     elif kind == "active":
-        ref = {ac: O.active_outputs(sc, o, d, autocast=ac) for ac in (None, torch.float16)}
+        ref = {ac: O.active_outputs(sc, o, d, autocast=ac, diagnostics=None if ac else diag) for ac in (None, torch.float16)}
     else:
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
         kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
         noise = torch.randn(100, H * W, 48, generator=torch.Generator().manual_seed(8))
         shade = dict(depth_noise=noise.to(dev))
-        ref = {ac: O.laplace_outputs(sc, o, d, wsd, wsr, noise, autocast=ac) for ac in (None, torch.float16)}
+        ref = {ac: O.laplace_outputs(sc, o, d, wsd, wsr, noise, autocast=ac, diagnostics=None if ac else diag) for ac in (None, torch.float16)}
     sd = synthetic.scene_to_device(t, dev, **kw)
     sd.field.precision = "f16"
     out = render.render_rays(sd, o.to(dev), d.to(dev), **shade)
     v = lambda x: x.cpu().view(H, W, -1)
-    _gates(f"f16-{kind}", v(out["rgb"]), v(out["rgb_std"]), v(ref[None]["rgb"]), v(ref[None]["rgb_std"]))
+    _gates(f"f16-{kind}", v(out["rgb"]), v(out["rgb_std"]), v(ref[None]["rgb"]), v(ref[None]["rgb_std"]), out=out, ref=ref[None],
+           diag=diag, precision="f16")
     _img_close(out["rgb"], ref[torch.float16]["rgb"], 1e-4, 0, "rgb vs the autocast(fp16) oracle")
     _img_close(out["rgb"], ref[None]["rgb"], 1e-4, 0, "rgb vs the fp32 oracle")
     _img_close(out["accumulation"], ref[None]["accumulation"], 6e-4, 0, "accumulation")

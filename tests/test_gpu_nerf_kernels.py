@@ -48,6 +48,35 @@ def test_generate_rays_matches_oracle_and_row_major_indexing(dev):
     assert torch.equal(d2, d[a:b]) and torch.equal(o2, o[a:b])
 
 
+# (k1, k2, k3, k4, p1, p2): COLMAP-typical OPENCV (an `ns-process-data images` scene), radial only, all six terms
+LENSES = [(-0.05, 0.02, 0.0, 0.0, 1e-3, -1e-3), (0.12, -0.03, 0.0, 0.0, 0.0, 0.0), (-0.2, 0.06, -0.01, 0.002, 4e-3, 2e-3),
+          (0.0, 0.0, 0.0, 0.0, 2e-3, 0.0)]
+
+
+@pytest.mark.parametrize("lens", LENSES)
+def test_generate_rays_with_lens_distortion_matches_oracle(dev, lens):
+    """Cameras.generate_rays with non-zero distortion_params (the reference's ns-process-data / OPENCV cameras,
+    dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:248-274): origins exact, directions to 3e-7 as for
+    the distortion-free camera, pixel_area (two more undistorted coordinates per pixel) to 1e-3 relative; slices of the
+    bundle are bit-identical to the full bundle; six zeros are the distortion-free camera bit for bit."""
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    c2w = synthetic.orbit_c2w(1.1)
+    H, W = 54, 96                      # 16:9 at fx = 0.58 W: the field of view of the 1080p bench camera (fx 1111)
+    fx, fy, cx, cy = 0.58 * W, 0.57 * W, W / 2 - 0.7, H / 2 + 0.4
+    o_ref, d_ref, pa_ref = O.generate_rays(c2w, fx, fy, cx, cy, H, W, distortion=lens)
+    o, d, pa = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, pixel_area=True, distortion=lens)
+    _close(o, o_ref.reshape(-1, 3), 0, 0, "origins")
+    _close(d, d_ref.reshape(-1, 3), 0, 3e-7, "directions")
+    _close(pa, pa_ref.reshape(-1, 1), 1e-3, 1e-9, "pixel_area")
+    plain = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, pixel_area=True)
+    assert (plain[1] - d).abs().max().item() > 1e-4, "the lens parameters did not move the rays"
+    a, b = 1234, 1234 + 2000
+    o2, d2, pa2 = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, ray_start=a, count=b - a, pixel_area=True, distortion=lens)
+    assert torch.equal(d2, d[a:b]) and torch.equal(o2, o[a:b]) and torch.equal(pa2, pa[a:b])
+    zero = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, pixel_area=True, distortion=[0.0] * 6)
+    assert all(torch.equal(x, y) for x, y in zip(zero, plain))
+
+
 @pytest.mark.parametrize("L,min_res,max_res,log2T", [(16, 16, 2048, 14), (5, 16, 128, 12), (5, 16, 256, 17), (16, 16, 2048, 19)])
 def test_hashgrid_indices_and_features_bit_exact(dev, L, min_res, max_res, log2T):
     from uncertainty_nerf_gs_amd import ops, synthetic
@@ -326,6 +355,45 @@ def test_field_laplace_matches_oracle(dev, use_mfma, precision, n_samples):
     # variances are E[x^2]-E[x]^2 in fp32: compare against the scale of E[x^2]
     _close(dvar, var_d, 0, 2e-5 * float((mu_d ** 2).max()), "var_d")
     _close(rvar, var_rgb, 0, 2e-6, "var_rgb")
+
+
+@pytest.mark.parametrize("use_mfma,precision", [(True, "f16x2"), (True, "f16"), (True, "fp32"), (False, "fp32")],
+                         ids=["mfma16", "mfma16-f16", "mfma32", "valu"])
+def test_field_laplace_per_chunk_sample_sets(dev, use_mfma, precision):
+    """unerf_field_params.lap_chunk_rays: the reference draws a fresh set of last-layer samples in every eval chunk
+    (laplace_model.py:432-443 -> laplace_field.py:331-339, 468-476, 545).  A stack of sets [sets, n, P]; ray g is
+    evaluated with set g // lap_chunk_rays -- checked per chunk against the oracle with that chunk's set, with a ray
+    offset (a later launch group of a frame) and a ragged last chunk; rays beyond the stack are refused."""
+    from uncertainty_nerf_gs_amd import lib as L, ops, synthetic
+    t, sc, _ = _scene("laplace", dev)
+    chunk, n = 64, 40
+    H, W = 10, 23                               # 230 rays = 3 chunks of 64 + 38
+    o, d = _rays(H, W)
+    R = o.shape[0]
+    off = 3 * chunk                             # this launch starts at chunk 3 of its frame
+    sets = off // chunk + -(-R // chunk)
+    ws = [synthetic.laplace_weight_samples(t, seed=100 + i, n_samples=n) for i in range(sets)]
+    wsd, wsr = torch.stack([w[0] for w in ws]), torch.stack([w[1] for w in ws])
+    sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev), lap_chunk_rays=chunk)
+    sd.field.use_mfma, sd.field.precision = use_mfma, precision
+    assert sd.field.lap_blob.shape == sd.field.lap16_blob.shape == (sets, ops.LAP_BLOB_FLOATS)
+    sb = _final_bins(sc, o, d)
+    eb = O.spacing_to_euclidean(sb, NEAR, FAR)
+    dens, rgb, dvar, rvar = ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR, ray_offset=off, image_width=W)
+    f16 = precision == "f16"
+    for c in range(-(-R // chunk)):
+        sl = slice(c * chunk, min(R, (c + 1) * chunk))
+        mu_d, var_d, mu_rgb, var_rgb = O.laplace_field(o[sl], d[sl], eb[sl], sc.field, wsd[off // chunk + c], wsr[off // chunk + c])
+        _close(dens[0][sl], mu_d, 2e-3 if f16 else 2e-4, 1e-7, f"mu_d chunk {c}")
+        _close(rgb[0][sl], mu_rgb, 0, 2e-4 if f16 else 2e-5, f"mu_rgb chunk {c}")
+        _close(rvar[sl], var_rgb, 0, 2e-5 if f16 else 2e-6, f"var_rgb chunk {c}")
+        if c > 0:    # the sets differ: chunk c evaluated with chunk 0's set is somewhere else
+            other = O.laplace_field(o[sl], d[sl], eb[sl], sc.field, wsd[off // chunk], wsr[off // chunk])[2]
+            assert float((other - mu_rgb).abs().max()) > 1e-3
+    with pytest.raises(L.UnerfError, match="reach past"):
+        ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR, ray_offset=off + chunk)
+    with pytest.raises(L.UnerfError, match="multiples of 32"):
+        ops.field_fwd(o.to(dev), d.to(dev), sb.to(dev), sd.field, NEAR, FAR, ray_offset=8)
 
 
 @pytest.mark.parametrize("use_mfma,precision", _KERNELS, ids=_KERNEL_IDS)

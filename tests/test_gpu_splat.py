@@ -279,6 +279,35 @@ def test_full_size_splat_frame_properties(dev):
     assert bool((tight[5] <= tiles).all()) and 0.4 * I < int(tight[5].sum()) < 0.7 * I
 
 
+@pytest.mark.parametrize("N,H,W,tight", [(6000, 48, 64, False), (6000, 48, 64, True), (300000, 600, 800, True),
+                                         (1_000_000, 1080, 1920, True), (1_000_000, 1080, 1920, False), (50, 1080, 1920, True)])
+def test_one_pass_tile_sort_gives_the_radix_sorts_lists(dev, N, H, W, tight, monkeypatch):
+    """unerf_splat_bin_sort's own tile sort (one LDS-digit scatter pass: 8,160 tile counters fit a wave's LDS) against
+    rocprim's two-pass radix sort of the same (tile, splat) pairs (UNERF_SPLAT_TILE_SORT=radix keeps that path for A/B
+    runs): gaussian_ids_sorted, tile_bins and the 64-bit isect ids are bit-identical -- at toy sizes, with box and tight
+    lists, at the BASELINE size (37 M / 20 M pairs, every one of the 1024 chunks busy) and with a handful of pairs."""
+    from uncertainty_nerf_gs_amd import ops, splat, synthetic
+    gp = {k: v.to(dev) for k, v in synthetic.make_splat_tensors(seed=11, N=N).items()}
+    if N <= 6000:
+        gp["scales"] = gp["scales"] + 1.5
+    c2w = synthetic.orbit_c2w(0.7, radius=2.5, height=0.5)
+    V = splat.viewmat_from_c2w(c2w)
+    f = 1111.0 * W / 1920
+    logits = gp["opacities"].reshape(-1).contiguous()
+    pr = ops.splat_project(gp["means"], gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], f, f, W / 2, H / 2, H, W,
+                           raw=True, opacity_logits=logits if tight else None)
+    xys, depths, radii, conics, comp, tiles = pr[:6]
+    tl = (conics, pr[7]) if tight else None
+    monkeypatch.delenv("UNERF_SPLAT_TILE_SORT", raising=False)
+    I, _, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, tight=tl)
+    monkeypatch.setenv("UNERF_SPLAT_TILE_SORT", "radix")
+    I2, _, keys2, gids2, bins2 = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, tight=tl)
+    assert I == I2 and I > 0
+    assert torch.equal(bins, bins2), "tile ranges"
+    assert torch.equal(gids, gids2), "depth-ordered splat ids of every tile"
+    assert torch.equal(keys, keys2), "(tile << 32 | depth bits) ids"
+
+
 @pytest.mark.parametrize("C", [1, 5])
 def test_wave_level_culling_and_bounded_pass_change_no_bit(dev, C):
     """the default schedule (a wave walks only the splats whose alpha >= 1/255 ellipse reaches its 4 x 16 strip) against

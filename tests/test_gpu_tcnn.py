@@ -34,6 +34,7 @@ def test_tcnn_hashgrid_rows_bit_exact_and_features(dev, L, base, max_res, log2T)
 
 @pytest.mark.parametrize("kind", ["active", "mcdropout", "laplace"])
 def test_tcnn_layout_camera_parity(dev, kind):
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import ops, render, synthetic
     t = synthetic.make_scene_tensors(seed=5, kind=kind, log2T=14, prop_log2T=12, grid="tcnn")
     sc = O.scene_from_tensors(t)
@@ -45,12 +46,12 @@ def test_tcnn_layout_camera_parity(dev, kind):
         sd = synthetic.scene_to_device(t, dev)
         sd.chunk_rays = 512
         out = render.render_camera(sd, c2w, rays_per_launch=1024, keep_density=True, **cam)
-        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd), o, d, chunk=512)
+        ref = O.render_camera(lambda oo, dd, off: O.active_outputs(sc, oo, dd, diagnostics=diag), o, d, chunk=512)
     elif kind == "mcdropout":
         sd = synthetic.scene_to_device(t, dev, K=8, seed=9, p_drop=0.2)   # K = 8: the BASELINE config
         sd.chunk_rays = 512
         out = render.render_camera(sd, c2w, rays_per_launch=1024, **cam)
-        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 9, 0.2, ray_offset=off), o, d, chunk=512)
+        ref = O.render_camera(lambda oo, dd, off: O.mcdropout_outputs(sc, oo, dd, 8, 9, 0.2, ray_offset=off, diagnostics=diag), o, d, chunk=512)
     else:
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
         sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
@@ -58,9 +59,9 @@ def test_tcnn_layout_camera_parity(dev, kind):
         od, dd_, _ = ops.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, dev)
         out = {k: v.view(H, W, -1) for k, v in render.render_rays(sd, od, dd_, depth_noise=noise.to(dev)).items()}
         ref = {k: v.view(H, W, -1) for k, v in
-               O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise).items()}
+               O.laplace_outputs(sc, o.reshape(-1, 3), d.reshape(-1, 3), wsd, wsr, noise, diagnostics=diag).items()}
     assert sd.field.tcnn_levels is not None and sd.props[0].tcnn_levels is not None and sd.field.sh_remap == 1
-    _gates(f"tcnn_{kind}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"])
+    _gates(f"tcnn_{kind}", out["rgb"].cpu(), out["rgb_std"].cpu(), ref["rgb"], ref["rgb_std"], out=out, ref=ref, diag=diag)
     _img_close(out["rgb"], ref["rgb"], 5e-5, 0, "rgb")
     _img_close(out["rgb_std"], ref["rgb_std"], 2e-5, 5e-3, "rgb_std", max_bad_frac=2e-3)
     _img_close(out["accumulation"], ref["accumulation"], 3e-4, 0, "accumulation")
@@ -118,7 +119,11 @@ def test_model_from_tcnn_layout_checkpoint(dev):
                         fy=torch.tensor([0.9 * W]), cx=W / 2, cy=H / 2, height=H, width=W)
     with torch.cuda.device(dev):
         out = model.get_outputs_for_camera(cam)
-    direct = render.render_camera(synthetic.scene_to_device(t, dev), cam.camera_to_worlds[0], fx=0.9 * W, fy=0.9 * W,
+    # implementation="tcnn": the reference's MLPs are fp16 FullyFusedMLPs, so the model renders with precision "f16"
+    assert model.device_scene().field.precision == "f16"
+    sd = synthetic.scene_to_device(t, dev)
+    sd.field.precision = "f16"
+    direct = render.render_camera(sd, cam.camera_to_worlds[0], fx=0.9 * W, fy=0.9 * W,
                                   cx=W / 2, cy=H / 2, H=H, W=W, keep_density=True)
     for k in direct:
         assert torch.equal(out[k], direct[k]), k

@@ -84,6 +84,7 @@ def test_field_kernels_on_trained_like_magnitudes(dev, use_mfma, precision):
 
 @pytest.mark.parametrize("kind", ["active", "mcdropout", "laplace"])
 def test_trained_like_scene_end_to_end(dev, kind):
+    diag = {}   # the oracle's median margins of the render the gates compare with
     from uncertainty_nerf_gs_amd import metrics, render, synthetic
     t, sc, _ = _scene(kind, dev)
     H, W = 32, 40
@@ -93,22 +94,23 @@ def test_trained_like_scene_end_to_end(dev, kind):
     o, d = o.reshape(-1, 3), d.reshape(-1, 3)
     if kind == "active":
         sd = synthetic.scene_to_device(t, dev)
-        ref = O.active_outputs(sc, o, d)
+        ref = O.active_outputs(sc, o, d, diagnostics=diag)
         out = render.render_rays(sd, o.to(dev), d.to(dev))
     elif kind == "mcdropout":
         sd = synthetic.scene_to_device(t, dev, K=8, seed=2, p_drop=0.2)
-        ref = O.mcdropout_outputs(sc, o, d, 8, 2, 0.2)
+        ref = O.mcdropout_outputs(sc, o, d, 8, 2, 0.2, diagnostics=diag)
         out = render.render_rays(sd, o.to(dev), d.to(dev))
     else:
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=5, n_samples=30)
         sd = synthetic.scene_to_device(t, dev, ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
         noise = torch.randn(20, H * W, 48, generator=torch.Generator().manual_seed(8))
-        ref = O.laplace_outputs(sc, o, d, wsd, wsr, noise)
+        ref = O.laplace_outputs(sc, o, d, wsd, wsr, noise, diagnostics=diag)
         out = render.render_rays(sd, o.to(dev), d.to(dev), depth_noise=noise.to(dev), depth_draws=20)
     assert all(torch.isfinite(v).all() for v in out.values())
     from test_gpu_nerf_e2e import _gates
     v = lambda x: x.view(H, W, -1)
-    _gates(f"trained-like-{kind}", v(out["rgb"].cpu()), v(out["rgb_std"].cpu()), v(ref["rgb"]), v(ref["rgb_std"]))
+    _gates(f"trained-like-{kind}", v(out["rgb"].cpu()), v(out["rgb_std"].cpu()), v(ref["rgb"]), v(ref["rgb_std"]), out=out, ref=ref, diag=diag,
+           tie_margin=1e-2)     # densities up to e^12: see test_gpu_nerf_e2e.TIE_MARGIN
     _close(out["rgb"], ref["rgb"], 0, 2e-4, "rgb", max_bad_frac=5e-3)
     _close(out["accumulation"], ref["accumulation"], 0, 5e-4, "accumulation", max_bad_frac=5e-3)
 
@@ -162,6 +164,46 @@ def test_f16_operand_overflow_is_flagged_and_rerendered_in_fp32(dev, kind, preci
     sd2.field.precision = precision
     render.render_camera(sd2, c2w, rays_per_launch=512, **cam, **shade)
     assert sd2.overflow_rerenders == 0
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "f16"])
+@pytest.mark.parametrize("kind", ["active", "mcdropout", "laplace"])
+def test_colour_head_overflow_is_flagged_too(dev, kind, precision):
+    """An f16 operand overflow in the colour head's FIRST hidden layer: the ReLUs between the layers are
+    integer maxima on the bit pattern and map a NaN or -inf whose sign bit is set to 0, so such an overflow could in
+    principle be zeroed two layers before any output and leave a plausible finite colour behind.  It is not: the
+    unit's f16 operand is +inf (it sits behind a ReLU), every unit of the next layer receives inf * w, the positive ones
+    stay +inf through the ReLU and reach the 64 -> 3 layer, whose pre-activation is then inf or NaN -> flagged, and the
+    launch group is rendered again on the exact-fp32 kernels."""
+    from uncertainty_nerf_gs_amd import ops, render, synthetic
+    t = synthetic.make_scene_tensors(seed=31, kind=kind, log2T=14, prop_log2T=12, sharp=True, head_overflow_units=(7, 50))
+    kw = {}
+    if kind == "mcdropout":
+        kw = dict(K=4, seed=2, p_drop=0.2)
+    if kind == "laplace":
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=5, n_samples=30)
+        kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+    sd = synthetic.scene_to_device(t, dev, **kw)
+    assert sd.field.mfma16_blob is not None
+    sd.chunk_rays = 256
+    H, W = 32, 48
+    cam = dict(fx=0.9 * W, fy=0.9 * W, cx=W / 2, cy=H / 2, H=H, W=W)
+    c2w = synthetic.orbit_c2w(0.8)
+    shade = dict(depth_seed=3) if kind == "laplace" else {}
+    # the overflow is real: the oracle's first colour layer goes past 65504 on some samples
+    sc = O.scene_from_tensors(t)
+    o, d = _rays(H, W)
+    x = O._color_inputs(d, 1, torch.zeros(d.shape[0], 1, 15), sc.field.appearance)
+    over = torch.relu(torch.nn.functional.linear(x, sc.field.head_w[0], sc.field.head_b[0]))[:, [7, 50]] > 65504
+    assert 0.0 < over.float().mean() < 0.98, "some samples overflow the f16 operand range in these units, not all"
+    sd.field.precision = "fp32"
+    want = render.render_camera(sd, c2w, rays_per_launch=512, **cam, **shade)
+    assert all(torch.isfinite(v).all() for v in want.values())
+    sd.field.precision = precision
+    got = render.render_camera(sd, c2w, rays_per_launch=512, **cam, **shade)
+    assert sd.overflow_rerenders >= 1
+    for k in want:     # every launch group with an overflowing sample was caught: the frame IS the fp32-kernel frame
+        assert torch.equal(got[k], want[k]), k
 
 
 def test_composite_nan_flag(dev):

@@ -225,15 +225,20 @@ def test_mcdropout_model_draws_fresh_masks_for_every_render():
 
 
 def test_cameras_the_ray_kernel_does_not_model_are_refused():
-    """unerf_generate_rays restates Cameras.generate_rays for one distortion-free perspective camera; a fisheye camera,
-    lens distortion or a camera batch must not render silently wrong rays"""
+    """unerf_generate_rays restates Cameras.generate_rays for one perspective camera (with its OPENCV lens parameters); a
+    fisheye camera or a camera batch must not render silently wrong rays"""
     from types import SimpleNamespace
     base = dict(camera_to_worlds=torch.eye(4)[None, :3], fx=torch.tensor([[50.0]]), fy=torch.tensor([[50.0]]),
                 cx=torch.tensor([[8.0]]), cy=torch.tensor([[6.0]]), height=torch.tensor([[12]]), width=torch.tensor([[16]]))
     c2w, cam = M._camera_args(SimpleNamespace(**base, distortion_params=torch.zeros(1, 6), camera_type=torch.tensor([[1]])))
     assert c2w.shape == (3, 4) and cam == dict(fx=50.0, fy=50.0, cx=8.0, cy=6.0, H=12, W=16)
-    with pytest.raises(NotImplementedError, match="distortion"):
-        M._camera_args(SimpleNamespace(**base, distortion_params=torch.tensor([[0.1, 0, 0, 0, 0, 0]])))
+    # lens parameters travel to the ray kernel (k1, k2, k3, k4, p1, p2); the splat models never read them
+    _, cam = M._camera_args(SimpleNamespace(**base, distortion_params=torch.tensor([[-0.05, 0.02, 0, 0, 1e-3, -1e-3]])))
+    assert cam["distortion"] == pytest.approx([-0.05, 0.02, 0.0, 0.0, 1e-3, -1e-3])
+    _, cam = M._camera_args(SimpleNamespace(**base, distortion_params=torch.tensor([[-0.05, 0.02, 0, 0, 1e-3, -1e-3]])), lens=False)
+    assert "distortion" not in cam
+    with pytest.raises(ValueError, match="expected 6 values"):
+        M._camera_args(SimpleNamespace(**base, distortion_params=torch.tensor([[0.1, 0, 0, 0]])))
     with pytest.raises(NotImplementedError, match="camera_type 2"):
         M._camera_args(SimpleNamespace(**base, camera_type=torch.tensor([[2]])))
     with pytest.raises(ValueError, match="one camera"):

@@ -370,3 +370,20 @@ def test_split_f16_laplace_heads_layout():
             Wp = np.zeros((128, 64))
             Wp[:n] = W.double().numpy()
             np.testing.assert_allclose(rows, x @ Wp[32 * blk:32 * blk + 32].T, rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize("n,exp2_rows,softplus", [(100, True, False), (100, False, False), (37, True, True), (128, True, False)])
+def test_batched_laplace_packer_equals_the_per_set_packers(n, exp2_rows, softplus):
+    """ops.pack_laplace_sets (one gather per blob, on the device; the per-chunk draws make 64 sets per 1080p frame) is the
+    loops of pack_laplace_heads / pack_laplace_heads16 as index maps: every set bit for bit"""
+    g = torch.Generator().manual_seed(9)
+    T = 3
+    ws_d, ws_r = torch.randn(T, n, 65, generator=g) * 0.3, torch.randn(T, n, 195, generator=g) * 0.3
+    blob, blob16 = ops.pack_laplace_sets(ws_d, ws_r, "cpu", exp2_rows=exp2_rows, softplus=softplus)
+    assert blob.shape == blob16.shape == (T, ops.LAP_BLOB_FLOATS) and blob16.is_contiguous()
+    for t in range(T):
+        assert torch.equal(blob[t], ops.pack_laplace_heads(ws_d[t], ws_r[t]))
+        want = ops.pack_laplace_heads16(ws_d[t], ws_r[t], exp2_rows=exp2_rows, softplus=softplus)
+        assert torch.equal(blob16[t].view(torch.int32), want.view(torch.int32))      # bit patterns (f16 pairs read as fp32)
+    ws_r[1, 5, 7] = 7.0e4                                                            # beyond the f16 range: no f16 blob
+    assert ops.pack_laplace_sets(ws_d, ws_r, "cpu")[1] is None

@@ -198,6 +198,8 @@ struct RayGenArgs {
     float R[9];
     float T[3];
     float fx, fy, cx, cy;
+    float k1, k2, k3, k4, p1, p2;   // OPENCV lens parameters, nerfstudio's order
+    int distorted;                  // any of the six != 0
     int H, W;
     int64_t start, count;
     float* o;
@@ -205,7 +207,39 @@ struct RayGenArgs {
     float* pa;
 };
 
+// camera_utils.radial_and_tangential_undistort [UPSTREAM nerfstudio 1.1.0, after MultiNeRF]: Newton iterations from the
+// distorted point on  f(x, y) = (x d + 2 p1 x y + p2 (r + 2 x^2) - xd,  y d + 2 p2 x y + p1 (r + 2 y^2) - yd),
+// r = x^2 + y^2, d = 1 + r (k1 + r (k2 + r (k3 + r k4))); every product and sum in the order the torch expression
+// evaluates it (fp32, nothing contracted), a step only where |det J| > eps.
+__device__ __forceinline__ void raygen_undistort(const RayGenArgs& a, float& u, float& v) {
+    const float xd = u, yd = v;
+    float x = xd, y = yd;
+#pragma unroll 1
+    for (int it = 0; it < UNERF_UNDISTORT_ITERATIONS; ++it) {
+        const float r = x * x + y * y;
+        const float d = 1.0f + r * (a.k1 + r * (a.k2 + r * (a.k3 + r * a.k4)));
+        const float fx = ((d * x + ((2.f * a.p1) * x) * y) + a.p2 * (r + (2.f * x) * x)) - xd;
+        const float fy = ((d * y + ((2.f * a.p2) * x) * y) + a.p1 * (r + (2.f * y) * y)) - yd;
+        const float d_r = a.k1 + r * (2.0f * a.k2 + r * (3.0f * a.k3 + (r * 4.0f) * a.k4));
+        const float d_x = (2.0f * x) * d_r;
+        const float d_y = (2.0f * y) * d_r;
+        const float fx_x = ((d + d_x * x) + (2.0f * a.p1) * y) + (6.0f * a.p2) * x;
+        const float fx_y = (d_y * x + (2.0f * a.p1) * x) + (2.0f * a.p2) * y;
+        const float fy_x = (d_x * y + (2.0f * a.p2) * y) + (2.0f * a.p1) * x;
+        const float fy_y = ((d + d_y * y) + (2.0f * a.p2) * x) + (6.0f * a.p1) * y;
+        const float den = fy_x * fx_y - fx_x * fy_y;
+        const float xn = fx * fy_y - fy * fx_y;
+        const float yn = fy * fx_x - fx * fy_x;
+        const bool ok = fabsf(den) > UNERF_UNDISTORT_EPS;
+        x = x + (ok ? xn / den : 0.f);
+        y = y + (ok ? yn / den : 0.f);
+    }
+    u = x;
+    v = y;
+}
+
 __device__ __forceinline__ void raygen_dir(const RayGenArgs& a, float u, float v, float& dx, float& dy, float& dz) {
+    if (a.distorted) raygen_undistort(a, u, v);
     // sum_c dir[c] * R[r][c], dir = (u, v, -1); torch.sum over 3 elements left to right
     float x = (u * a.R[0] + v * a.R[1]) + (-1.f) * a.R[2];
     float y = (u * a.R[3] + v * a.R[4]) + (-1.f) * a.R[5];
@@ -244,8 +278,8 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a) {
     }
 }
 
-extern "C" int unerf_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, int H, int W,
-                                   int64_t ray_start, int64_t count, float* origins, float* directions,
+extern "C" int unerf_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, const float* distortion,
+                                   int H, int W, int64_t ray_start, int64_t count, float* origins, float* directions,
                                    float* pixel_area, void* stream) {
     UNERF_REQUIRE(c2w && (count == 0 || (origins && directions)), "generate_rays: null pointer");
     UNERF_REQUIRE(H > 0 && W > 0 && ray_start >= 0 && count >= 0 && ray_start + count <= (int64_t)H * W,
@@ -257,6 +291,16 @@ extern "C" int unerf_generate_rays(const float* c2w, float fx, float fy, float c
         a.T[r] = c2w[r * 4 + 3];
     }
     a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.H = H; a.W = W;
+    a.k1 = a.k2 = a.k3 = a.k4 = a.p1 = a.p2 = 0.f;
+    a.distorted = 0;
+    if (distortion) {
+        for (int i = 0; i < 6; ++i) {
+            UNERF_REQUIRE(std::isfinite(distortion[i]), "generate_rays: distortion[%d] is not finite", i);
+            a.distorted |= distortion[i] != 0.f;
+        }
+        a.k1 = distortion[0]; a.k2 = distortion[1]; a.k3 = distortion[2]; a.k4 = distortion[3];
+        a.p1 = distortion[4]; a.p2 = distortion[5];
+    }
     a.start = ray_start; a.count = count; a.o = origins; a.d = directions; a.pa = pixel_area;
     hipLaunchKernelGGL(raygen_kernel, dim3(blocks_for(count, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return unerf_check_launch("generate_rays");
@@ -955,6 +999,8 @@ struct FieldArgs {
     const float* features;  // optional [16][N][2] level-major planes from unerf_field_gather (MFMA kernel)
     TileMap tm;
     unerf_norm_box box;
+    FastDiv div_chunk;      // LAPLACE per-chunk sample sets: division by p.lap_chunk_rays
+    uint32_t chunk0;        // ... and ray_offset as a 32-bit ray index (the sample counter bound keeps it below 2^31)
 };
 
 // Bin edge -> Euclidean distance.  unerf_field_fwd(near_plane < 0) sets s_near = -1: sbins then already holds
@@ -1033,6 +1079,15 @@ __device__ __forceinline__ OutIndex out_index(const FieldArgs& a, int k, const T
         o.aux = ts.n;
     }
     return o;
+}
+
+// LAPLACE with per-chunk sample sets (unerf_field_params.lap_chunk_rays): the blob of the set a tile's rays belong to.
+// Tiles are 1-D there (32 consecutive rays, host: make_tiles without an image width) and chunk / launch boundaries are
+// multiples of 32, so the set is uniform over the tile; `tile` is wave-uniform, so this is scalar arithmetic.
+__device__ __forceinline__ const float* lap_set_blob(const FieldArgs& a, const float* blob, uint32_t tile, const FastDiv& div_s) {
+    if (a.p.lap_chunk_rays == 0) return blob;
+    const uint32_t set = fastdiv(a.chunk0 + fastdiv(tile, div_s) * 32u, a.div_chunk);
+    return blob + (size_t)set * UNERF_LAP_BLOB_FLOATS;
 }
 
 // host side: fills a.tm and returns the number of tiles
@@ -1212,10 +1267,12 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
         store_act<64>(A, lane, acc, 0, false);
         float geo[15];
         dense_lds<64, 15>(a.p.w1t, a.p.b1, A, lane, geo);
-        const int nl = a.p.n_lap;
+        const int nl = a.p.n_lap, nr = a.p.n_lap_rgb;
+        // per-chunk sample sets (unerf_field_params.lap_chunk_rays): a wave of 64 consecutive samples may straddle two
+        const size_t set = a.p.lap_chunk_rays ? (size_t)fastdiv(a.chunk0 + (uint32_t)r, a.div_chunk) : 0;
         float mu = 0.f, mu2 = 0.f;
         for (int q = 0; q < nl; ++q) {
-            const float* __restrict__ w = a.p.ws_density + (size_t)q * 65;
+            const float* __restrict__ w = a.p.ws_density + (set * nl + (size_t)q) * 65;
             float pre = 0.f;
 #pragma unroll
             for (int i = 0; i < 64; ++i) pre = fmaf(acc[i], w[i], pre);
@@ -1235,8 +1292,8 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
 #pragma unroll
         for (int i = 0; i < 64; ++i) acc[i] = fmaxf(acc[i], 0.f);
         float m1[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
-        for (int q = 0; q < nl; ++q) {
-            const float* __restrict__ w = a.p.ws_rgb + (size_t)q * 195;
+        for (int q = 0; q < nr; ++q) {
+            const float* __restrict__ w = a.p.ws_rgb + (set * nr + (size_t)q) * 195;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float pre = 0.f;
@@ -1251,8 +1308,8 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
         float vsum = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            m1[c] /= (float)nl;
-            m2[c] /= (float)nl;
+            m1[c] /= (float)nr;
+            m2[c] /= (float)nr;
             vsum += fmaxf(m2[c] - m1[c] * m1[c], 0.f);
         }
         if (valid) {
@@ -1812,7 +1869,8 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const uint32_t tpx = (num_tiles + 7u) / 8u;
     const uint32_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
-    bool f1_bad = false;   // F1: an output pre-activation of this lane was inf / NaN (see the epilogue)
+    bool f1_bad = false;   // an f16 operand overflowed: F1 -- an output pre-activation of this lane was inf / NaN (see the
+                           // epilogue); split form -- a colour layer's pre-activations were NaN (see colour 0 below)
     for (uint32_t tile = xcd * tpx + (uint32_t)slot * 4u + (uint32_t)wv; tile < tile_end; tile += (uint32_t)bpx * 4u) {
         int lane = lane_c;  // opaque per iteration: keeps the (tile-invariant) LDS operand reads inside the loop
         asm volatile("" : "+v"(lane));
@@ -1940,6 +1998,12 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 mf16_mac2<F1>(lds, 8, 9, lane, bhi, blo, c0, c1);
             }
             if (!F1) {   // F1: ReLU on the packed f16 operands instead (mf16_split_relu: half the instructions)
+                // Split form: an activation beyond 65504 is carried as hi = +inf, lo = -inf, and EVERY unit of the layer it
+                // feeds becomes inf - inf = NaN.  Trunk overflows reach the density logit as NaN and are caught by the
+                // composite kernels; behind a ReLU they would not be -- the integer maximum below maps a NaN whose sign bit
+                // is set to 0, and the layers after it then see a plausible all-zero hidden vector.  So one accumulator of
+                // each colour layer is tested before its ReLU (all 64 are NaN or none): two compares per pass.
+                f1_bad |= c0[0] != c0[0];
                 c0 = mf_relu(c0);
                 c1 = mf_relu(c1);
             }
@@ -1965,6 +2029,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             // gate; profiles/r3_exp_f16_rgb_on_mfma.json, DESIGN.md 4.5.  The colour layer stays fp32 in every form.)
             float o[3];
             {
+            if (!F1) f1_bad |= d0[0] != d0[0];
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
             if (drop_head1) {   // masks on the fp32 accumulators: one half-word compare + one select per unit
@@ -2020,7 +2085,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             }
         }
     }
-    if (F1 && a.p.overflow_flag) {   // one atomic per offending wave and launch
+    if (a.p.overflow_flag) {   // one atomic per offending wave and launch
         const uint64_t m = __builtin_amdgcn_ballot_w64(f1_bad);
         if (m != 0 && lane_c == (int)__builtin_ctzll(m)) atomicOr(a.p.overflow_flag, 1);
     }
@@ -2123,7 +2188,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
     const int j = lane_c & 31, h = lane_c >> 5;
     const int64_t N = a.R * (int64_t)a.S;
     const uint32_t mask = (1u << a.p.log2T) - 1u;
-    const float inv_n = 1.f / (float)a.p.n_lap;
+    const float inv_n = 1.f / (float)a.p.n_lap, inv_nr = 1.f / (float)a.p.n_lap_rgb;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const uint32_t tpx = (num_tiles + 7u) / 8u;  // num_tiles < 2^28 (the RNG counter bound in unerf_field_fwd)
     const uint32_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
@@ -2161,7 +2226,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
             }
         } else {
             float d1, d2;
-            mf_lap_head<false>(a.p.lap_blob, 0, lane, h, hb0, hb1, d1, d2, a.p.lap_softplus);
+            mf_lap_head<false>(lap_set_blob(a, a.p.lap_blob, tile, div_s), 0, lane, h, hb0, hb1, d1, d2, a.p.lap_softplus);
             mu_d = d1 * inv_n;
             mu2_d = d2 * inv_n;
             if (a.p.lap_mask_density) {  // use_deterministic_density: selector-masked mean, no variance
@@ -2217,9 +2282,9 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float c1s, c2s;
-                mf_lap_head<true>(a.p.lap_blob, 1 + c, lane, h, x0, x1, c1s, c2s);
-                mu_c[c] = c1s * inv_n;
-                vsum += fmaxf(c2s * inv_n - mu_c[c] * mu_c[c], 0.f);
+                mf_lap_head<true>(lap_set_blob(a, a.p.lap_blob, tile, div_s), 1 + c, lane, h, x0, x1, c1s, c2s);
+                mu_c[c] = c1s * inv_nr;
+                vsum += fmaxf(c2s * inv_nr - mu_c[c] * mu_c[c], 0.f);
             }
         }
         if (valid && h == 0) {
@@ -2325,7 +2390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane_c & 31, h = lane_c >> 5;
     const uint32_t mask = (1u << a.p.log2T) - 1u;
-    const float inv_n = 1.f / (float)a.p.n_lap;
+    const float inv_n = 1.f / (float)a.p.n_lap, inv_nr = 1.f / (float)a.p.n_lap_rgb;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const uint32_t tpx = (num_tiles + 7u) / 8u;
     const uint32_t tile_end = (xcd + 1) * tpx < num_tiles ? (xcd + 1) * tpx : num_tiles;
@@ -2358,8 +2423,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
 #pragma unroll
         for (int st = 0; st < 4; ++st) t = mf16_mac<F1>(lds, 4 + st, lane, xhi[st], xlo[st], t);
         float d1, d2;
-        if (a.p.lap_softplus) mf16_lap_head<2, F1>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);   // uniform
-        else mf16_lap_head<0, F1>(a.p.lap16_blob, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
+        const float* lap16 = lap_set_blob(a, a.p.lap16_blob, tile, div_s);
+        if (a.p.lap_softplus) mf16_lap_head<2, F1>(lap16, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);   // uniform
+        else mf16_lap_head<0, F1>(lap16, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
         float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
         if (a.p.lap_mask_density) {  // use_deterministic_density: selector-masked mean, no variance
             mu_d *= sel;
@@ -2388,10 +2454,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
             mf16_split8<F1>(mine, bhi, blo);
             mf16_mac2<F1>(lds, 10, 11, lane, bhi, blo, c0, c1);
         }
+        // (an overflowed operand of the split form makes every unit of the next layer NaN, which the integer-maximum ReLU
+        // may turn into 0: one accumulator per colour layer is tested first -- see field_kernel_mfma16)
+        if (!F1) f1_bad |= c0[0] != c0[0];
         c0 = mf_relu(c0);
         c1 = mf_relu(c1);
         f32x16 x0 = mf16_bias(lds, 5, h), x1 = mf16_bias(lds, 6, h);
         mf16_layer64<2, F1>(lds, 12, lane, c0, c1, x0, x1);
+        if (!F1) f1_bad |= x0[0] != x0[0];
         x0 = mf_relu(x0);
         x1 = mf_relu(x1);
 #pragma unroll
@@ -2400,9 +2470,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float c1s, c2s;
-            mf16_lap_head<1, F1>(a.p.lap16_blob, 1 + c, a.p.n_lap, lane, xhi, xlo, h, c1s, c2s);
-            mu_c[c] = c1s * inv_n;
-            vsum += fmaxf(c2s * inv_n - mu_c[c] * mu_c[c], 0.f);
+            mf16_lap_head<1, F1>(lap16, 1 + c, a.p.n_lap_rgb, lane, xhi, xlo, h, c1s, c2s);
+            mu_c[c] = c1s * inv_nr;
+            vsum += fmaxf(c2s * inv_nr - mu_c[c] * mu_c[c], 0.f);
         }
         // F1: an f16 operand beyond 65504 turns the sampled rows into +-inf / NaN; a density mean of +inf from a FINITE
         // logit is not possible below e^88, so non-finite means are treated as operand overflow (see field_kernel_mfma16)
@@ -2416,7 +2486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
             a.rgb[n * 3 + 2] = mu_c[2];
         }
     }
-    if (F1 && a.p.overflow_flag) {
+    if (a.p.overflow_flag) {
         const uint64_t m = __builtin_amdgcn_ballot_w64(f1_bad);
         if (m != 0 && lane_c == (int)__builtin_ctzll(m)) atomicOr(a.p.overflow_flag, 1);
     }
@@ -2548,6 +2618,9 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     a.s_near = near_plane < 0.f ? -1.f : unerf_spacing_of(near_plane, spacing);   // < 0: sbins are Euclidean edges
     a.s_far = unerf_spacing_of(far_plane, spacing); a.ray_offset = ray_offset;
     a.p = *p; a.density = density; a.rgb = rgb; a.aux = aux; a.aux2 = aux2;
+    if (a.p.n_lap_rgb <= 0) a.p.n_lap_rgb = a.p.n_lap;
+    a.div_chunk = make_fastdiv(p->lap_chunk_rays > 0 ? (uint32_t)p->lap_chunk_rays : 1u);
+    a.chunk0 = (uint32_t)ray_offset;
     a.features = features;
     a.box = make_norm_box(p->use_aabb, p->aabb);
     UNERF_REQUIRE(!(features && p->use_aabb), "field_fwd: pre-gathered feature planes are built for the contraction path only");
@@ -2621,6 +2694,18 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_LAPLACE:
             UNERF_REQUIRE(p->out1 == 15 && aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1,
                           "field_fwd LAPLACE: need out1=15, aux, aux2, ws_density, ws_rgb, n_lap>=1");
+            UNERF_REQUIRE(!(p->lap_blob || p->lap16_blob) || a.p.n_lap_rgb <= 32 * LAP_BLOCKS || p->n_lap > 32 * LAP_BLOCKS,
+                          "field_fwd LAPLACE: n_lap_rgb=%d rows do not fit the head blobs (at most %d); pass them as ws_* only",
+                          a.p.n_lap_rgb, 32 * LAP_BLOCKS);
+            if (p->lap_chunk_rays != 0) {   // per-chunk sample sets: 1-D tiles that never straddle two sets
+                UNERF_REQUIRE(p->lap_chunk_rays > 0 && p->lap_chunk_rays % 32 == 0 && ray_offset % 32 == 0 && p->lap_sets >= 1,
+                              "field_fwd LAPLACE: lap_chunk_rays=%d and ray_offset=%lld must be multiples of 32, lap_sets=%d >= 1",
+                              p->lap_chunk_rays, (long long)ray_offset, p->lap_sets);
+                UNERF_REQUIRE((ray_offset + R - 1) / p->lap_chunk_rays < p->lap_sets,
+                              "field_fwd LAPLACE: rays [%lld, +%lld) reach past the %d sample sets of %d rays",
+                              (long long)ray_offset, (long long)R, p->lap_sets, p->lap_chunk_rays);
+                a.p.image_width = 0;
+            }
             if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS && f1) {
                 if (tc) launch_matrix_kernel(field_kernel_mfma16_laplace<true, true>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16_laplace<false, true>, MF_LDS_F16, a, st);

@@ -7,6 +7,9 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+#include <cstring>
+
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 // ======================================================================================
@@ -445,11 +448,29 @@ extern "C" int unerf_splat_shade_inputs(int degree, const float* means3d, const 
 // bin and sort (once per frame)
 // ======================================================================================
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+#define TS_SEG 32          // one-pass tile sort (below): the prefix over chunks runs in 32 independent row segments
+#define TS_MAX_T1 16000    // tiles + 1 sentinel: the counters of one wave must fit 64 KB of LDS (beyond: rocprim)
+struct TileSortPlan {
+    int chunk, nblk, rows, T1;
+};
+static TileSortPlan tile_sort_plan(int64_t I, int tiles) {
+    TileSortPlan p;
+    p.T1 = tiles + 1;
+    // one single-wave workgroup per chunk, four of them per CU (their 32-KB tables): ~1024 chunks fill the chip
+    int64_t chunk = (I + 1023) / 1024;
+    chunk = ((chunk + 255) / 256) * 256;
+    if (chunk < 2048) chunk = 2048;
+    p.chunk = (int)chunk;
+    p.nblk = (int)((I + chunk - 1) / chunk);
+    if (p.nblk < 1) p.nblk = 1;
+    p.rows = ((p.nblk + TS_SEG - 1) / TS_SEG) * TS_SEG;
+    return p;
+}
 
-static int tile_bits(int H, int W, int bw) {
+static int tile_bits(int H, int W, int bw) {   // bits of the largest key: tiles - 1, and `tiles` itself (the sentinel)
     int64_t tiles = (int64_t)((W + bw - 1) / bw) * ((H + bw - 1) / bw);
     int b = 1;
-    while (((int64_t)1 << b) < tiles) ++b;
+    while (((int64_t)1 << b) <= tiles) ++b;
     return b;
 }
 
@@ -467,7 +488,7 @@ static hipError_t depth_sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_t*
 }
 
 struct SortWs {
-    int64_t tmp, dkey_in, dkey_out, id_in, order, counts, cum, tkey_in, tkey_out, val_in, total;
+    int64_t tmp, dkey_in, dkey_out, id_in, order, counts, cum, tkey_in, tkey_out, val_in, ts_table, ts_segsum, ts_start, total;
 };
 static SortWs sort_ws_layout(int64_t N, int64_t I) {
     size_t scan_tmp = 0, sortN_tmp = 0, sortI_tmp = 0;
@@ -486,6 +507,11 @@ static SortWs sort_ws_layout(int64_t N, int64_t I) {
     w.dkey_in = take(N * 4); w.dkey_out = take(N * 4); w.id_in = take(N * 4); w.order = take(N * 4);
     w.counts = take(N * 4); w.cum = take(N * 4);
     w.tkey_in = take(I * 4); w.tkey_out = take(I * 4); w.val_in = take(I * 4);
+    // the one-pass tile sort's tables, sized for the largest tile count it serves (the image size is not known here)
+    const TileSortPlan tp = tile_sort_plan(I, TS_MAX_T1 - 1);
+    w.ts_table = take((int64_t)tp.rows * TS_MAX_T1 * 4);
+    w.ts_segsum = take((int64_t)TS_SEG * TS_MAX_T1 * 4);
+    w.ts_start = take((int64_t)(TS_MAX_T1 + 1) * 4);
     w.total = off + 1024;
     return w;
 }
@@ -557,6 +583,12 @@ __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __rest
     if (conics) {   // uniform: tight lists -- the rows project_kernel counted, in the same order
         const TightSplat t = tight_splat(sx, sy, opac[i], conics[(int64_t)i * 3], conics[(int64_t)i * 3 + 1],
                                          conics[(int64_t)i * 3 + 2]);
+        // The slot [first, end) was sized by project_kernel's tight_count -- a second inlining of tight_row on the same
+        // stored numbers.  Should the two ever disagree (another build behind UNERF_LIB, a compiler that contracts one of
+        // them), the emission stays inside its slot and pads what is left with the sentinel tile `tbx * tby`, which the
+        // sort puts behind every real tile and tile_bins never covers: a wrong count costs pairs, never memory safety.
+        const int64_t end = cum_sorted[j];
+        const TKey sentinel = (TKey)(tbx * tby);
         // 16 tile rows at a time, one per lane of the splat's 16-lane group; their widths are scanned inside the group and
         // the round's entries go out striped over the lanes like the box form below (a row is only ~5 tiles wide: a
         // lane-per-row or row-by-row emission leaves most lanes of every store idle -- 2.5 x the kernel time)
@@ -583,12 +615,16 @@ __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __rest
                 }
                 r = min(r, 15);
                 const int rex = __shfl(excl, r, 16), ra0 = __shfl(a0, r, 16);
-                if (e < total) {
+                if (e < total && at + e < end) {
                     tkeys[at + e] = (TKey)((y0 + rb + r) * tbx + ra0 + (e - rex));
                     vals[at + e] = i;
                 }
             }
             at += total;
+        }
+        for (int64_t e = at + l16; e < end; e += 16) {        // never taken when the two counts agree
+            tkeys[e] = sentinel;
+            vals[e] = i;
         }
         return;
     }
@@ -605,31 +641,175 @@ __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __rest
     }
 }
 
-// tile ranges + the gsplat-style 64-bit ids (tile << 32 | depth bits) of the sorted intersections
+// tile ranges + the gsplat-style 64-bit ids (tile << 32 | depth bits) of the sorted intersections (rocprim path; entries
+// with the sentinel tile `tiles` sort behind every real tile and belong to no range)
 template <typename TKey>
 __global__ __launch_bounds__(256) void tile_edges_kernel(const TKey* __restrict__ tkeys,
                                                          const int32_t* __restrict__ gids,
-                                                         const float* __restrict__ depths, int64_t I,
+                                                         const float* __restrict__ depths, int64_t I, int32_t tiles,
                                                          int32_t* __restrict__ bins, int64_t* __restrict__ isect_ids) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= I) return;
     const int32_t cur = (int32_t)tkeys[i];
     if (isect_ids) isect_ids[i] = ((int64_t)cur << 32) | (int64_t)(uint32_t)__float_as_int(depths[gids[i]]);
+    const int32_t prev = i > 0 ? (int32_t)tkeys[i - 1] : -1;
+    if (cur >= tiles) {
+        if (prev >= 0 && prev < tiles) bins[prev * 2 + 1] = (int32_t)i;
+        return;
+    }
     if (i == 0) bins[cur * 2] = 0;
     if (i == I - 1) bins[cur * 2 + 1] = (int32_t)I;
-    if (i > 0) {
-        const int32_t prev = (int32_t)tkeys[i - 1];
-        if (prev != cur) {
-            bins[prev * 2 + 1] = (int32_t)i;
-            bins[cur * 2] = (int32_t)i;
-        }
+    if (i > 0 && prev != cur) {
+        bins[prev * 2 + 1] = (int32_t)i;
+        bins[cur * 2] = (int32_t)i;
     }
+}
+
+// ---- stable ONE-PASS tile sort ---------------------------------------------------------------------------------------
+// The emission above leaves (tile, splat) pairs in depth order; what remains is a STABLE sort by tile -- at 1080p 8,160
+// tiles, a 13-bit key.  rocprim's radix sort takes 8 bits per pass, i.e. two read-and-scatter sweeps over keys and
+// values plus a histogram sweep (0.28 ms for the 20 M pairs of the bench frame).  A key range this small fits a
+// workgroup's LDS as ONE digit: 8,161 32-bit counters are 32 KB of the CU's 160 KB.  So: one histogram per chunk of the
+// pair stream (tile_hist_kernel), a prefix over chunks and tiles that turns the counts into write offsets -- which are
+// also the tile_bins the rasteriser wants, so no edge-detection sweep either -- and ONE scatter sweep in which a single
+// wave owns a chunk and its offset table (tile_scatter_kernel).  Stability inside a wave costs nothing here: the pairs
+// of one splat name distinct tiles, so a wave hands out slots splat segment by splat segment with plain LDS atomics,
+// which the LDS executes in program order.  The sorted tile keys are never written: the bins say where each tile's ids
+// sit.  Same lists as the radix sort, bit for bit (tests/test_gpu_splat.py).
+template <typename TKey>
+__global__ __launch_bounds__(256) void tile_hist_kernel(const TKey* __restrict__ keys, int64_t I, int chunk, int T1,
+                                                        uint32_t* __restrict__ table) {
+    extern __shared__ uint32_t s_hist[];
+    for (int t = threadIdx.x; t < T1; t += 256) s_hist[t] = 0u;
+    __syncthreads();
+    const int64_t k0 = (int64_t)blockIdx.x * chunk, k1 = (k0 + chunk < I) ? k0 + chunk : I;   // rows past the last chunk: zeros
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+        const uint32_t key = (uint32_t)keys[k];
+        atomicAdd(&s_hist[key < (uint32_t)T1 ? key : (uint32_t)(T1 - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * T1;
+    for (int t = threadIdx.x; t < T1; t += 256) row[t] = s_hist[t];
+}
+
+// column sums of each row segment: segsum[seg][t] = sum over the segment's rows of table[row][t]
+__global__ __launch_bounds__(256) void tile_colsum_kernel(const uint32_t* __restrict__ table, int rows_per_seg, int T1,
+                                                          uint32_t* __restrict__ segsum) {
+    const int t = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
+    if (t >= T1) return;
+    const uint32_t* col = table + (size_t)seg * rows_per_seg * T1 + t;
+    uint32_t sum = 0u;
+#pragma unroll 8
+    for (int r = 0; r < rows_per_seg; ++r) sum += col[(size_t)r * T1];
+    segsum[(size_t)seg * T1 + t] = sum;
+}
+
+// one workgroup: per tile the exclusive prefix over the segments, then the exclusive prefix of the tile totals over the
+// tiles; segsum[seg][t] becomes the first write offset of segment seg in tile t, and tile_bins the tiles' ranges
+__global__ __launch_bounds__(1024) void tile_scan_kernel(uint32_t* __restrict__ segsum, int T1, int tiles,
+                                                         uint32_t* __restrict__ start, int32_t* __restrict__ bins) {
+    __shared__ uint32_t s_part[1024];
+    const int per = (T1 + 1023) / 1024;
+    const int t0 = threadIdx.x * per, t1 = (t0 + per < T1) ? t0 + per : T1;
+    uint32_t mine = 0u;
+    for (int t = t0; t < t1; ++t) {
+        uint32_t run = 0u;
+        for (int seg = 0; seg < TS_SEG; ++seg) {
+            const uint32_t x = segsum[(size_t)seg * T1 + t];
+            segsum[(size_t)seg * T1 + t] = run;
+            run += x;
+        }
+        start[t] = run;      // the tile's total for now
+        mine += run;
+    }
+    s_part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {      // Hillis-Steele over the 1024 partial sums
+        const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - mine;
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t total = start[t];
+        start[t] = run;
+        for (int seg = 0; seg < TS_SEG; ++seg) segsum[(size_t)seg * T1 + t] += run;
+        if (t < tiles) {      // an empty tile keeps the (0, 0) of gsplat's zero-filled tile_bins
+            bins[t * 2] = total ? (int32_t)run : 0;
+            bins[t * 2 + 1] = total ? (int32_t)(run + total) : 0;
+        }
+        run += total;
+    }
+    if (threadIdx.x == 1023) start[T1] = run;
+}
+
+// counts -> write offsets, in place: table[row][t] = segsum[seg][t] + sum of the segment's earlier rows
+__global__ __launch_bounds__(256) void tile_apply_kernel(uint32_t* __restrict__ table, int rows_per_seg, int T1,
+                                                         const uint32_t* __restrict__ segsum) {
+    const int t = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
+    if (t >= T1) return;
+    uint32_t* col = table + (size_t)seg * rows_per_seg * T1 + t;
+    uint32_t run = segsum[(size_t)seg * T1 + t];
+#pragma unroll 8
+    for (int r = 0; r < rows_per_seg; ++r) {
+        const uint32_t c = col[(size_t)r * T1];
+        col[(size_t)r * T1] = run;
+        run += c;
+    }
+}
+
+// One wave per chunk.  Pairs arrive in depth order; within a 64-pair vector the pairs of ONE splat (a run of equal ids)
+// name distinct tiles, so all of them can take their slots with one conflict-free LDS atomic; runs are served in order
+// (the LDS executes a wave's operations in program order), which makes the scatter stable.
+template <typename TKey>
+__global__ __launch_bounds__(64) void tile_scatter_kernel(const TKey* __restrict__ keys, const int32_t* __restrict__ vals,
+                                                          int64_t I, int chunk, int T1, const uint32_t* __restrict__ table,
+                                                          int32_t* __restrict__ out) {
+    extern __shared__ uint32_t s_off[];
+    const int lane = threadIdx.x;
+    const uint32_t* row = table + (size_t)blockIdx.x * T1;
+    for (int t = lane; t < T1; t += 64) s_off[t] = row[t];
+    __syncthreads();
+    const int64_t k0 = (int64_t)blockIdx.x * chunk, k1 = (k0 + chunk < I) ? k0 + chunk : I;
+    for (int64_t k = k0; k < k1; k += 64) {
+        const int64_t e = k + lane;
+        const bool valid = e < k1;
+        uint32_t key = valid ? (uint32_t)keys[e] : 0u;
+        const int32_t id = valid ? vals[e] : -1;
+        if (key >= (uint32_t)T1) key = (uint32_t)(T1 - 1);
+        const int32_t prev = __shfl_up(id, 1, 64);
+        uint64_t starts = __builtin_amdgcn_ballot_w64(valid && (lane == 0 || id != prev));
+        uint32_t pos = 0u;
+        while (starts) {      // uniform: one round per splat run of the vector
+            const int lo = __builtin_ctzll(starts);
+            starts &= starts - 1;
+            const int hi = starts ? __builtin_ctzll(starts) : 64;
+            if (valid && lane >= lo && lane < hi) pos = atomicAdd(&s_off[key], 1u);
+        }
+        if (valid) out[pos] = id;      // (sentinel pairs land behind the last tile's range)
+    }
+}
+
+// the gsplat-style 64-bit ids of the sorted lists (on request only): the tile of entry i is found in the tile offsets
+__global__ __launch_bounds__(256) void tile_isect_ids_kernel(const uint32_t* __restrict__ start, int T1,
+                                                             const int32_t* __restrict__ gids,
+                                                             const float* __restrict__ depths, int64_t n,
+                                                             int64_t* __restrict__ isect_ids) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = T1;                       // last tile t with start[t] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (start[mid] <= (uint32_t)i) lo = mid; else hi = mid;
+    }
+    isect_ids[i] = ((int64_t)lo << 32) | (int64_t)(uint32_t)__float_as_int(depths[gids[i]]);
 }
 
 template <typename TKey>
 static int bin_sort_impl(const float* xys, const float* depths, const int32_t* radii, const int32_t* order,
                          const int32_t* cum_sorted, const float* conics, const float* opac, int64_t N, int64_t I, int bw,
-                         int tbx, int tby, int bits,
+                         int tbx, int tby, int bits, bool own_sort,
                          int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted, int32_t* tile_bins, char* ws,
                          const SortWs& L, size_t tmp_bytes, hipStream_t st) {
     TKey* tk_in = reinterpret_cast<TKey*>(ws + L.tkey_in);
@@ -639,6 +819,25 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
                        cum_sorted, N, bw, tbx, tby, conics, opac, tk_in, v_in);
     int rc = unerf_check_launch("splat_bin_sort map");
     if (rc) return rc;
+    const int tiles = tbx * tby;
+    if (own_sort) {   // the one-pass LDS-digit sort (above)
+        const TileSortPlan tp = tile_sort_plan(I, tiles);
+        uint32_t* table = reinterpret_cast<uint32_t*>(ws + L.ts_table);
+        uint32_t* segsum = reinterpret_cast<uint32_t*>(ws + L.ts_segsum);
+        uint32_t* start = reinterpret_cast<uint32_t*>(ws + L.ts_start);
+        const size_t lds = (size_t)tp.T1 * sizeof(uint32_t);
+        const int rps = tp.rows / TS_SEG;
+        hipLaunchKernelGGL((tile_hist_kernel<TKey>), dim3(tp.rows), dim3(256), lds, st, tk_in, I, tp.chunk, tp.T1, table);
+        hipLaunchKernelGGL(tile_colsum_kernel, dim3(blocks_for(tp.T1, 256), TS_SEG), dim3(256), 0, st, table, rps, tp.T1, segsum);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, segsum, tp.T1, tiles, start, tile_bins);
+        hipLaunchKernelGGL(tile_apply_kernel, dim3(blocks_for(tp.T1, 256), TS_SEG), dim3(256), 0, st, table, rps, tp.T1, segsum);
+        hipLaunchKernelGGL((tile_scatter_kernel<TKey>), dim3(tp.nblk), dim3(64), lds, st, tk_in, v_in, I, tp.chunk, tp.T1, table,
+                           gaussian_ids_sorted);
+        if (isect_ids_sorted)
+            hipLaunchKernelGGL(tile_isect_ids_kernel, dim3(blocks_for(I, 256)), dim3(256), 0, st, start, tp.T1,
+                               gaussian_ids_sorted, depths, I, isect_ids_sorted);
+        return unerf_check_launch("splat_bin_sort tile sort");
+    }
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(ws + L.tmp, tmp_bytes, tk_in, tk_out, v_in, gaussian_ids_sorted,
                                                       (int)I, 0, bits, st);
     if (e != hipSuccess) {
@@ -646,7 +845,7 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
         return UNERF_ERR_HIP;
     }
     hipLaunchKernelGGL((tile_edges_kernel<TKey>), dim3(blocks_for(I, 256)), dim3(256), 0, st, tk_out,
-                       gaussian_ids_sorted, depths, I, tile_bins, isect_ids_sorted);
+                       gaussian_ids_sorted, depths, I, tiles, tile_bins, isect_ids_sorted);
     return unerf_check_launch("splat_bin_sort edges");
 }
 
@@ -692,14 +891,17 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
         unerf_set_error("splat_bin_sort: scan: %s", hipGetErrorString(e));
         return UNERF_ERR_HIP;
     }
-    // 3. emit in depth order, stable sort by tile, edges + ids
-    const int bits = tile_bits(H, W, block_width);
+    // 3. emit in depth order, stable sort by tile (one LDS-digit pass when the tile counters fit a wave's LDS, rocprim's
+    // radix sort otherwise or when UNERF_SPLAT_TILE_SORT=radix asks for it -- A/B timing), tile ranges + ids
+    const int bits = tile_bits(H, W, block_width);      // (the sentinel tile `tbx * tby` included)
+    const char* env = getenv("UNERF_SPLAT_TILE_SORT");
+    const bool own_sort = tbx * tby + 1 <= TS_MAX_T1 && !(env && strcmp(env, "radix") == 0);
     tmp_bytes = (size_t)(L.dkey_in - L.tmp);
     if (bits <= 16)
         return bin_sort_impl<uint16_t>(xys, depths, radii, order, cum_sorted, tight_conics, tight_opacities, N, I, block_width, tbx, tby, bits,
-                                       isect_ids_sorted, gaussian_ids_sorted, tile_bins, ws, L, tmp_bytes, st);
+                                       own_sort, isect_ids_sorted, gaussian_ids_sorted, tile_bins, ws, L, tmp_bytes, st);
     return bin_sort_impl<uint32_t>(xys, depths, radii, order, cum_sorted, tight_conics, tight_opacities, N, I, block_width, tbx, tby, bits,
-                                   isect_ids_sorted, gaussian_ids_sorted, tile_bins, ws, L, tmp_bytes, st);
+                                   own_sort, isect_ids_sorted, gaussian_ids_sorted, tile_bins, ws, L, tmp_bytes, st);
 }
 
 // ======================================================================================

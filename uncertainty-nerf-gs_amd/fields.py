@@ -500,25 +500,35 @@ class NerfactoLaplaceField(_NerfactoFieldBase):
         self.mlp_rgb_ggn = torch.zeros(hidden_dim_color * 3 + 3)
 
     def sample_last_layers(self, n_samples=100, prior_prec=1.0, eps=1e-9, generator=None, rgb_prior_prec=1.0,
-                           rgb_n_samples=100, rgb_eps=1e-9, deterministic_density: bool = False):
+                           rgb_n_samples=100, rgb_eps=1e-9, deterministic_density: bool = False, n_sets: Optional[int] = None):
         """The draw of `sample_laplace` (laplace_field.py:538-547) for both heads: mu + randn * 1/sqrt(ggn+prior+eps).
         Quirk kept: forward_unc does not forward prior_prec / n_samples / eps to the colour head
         (laplace_field.py:516-520), which therefore always runs with the defaults 1.0 / 100 / 1e-9.
         deterministic_density (use_deterministic_density=True, laplace_field.py:501-506): no density draw is made
         (the generator is consumed by the colour head only, as in the reference); the density rows are copies of
-        the mean."""
+        the mean.
+        n_sets: None -> one set, (ws_density [n,65], ws_rgb [n,195]).  An int -> that many INDEPENDENT sets
+        ([n_sets,n,65], [n_sets,n,195]), drawn in the order the reference consumes its generator when it renders a frame
+        chunk by chunk (laplace_model.py:432-443): chunk 0 density, chunk 0 colour, chunk 1 density, ..."""
         from torch.nn.utils import parameters_to_vector
-        out = []
-        for i, (mod, ggn, pp, n, e) in enumerate(((self.mlp_density, self.mlp_density_ggn, prior_prec, n_samples, eps),
-                                                  (self.mlp_rgb_ll, self.mlp_rgb_ggn, rgb_prior_prec, rgb_n_samples, rgb_eps))):
+        heads = []
+        for mod, ggn, pp, n, e in ((self.mlp_density, self.mlp_density_ggn, prior_prec, n_samples, eps),
+                                   (self.mlp_rgb_ll, self.mlp_rgb_ggn, rgb_prior_prec, rgb_n_samples, rgb_eps)):
             mu = parameters_to_vector(mod.parameters()).detach()
-            if i == 0 and deterministic_density:
-                out.append(mu.view(1, -1).repeat(rgb_n_samples, 1))
-                continue
-            std = 1 / torch.sqrt(ggn.to(mu) + pp + e)
-            noise = torch.randn(n, mu.numel(), generator=generator, device=mu.device)
-            out.append(mu.view(1, -1) + noise * std.view(1, -1))
-        return out[0], out[1]
+            heads.append((mu, 1 / torch.sqrt(ggn.to(mu) + pp + e), n))
+        sets = []
+        for _ in range(1 if n_sets is None else int(n_sets)):
+            out = []
+            for i, (mu, std, n) in enumerate(heads):
+                if i == 0 and deterministic_density:
+                    out.append(mu.view(1, -1).repeat(rgb_n_samples, 1))
+                    continue
+                noise = torch.randn(n, mu.numel(), generator=generator, device=mu.device)
+                out.append(mu.view(1, -1) + noise * std.view(1, -1))
+            sets.append(out)
+        if n_sets is None:
+            return sets[0][0], sets[0][1]
+        return torch.stack([s_[0] for s_ in sets]), torch.stack([s_[1] for s_ in sets])
 
     @torch.no_grad()
     def forward_unc(self, ray_samples, compute_normals: bool = False, is_inference: bool = False,

@@ -108,10 +108,11 @@ class FieldParams(C.Structure):
         ("image_width", C.c_int), ("sample_major", C.c_int), ("drop_sites", C.c_int), ("lap_softplus", C.c_int), ("use_aabb", C.c_int),
         ("aabb", C.c_float * 6), ("f16_single", C.c_int), ("overflow_flag", C.c_void_p),
         ("h0_full_t", C.c_void_p), ("hb0_raw", C.c_void_p), ("app_embed", C.c_void_p),
+        ("lap_chunk_rays", C.c_int), ("lap_sets", C.c_int), ("n_lap_rgb", C.c_int),
     ]
 
 
-ABI_VERSION = 1230                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
+ABI_VERSION = 1300                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
 SPACING_PIECEWISE, SPACING_UNIFORM = 0, 1         # include/unerf.h: UNERF_SPACING_*
 BG_LAST_SAMPLE, BG_NONE, BG_COLOR = 0, 1, 2       # include/unerf.h: UNERF_BG_*
@@ -128,7 +129,7 @@ SIGNATURES = {
     "unerf_version": (_i, []),
     "unerf_build_flags": (_i, []),
     "unerf_device_count": (_i, []),
-    "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _fp, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "unerf_ray_box_bins": (_i, [_vp, _vp, _i64, _fp, _fp, _f, _f, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "unerf_ray_planes_bins": (_i, [_vp, _vp, _i64, _f, _f, _i, _vp, _i, _vp, _vp]),
     "unerf_hashgrid_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),

@@ -40,25 +40,33 @@ def _scalar(v) -> float:
     return float(v.reshape(-1)[0].item()) if torch.is_tensor(v) else float(v)
 
 
-def _camera_args(camera) -> Tuple[torch.Tensor, Dict[str, Any]]:
-    """[UPSTREAM Cameras.generate_rays] is restated (unerf_generate_rays) for ONE distortion-free perspective camera, which
-    is what the reference's eval loops hand over (one eval image at a time, undistorted datasets).  Anything else a
-    nerfstudio `Cameras` can describe would silently render the wrong rays, so it is refused here."""
+def _camera_args(camera, lens: bool = True) -> Tuple[torch.Tensor, Dict[str, Any]]:
+    """[UPSTREAM Cameras.generate_rays] is restated (unerf_generate_rays) for ONE perspective camera, with the OPENCV lens
+    parameters `distortion_params` = (k1, k2, k3, k4, p1, p2) the reference's dataparsers attach to it
+    (dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:248-274: every `ns-process-data images` scene) --
+    one eval image at a time is what the reference's eval loops hand over.  Anything else a nerfstudio `Cameras` can
+    describe (fisheye / equirectangular / ... types, camera batches) would silently render the wrong rays, so it is
+    refused here.  lens=False (the splat models): the parameters are not looked at, as upstream Splatfacto.get_outputs
+    never reads them (its datamanager undistorts the images instead)."""
     c2w = camera.camera_to_worlds
     if c2w.dim() == 3 and c2w.shape[0] != 1:
         raise ValueError(f"get_outputs_for_camera takes one camera, got a batch of {c2w.shape[0]}")
-    dist_params = getattr(camera, "distortion_params", None)
-    if dist_params is not None and bool(torch.as_tensor(dist_params).abs().max() > 0):
-        raise NotImplementedError("cameras with lens distortion parameters are not built (generate_rays would bend the rays); "
-                                  "undistort the dataset")
     ctype = getattr(camera, "camera_type", None)
     if ctype is not None:
         v = int(torch.as_tensor(ctype).reshape(-1)[0]) if torch.is_tensor(ctype) else int(getattr(ctype, "value", ctype))
         if v != 1:      # nerfstudio CameraType.PERSPECTIVE = 1
             raise NotImplementedError(f"camera_type {v}: only perspective cameras (CameraType.PERSPECTIVE = 1) are built")
     c2w = c2w[0] if c2w.dim() == 3 else c2w
-    return c2w[:3, :4], dict(fx=_scalar(camera.fx), fy=_scalar(camera.fy), cx=_scalar(camera.cx), cy=_scalar(camera.cy),
-                             H=int(_scalar(camera.height)), W=int(_scalar(camera.width)))
+    args = dict(fx=_scalar(camera.fx), fy=_scalar(camera.fy), cx=_scalar(camera.cx), cy=_scalar(camera.cy),
+                H=int(_scalar(camera.height)), W=int(_scalar(camera.width)))
+    dist_params = getattr(camera, "distortion_params", None) if lens else None
+    if dist_params is not None:
+        dp = torch.as_tensor(dist_params).detach().cpu().to(torch.float32).reshape(-1)
+        if dp.numel() != 6:
+            raise ValueError(f"distortion_params: expected 6 values (k1, k2, k3, k4, p1, p2), got {dp.numel()}")
+        if bool((dp != 0).any()):
+            args["distortion"] = [float(v) for v in dp]
+    return c2w[:3, :4], args
 
 
 # ------------------------------------------------------------------ configs ----------------
@@ -264,6 +272,9 @@ class _ImageMetrics:
 
 class _NerfactoBase(nn.Module, _ImageMetrics):
     config: NerfactoModelConfig
+    # Arithmetic of the main field's dense layers (ops.FieldDev.precision).  None = what the REFERENCE computes this model
+    # in at eval (reference_precision()); "f16x2" (fp32-equivalent), "f16" or "fp32" force one form.
+    precision: Optional[str] = None
 
     def __init__(self, config, scene_box=None, num_train_data: int = 1, **_kw):
         super().__init__()
@@ -321,10 +332,22 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         return dict(spacing=_lib.SPACING_UNIFORM if c.proposal_initial_sampler == "uniform" else _lib.SPACING_PIECEWISE,
                     background=ops.background_of(c.background_color))
 
+    def reference_precision(self) -> str:
+        """The arithmetic the reference runs this model's Linear layers in at eval: tiny-cuda-nn FullyFusedMLPs (fp16
+        weights and activations) when config.implementation == "tcnn" -- upstream's default, handed to the field at
+        activenerfacto_model.py:77 -- and torch fp32 Linears otherwise.  -> "f16" (one f16 product per MAC, fp32
+        accumulate: no narrower than tcnn) | "f16x2" (fp32-equivalent)."""
+        return "f16" if self.config.implementation == "tcnn" else "f16x2"
+
     def device_scene(self, device=None) -> NerfSceneDev:
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self._dev_scene is None or self._dev_scene.device != device:
-            self._dev_scene = self._build_scene(device, self._field_to_device(device))
+            fd = self._field_to_device(device)
+            want = self.precision or self.reference_precision()
+            if want == "f16" and (fd.mfma16_blob is None or not fd.use_mfma):
+                want = "fp32"       # weights beyond the f16 range (or a VALU-only layout): the exact kernels
+            fd.precision = want
+            self._dev_scene = self._build_scene(device, fd)
         return self._dev_scene
 
     def _build_scene(self, device, fd) -> NerfSceneDev:
@@ -500,6 +523,11 @@ class NerfactoMCDropoutModel(_NerfactoBase):
         scene.field.seed = frame_seed(self.seed, self.frame_counter if self.fresh_masks_per_render else 0)
         self.frame_counter += 1
 
+    def reference_precision(self) -> str:
+        """mcdropout_models.py:86-92: `forward` wraps every render in torch.autocast(enabled=True) -- the Linear layers run
+        in float16 on a GPU whatever the implementation"""
+        return "f16"
+
     def _make_field(self):
         c = self.config
         return F.NerfactoMCDropoutField(dropout_rate=c.dropout_rate, rgb_dropout_layers=c.rgb_dropout_layers,
@@ -512,9 +540,19 @@ class NerfactoMCDropoutModel(_NerfactoBase):
 class NerfactoLaplaceModel(_NerfactoBase):
     config: NerfactoLaplaceModelConfig
     depth_seed: int = 0
+    # How often the last-layer samples are redrawn inside one get_outputs_for_camera_unc frame.  "chunk" (the reference):
+    # sample_laplace runs inside get_outputs_unc, i.e. once per eval chunk of config.eval_num_rays_per_chunk rays
+    # (laplace_model.py:432-443 -> laplace_field.py:331-339, 468-476, 545) -- a 1080p frame is rendered with 64
+    # independent sets of n_samples draws, so its Monte-Carlo error is independent from chunk to chunk.  "camera": one
+    # set for the whole frame (no visible seams between chunks; the field kernel keeps its 8x4 pixel-patch tiles).
+    resample: str = "chunk"
 
     def _make_field(self):
         return F.NerfactoLaplaceField(density_activation=self.config.density_activation, **self._field_kwargs())
+
+    def reference_precision(self) -> str:
+        """laplace_field.py:305, :460: `.float()` in front of every Linear, no autocast around the model -> fp32"""
+        return "f16x2"
 
     _ws = None                       # sampled last layers of the current *_unc call; None: the mean heads
     _deterministic_density = False
@@ -529,8 +567,8 @@ class NerfactoLaplaceModel(_NerfactoBase):
             ws_r = parameters_to_vector(self.field.mlp_rgb_ll.parameters()).detach().reshape(1, -1)
             return self.field.to_device(device, ws_density=ws_d, ws_rgb=ws_r, lap_mask_density=1)
         ws_d, ws_r = self._ws
-        return self.field.to_device(device, ws_density=ws_d, ws_rgb=ws_r,
-                                    lap_mask_density=int(self._deterministic_density))
+        return self.field.to_device(device, ws_density=ws_d, ws_rgb=ws_r, lap_mask_density=int(self._deterministic_density),
+                                    lap_chunk_rays=int(self.config.eval_num_rays_per_chunk) if ws_d.dim() == 3 else 0)
 
     @torch.no_grad()
     def get_outputs_for_camera(self, camera, obb_box=None):
@@ -550,8 +588,14 @@ class NerfactoLaplaceModel(_NerfactoBase):
         mean head (no density samples, no depth draws); the colour head is still sampled."""
         if not is_inference:
             raise NotImplementedError("is_inference=False is the training forward (used by compute_hessian_naive only)")
+        if self.resample not in ("chunk", "camera"):
+            raise ValueError(f"NerfactoLaplaceModel.resample={self.resample!r}: expected 'chunk' or 'camera'")
+        n_sets = None
+        if self.resample == "chunk":
+            _, cam = _camera_args(camera)
+            n_sets = -(-(cam["H"] * cam["W"]) // int(self.config.eval_num_rays_per_chunk))
         self._ws = self.field.sample_last_layers(n_samples=n_samples, prior_prec=prior_prec, eps=eps, generator=generator,
-                                                 deterministic_density=use_deterministic_density)
+                                                 deterministic_density=use_deterministic_density, n_sets=n_sets)
         self._deterministic_density = bool(use_deterministic_density)
         self.invalidate()
         self._in_unc_call = True
@@ -670,7 +714,7 @@ class SplatfactoModel(nn.Module, _ImageMetrics):
 
     @torch.no_grad()
     def get_outputs(self, camera) -> Dict[str, Optional[torch.Tensor]]:
-        c2w, cam = _camera_args(camera)
+        c2w, cam = _camera_args(camera, lens=False)
         n = min(self.step // self.config.sh_degree_interval, self.config.sh_degree) if self.config.sh_degree > 0 else 0
         gp = {k: v.detach() for k, v in self.gauss_params.items()}
         crop_ids = None

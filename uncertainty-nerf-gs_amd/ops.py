@@ -78,17 +78,29 @@ def _host12(m: torch.Tensor):
 
 # ------------------------------------------------------------------ rays ---------------
 
+def _host_distortion(distortion):
+    """camera `distortion_params` (k1, k2, k3, k4, p1, p2; nerfstudio's order) -> 6 host floats, or None"""
+    if distortion is None:
+        return None
+    vals = [float(v) for v in torch.as_tensor(distortion).detach().cpu().to(torch.float32).reshape(-1)]
+    if len(vals) != 6:
+        raise _l.UnerfError(f"distortion: expected 6 parameters (k1, k2, k3, k4, p1, p2), got {len(vals)}")
+    return (C.c_float * 6)(*vals)
+
+
 def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int, device,
-                  ray_start: int = 0, count: Optional[int] = None, pixel_area: bool = False):
-    """-> origins [count,3], directions [count,3], (pixel_area [count,1] | None)"""
+                  ray_start: int = 0, count: Optional[int] = None, pixel_area: bool = False, distortion=None):
+    """-> origins [count,3], directions [count,3], (pixel_area [count,1] | None)
+    distortion: the camera's 6 OPENCV lens parameters (include/unerf.h: unerf_generate_rays) or None"""
     lib = _l.load()
     count = H * W - ray_start if count is None else count
     o = torch.empty(count, 3, device=device, dtype=torch.float32)
     d = torch.empty(count, 3, device=device, dtype=torch.float32)
     pa = torch.empty(count, 1, device=device, dtype=torch.float32) if pixel_area else None
+    dist = _host_distortion(distortion)
     with _ctx(o.device):
-        _run("generate_rays", lambda: lib.unerf_generate_rays(_host12(c2w), fx, fy, cx, cy, H, W, ray_start, count, _p(o), _p(d),
-                                         _p(pa), _stream()))
+        _run("generate_rays", lambda: lib.unerf_generate_rays(_host12(c2w), fx, fy, cx, cy, dist, H, W, ray_start, count,
+                                                              _p(o), _p(d), _p(pa), _stream()))
     return o, d, pa
 
 
@@ -313,6 +325,10 @@ class FieldDev:
     packed_lap_softplus: int = -1                # the density activation lap16_blob's density rows were scaled for
     packed_mode: int = -1                        # the mode mfma16_blob was laid out for (MCDROPOUT: folded trunk-out slabs)
     lap_softplus: int = 0                        # LAPLACE: density_activation "softplus" instead of trunc_exp
+    # LAPLACE, per-chunk last-layer samples (laplace_model.py:432-443: sample_laplace runs inside every eval chunk):
+    # ws_density / ws_rgb [sets, n, P] and the blobs [sets, LAP_BLOB_FLOATS]; ray g uses set g // lap_chunk_rays.
+    # 0: one set [n, P] for every ray
+    lap_chunk_rays: int = 0
     aabb: Optional[Tuple[float, ...]] = None     # 6 floats: scene-box normalisation instead of the contraction
     # the first colour layer UNFOLDED -- [63][64] transposed weights, bias without the appearance term, the eval embedding:
     # read only when drop_sites contains DROP_HEADIN (dropout on the head's inputs; VALU kernel, include/unerf.h)
@@ -343,13 +359,19 @@ class FieldDev:
         kw["packed_mode"] = mode
         kw["mfma16_blob"] = None if blob16 is None else f(blob16)   # None (weights beyond the f16 range): exact kernels
         lap_blob = None
-        if lap and kw.get("ws_density") is not None and kw["ws_density"].shape[0] <= 32 * LAP_BLOCKS:
-            lap_blob = f(pack_laplace_heads(kw["ws_density"], kw["ws_rgb"]))
-            lap16 = pack_laplace_heads16(kw["ws_density"], kw["ws_rgb"],
-                                         exp2_rows=bool(_l.load().unerf_build_flags() & _l.BUILD_LAP_EXP2),
-                                         softplus=bool(kw.get("lap_softplus", 0)))
-            kw["lap16_blob"] = None if lap16 is None else f(lap16)
+        if lap and kw.get("ws_density") is not None and kw["ws_density"].dim() == 3 and not kw.get("lap_chunk_rays"):
+            raise _l.UnerfError("FieldDev: stacked Laplace sample sets [sets, n, P] need lap_chunk_rays (rays per set)")
+        if lap and kw.get("ws_density") is not None and max(kw["ws_density"].shape[-2], kw["ws_rgb"].shape[-2]) <= 32 * LAP_BLOCKS:
+            wsd, wsr = kw["ws_density"], kw["ws_rgb"]
+            stacked = wsd.dim() == 3
+            lap_blob, lap16 = pack_laplace_sets(wsd if stacked else wsd[None], wsr if stacked else wsr[None], device,
+                                                exp2_rows=bool(_l.load().unerf_build_flags() & _l.BUILD_LAP_EXP2),
+                                                softplus=bool(kw.get("lap_softplus", 0)))
+            lap_blob = lap_blob.contiguous() if stacked else lap_blob[0].contiguous()
+            kw["lap16_blob"] = None if lap16 is None else (lap16 if stacked else lap16[0].contiguous())
             kw["packed_lap_softplus"] = int(bool(kw.get("lap_softplus", 0)))
+        if kw.get("ws_density") is not None:
+            kw["ws_density"], kw["ws_rgb"] = f(kw["ws_density"]), f(kw["ws_rgb"])
         return cls(mode, f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
                    f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
                    mfma_blob=blob, lap_blob=lap_blob, h0_full_t=f(h0.t()), hb0_raw=f(head_b[0]), app_embed=f(appearance),
@@ -390,14 +412,17 @@ class FieldDev:
             _p(self.w0t), _p(self.b0), _p(self.w1t), _p(self.b1), self.b1.numel(),
             _p(self.h0t), _p(self.hb0), _p(self.h1t), _p(self.hb1), _p(self.h2t), _p(self.hb2),
             self.average_init_density, self.beta_min, self.sh_remap, self.K, self.seed & 0xFFFFFFFF, self.p_drop,
-            _p(self.ws_density), _p(self.ws_rgb), 0 if self.ws_density is None else self.ws_density.shape[0],
+            _p(self.ws_density), _p(self.ws_rgb), 0 if self.ws_density is None else self.ws_density.shape[-2],
             int(self.lap_mask_density),
             _p(self.mfma_blob) if self.use_mfma else None, _p(self.lap_blob) if self.use_mfma else None,
             _p(self.tcnn_levels, torch.int32),
             _p(self.mfma16_blob) if (self.use_mfma and h16) else None,
             _p(self.lap16_blob) if (self.use_mfma and h16) else None, 0, 0, int(self.drop_sites), int(self.lap_softplus),
             0 if self.aabb is None else 1, _aabb6(self.aabb), 1 if self.precision == "f16" else 0, None,
-            _p(self.h0_full_t), _p(self.hb0_raw), _p(self.app_embed))
+            _p(self.h0_full_t), _p(self.hb0_raw), _p(self.app_embed),
+            int(self.lap_chunk_rays) if (self.ws_density is not None and self.ws_density.dim() == 3) else 0,
+            self.ws_density.shape[0] if (self.ws_density is not None and self.ws_density.dim() == 3) else 1,
+            0 if self.ws_rgb is None else self.ws_rgb.shape[-2])
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------
@@ -624,6 +649,68 @@ def pack_laplace_heads16(ws_density: torch.Tensor, ws_rgb: torch.Tensor, exp2_ro
     return torch.cat([head, tail.reshape(-1)])
 
 
+_LAP_MAPS: Dict[str, Tuple[torch.Tensor, ...]] = {}
+
+
+def _lap_maps(device):
+    """Row / column index maps of the two Laplace blob layouts (the loops of pack_laplace_heads / pack_laplace_heads16
+    as gather indices), built once per device."""
+    key = str(device)
+    if key not in _LAP_MAPS:
+        lane = torch.arange(64)
+        i, h = lane & 31, lane >> 5
+        b, bi, r = torch.arange(LAP_BLOCKS), torch.arange(2), torch.arange(16)
+        rows32 = ((32 * b)[:, None, None, None] + i[None, None, None, :]).expand(LAP_BLOCKS, 2, 16, 64)
+        cols32 = ((32 * bi)[None, :, None, None] + _mfma_unit(r[None, None, :, None], h[None, None, None, :])).expand(LAP_BLOCKS, 2, 16, 64)
+        brow = (32 * b)[:, None, None] + _mfma_unit(r[None, None, :], bi[None, :, None])                    # [B,2,16]
+        st, e = torch.arange(4), torch.arange(8)
+        rows16 = ((32 * b)[:, None, None, None] + i[None, None, :, None]).expand(LAP_BLOCKS, 4, 64, 8)
+        cols16 = (32 * (st >> 1)[None, :, None, None]
+                  + _mf16_unit((st & 1)[None, :, None, None], h[None, None, :, None], e[None, None, None, :])).expand(LAP_BLOCKS, 4, 64, 8)
+        _LAP_MAPS[key] = tuple(t.contiguous().to(device) for t in (rows32, cols32, brow, rows16, cols16))
+    return _LAP_MAPS[key]
+
+
+def pack_laplace_sets(ws_density: torch.Tensor, ws_rgb: torch.Tensor, device, exp2_rows: bool = False,
+                      softplus: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """T sets of sampled last layers at once, packed ON `device` (one gather per blob; the per-chunk draws of
+    NerfactoLaplaceModel make 64 sets per 1080p frame): ws_density [T,n,65], ws_rgb [T,n,195] ->
+    (lap_blob [T, LAP_BLOB_FLOATS], lap16_blob [T, LAP_BLOB_FLOATS] | None).  Row t equals
+    pack_laplace_heads(ws_density[t], ws_rgb[t]) / pack_laplace_heads16(..., exp2_rows, softplus) bit for bit
+    (tests/test_mfma_pack_cpu.py); None when an operand is outside the f16 range."""
+    wd = ws_density.detach().to(device=device, dtype=torch.float32)
+    wr = ws_rgb.detach().to(device=device, dtype=torch.float32)
+    T, n, nr = wd.shape[0], wd.shape[1], wr.shape[1]      # the colour head may carry its own number of rows
+    assert wd.shape == (T, n, 65) and wr.shape == (T, nr, 195) and 1 <= n <= 32 * LAP_BLOCKS and 1 <= nr <= 32 * LAP_BLOCKS
+    rows32, cols32, brow, rows16, cols16 = _lap_maps(wd.device)
+    rows = 32 * LAP_BLOCKS
+
+    def stack(d, c, pad_d, pad_c):
+        """-> W [T,4,rows,64] (padding rows 0), B [T,4,rows] (padding rows pad_*)"""
+        W = torch.zeros(T, 4, rows, 64, device=wd.device)
+        B = torch.empty(T, 4, rows, device=wd.device)
+        B[:, 0], B[:, 1:] = pad_d, pad_c
+        W[:, 0, :n], B[:, 0, :n] = d[:, :, :64], d[:, :, 64]
+        for ch in range(3):
+            W[:, 1 + ch, :nr], B[:, 1 + ch, :nr] = c[:, :, ch * 64:(ch + 1) * 64], c[:, :, 192 + ch]
+        return W, B
+
+    W, B = stack(wd, wr, LAP_PAD_BIAS, LAP_PAD_BIAS)
+    blob = torch.cat([W[:, :, rows32, cols32].reshape(T, -1), B[:, :, brow].reshape(T, -1)], dim=1)
+    assert blob.shape[1] == LAP_BLOB_FLOATS
+    if exp2_rows:   # the base change of the activation behind each row (pack_laplace_heads16)
+        wd = (wd.double() * (1.0 if softplus else LOG2E)).to(torch.float32)
+        wr = (wr.double() * -LOG2E).to(torch.float32)
+    if max(float(wd.abs().max()), float(wr.abs().max())) >= F16_OPERAND_LIMIT:
+        return blob, None
+    W, B = stack(wd, wr, LAP_PAD_BIAS, -LAP_PAD_BIAS if exp2_rows else LAP_PAD_BIAS)
+    hi, lo = _split_f16(W[:, :, rows16, cols16])                       # [T,4,B,4,64,8]
+    frag = torch.stack([hi, lo], dim=4).contiguous()                   # [T][q][b][s][hi|lo][lane][8]
+    head = frag.view(torch.int16).reshape(T, -1).view(torch.float32)
+    assert head.shape[1] == LAP_BIAS_OFF
+    return blob, torch.cat([head, B[:, :, brow].reshape(T, -1)], dim=1).contiguous()
+
+
 # ------------------------------------------------------- proposal sampling -------------
 
 def proposal_density(origins, directions, sbins, net: DensityNetDev, near: float, far: float,
@@ -718,7 +805,7 @@ def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: flo
     cs = field.cstruct()
     cs.image_width = int(image_width)
     cs.sample_major = 1 if sample_major else 0
-    cs.overflow_flag = _p(nonfinite_flag, torch.int32)      # read by the single-product (precision "f16") kernels only
+    cs.overflow_flag = _p(nonfinite_flag, torch.int32)      # set by the f16 matrix kernels (either form) on operand overflow
     with _ctx(dev):
         _run("field_fwd", lambda: lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, spacing, ray_offset,
                                      C.byref(cs), _p(features), _p(density), _p(rgb), _p(aux), _p(aux2), _stream()))
@@ -752,7 +839,7 @@ def laplace_ggn_diag(origins, directions, sbins, field: FieldDev, density_mean: 
     rm = rgb_mean.detach().to(device=dev, dtype=torch.float32).contiguous()
     if dm.numel() != 65 or rm.numel() != 195:
         raise _l.UnerfError("laplace_ggn_diag: density_mean must have 65 and rgb_mean 195 entries")
-    cs.ws_density, cs.ws_rgb, cs.n_lap = _p(dm), _p(rm), 1
+    cs.ws_density, cs.ws_rgb, cs.n_lap, cs.n_lap_rgb, cs.lap_chunk_rays, cs.lap_sets = _p(dm), _p(rm), 1, 1, 0, 1
     cs.mfma_blob = _p(field.mfma_blob)
     nbytes = lib.unerf_laplace_ggn_workspace_bytes(R, S)
     ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)

@@ -51,7 +51,8 @@ def _grid_tcnn(gen, num_levels, min_res, max_res, log2T, table_scale):
 def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, prop_log2T: int = 17,
                        max_res: int = 2048, table_scale: float = 0.5, density_gain: float = 16.0,
                        density_bias: float = -2.0, color_gain: float = 4.0, beta_gain: float = 12.0,
-                       grid: str = "torch", sharp: bool = False, overflow_units: Tuple[int, ...] = ()) -> Dict:
+                       grid: str = "torch", sharp: bool = False, overflow_units: Tuple[int, ...] = (),
+                       head_overflow_units: Tuple[int, ...] = ()) -> Dict:
     """Random-init nerfacto-shaped scene.  Tables U(-1,1)*table_scale; Linear layers
     Kaiming-uniform like nn.Linear; the density row is gained up so accumulation, depth and the
     variances vary over the image instead of saturating.
@@ -61,7 +62,11 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
     scaled up, the next layer's weights scaled down to match), proposal logits likewise.
     overflow_units: trunk hidden units whose pre-activations reach past 65504 -- beyond the f16 operand range of the
     f16 matrix kernels -- on ~9 % of the samples (first-layer rows of +-5e4, inside the weight limit the packer checks);
-    their outgoing weights are 1e-6-small, so in fp32 arithmetic they move the outputs by less than 1."""
+    their outgoing weights are 1e-6-small, so in fp32 arithmetic they move the outputs by less than 1.
+    head_overflow_units: the same for units of the COLOUR head's first hidden layer (rows of +-5e4 around a bias of 6e4
+    -- the bias is not an f16 operand --, i.e. pre-activations of 6e4 +- 2e4: past 65504 on about a third of the samples;
+    outgoing weights of 1e-6 into the second hidden layer): the overflow then happens behind a ReLU and two layers
+    away from any output."""
     assert kind in ("active", "mcdropout", "laplace") and grid in ("torch", "tcnn")
     gen = torch.Generator().manual_seed(seed)
     make_grid = _grid_tcnn if grid == "tcnn" else _grid
@@ -117,6 +122,10 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
         f["w1"][:, u] = torch.sign(f["w1"][:, u]) * 1e-6
         if kind == "laplace":
             f["density_w"][:, u] = torch.sign(f["density_w"][:, u]) * 1e-6
+    for u in head_overflow_units:
+        f["head_w"][0][u] = torch.sign(f["head_w"][0][u]) * 5e4
+        f["head_b"][0][u] = 6e4
+        f["head_w"][1][:, u] = torch.sign(f["head_w"][1][:, u]) * 1e-6
     return {"kind": kind, "field": f, "props": props, "near": 0.05, "far": 1000.0, "num_prop": (256, 96),
             "num_nerf": 48, "prop_average_init_density": 0.01}
 
