@@ -16,7 +16,12 @@ cd /tmp
 
 margs() {  # profile id -> bench.py arguments
     case $1 in
+        # profile ids name the arithmetic: <method> = the split-f16 (fp32-equivalent) kernels, <method>_f16 = one f16
+        # product per MAC (bench.py's default for mcdropout and active: the reference's own eval precision)
+        mcdropout) echo "--method mcdropout --precision f16x2" ;;
         mcdropout_f16) echo "--method mcdropout --precision f16" ;;
+        active) echo "--method active --precision f16x2" ;;
+        active_f16) echo "--method active --precision f16" ;;
         *) echo "--method $1" ;;
     esac
 }
@@ -40,7 +45,7 @@ pmc() {  # method, set name, counters...
     [ -n "$f" ] && python3 "$ROOT/benchmarks/summarize_pmc.py" reduce "$f" "$DST/${TAG}_${m}_pmc_$name.csv"
 }
 
-ALL="active mcdropout mcdropout_f16 laplace splat"
+ALL="active active_f16 mcdropout mcdropout_f16 laplace splat"
 for m in $ALL; do stats $m; done
 for m in $ALL; do
     pmc $m fetch FETCH_SIZE

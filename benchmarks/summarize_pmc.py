@@ -38,11 +38,16 @@ def reduce(src, dst):
 
 # the dominant field kernel of a method = the first kernel name with one of these prefixes (template arguments after the
 # prefix -- tcnn / sites / drop flags -- vary with the round)
-FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false", "field_kernel_mfma<0, false"),
+FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false, false, false, false", "field_kernel_mfma<0, false"),
+                 "active_f16": ("field_kernel_mfma16<0, false, false, false, true",),
                  "mcdropout": ("field_kernel_mfma16<1, false, false, true, false", "field_kernel_mfma16<1, false", "field_kernel_mfma<1, false"),
                  "mcdropout_f16": ("field_kernel_mfma16<1, false, false, true, true",),
                  "laplace": ("field_kernel_mfma16_laplace<false, false", "field_kernel_mfma16_laplace<false"),
                  "splat": ("raster_kernel<5",)}
+# the kernels of one unerf_splat_bin_sort call (substrings of the short names)
+SORT_KERNELS = ("depth_keys_kernel", "sorted_counts_kernel", "map_intersects_kernel", "tile_hist_kernel", "tile_colsum_kernel",
+                "tile_segscan_kernel", "tile_scan_kernel", "tile_apply_kernel", "tile_scatter_kernel", "tile_edges_kernel",
+                "merge_sort", "radix_sort", "onesweep", "scan_config", "lookback_scan")
 # further kernels of a profile that get their own issue_<name>.json (same definition)
 EXTRA_ISSUE = {"laplace": {"lap_depth": ("lap_depth_kernel<3",)}, "splat": {"splat_raster1": ("raster_kernel<1",)}}
 K_OF = {"mcdropout": 8, "mcdropout_f16": 8}
@@ -71,7 +76,7 @@ def _source_digest():
 
 def summary(d, tag):
     digest = _source_digest()
-    for method in ("active", "mcdropout", "mcdropout_f16", "laplace", "splat"):
+    for method in ("active", "active_f16", "mcdropout", "mcdropout_f16", "laplace", "splat"):
         kernels = defaultdict(dict)
         for fn in sorted(os.listdir(d)):
             m = re.match(rf"{tag}_{method}_pmc_(\w+)\.csv$", fn)
@@ -101,6 +106,19 @@ def summary(d, tag):
                      "write_bytes": kernels[fk]["WRITE_SIZE"] * 1024.0,
                      "correction": "none: the reads are 8-byte gathers (one 64-B fabric request each), not the wide "
                                    "coalesced streams for which MI355X_MICROARCH.md prescribes x2; writes read exact"}}}
+            if method == "splat":
+                # the bin-and-sort CALL is a dozen kernels (depth keys, rocprim merge sort + scans, emission, the one-pass
+                # tile sort): its fabric traffic = the per-frame sum of their FETCH_SIZE + WRITE_SIZE
+                sort_names = [k for k in kernels if any(p in k for p in SORT_KERNELS) and "FETCH_SIZE" in kernels[k]
+                              and "WRITE_SIZE" in kernels[k]]
+                per_frame = lambda k, c: kernels[k][c] * 1024.0 * kernels[k].get("launches", 0) / PMC_FRAMES
+                t["kernels"]["splat_bin_sort"] = {
+                    "kernel_names": sorted(sort_names),
+                    "fetch_bytes": sum(per_frame(k, "FETCH_SIZE") for k in sort_names),
+                    "write_bytes": sum(per_frame(k, "WRITE_SIZE") for k in sort_names),
+                    "per_kernel_bytes": {k: {"fetch": per_frame(k, "FETCH_SIZE"), "write": per_frame(k, "WRITE_SIZE"),
+                                             "launches_per_frame": kernels[k].get("launches", 0) / PMC_FRAMES} for k in sorted(sort_names)},
+                    "correction": "none (see field_fwd)"}
             with open(os.path.join(d, f"traffic_{method}.json"), "w") as f:
                 json.dump(t, f, indent=1)
         need = ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")

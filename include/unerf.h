@@ -323,6 +323,12 @@ typedef struct {
        reference's forward_unc does not pass n_samples on to the colour head (laplace_field.py:516-520), which therefore
        always draws its default 100 whatever the density head was asked for. */
     int n_lap_rgb;
+    /* ACTIVE / MCDROPOUT, ray-major layout: 1 = the outputs leave as ONE 16-byte row (sigma, r, g, b) per (pass, ray,
+       sample): `rgb` is [B,R,S,4] and `density` is not written (may be NULL).  A kernel tile is 32 rays at one sample
+       slot, so every store of the [B,R,S] + [B,R,S,3] layout is a lone 4-byte write into its own cache line; the packed
+       row is one dwordx4 store, and unerf_composite_var / unerf_composite_moments read it back with one 16-byte load
+       (pass density = NULL and the packed rows as rgb).  Same values either way. */
+    int packed_out;
 } unerf_field_params;
 #define UNERF_DROP_TRUNK 1
 #define UNERF_DROP_HEAD0 2

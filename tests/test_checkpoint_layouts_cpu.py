@@ -244,3 +244,23 @@ def test_ensemble_member_configs_exist_for_every_method_the_reference_ensembles(
     m = _model("nerfacto")
     assert isinstance(m.field, F.NerfactoField) and m.field.average_init_density == 0.01
     assert M.NerfactoModelConfig().proposal_initial_sampler == "piecewise" and M.NerfactoModelConfig().background_color == "last_sample"
+
+
+def test_an_alias_next_to_its_canonical_key_must_agree():
+    """a checkpoint that carries BOTH `n.0.hash_table` (older Sequential layout) and `n.encoder.hash_table` with
+    different tensors used to keep the canonical one and drop the alias silently; equal tensors are fine, different ones
+    raise, and keys under the alias prefixes that are not one of the modules' leaves are left alone (unexpected keys)."""
+    m = _model("nerfacto")
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    canon = "proposal_networks.0.mlp_base.encoder.hash_table"
+    assert canon in sd
+    both = dict(sd)
+    both["proposal_networks.0.mlp_base.0.hash_table"] = sd[canon].clone()
+    M.load_checked(m, both, strict=True)                                       # the same tensor twice: loads
+    both["proposal_networks.0.mlp_base.0.hash_table"] = sd[canon] + 1.0
+    with pytest.raises(RuntimeError, match="different contents"):
+        M.load_checked(m, both)
+    odd = dict(sd)
+    odd["proposal_networks.0.mlp_base.0.running_mean"] = torch.zeros(3)        # not a leaf these modules own
+    rep = M.load_checked(m, odd)
+    assert "proposal_networks.0.mlp_base.0.running_mean" in rep.unexpected_keys

@@ -359,6 +359,37 @@ def test_field_laplace_matches_oracle(dev, use_mfma, precision, n_samples):
 
 @pytest.mark.parametrize("use_mfma,precision", [(True, "f16x2"), (True, "f16"), (True, "fp32"), (False, "fp32")],
                          ids=["mfma16", "mfma16-f16", "mfma32", "valu"])
+@pytest.mark.parametrize("kind", ["active", "mcdropout"])
+def test_packed_output_rows_hold_the_same_bits(dev, kind, use_mfma, precision):
+    """unerf_field_params.packed_out: one 16-byte row (sigma, r, g, b) per (pass, ray, sample) instead of a dword into
+    `density` and three into `rgb` -- the same values bit for bit from every kernel set, with and without the pixel-patch
+    tile schedule, and the composite entry points give the same images from either layout."""
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    kw = dict(K=3, seed=5, p_drop=0.2) if kind == "mcdropout" else {}
+    t, sc, sd = _scene(kind, dev, **kw)
+    sd.field.use_mfma, sd.field.precision = use_mfma, precision
+    H, W = 12, 40
+    o, d = _rays(H, W)
+    sb = _final_bins(sc, o, d).to(dev)
+    o, d = o.to(dev), d.to(dev)
+    for iw in (0, W):
+        dens, rgb, aux, _ = ops.field_fwd(o, d, sb, sd.field, NEAR, FAR, image_width=iw)
+        none, rows, aux2, _ = ops.field_fwd(o, d, sb, sd.field, NEAR, FAR, image_width=iw, packed=True)
+        assert none is None and rows.shape == dens.shape + (4,)
+        assert torch.equal(rows[..., 0], dens) and torch.equal(rows[..., 1:], rgb)
+        assert (aux is None and aux2 is None) or torch.equal(aux, aux2)
+    if kind == "active":
+        a = ops.composite_var(dens, rgb, sb, NEAR, FAR, beta=aux)
+        b = ops.composite_var(None, rows, sb, NEAR, FAR, beta=aux)
+        assert torch.equal(a, b)
+    else:
+        for x, y in zip(ops.composite_moments(dens, rgb, sb, NEAR, FAR), ops.composite_moments(None, rows, sb, NEAR, FAR)):
+            assert torch.equal(x, y)
+        assert torch.equal(ops.composite_var(dens, rgb, sb, NEAR, FAR), ops.composite_var(None, rows, sb, NEAR, FAR))
+
+
+@pytest.mark.parametrize("use_mfma,precision", [(True, "f16x2"), (True, "f16"), (True, "fp32"), (False, "fp32")],
+                         ids=["mfma16", "mfma16-f16", "mfma32", "valu"])
 def test_field_laplace_per_chunk_sample_sets(dev, use_mfma, precision):
     """unerf_field_params.lap_chunk_rays: the reference draws a fresh set of last-layer samples in every eval chunk
     (laplace_model.py:432-443 -> laplace_field.py:331-339, 468-476, 545).  A stack of sets [sets, n, P]; ray g is

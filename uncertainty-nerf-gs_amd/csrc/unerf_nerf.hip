@@ -1080,6 +1080,13 @@ __device__ __forceinline__ OutIndex out_index(const FieldArgs& a, int k, const T
     }
     return o;
 }
+// packed_out: ONE 16-byte row (sigma, r, g, b) per (pass, ray, sample) in `rgb` [B,R,S,4] instead of a dword into
+// `density` and three into `rgb`.  A tile's columns are 32 rays at one sample slot, so every store of the ray-major
+// layouts is a lone write into its own cache line: four 4-byte stores per sample reached the fabric as 1.84 x (K-pass)
+// to 3.4 x (ACTIVE) the algorithmic bytes at 2^20-ray launch groups (profiles/traffic_*.json, round 3).
+__device__ __forceinline__ void store_packed(const FieldArgs& a, int k, int64_t n, float sigma, float r, float g, float b) {
+    reinterpret_cast<float4*>(a.rgb)[(int64_t)k * (a.R * (int64_t)a.S) + n] = make_float4(sigma, r, g, b);
+}
 
 // LAPLACE with per-chunk sample sets (unerf_field_params.lap_chunk_rays): the blob of the set a tile's rays belong to.
 // Tiles are 1-D there (32 consecutive rays, host: make_tiles without an image width) and chunk / launch boundaries are
@@ -1218,11 +1225,15 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
         float c[3];
         dense_lds<64, 3>(a.p.h2t, a.p.hb2, A, lane, c);
         if (valid) {
-            a.density[n] = density;
             a.aux[n] = beta;
-            a.rgb[n * 3 + 0] = unerf_sigmoid(c[0]);
-            a.rgb[n * 3 + 1] = unerf_sigmoid(c[1]);
-            a.rgb[n * 3 + 2] = unerf_sigmoid(c[2]);
+            if (a.p.packed_out) {
+                store_packed(a, 0, n, density, unerf_sigmoid(c[0]), unerf_sigmoid(c[1]), unerf_sigmoid(c[2]));
+            } else {
+                a.density[n] = density;
+                a.rgb[n * 3 + 0] = unerf_sigmoid(c[0]);
+                a.rgb[n * 3 + 1] = unerf_sigmoid(c[1]);
+                a.rgb[n * 3 + 2] = unerf_sigmoid(c[2]);
+            }
         }
     } else if constexpr (MODE == UNERF_FIELD_MCDROPOUT) {
         store_act<64>(A, lane, acc, 0, true);  // hidden h stays in A for every pass
@@ -1255,7 +1266,9 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
             float c[3];
             if (a.drop_sites & UNERF_DROP_HEAD1) dense_lds_dropout<3>(a.p.h2t, a.p.hb2, Bf, lane, base, k, 1u, a.keep_hi, a.drop_scale, c);
             else dense_lds<64, 3>(a.p.h2t, a.p.hb2, Bf, lane, c);
-            if (valid) {
+            if (valid && a.p.packed_out) {
+                store_packed(a, k, n, density, unerf_sigmoid(c[0]), unerf_sigmoid(c[1]), unerf_sigmoid(c[2]));
+            } else if (valid) {
                 int64_t q = (int64_t)k * N + n;
                 a.density[q] = density;
                 a.rgb[q * 3 + 0] = unerf_sigmoid(c[0]);
@@ -1635,10 +1648,15 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             }
             if (valid && h == 0) {
                 const OutIndex q = out_index(a, k, ts);
-                a.density[q.dens] = a.p.average_init_density * expf(t[0]) * sel;
-                a.rgb[q.rgb] = rgbv[0];
-                a.rgb[q.rgb + q.rgb_stride] = rgbv[1];
-                a.rgb[q.rgb + 2 * q.rgb_stride] = rgbv[2];
+                const float sigma = a.p.average_init_density * expf(t[0]) * sel;
+                if (a.p.packed_out) {   // uniform
+                    store_packed(a, k, ts.n, sigma, rgbv[0], rgbv[1], rgbv[2]);
+                } else {
+                    a.density[q.dens] = sigma;
+                    a.rgb[q.rgb] = rgbv[0];
+                    a.rgb[q.rgb + q.rgb_stride] = rgbv[1];
+                    a.rgb[q.rgb + 2 * q.rgb_stride] = rgbv[2];
+                }
                 if (MODE == UNERF_FIELD_ACTIVE) a.aux[q.aux] = unerf_softplus(t[8]) + a.p.beta_min;
             }
         }
@@ -2078,9 +2096,18 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 if (F1) f1_bad |= !(fabsf(x) < INFINITY) | !(fabsf(y) < INFINITY);
                 const float ey = __expf(y);
                 const float vy = h ? __builtin_amdgcn_rcpf(1.f + ey) : a.p.average_init_density * ey * sel;
-                a.rgb[q.rgb + (h ? q.rgb_stride : 0)] = mf_sigmoid_fast(x);
-                float* py = h ? a.rgb + (q.rgb + 2 * q.rgb_stride) : a.density + q.dens;
-                *py = vy;
+                const float vx = mf_sigmoid_fast(x);
+                if (a.p.packed_out) {   // uniform.  (vx, vy) = (red, sigma) in the h = 0 half, (green, blue) in the h = 1 half:
+                    // one v_permlane32_swap each brings the upper half's pair down, and the lower half stores 16 bytes
+                    // (a column's two lanes are the same sample: `valid` is the same in both)
+                    const auto gx = __builtin_amdgcn_permlane32_swap(__float_as_uint(vx), __float_as_uint(vx), false, false);
+                    const auto gy = __builtin_amdgcn_permlane32_swap(__float_as_uint(vy), __float_as_uint(vy), false, false);
+                    if (h == 0) store_packed(a, k, ts.n, vy, vx, __uint_as_float(gx[1]), __uint_as_float(gy[1]));
+                } else {
+                    a.rgb[q.rgb + (h ? q.rgb_stride : 0)] = vx;
+                    float* py = h ? a.rgb + (q.rgb + 2 * q.rgb_stride) : a.density + q.dens;
+                    *py = vy;
+                }
                 if (MODE == UNERF_FIELD_ACTIVE && h == 0) a.aux[q.aux] = unerf_softplus(t[8]) + a.p.beta_min;
             }
         }
@@ -2376,6 +2403,80 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
     sum2 = s12.y + __shfl_xor(s12.y, 32, 64);
 }
 
+// UNERF_LAP_PREFETCH >= 2: the same head evaluation as ONE operand stream over NHEADS consecutive heads with the loads
+// running TWO row blocks ahead of the matrix work (three rotating register buffers instead of two).  The kernel was
+// latency-bound on exactly this stream -- 8 KB per wave and block from L2, one block (~0.9 us of two waves' work) of
+// lead against ~1.4 us of loaded L2 latency: issue-busy 0.575, SQ_WAIT_ANY 0.34 (profiles/issue_laplace.json, round
+// 3) -- and every head started cold; the three colour heads now run as one 12-block stream.
+#ifndef UNERF_LAP_PREFETCH
+#define UNERF_LAP_PREFETCH 2
+#endif
+#ifndef UNERF_LAP_BIAS_LDS
+#define UNERF_LAP_BIAS_LDS 1     // the 512 bias words of a sample set staged in LDS per wave and tile (see the kernel)
+#endif
+template <int ACT, bool F1, int NHEADS>
+__device__ __forceinline__ void mf16_lap_stream(const float* __restrict__ lap, const float* __restrict__ lds_bias, int q0,
+                                                int n_lap, int lane, const f16x8 (&bhi)[4], const f16x8 (&blo)[4], int h,
+                                                float (&sum1)[NHEADS], float (&sum2)[NHEADS]) {
+    constexpr int NB = NHEADS * LAP_BLOCKS;
+    f16x8 buf[3][8];
+    const float* base = lap + (size_t)(q0 * LAP_BLOCKS * 8) * 256 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 8; i += (F1 ? 2 : 1)) buf[0][i] = *reinterpret_cast<const f16x8*>(base + i * 256);
+    if (NB > 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i += (F1 ? 2 : 1)) buf[1][i] = *reinterpret_cast<const f16x8*>(base + (8 + i) * 256);
+    }
+    unerf_v2f s12 = {0.f, 0.f}, pr = {1.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        const int b = blk % LAP_BLOCKS, hd = blk / LAP_BLOCKS;
+        if (blk + 2 < NB) {
+#pragma unroll
+            for (int i = 0; i < 8; i += (F1 ? 2 : 1))
+                buf[(blk + 2) % 3][i] = *reinterpret_cast<const f16x8*>(base + ((blk + 2) * 8 + i) * 256);
+        }
+        const f16x8 (&cur)[8] = buf[blk % 3];
+        const float4* bp = reinterpret_cast<const float4*>((UNERF_LAP_BIAS_LDS ? lds_bias : lap + LAP_BIAS_OFF) +
+                                                           (((q0 + hd) * LAP_BLOCKS + b) * 2 + h) * 16);
+        float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+        if (b == 0) s12 = unerf_v2f{0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);   // (see mf16_lap_head: the inline-asm packed fma and its operands stay in one region)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            if (!F1) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st + 1], bhi[st], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st], blo[st], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * st], bhi[st], acc, 0, 0, 0);
+        }
+        const int rows = n_lap - 32 * b;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            if (8 * qd < rows) {  // uniform
+#pragma unroll
+                for (int r = 4 * qd; r < 4 * qd + 4; ++r) {
+                    float p;
+                    if (ACT == 2) {
+                        p = mf_softplus_fast(acc[r]);
+                    } else {
+                        const float e = UNERF_LAP_EXP2 ? __builtin_amdgcn_exp2f(acc[r]) : __expf(ACT == 1 ? -acc[r] : acc[r]);
+                        p = ACT == 1 ? __builtin_amdgcn_rcpf(1.f + e) : e;
+                    }
+                    pr.y = p;
+                    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(s12) : "v"(pr));
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (b == LAP_BLOCKS - 1) {
+            sum1[hd] = s12.x + __shfl_xor(s12.x, 32, 64);
+            sum2[hd] = s12.y + __shfl_xor(s12.y, 32, 64);
+        }
+    }
+}
+
 template <bool TCNN, bool F1 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCNN) ? 3 : 2))) void field_kernel_mfma16_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
@@ -2385,6 +2486,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
     __shared__ uint32_t s_tl[TCNN ? MF_TL_WORDS : 1];
+    // The bias rows of the sampled heads (16 per lane half and row block: the accumulators' initial values).  As global
+    // loads in front of every block's first MFMA they were the one load of the head loop whose latency nothing hid --
+    // 16 round trips to L2 per tile.  Each wave brings its tile's 512 words in with two 16-byte loads per lane while the
+    // hash grid is gathered, parks them in LDS, and the blocks read them back with ds_read_b128.
+    __shared__ float s_lbias[UNERF_LAP_BIAS_LDS && UNERF_LAP_PREFETCH >= 2 ? 4 : 1][UNERF_LAP_BIAS_LDS && UNERF_LAP_PREFETCH >= 2 ? 512 : 4];
     if (TCNN) mf_stage_tcnn_levels(a, s_tl);
     __syncthreads();
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2405,8 +2511,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
         float px = ts.px, py = ts.py, pz = ts.pz;
         // inference: the returned mu_d is NOT selector-masked (laplace_field.py:356-362) unless lap_mask_density
         const float sel = unerf_normalize_position(px, py, pz, a.box);
+        constexpr bool BIAS_LDS = UNERF_LAP_BIAS_LDS && UNERF_LAP_PREFETCH >= 2 && !(F1 && !TCNN);
+        float4 lb0, lb1;
+        if (BIAS_LDS) {
+            const float4* lbsrc = reinterpret_cast<const float4*>(lap_set_blob(a, a.p.lap16_blob, tile, div_s) + LAP_BIAS_OFF) + lane_c * 2;
+            lb0 = lbsrc[0];
+            lb1 = lbsrc[1];
+        }
         const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
+        if (BIAS_LDS) {   // (the previous tile's heads are done with the buffer: a wave's LDS operations execute in order)
+            float4* dst = reinterpret_cast<float4*>(s_lbias[wv]) + lane_c * 2;
+            dst[0] = lb0;
+            dst[1] = lb1;
+        }
 
+        const float* lap16 = lap_set_blob(a, a.p.lap16_blob, tile, div_s);
+        // (the single-product kernel at three waves per SIMD has no registers for a third operand buffer: it keeps the
+        // one-block-ahead heads)
+        constexpr bool STREAM = UNERF_LAP_PREFETCH >= 2 && !(F1 && !TCNN);
         // base_mlp: bare Linear 32 -> 64 (no ReLU, utils.py:22-23)
         f32x16 hb0 = mf16_bias(lds, 0, h), hb1 = mf16_bias(lds, 1, h);
 #pragma unroll
@@ -2423,9 +2545,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
 #pragma unroll
         for (int st = 0; st < 4; ++st) t = mf16_mac<F1>(lds, 4 + st, lane, xhi[st], xlo[st], t);
         float d1, d2;
-        const float* lap16 = lap_set_blob(a, a.p.lap16_blob, tile, div_s);
-        if (a.p.lap_softplus) mf16_lap_head<2, F1>(lap16, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);   // uniform
-        else mf16_lap_head<0, F1>(lap16, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
+        if constexpr (STREAM) {
+            float ds1[1], ds2[1];
+            if (a.p.lap_softplus) mf16_lap_stream<2, F1, 1>(lap16, s_lbias[wv], 0, a.p.n_lap, lane, xhi, xlo, h, ds1, ds2);   // uniform
+            else mf16_lap_stream<0, F1, 1>(lap16, s_lbias[wv], 0, a.p.n_lap, lane, xhi, xlo, h, ds1, ds2);
+            d1 = ds1[0];
+            d2 = ds2[0];
+        } else {
+            if (a.p.lap_softplus) mf16_lap_head<2, F1>(lap16, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);   // uniform
+            else mf16_lap_head<0, F1>(lap16, 0, a.p.n_lap, lane, xhi, xlo, h, d1, d2);
+        }
         float mu_d = d1 * inv_n, mu2_d = d2 * inv_n;
         if (a.p.lap_mask_density) {  // use_deterministic_density: selector-masked mean, no variance
             mu_d *= sel;
@@ -2467,12 +2596,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
 #pragma unroll
         for (int st = 0; st < 4; ++st) mf16_split<F1>(st < 2 ? x0 : x1, st & 1, xhi[st], xlo[st]);
         float mu_c[3], vsum = 0.f;
+        if constexpr (STREAM) {
+            float cs1[3], cs2[3];
+            mf16_lap_stream<1, F1, 3>(lap16, s_lbias[wv], 1, a.p.n_lap_rgb, lane, xhi, xlo, h, cs1, cs2);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float c1s, c2s;
-            mf16_lap_head<1, F1>(lap16, 1 + c, a.p.n_lap_rgb, lane, xhi, xlo, h, c1s, c2s);
-            mu_c[c] = c1s * inv_nr;
-            vsum += fmaxf(c2s * inv_nr - mu_c[c] * mu_c[c], 0.f);
+            for (int c = 0; c < 3; ++c) {
+                mu_c[c] = cs1[c] * inv_nr;
+                vsum += fmaxf(cs2[c] * inv_nr - mu_c[c] * mu_c[c], 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float c1s, c2s;
+                mf16_lap_head<1, F1>(lap16, 1 + c, a.p.n_lap_rgb, lane, xhi, xlo, h, c1s, c2s);
+                mu_c[c] = c1s * inv_nr;
+                vsum += fmaxf(c2s * inv_nr - mu_c[c] * mu_c[c], 0.f);
+            }
         }
         // F1: an f16 operand beyond 65504 turns the sampled rows into +-inf / NaN; a density mean of +inf from a FINITE
         // logit is not possible below e^88, so non-finite means are treated as operand overflow (see field_kernel_mfma16)
@@ -2596,7 +2735,9 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                                float near_plane, float far_plane, int spacing, int64_t ray_offset, const unerf_field_params* p,
                                const float* features, float* density, float* rgb, float* aux, float* aux2,
                                void* stream) {
-    UNERF_REQUIRE(p && (R == 0 || (origins && directions && sbins && density && rgb)), "field_fwd: null pointer");
+    UNERF_REQUIRE(p && (R == 0 || (origins && directions && sbins && (density || p->packed_out) && rgb)), "field_fwd: null pointer");
+    UNERF_REQUIRE(!p->packed_out || (p->mode != UNERF_FIELD_LAPLACE && !p->sample_major),
+                  "field_fwd: packed_out rows are written by the ACTIVE / MCDROPOUT kernels in the ray-major layout only");
     UNERF_REQUIRE(p->table && (p->scalings || p->tcnn_levels) && p->w0t && p->b0 && p->w1t && p->b1 && p->h0t &&
                       p->hb0 && p->h1t && p->hb1 && p->h2t && p->hb2,
                   "field_fwd: null weight pointer");
@@ -2963,19 +3104,31 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
                                               const CompGeom<SPL>& gm) {
     const int S = a.S, k0 = l16 * SPL;
     float delta[SPL], steps[SPL], dens[SPL], w[SPL];
+    struct Rgb { float r, g, b; };
+    Rgb col[SPL];
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
         delta[e] = gm.delta[e];
         steps[e] = gm.steps[e];
-        dens[e] = (!RAGGED || k0 + e < S) ? a.density[g * S + k0 + e] : 0.f;
     }
-    // colours requested with the densities, one 12-byte load per sample (the three channels as separate dword
-    // loads tripled the texture-unit work of this kernel), and consumed after the scan
-    struct Rgb { float r, g, b; };
-    Rgb col[SPL];
+    if (a.density == nullptr) {   // uniform: packed rows (sigma, r, g, b) [B,R,S,4] (unerf_field_params.packed_out): one
+        // 16-byte load per sample
 #pragma unroll
-    for (int e = 0; e < SPL; ++e)
-        col[e] = (!RAGGED || k0 + e < S) ? reinterpret_cast<const Rgb*>(a.rgb)[g * S + k0 + e] : Rgb{0.f, 0.f, 0.f};
+        for (int e = 0; e < SPL; ++e) {
+            const float4 v = (!RAGGED || k0 + e < S) ? reinterpret_cast<const float4*>(a.rgb)[g * S + k0 + e]
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            dens[e] = v.x;
+            col[e] = Rgb{v.y, v.z, v.w};
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) dens[e] = (!RAGGED || k0 + e < S) ? a.density[g * S + k0 + e] : 0.f;
+        // colours requested with the densities, one 12-byte load per sample (the three channels as separate dword
+        // loads tripled the texture-unit work of this kernel), and consumed after the scan
+#pragma unroll
+        for (int e = 0; e < SPL; ++e)
+            col[e] = (!RAGGED || k0 + e < S) ? reinterpret_cast<const Rgb*>(a.rgb)[g * S + k0 + e] : Rgb{0.f, 0.f, 0.f};
+    }
     if (a.flag) {   // uniform.  NaN inputs: the signature of an f16 operand overflow in the field kernel (|x| >= 65504 ->
         // hi = inf, lo = -inf -> NaN), which the nan_to_num calls below would otherwise turn into a plausible pixel.
         // One ballot per wave, one atomic per OFFENDING wave.
@@ -3158,7 +3311,7 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
                                    const float* sbins, int B, int64_t R, int S, float near_plane, float far_plane, int spacing,
                                    const float* clip_minmax, int64_t ray_offset, int64_t chunk_rays, int background,
                                    const float* background_rgb, int32_t* nonfinite_flag, float* out, void* stream) {
-    UNERF_REQUIRE(R == 0 || (density && rgb && sbins && out), "composite_var: null pointer");
+    UNERF_REQUIRE(R == 0 || (rgb && sbins && out), "composite_var: null pointer");   // density NULL: rgb holds packed rows
     UNERF_REQUIRE(B >= 1 && R >= 0, "composite_var: bad B/R");
     UNERF_REQUIRE(S >= 1 && S <= 256, "composite_var: S=%d outside [1,256]", S);
     UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "composite_var: chunk_rays must be > 0 with clip_minmax");
@@ -3179,7 +3332,7 @@ extern "C" int unerf_composite_moments(const float* density, const float* rgb, c
                                        float near_plane, float far_plane, int spacing, const float* clip_minmax, int64_t ray_offset,
                                        int64_t chunk_rays, int background, const float* background_rgb,
                                        int32_t* nonfinite_flag, float* mean_out, float* var_out, void* stream) {
-    UNERF_REQUIRE(R == 0 || (density && rgb && sbins && mean_out && var_out), "composite_moments: null pointer");
+    UNERF_REQUIRE(R == 0 || (rgb && sbins && mean_out && var_out), "composite_moments: null pointer");   // density NULL: packed rows
     UNERF_REQUIRE(B >= 1 && B <= 16 && R >= 0, "composite_moments: B=%d outside [1,16] (use composite_var + moments)", B);
     UNERF_REQUIRE(S >= 1 && S <= 256, "composite_moments: S=%d outside [1,256]", S);
     UNERF_REQUIRE(!clip_minmax || chunk_rays > 0, "composite_moments: chunk_rays must be > 0 with clip_minmax");

@@ -511,7 +511,7 @@ static SortWs sort_ws_layout(int64_t N, int64_t I) {
     const TileSortPlan tp = tile_sort_plan(I, TS_MAX_T1 - 1);
     w.ts_table = take((int64_t)tp.rows * TS_MAX_T1 * 4);
     w.ts_segsum = take((int64_t)TS_SEG * TS_MAX_T1 * 4);
-    w.ts_start = take((int64_t)(TS_MAX_T1 + 1) * 4);
+    w.ts_start = take((int64_t)(2 * TS_MAX_T1 + 2) * 4);     // start [T1 + 1] + total [T1]
     w.total = off + 1024;
     return w;
 }
@@ -683,7 +683,25 @@ __global__ __launch_bounds__(256) void tile_hist_kernel(const TKey* __restrict__
     for (int t = threadIdx.x; t < T1; t += 256) s_hist[t] = 0u;
     __syncthreads();
     const int64_t k0 = (int64_t)blockIdx.x * chunk, k1 = (k0 + chunk < I) ? k0 + chunk : I;   // rows past the last chunk: zeros
-    for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+    // 16 bytes of keys per lane and load (chunk starts are multiples of 256 keys: aligned); the tail key by key
+    constexpr int PER = 16 / (int)sizeof(TKey);
+    const int64_t nvec = k1 > k0 ? (k1 - k0) / PER : 0;
+    const uint4* kv = reinterpret_cast<const uint4*>(keys + k0);
+    for (int64_t v = threadIdx.x; v < nvec; v += 256) {
+        const uint4 q = kv[v];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (sizeof(TKey) == 2) {
+                const uint32_t a = w[i] & 0xFFFFu, b = w[i] >> 16;
+                atomicAdd(&s_hist[a < (uint32_t)T1 ? a : (uint32_t)(T1 - 1)], 1u);
+                atomicAdd(&s_hist[b < (uint32_t)T1 ? b : (uint32_t)(T1 - 1)], 1u);
+            } else {
+                atomicAdd(&s_hist[w[i] < (uint32_t)T1 ? w[i] : (uint32_t)(T1 - 1)], 1u);
+            }
+        }
+    }
+    for (int64_t k = k0 + nvec * PER + threadIdx.x; k < k1; k += 256) {
         const uint32_t key = (uint32_t)keys[k];
         atomicAdd(&s_hist[key < (uint32_t)T1 ? key : (uint32_t)(T1 - 1)], 1u);
     }
@@ -704,24 +722,31 @@ __global__ __launch_bounds__(256) void tile_colsum_kernel(const uint32_t* __rest
     segsum[(size_t)seg * T1 + t] = sum;
 }
 
-// one workgroup: per tile the exclusive prefix over the segments, then the exclusive prefix of the tile totals over the
-// tiles; segsum[seg][t] becomes the first write offset of segment seg in tile t, and tile_bins the tiles' ranges
-__global__ __launch_bounds__(1024) void tile_scan_kernel(uint32_t* __restrict__ segsum, int T1, int tiles,
+// per tile: the exclusive prefix of its segment sums over the segments (in place) and the tile's total
+__global__ __launch_bounds__(256) void tile_segscan_kernel(uint32_t* __restrict__ segsum, int T1, uint32_t* __restrict__ total) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T1) return;
+    uint32_t x[TS_SEG];
+#pragma unroll
+    for (int seg = 0; seg < TS_SEG; ++seg) x[seg] = segsum[(size_t)seg * T1 + t];
+    uint32_t run = 0u;
+#pragma unroll
+    for (int seg = 0; seg < TS_SEG; ++seg) {
+        segsum[(size_t)seg * T1 + t] = run;
+        run += x[seg];
+    }
+    total[t] = run;
+}
+
+// one workgroup: the exclusive prefix of the tile totals over the tiles -> start[t] (start[T1] = all pairs), and the
+// tile_bins the rasteriser reads
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ total, int T1, int tiles,
                                                          uint32_t* __restrict__ start, int32_t* __restrict__ bins) {
     __shared__ uint32_t s_part[1024];
     const int per = (T1 + 1023) / 1024;
     const int t0 = threadIdx.x * per, t1 = (t0 + per < T1) ? t0 + per : T1;
     uint32_t mine = 0u;
-    for (int t = t0; t < t1; ++t) {
-        uint32_t run = 0u;
-        for (int seg = 0; seg < TS_SEG; ++seg) {
-            const uint32_t x = segsum[(size_t)seg * T1 + t];
-            segsum[(size_t)seg * T1 + t] = run;
-            run += x;
-        }
-        start[t] = run;      // the tile's total for now
-        mine += run;
-    }
+    for (int t = t0; t < t1; ++t) mine += total[t];
     s_part[threadIdx.x] = mine;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {      // Hillis-Steele over the 1024 partial sums
@@ -732,25 +757,25 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(uint32_t* __restrict__ 
     }
     uint32_t run = s_part[threadIdx.x] - mine;
     for (int t = t0; t < t1; ++t) {
-        const uint32_t total = start[t];
+        const uint32_t n = total[t];
         start[t] = run;
-        for (int seg = 0; seg < TS_SEG; ++seg) segsum[(size_t)seg * T1 + t] += run;
         if (t < tiles) {      // an empty tile keeps the (0, 0) of gsplat's zero-filled tile_bins
-            bins[t * 2] = total ? (int32_t)run : 0;
-            bins[t * 2 + 1] = total ? (int32_t)(run + total) : 0;
+            bins[t * 2] = n ? (int32_t)run : 0;
+            bins[t * 2 + 1] = n ? (int32_t)(run + n) : 0;
         }
-        run += total;
+        run += n;
     }
     if (threadIdx.x == 1023) start[T1] = run;
 }
 
-// counts -> write offsets, in place: table[row][t] = segsum[seg][t] + sum of the segment's earlier rows
+// counts -> write offsets, in place: table[row][t] = start[t] + segsum[seg][t] + sum of the segment's earlier rows
 __global__ __launch_bounds__(256) void tile_apply_kernel(uint32_t* __restrict__ table, int rows_per_seg, int T1,
-                                                         const uint32_t* __restrict__ segsum) {
+                                                         const uint32_t* __restrict__ segsum,
+                                                         const uint32_t* __restrict__ start) {
     const int t = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
     if (t >= T1) return;
     uint32_t* col = table + (size_t)seg * rows_per_seg * T1 + t;
-    uint32_t run = segsum[(size_t)seg * T1 + t];
+    uint32_t run = start[t] + segsum[(size_t)seg * T1 + t];
 #pragma unroll 8
     for (int r = 0; r < rows_per_seg; ++r) {
         const uint32_t c = col[(size_t)r * T1];
@@ -761,33 +786,57 @@ __global__ __launch_bounds__(256) void tile_apply_kernel(uint32_t* __restrict__ 
 
 // One wave per chunk.  Pairs arrive in depth order; within a 64-pair vector the pairs of ONE splat (a run of equal ids)
 // name distinct tiles, so all of them can take their slots with one conflict-free LDS atomic; runs are served in order
-// (the LDS executes a wave's operations in program order), which makes the scatter stable.
+// (the LDS executes a wave's operations in program order), which makes the scatter stable.  A wave is alone with its
+// memory latency (four waves per CU: the 32-KB tables), so it works on four vectors per round and asks for the next
+// round's pairs before it ranks this round's.
+#define TS_VEC 4
 template <typename TKey>
 __global__ __launch_bounds__(64) void tile_scatter_kernel(const TKey* __restrict__ keys, const int32_t* __restrict__ vals,
                                                           int64_t I, int chunk, int T1, const uint32_t* __restrict__ table,
                                                           int32_t* __restrict__ out) {
     extern __shared__ uint32_t s_off[];
     const int lane = threadIdx.x;
-    const uint32_t* row = table + (size_t)blockIdx.x * T1;
-    for (int t = lane; t < T1; t += 64) s_off[t] = row[t];
+    {
+        const uint32_t* row = table + (size_t)blockIdx.x * T1;
+#pragma unroll 8
+        for (int t = lane; t < T1; t += 64) s_off[t] = row[t];
+    }
     __syncthreads();
     const int64_t k0 = (int64_t)blockIdx.x * chunk, k1 = (k0 + chunk < I) ? k0 + chunk : I;
-    for (int64_t k = k0; k < k1; k += 64) {
-        const int64_t e = k + lane;
-        const bool valid = e < k1;
-        uint32_t key = valid ? (uint32_t)keys[e] : 0u;
-        const int32_t id = valid ? vals[e] : -1;
-        if (key >= (uint32_t)T1) key = (uint32_t)(T1 - 1);
-        const int32_t prev = __shfl_up(id, 1, 64);
-        uint64_t starts = __builtin_amdgcn_ballot_w64(valid && (lane == 0 || id != prev));
-        uint32_t pos = 0u;
-        while (starts) {      // uniform: one round per splat run of the vector
-            const int lo = __builtin_ctzll(starts);
-            starts &= starts - 1;
-            const int hi = starts ? __builtin_ctzll(starts) : 64;
-            if (valid && lane >= lo && lane < hi) pos = atomicAdd(&s_off[key], 1u);
+    uint32_t key[TS_VEC], nkey[TS_VEC];
+    int32_t id[TS_VEC], nid[TS_VEC];
+    auto fetch = [&](int64_t k, uint32_t (&kk)[TS_VEC], int32_t (&ii)[TS_VEC]) {
+#pragma unroll
+        for (int v = 0; v < TS_VEC; ++v) {
+            const int64_t e = k + 64 * v + lane;
+            const bool ok = e < k1;
+            kk[v] = ok ? (uint32_t)keys[e] : 0u;
+            ii[v] = ok ? vals[e] : -1;
         }
-        if (valid) out[pos] = id;      // (sentinel pairs land behind the last tile's range)
+    };
+    fetch(k0, nkey, nid);
+    for (int64_t k = k0; k < k1; k += 64 * TS_VEC) {
+#pragma unroll
+        for (int v = 0; v < TS_VEC; ++v) {
+            key[v] = nkey[v];
+            id[v] = nid[v];
+        }
+        if (k + 64 * TS_VEC < k1) fetch(k + 64 * TS_VEC, nkey, nid);
+#pragma unroll
+        for (int v = 0; v < TS_VEC; ++v) {
+            const bool valid = k + 64 * v + lane < k1;
+            const uint32_t kq = key[v] < (uint32_t)T1 ? key[v] : (uint32_t)(T1 - 1);
+            const int32_t prev = __shfl_up(id[v], 1, 64);
+            uint64_t starts = __builtin_amdgcn_ballot_w64(valid && (lane == 0 || id[v] != prev));
+            uint32_t pos = 0u;
+            while (starts) {      // uniform: one round per splat run of the vector
+                const int lo = __builtin_ctzll(starts);
+                starts &= starts - 1;
+                const int hi = starts ? __builtin_ctzll(starts) : 64;
+                if (valid && lane >= lo && lane < hi) pos = atomicAdd(&s_off[kq], 1u);
+            }
+            if (valid) out[pos] = id[v];      // (sentinel pairs land behind the last tile's range)
+        }
     }
 }
 
@@ -829,8 +878,11 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
         const int rps = tp.rows / TS_SEG;
         hipLaunchKernelGGL((tile_hist_kernel<TKey>), dim3(tp.rows), dim3(256), lds, st, tk_in, I, tp.chunk, tp.T1, table);
         hipLaunchKernelGGL(tile_colsum_kernel, dim3(blocks_for(tp.T1, 256), TS_SEG), dim3(256), 0, st, table, rps, tp.T1, segsum);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, segsum, tp.T1, tiles, start, tile_bins);
-        hipLaunchKernelGGL(tile_apply_kernel, dim3(blocks_for(tp.T1, 256), TS_SEG), dim3(256), 0, st, table, rps, tp.T1, segsum);
+        uint32_t* total = start + tp.T1 + 1;
+        hipLaunchKernelGGL(tile_segscan_kernel, dim3(blocks_for(tp.T1, 256)), dim3(256), 0, st, segsum, tp.T1, total);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, total, tp.T1, tiles, start, tile_bins);
+        hipLaunchKernelGGL(tile_apply_kernel, dim3(blocks_for(tp.T1, 256), TS_SEG), dim3(256), 0, st, table, rps, tp.T1, segsum,
+                           start);
         hipLaunchKernelGGL((tile_scatter_kernel<TKey>), dim3(tp.nblk), dim3(64), lds, st, tk_in, v_in, I, tp.chunk, tp.T1, table,
                            gaussian_ids_sorted);
         if (isect_ids_sorted)

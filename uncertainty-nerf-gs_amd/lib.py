@@ -108,7 +108,7 @@ class FieldParams(C.Structure):
         ("image_width", C.c_int), ("sample_major", C.c_int), ("drop_sites", C.c_int), ("lap_softplus", C.c_int), ("use_aabb", C.c_int),
         ("aabb", C.c_float * 6), ("f16_single", C.c_int), ("overflow_flag", C.c_void_p),
         ("h0_full_t", C.c_void_p), ("hb0_raw", C.c_void_p), ("app_embed", C.c_void_p),
-        ("lap_chunk_rays", C.c_int), ("lap_sets", C.c_int), ("n_lap_rgb", C.c_int),
+        ("lap_chunk_rays", C.c_int), ("lap_sets", C.c_int), ("n_lap_rgb", C.c_int), ("packed_out", C.c_int),
     ]
 
 

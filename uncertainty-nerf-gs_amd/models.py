@@ -14,6 +14,7 @@ length 1 satisfies this.
 """
 from __future__ import annotations
 
+import re
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, NamedTuple, Optional, Tuple, Type
 
@@ -200,11 +201,22 @@ def remap_checkpoint_keys(model: nn.Module, sd: Dict[str, torch.Tensor]) -> Dict
                                        f"(HashGrid) = {n_mlp + n_grid} for this configuration")
                 out[f"{name}.mlp.tcnn_encoding.params"] = vec[:n_mlp]
                 out[f"{name}.encoder.tcnn_encoding.params"] = vec[n_mlp:]
+        # alias rules apply to the exact leaves these modules own -- `hash_table`, `tcnn_encoding.params`,
+        # `layers.N.weight|bias` -- and an alias that arrives NEXT TO its canonical key must carry the same tensor:
+        # dropping one of two different tensors silently would hide a mixed-up checkpoint
+        leaf = re.compile(r"^(hash_table|tcnn_encoding\.params|layers\.\d+\.(weight|bias))$")
         for k in list(out):
             for old, new in ((f"{parent}encoding.", f"{name}.encoder."), (f"{name}.0.", f"{name}.encoder."),
                              (f"{name}.1.", f"{name}.mlp.")):
-                if k.startswith(old):
-                    out.setdefault(new + k[len(old):], out[k])
+                if k.startswith(old) and leaf.match(k[len(old):]):
+                    canon = new + k[len(old):]
+                    if canon in out and canon != k:
+                        a, b = out[canon], out[k]
+                        if not (torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and torch.equal(a, b)):
+                            raise RuntimeError(f"checkpoint carries both {k} and {canon} with different contents: "
+                                               "cannot tell which one this model should load")
+                    else:
+                        out[canon] = out[k]
                     del out[k]
                     break
     return out

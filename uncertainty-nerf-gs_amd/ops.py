@@ -780,23 +780,37 @@ def supports_planes(field: FieldDev) -> bool:
     return field.mode != _l.FIELD_LAPLACE and field.use_mfma and (field.mfma_blob is not None or field.mfma16_blob is not None)
 
 
+def supports_packed(field: "FieldDev") -> bool:
+    """unerf_field_params.packed_out: the ACTIVE / MCDROPOUT kernels can leave one 16-byte row per sample"""
+    return field.mode in (_l.FIELD_ACTIVE, _l.FIELD_MCDROPOUT)
+
+
 def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0,
               features: Optional[torch.Tensor] = None, image_width: int = 0, euclidean_bins: bool = False,
-              sample_major: bool = False, spacing: int = 0, nonfinite_flag: Optional[torch.Tensor] = None):
+              sample_major: bool = False, spacing: int = 0, nonfinite_flag: Optional[torch.Tensor] = None,
+              packed: bool = False):
     """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h).  image_width > 0 tells the kernel that
     rays [ray_offset, ray_offset+R) are consecutive pixels of a row-major image (8x4-pixel tiles: same results).
     euclidean_bins: `sbins` holds Euclidean bin edges (a caller-made RaySamples) instead of spacing-domain bins.
-    sample_major: the outputs are planes density [B,S,R], rgb [B,S,3,R], aux [S,R] (composite_*_planes read them)."""
+    sample_major: the outputs are planes density [B,S,R], rgb [B,S,3,R], aux [S,R] (composite_*_planes read them).
+    packed (ACTIVE / MCDROPOUT, ray-major): -> None, rows [B,R,S,4] = (sigma, r, g, b), aux, None -- one 16-byte store
+    per sample; composite_var / composite_moments take the rows as `rgb` with density=None."""
     if euclidean_bins:
         near = -1.0
     lib = _l.load()
     R, S = sbins.shape[0], sbins.shape[1] - 1
     B = max(field.K, 1) if field.mode == _l.FIELD_MCDROPOUT else 1
     dev = origins.device
+    if packed and (sample_major or not supports_packed(field)):
+        raise _l.UnerfError("field_fwd: packed rows are written by the ACTIVE / MCDROPOUT kernels in the ray-major layout only")
     if sample_major:
         density = torch.empty(B, S, R, device=dev, dtype=torch.float32)
         rgb = torch.empty(B, S, 3, R, device=dev, dtype=torch.float32)
         aux = torch.empty(S, R, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
+    elif packed:
+        density = None
+        rgb = torch.empty(B, R, S, 4, device=dev, dtype=torch.float32)
+        aux = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
     else:
         density = torch.empty(B, R, S, device=dev, dtype=torch.float32)
         rgb = torch.empty(B, R, S, 3, device=dev, dtype=torch.float32)
@@ -805,6 +819,7 @@ def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: flo
     cs = field.cstruct()
     cs.image_width = int(image_width)
     cs.sample_major = 1 if sample_major else 0
+    cs.packed_out = 1 if packed else 0
     cs.overflow_flag = _p(nonfinite_flag, torch.int32)      # set by the f16 matrix kernels (either form) on operand overflow
     with _ctx(dev):
         _run("field_fwd", lambda: lib.unerf_field_fwd(_p(origins), _p(directions), _p(sbins), R, S, near, far, spacing, ray_offset,
@@ -878,14 +893,23 @@ def _background(background):
     return int(mode), (None if rgb is None else (C.c_float * 3)(*[float(v) for v in rgb]))
 
 
+def _packed_shape(density, rgb):
+    if density is not None:
+        return density.shape
+    if rgb.dim() != 4 or rgb.shape[-1] != 4:
+        raise _l.UnerfError(f"composite: density=None needs packed rows [B,R,S,4], got {tuple(rgb.shape)}")
+    return rgb.shape[:3]
+
+
 def composite_var(density, rgb, sbins, near: float, far: float, beta=None, weights_alt=None, clip_minmax=None,
                   ray_offset: int = 0, chunk_rays: int = 1 << 15, spacing: int = 0, background=None,
                   nonfinite_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """density [B,R,S] -> out [B,R,8] = rgb3, accumulation, depth, expected_depth, rgb_var, depth_var.
+    density=None: `rgb` holds the packed rows [B,R,S,4] = (sigma, r, g, b) of field_fwd(packed=True).
     nonfinite_flag: int32 device tensor (1 element) that receives |= 1 when a NaN density / colour is read"""
     lib = _l.load()
-    B, R, S = density.shape
-    out = torch.empty(B, R, 8, device=density.device, dtype=torch.float32)
+    B, R, S = _packed_shape(density, rgb)
+    out = torch.empty(B, R, 8, device=rgb.device, dtype=torch.float32)
     bg_mode, bg_rgb = _background(background)
     with _ctx(out.device):
         _run("composite_var", lambda: lib.unerf_composite_var(_p(density), _p(rgb), _p(beta), _p(weights_alt), _p(sbins), B, R, S, near,
@@ -896,11 +920,12 @@ def composite_var(density, rgb, sbins, near: float, far: float, beta=None, weigh
 
 def composite_moments(density, rgb, sbins, near: float, far: float, clip_minmax=None, ray_offset: int = 0,
                       chunk_rays: int = 1 << 15, spacing: int = 0, background=None, nonfinite_flag=None):
-    """density [B<=16,R,S], rgb [B,R,S,3] -> (mean [R,8], var [R,8]) over the B passes (fused composite + moments)"""
+    """density [B<=16,R,S], rgb [B,R,S,3] -> (mean [R,8], var [R,8]) over the B passes (fused composite + moments);
+    density=None: `rgb` holds the packed rows [B,R,S,4] of field_fwd(packed=True)"""
     lib = _l.load()
-    B, R, S = density.shape
-    mean = torch.empty(R, 8, device=density.device, dtype=torch.float32)
-    var = torch.empty(R, 8, device=density.device, dtype=torch.float32)
+    B, R, S = _packed_shape(density, rgb)
+    mean = torch.empty(R, 8, device=rgb.device, dtype=torch.float32)
+    var = torch.empty(R, 8, device=rgb.device, dtype=torch.float32)
     bg_mode, bg_rgb = _background(background)
     with _ctx(mean.device):
         _run("composite_moments", lambda: lib.unerf_composite_moments(_p(density), _p(rgb), _p(sbins), B, R, S, near, far,
@@ -1045,6 +1070,7 @@ class SplatCount:
     device idling through a full stream synchronisation and the launch latency of everything behind it."""
 
     _side: Dict = {}
+    _pinned: Dict = {}      # one pinned int32 per device and side stream, reused by every frame
 
     def __init__(self, num_tiles_hit: torch.Tensor):
         lib = _l.load()
@@ -1059,7 +1085,11 @@ class SplatCount:
             if key not in SplatCount._side:
                 SplatCount._side[key] = torch.cuda.Stream(device=self.dev)
             side = SplatCount._side[key]
-            self._host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            if key not in SplatCount._pinned:
+                SplatCount._pinned[key] = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            # (frames of one device run one after the other on the side stream: the previous frame's wait() has returned
+            # before this copy is queued, so the word is free)
+            self._host = SplatCount._pinned[key]
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
             with torch.cuda.stream(side):

@@ -68,6 +68,8 @@ class NerfSceneDev:
     # OverflowGuard: re-render launch groups whose f16 operands overflowed with fp32 kernels (UNERF_OVERFLOW_GUARD=0: off)
     overflow_guard: bool = field(default_factory=lambda: os.environ.get("UNERF_OVERFLOW_GUARD", "1") != "0")
     overflow_rerenders: int = 0      # how many launch groups that has happened to (diagnostic)
+    # field outputs as packed (sigma, r, g, b) rows (include/unerf.h: packed_out)
+    packed_out: bool = field(default_factory=lambda: os.environ.get("UNERF_PACKED_OUT", "1") != "0")
     _const: Dict[str, torch.Tensor] = field(default_factory=dict)
 
     @property
@@ -187,9 +189,12 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
     # ACTIVE / MCDROPOUT: the field kernel writes sample-major planes (whole 32-byte sectors per store) and the
     # composite walks them with a lane per ray; LAPLACE keeps the ray-major layout its depth-draw kernel reads
     planes = scene.sample_major and feats is None and ops.supports_planes(f)
+    # default (ACTIVE / MCDROPOUT): one 16-byte row (sigma, r, g, b) per sample instead of four scattered dwords
+    # (unerf_field_params.packed_out; UNERF_PACKED_OUT=0: the [B,R,S] + [B,R,S,3] layout of the Field-level API)
+    packed = scene.packed_out and not planes and ops.supports_packed(f)
     density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset, features=feats,
                                             image_width=image_width, sample_major=planes, spacing=scene.spacing,
-                                            nonfinite_flag=nonfinite_flag)
+                                            nonfinite_flag=nonfinite_flag, packed=packed)
     kw = dict(clip_minmax=clip, ray_offset=ray_offset, chunk_rays=scene.chunk_rays, spacing=scene.spacing,
               background=scene.background, nonfinite_flag=nonfinite_flag)
     res: Dict[str, torch.Tensor] = {}
@@ -202,7 +207,7 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
         res["rgb_std"] = res["rgb_var"].sqrt()
         res["depth_std"] = res["depth_var"].sqrt()
         if keep_density:   # the reference returns density [R,48,1] (activenerfacto_model.py:115,122)
-            res["density"] = density[0].t().contiguous() if planes else density[0]
+            res["density"] = rgb[0][..., 0] if packed else (density[0].t().contiguous() if planes else density[0])
     elif f.mode == _l.FIELD_MCDROPOUT:
         if planes and f.K >= 2:
             mean, var = ops.composite_moments_planes(density, rgb, sb, scene.near, scene.far, **kw)

@@ -79,6 +79,10 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
         gp = {k: v[crop_ids].contiguous() for k, v in gp.items()}
     means = gp["means"].contiguous()
     dev = means.device
+    # the pose goes to the host ONCE, here, before anything is queued: a device-resident camera_to_worlds (the normal
+    # nerfstudio model path) would otherwise be read back behind the projection and the scan -- a blocking stream sync
+    # exactly where the intersection count's read-back is meant to overlap the SH-colour kernel
+    c2w = c2w.detach().to("cpu", torch.float32)
     V = viewmat_from_c2w(c2w)
     if rasterize_mode not in ("classic", "antialiased"):
         raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
