@@ -310,7 +310,7 @@ def test_one_pass_tile_sort_gives_the_radix_sorts_lists(dev, N, H, W, tight, mon
 
 @pytest.mark.parametrize("C", [1, 5])
 def test_wave_level_culling_and_bounded_pass_change_no_bit(dev, C):
-    """the default schedule (a wave walks only the splats whose alpha >= 1/255 ellipse reaches its 4 x 16 strip) against
+    """the default schedule (a wave walks only the splats whose alpha >= 1/255 ellipse reaches its 8 x 8 quadrant of the tile) against
     gsplat's (every wave walks every staged splat): identical images, transmittances and final indices; and a second
     pass bounded by the first pass's final indices (the depth-variance pass) equals the unbounded one.  Splats with
     tiny opacity and huge / needle-shaped / degenerate / indefinite conics are in the set."""

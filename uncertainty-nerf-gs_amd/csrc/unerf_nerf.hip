@@ -43,6 +43,7 @@ int unerf_check_launch(const char* what) {
 #ifndef UNERF_TRUNK_RESIDENT
 #define UNERF_TRUNK_RESIDENT 1   // ... and its operands kept in registers across the passes (-3.5 %)
 #endif
+
 extern "C" const char* unerf_last_error(void) { return g_err; }
 extern "C" int unerf_build_flags(void) {
     return (UNERF_TRUNK_FOLD ? UNERF_BUILD_TRUNK_FOLD : 0) | (UNERF_LAP_EXP2 ? UNERF_BUILD_LAP_EXP2 : 0);

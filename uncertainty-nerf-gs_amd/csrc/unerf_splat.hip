@@ -53,7 +53,7 @@ __device__ __forceinline__ void tile_bbox(float cx, float cy, float radius, int 
 // loop then skips each (pixel, splat) pair with alpha = min(0.999, o exp(-sigma)) < 1/255, i.e. everything outside the
 // ellipse sigma <= ln(255 o): for an anisotropic or faint splat most tiles of the square hold no such pixel (49 % of
 // the 37 M pairs of the 1 M-splat bench frame), yet each costs a sort entry and a staging slot in the rasteriser.
-// TightSplat describes that ellipse (padded far above fp32 rounding, as raster_strip_mask); tight_row gives, for one
+// TightSplat describes that ellipse (padded far above fp32 rounding, as raster_quad_mask); tight_row gives, for one
 // tile row, the range of tiles whose pixel centres it can reach -- always a subset of gsplat's box, so the lists
 // lose only pairs the blend loop would have skipped: images, transmittances and orders of the blended terms are
 // bit-identical (tests/test_gpu_splat.py::test_tight_tile_lists_*).
@@ -961,12 +961,12 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
 // ======================================================================================
 // gsplat's schedule (a tile per workgroup, a pixel per thread, the tile's depth-sorted splats staged through shared
 // memory in batches) with two MI355X-side changes that leave every blended term untouched:
-//  * WAVE-LEVEL CULLING.  A wave64 of a 16 x 16 tile is a strip of 4 rows x 16 pixels.  A splat contributes to a pixel
+//  * WAVE-LEVEL CULLING.  A wave64 of a 16 x 16 tile is one 8 x 8 quadrant of it.  A splat contributes to a pixel
 //    only where alpha = min(0.999, o e^-sigma) >= 1/255, i.e. inside the ellipse sigma <= ln(255 o) -- usually a good
 //    deal smaller than the 3-sigma square the tile lists are built from (and empty when o < 1/255).  The thread that
-//    stages a splat tests the ellipse's bounding box against the tile's four strips (conservatively: a margin far above
-//    the rounding of the in-loop test) and leaves a 4-bit mask; every wave then compacts the batch into its own index
-//    list with ballots and walks only that.  A culled (pixel, splat) pair is one the loop body would have skipped with
+//    stages a splat tests the ellipse's bounding box against the tile's four quadrants (conservatively: a margin far
+//    above the rounding of the in-loop test) and leaves a 4-bit mask; every wave then compacts the batch into its own
+//    index list with ballots and walks only that.  A culled (pixel, splat) pair is one the loop body would have skipped with
 //    `continue`, so sums, transmittances and final indices are bit-identical to the uncull loop (test_gpu_splat.py).
 //  * BOUNDED second pass.  The depth-variance pass blends with the same alphas as the first, so each pixel stops at the
 //    final index the first pass recorded instead of re-deriving it from the transmittance (stop_idx).
@@ -988,9 +988,11 @@ struct RasterArgs {
     int max_ch;
 };
 
-// which of the tile's four 4-row strips can see the splat?  Conservative: returns 0xF when in doubt.
-__device__ __forceinline__ uint32_t raster_strip_mask(float x, float y, float op, float ca, float cb, float cc, float tile_x0,
-                                                      float tile_y0) {
+// which of the tile's four 8 x 8 quadrants can see the splat?  Conservative: returns 0xF when in doubt.  (A wave64 of the
+// 16 x 16 tile is one quadrant -- bit q = 2 (row half) + (column half) -- instead of a 4-row strip: the square has the
+// smallest perimeter a 64-pixel footprint can have, so an r = 2..4 px ellipse reaches fewer of them.)
+__device__ __forceinline__ uint32_t raster_quad_mask(float x, float y, float op, float ca, float cb, float cc, float tile_x0,
+                                                     float tile_y0) {
     if (!(op >= 0.0039f)) return (op != op) ? 0xFu : 0u;      // alpha <= opacity < 1/255 (0.00392...) everywhere
     const float det = ca * cc - cb * cb;
     if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0xFu;   // not an ellipse (or NaN): no culling
@@ -1000,15 +1002,16 @@ __device__ __forceinline__ uint32_t raster_strip_mask(float x, float y, float op
     const float inv = 2.f * tau / det;
     const float hx = fmaf(sqrtf(inv * cc), 1.01f, 0.05f), hy = fmaf(sqrtf(inv * ca), 1.01f, 0.05f);
     if (!(hx == hx) || !(hy == hy)) return 0xFu;
-    // pixel centres of the tile: x in [x0 + 0.5, x0 + 15.5]; strip w: y in [y0 + 4 w + 0.5, y0 + 4 w + 3.5]
-    if (x + hx < tile_x0 + 0.5f || x - hx > tile_x0 + 15.5f) return 0u;
-    uint32_t m = 0u;
+    // pixel centres of quadrant (qx, qy): x in [x0 + 8 qx + 0.5, x0 + 8 qx + 7.5], y likewise
+    uint32_t mx = 0u, my = 0u;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const float ylo = tile_y0 + 4.f * (float)w + 0.5f;
-        if (!(y + hy < ylo || y - hy > ylo + 3.f)) m |= 1u << w;
+    for (int q = 0; q < 2; ++q) {
+        const float xlo = tile_x0 + 8.f * (float)q + 0.5f, ylo = tile_y0 + 8.f * (float)q + 0.5f;
+        if (!(x + hx < xlo || x - hx > xlo + 7.f)) mx |= 1u << q;
+        if (!(y + hy < ylo || y - hy > ylo + 7.f)) my |= 1u << q;
     }
-    return m;
+    // bit 2 qy + qx
+    return ((my & 1u) ? mx : 0u) | ((my & 2u) ? (mx << 2) : 0u);
 }
 
 template <int C, bool BOUNDED>
@@ -1023,7 +1026,10 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
     const int tbx = (a.W + bw - 1) / bw;
     const int tile = blockIdx.y * tbx + blockIdx.x;
     const int tr = threadIdx.x;
-    const int ly = tr / bw, lx = tr - ly * bw;
+    // 16-wide tiles: a wave owns one 8 x 8 quadrant (wave w: quadrant column w & 1, row w >> 1; lane l: pixel (l & 7,
+    // l >> 3) of it); narrower tiles keep the row-major mapping (no culling there)
+    const int ly = bw == 16 ? 8 * (tr >> 7) + ((tr & 63) >> 3) : tr / bw;
+    const int lx = bw == 16 ? 8 * ((tr >> 6) & 1) + (tr & 7) : tr - (tr / bw) * bw;
     const int i = blockIdx.y * bw + ly, j = blockIdx.x * bw + lx;
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const bool inside = (ly < bw) && (i < a.H) && (j < a.W);
@@ -1032,7 +1038,7 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
     const int r0 = a.bins[tile * 2], r1 = a.bins[tile * 2 + 1];
     const int nbatch = (r1 - r0 + 255) / 256;
     const int stop = (BOUNDED && inside) ? a.stop_idx[p] : 0;
-    const bool cull = a.cull && bw == 16;                       // uniform: the strip geometry below is the 16-wide tile's
+    const bool cull = a.cull && bw == 16;                       // uniform: the quadrant geometry is the 16-wide tile's
     const int wv = __builtin_amdgcn_readfirstlane(tr >> 6), lane = tr & 63;
     const float tile_x0 = (float)(blockIdx.x * bw), tile_y0 = (float)(blockIdx.y * bw);
     float T = 1.f;
@@ -1051,14 +1057,23 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
             const float ca = a.conics[g * 3], cb = a.conics[g * 3 + 1], cc = a.conics[g * 3 + 2];
             s_geo[tr] = make_float4(x, y, op, ca);
             s_bc[tr] = make_float2(cb, cc);
+            // the colour row: 16-byte loads where it has the length (rows of C floats are 4-byte aligned only: the packed
+            // type makes them alignment-4 dwordx4 loads), dwords for the rest -- one + one for the 5-channel row
+            struct __attribute__((packed, aligned(4))) Q4 { float x, y, z, w; };
+            const float* crow = a.colors + (int64_t)g * C;
 #pragma unroll
-            for (int c = 0; c < C; ++c) s_col[tr * C + c] = a.colors[(int64_t)g * C + c];
-            if (cull) s_mask[tr] = (uint8_t)raster_strip_mask(x, y, op, ca, cb, cc, tile_x0, tile_y0);
+            for (int c4 = 0; c4 + 4 <= C; c4 += 4) {
+                const Q4 q = *reinterpret_cast<const Q4*>(crow + c4);
+                s_col[tr * C + c4] = q.x; s_col[tr * C + c4 + 1] = q.y; s_col[tr * C + c4 + 2] = q.z; s_col[tr * C + c4 + 3] = q.w;
+            }
+#pragma unroll
+            for (int c = C & ~3; c < C; ++c) s_col[tr * C + c] = crow[c];
+            if (cull) s_mask[tr] = (uint8_t)raster_quad_mask(x, y, op, ca, cb, cc, tile_x0, tile_y0);
         }
         __syncthreads();
         const int bsz = min(256, r1 - start);
         int n_mine = bsz;
-        if (cull) {   // this wave's (order-preserving) list of the staged splats its strip can see
+        if (cull) {   // this wave's (order-preserving) list of the staged splats its quadrant can see
             n_mine = 0;
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {

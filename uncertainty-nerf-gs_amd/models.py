@@ -605,7 +605,11 @@ class NerfactoLaplaceModel(_NerfactoBase):
         n_sets = None
         if self.resample == "chunk":
             _, cam = _camera_args(camera)
-            n_sets = -(-(cam["H"] * cam["W"]) // int(self.config.eval_num_rays_per_chunk))
+            chunk = int(self.config.eval_num_rays_per_chunk)
+            if chunk <= 0 or chunk % 32:
+                raise ValueError(f"eval_num_rays_per_chunk={chunk}: per-chunk Laplace samples need a multiple of 32 rays per "
+                                 "chunk (a kernel tile is 32 rays); use such a chunk size or model.resample = 'camera'")
+            n_sets = -(-(cam["H"] * cam["W"]) // chunk)
         self._ws = self.field.sample_last_layers(n_samples=n_samples, prior_prec=prior_prec, eps=eps, generator=generator,
                                                  deterministic_density=use_deterministic_density, n_sets=n_sets)
         self._deterministic_density = bool(use_deterministic_density)

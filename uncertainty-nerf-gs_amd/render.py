@@ -12,7 +12,8 @@ min/max sample position) is reproduced exactly through `chunk_rays`.
 Kernel sequence per launch group:
   sampling stage : proposal_density(256) -> weights_pdf_resample(->96) -> proposal_density(96)
                    -> weights_pdf_resample(->48) -> field_gather (level-major hash-grid lookup)
-  shading stage  : field_fwd (fp32-MFMA MLPs) -> [laplace_depth_weights] -> composite_var -> [moments over K]
+  shading stage  : field_fwd (hash grid + MLPs on the f16 matrix pipe: "f16" / split-f16 "f16x2" / exact "fp32", see
+                   ops.FieldDev.precision) -> [laplace_depth_weights] -> composite_var | composite_moments over K
 
 By default the hash-grid lookup is fused into `field_fwd` and everything runs on the caller's
 stream.  Two measured alternatives are kept as options (numbers: DESIGN.md section 4.3):
@@ -108,7 +109,7 @@ class OverflowGuard:
         """launch groups that saw a NaN -- one device -> host read per frame"""
         if self.flags is None:
             return []
-        return [int(i) for i in torch.nonzero(self.flags).flatten().tolist()]
+        return [i for i, f in enumerate(self.flags.tolist()) if f]     # one small device -> host copy (the frame's sync)
 
     def redo(self, g: int, render_group):
         """render_group() again with the exact-fp32 kernels"""
