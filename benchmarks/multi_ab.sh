@@ -1,11 +1,11 @@
 #!/bin/bash
 # Same-box comparison of several explicit builds of libunerf (UNERF_LIB), three alternating repetitions each.
-# usage: multi_ab.sh method lib1 lib2 ... (names in benchmarks/build_probe/libunerf_<name>.so)
+# usage: [BENCH_ARGS="--precision f16x2"] multi_ab.sh method lib1 lib2 ... (names in benchmarks/build_probe/libunerf_<name>.so)
 cd "$(dirname "$0")/.."
 M=$1; shift
 mkdir -p gpurun_out
 for rep in 1 2 3; do for v in "$@"; do
-  UNERF_LIB=$PWD/benchmarks/build_probe/libunerf_$v.so python bench.py --method $M --steps 4 --warmup 2 --no-cpu-baseline --no-exact-check 2>/dev/null | tail -1 > gpurun_out/_m_${v}_$rep.json
+  UNERF_LIB=$PWD/benchmarks/build_probe/libunerf_$v.so python bench.py --method $M --steps 4 --warmup 2 --no-cpu-baseline --no-exact-check ${BENCH_ARGS:-} 2>/dev/null | tail -1 > gpurun_out/_m_${v}_$rep.json
 done; done
 python - "$@" <<'PY'
 import json, sys

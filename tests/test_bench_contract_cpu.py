@@ -49,8 +49,13 @@ def test_committed_bench_line_has_every_contract_field():
     assert os.path.exists(os.path.join(ROOT, iss["source"].split(" ")[0]))
     # oracle parity AT THE BENCH SIZE: the cpu_baseline leg's oracle outputs against the same rays of a GPU frame
     pb = d["parity_at_bench_size"]
-    assert pb["rays"] >= 4096 and pb["inside_gates"] is True and pb["d_psnr"] <= 1e-4 and pb["d_ause_mse"] <= 1e-3
+    assert pb["rays"] == 16384 and pb["inside_gates"] is True and pb["d_psnr"] <= 1e-4 and pb["d_ause_mse"] <= 1e-3
     assert pb["max_abs_rgb"] < 1e-4 and pb["precision"] == "f16"
+    # gated against a target whose error follows the uncertainty (0 < AUSE well below the ~0.66 of a random ranking); the
+    # uninformative target's figure is carried too (tie order: tests/tools/ause_conditioning.py)
+    assert 0.1 < pb["ause_mse_oracle"] < 0.5 and "informative" in pb["target"]
+    assert pb["d_ause_mse_uninformative_target"]["seeds"] == 8 and pb["d_ause_mse_uninformative_target"]["max"] < 5e-3
+    assert len(d["step_wall_ms"]) == d["steps"] and abs(sum(d["step_wall_ms"]) / d["steps"] - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
     subs = d["sub_records"]
     assert set(subs) == {"ensemble", "mcdropout_f32eq", "active", "laplace", "splat"}
     for k, v in subs.items():

@@ -2064,20 +2064,40 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             // output rows wasted), as packed fp32 FMAs it takes 48 + the half-to-half exchange (~240 cycles).
             {
                 const float4* wq = reinterpret_cast<const float4*>(lds + MF_H2_OFF + h * 48);
+                // Per 32-unit block the 12 weight quads (3 channels x 4) are read into an array FIRST and the 24 packed FMAs
+                // follow.  Written as one load per use the compiler issued each ds_read_b128 directly in front of its two FMAs
+                // and waited for it: 24 exposed LDS round trips per pass (`D1 W1 v1 n0 v1` 24 times in the listing), in which
+                // both waves of a SIMD tended to sit at once -- the K-pass "f16" kernel went 16.2 -> 15.0 ms per launch with the
+                // reads grouped (profiles/r4_exp_rgb_weight_reads_*.json).  Forcing the grouping further with
+                // sched_group_barrier was slower, and issuing the three channels' chains interleaved (no `s_nop` between
+                // dependent packed FMAs, 439 instead of 476 instructions per pass) changed nothing: the other wave fills
+                // those slots (profiles/r4_exp_rgb_interleave_*.json).
+                // (the split form has no registers for 12 quads in flight -- 28 B of scratch with them -- and groups 4)
+                constexpr int CG = F1 ? 3 : 1;   // channels whose weights are read together
+                unerf_v2f acc2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    unerf_v2f acc2 = {0.f, 0.f};
+                for (int blk = 0; blk < 2; ++blk) {
+                    const f32x16& dv = blk ? d1 : d0;
 #pragma unroll
-                    for (int blk = 0; blk < 2; ++blk) {
-                        const f32x16& dv = blk ? d1 : d0;
+                    for (int c0g = 0; c0g < 3; c0g += CG) {
+                        float4 wv[CG][4];
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const float4 w = wq[blk * 24 + c * 4 + q4];
-                            acc2 = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4], dv[4 * q4 + 1]}, unerf_v2f{w.x, w.y}, acc2);
-                            acc2 = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4 + 2], dv[4 * q4 + 3]}, unerf_v2f{w.z, w.w}, acc2);
+                        for (int c = 0; c < CG; ++c)
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) wv[c][q4] = wq[blk * 24 + (c0g + c) * 4 + q4];
+#pragma unroll
+                        for (int c = 0; c < CG; ++c) {
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) {
+                                acc2[c0g + c] = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4], dv[4 * q4 + 1]}, unerf_v2f{wv[c][q4].x, wv[c][q4].y}, acc2[c0g + c]);
+                                acc2[c0g + c] = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4 + 2], dv[4 * q4 + 3]}, unerf_v2f{wv[c][q4].z, wv[c][q4].w}, acc2[c0g + c]);
+                            }
                         }
                     }
-                    const float half_sum = acc2.x + acc2.y;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float half_sum = acc2[c].x + acc2[c].y;
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(half_sum), __float_as_uint(half_sum), false, false);
                     o[c] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + lds[MF_H2_OFF + 192 + c];
                 }
@@ -3100,7 +3120,7 @@ __device__ __forceinline__ CompGeom<SPL> composite_geom(const CompArgs& a, int64
     return gm;
 }
 
-template <int SPL, bool RAGGED = false>
+template <int SPL, bool RAGGED = false, bool PACKED = false>
 __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int64_t r, int l16, float (&o8)[8],
                                               const CompGeom<SPL>& gm) {
     const int S = a.S, k0 = l16 * SPL;
@@ -3112,8 +3132,8 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
         delta[e] = gm.delta[e];
         steps[e] = gm.steps[e];
     }
-    if (a.density == nullptr) {   // uniform: packed rows (sigma, r, g, b) [B,R,S,4] (unerf_field_params.packed_out): one
-        // 16-byte load per sample
+    if (PACKED) {   // packed rows (sigma, r, g, b) [B,R,S,4] (unerf_field_params.packed_out): one 16-byte load per sample
+        // (a compile-time switch: with both layouts in one kernel the K-pass form needs 72 registers instead of 59)
 #pragma unroll
         for (int e = 0; e < SPL; ++e) {
             const float4 v = (!RAGGED || k0 + e < S) ? reinterpret_cast<const float4*>(a.rgb)[g * S + k0 + e]
@@ -3218,8 +3238,8 @@ __device__ __forceinline__ void composite_one(const CompArgs& a, int64_t g, int6
     o8[4] = depth; o8[5] = ed; o8[6] = uvar; o8[7] = dv;
 }
 
-template <int SPL, bool RAGGED = false>
-__global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
+template <int SPL, bool RAGGED, bool PACKED>
+__device__ __forceinline__ void composite_kernel_body(const CompArgs& a) {
     const int l16 = threadIdx.x & 15;
     int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int64_t G = (int64_t)a.B * a.R;
@@ -3227,21 +3247,29 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
     if (!ok) g = G - 1;
     float o8[8];
     const int64_t r = g % a.R;
-    composite_one<SPL, RAGGED>(a, g, r, l16, o8, composite_geom<SPL, RAGGED>(a, r, l16));
+    composite_one<SPL, RAGGED, PACKED>(a, g, r, l16, o8, composite_geom<SPL, RAGGED>(a, r, l16));
     if (ok && l16 == 0) {
         float4* o = reinterpret_cast<float4*>(a.out + g * 8);
         o[0] = make_float4(o8[0], o8[1], o8[2], o8[3]);
         o[1] = make_float4(o8[4], o8[5], o8[6], o8[7]);
     }
 }
+template <int SPL, bool RAGGED = false>
+__global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
+    composite_kernel_body<SPL, RAGGED, false>(a);
+}
+template <int SPL, bool RAGGED = false>
+__global__ __launch_bounds__(256) void composite_kernel_packed(CompArgs a) {
+    composite_kernel_body<SPL, RAGGED, true>(a);
+}
 
 // K-pass form: one 16-lane group walks the B <= 16 passes of a ray, lane b keeps pass b's eight
 // outputs, and the per-pixel mean and unbiased variance over the passes (two-pass, like
 // torch.stack(...).mean(0) / .var(0), mcdropout_models.py:121-126) come out of two group reductions:
 // the [B,R,8] per-pass images never touch HBM.
-template <int SPL, bool RAGGED = false>
-__global__ __launch_bounds__(256) void composite_moments_kernel(CompArgs a, float* __restrict__ mean_out,
-                                                                float* __restrict__ var_out) {
+template <int SPL, bool RAGGED, bool PACKED>
+__device__ __forceinline__ void composite_moments_body(const CompArgs& a, float* __restrict__ mean_out,
+                                                       float* __restrict__ var_out) {
     const int l16 = threadIdx.x & 15;
     int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool ok = r < a.R;
@@ -3252,7 +3280,7 @@ __global__ __launch_bounds__(256) void composite_moments_kernel(CompArgs a, floa
     const CompGeom<SPL> gm = composite_geom<SPL, RAGGED>(a, r, l16);   // bin edges are the same in every pass
     for (int b = 0; b < a.B; ++b) {
         float o8[8];
-        composite_one<SPL, RAGGED>(a, (int64_t)b * a.R + r, r, l16, o8, gm);
+        composite_one<SPL, RAGGED, PACKED>(a, (int64_t)b * a.R + r, r, l16, o8, gm);
         if (l16 == b) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) mine[c] = o8[c];
@@ -3275,7 +3303,16 @@ __global__ __launch_bounds__(256) void composite_moments_kernel(CompArgs a, floa
         vo[1] = make_float4(v8[4], v8[5], v8[6], v8[7]);
     }
 }
-
+template <int SPL, bool RAGGED = false>
+__global__ __launch_bounds__(256) void composite_moments_kernel(CompArgs a, float* __restrict__ mean_out,
+                                                                float* __restrict__ var_out) {
+    composite_moments_body<SPL, RAGGED, false>(a, mean_out, var_out);
+}
+template <int SPL, bool RAGGED = false>
+__global__ __launch_bounds__(256) void composite_moments_kernel_packed(CompArgs a, float* __restrict__ mean_out,
+                                                                       float* __restrict__ var_out) {
+    composite_moments_body<SPL, RAGGED, true>(a, mean_out, var_out);
+}
 
 // Samples per lane: S = 16 * SPL for SPL in {1,2,3,4,6,8,16} (every nerfacto sample count) takes the aligned
 // kernels; any other 1 <= S <= 256 takes the RAGGED instantiation of the next SPL up, whose slots k >= S are masked.
@@ -3325,7 +3362,11 @@ extern "C" int unerf_composite_var(const float* density, const float* rgb, const
     a.flag = nonfinite_flag;
     dim3 grid(blocks_for((int64_t)B * R, 16)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    UNERF_DISPATCH_SPL(S, composite_kernel, grid, block, 0, st, a);
+    if (density) {
+        UNERF_DISPATCH_SPL(S, composite_kernel, grid, block, 0, st, a);
+    } else {
+        UNERF_DISPATCH_SPL(S, composite_kernel_packed, grid, block, 0, st, a);
+    }
     return unerf_check_launch("composite_var");
 }
 
@@ -3346,7 +3387,11 @@ extern "C" int unerf_composite_moments(const float* density, const float* rgb, c
     a.flag = nonfinite_flag;
     dim3 grid(blocks_for(R, 16)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    UNERF_DISPATCH_SPL(S, composite_moments_kernel, grid, block, 0, st, a, mean_out, var_out);
+    if (density) {
+        UNERF_DISPATCH_SPL(S, composite_moments_kernel, grid, block, 0, st, a, mean_out, var_out);
+    } else {
+        UNERF_DISPATCH_SPL(S, composite_moments_kernel_packed, grid, block, 0, st, a, mean_out, var_out);
+    }
     return unerf_check_launch("composite_moments");
 }
 
