@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), carrying `roofl
 dominant kernel and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same rays).
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -95,6 +96,12 @@ def _issue_profile(method, K):
     return j
 
 
+# _timed_region_gc: every timed loop below is bracketed by gc.freeze() / gc.unfreeze().  CPython's full (generation-2)
+# collection walks every tracked object of the process -- after `import torch` that is 15 - 120 ms during which the host
+# issues nothing -- and WHEN it runs depends on allocation counts: frame 42 of a 400-frame soak took 60 - 91 ms instead of 45
+# on every run, frame 1 of the five default steps 163 ms on a box that had parsed more JSON before (step_wall_ms of those runs;
+# with the long-lived objects frozen, or the collector off, no frame of 2 x 400 exceeded 47.1 ms).  freeze() moves what exists
+# after the warm-up into the permanent generation: the collector keeps running, on the young objects only.  No work is skipped.
 def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check=True, want_cpu=True, precision=None):
     """One NeRF method through the whole frame path; returns the record (headline fields + roofline + cpu_baseline)."""
     from uncertainty_nerf_gs_amd import ops, render, synthetic
@@ -132,6 +139,7 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
         out = frame(i)
     sync_all()
     ops.TIMER = ops.KernelTimer()
+    gc.freeze()   # see _timed_region_gc
     t0 = time.perf_counter()
     marks = []
     for i in range(steps):
@@ -139,6 +147,7 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
         marks.append(time.perf_counter())   # host time when frame i had been ISSUED (a frame ends with the overflow-flag read)
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.unfreeze()
     step_wall_ms = [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)]
     timer = ops.TIMER
     ops.TIMER = None
@@ -159,11 +168,13 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
         n_alt = max(1, min(steps, 3))
         ref = frame(warmup + steps - 1)          # also warms those kernels up
         sync_all()
+        gc.freeze()
         t1 = time.perf_counter()
         for i in range(n_alt):
             frame(warmup + i)
         sync_all()
         alt = time.perf_counter() - t1
+        gc.unfreeze()
         if dist is not None:
             tt = torch.tensor([alt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -473,11 +484,13 @@ def bench_ensemble(args, rank, world, dev, dist, steps, warmup):
         for i in range(warmup):
             out = frame(i)
         sync_all()
+        gc.freeze()   # _timed_region_gc
         t0 = time.perf_counter()
         for i in range(steps):
             out = frame(warmup + i)
         sync_all()
         elapsed = time.perf_counter() - t0
+        gc.unfreeze()
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -525,11 +538,13 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
         out = frame(i)
     sync_all()
     ops.TIMER = ops.KernelTimer()
+    gc.freeze()   # _timed_region_gc
     t0 = time.perf_counter()
     for i in range(steps):
         out = frame(warmup + i)
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.unfreeze()
     timer, ops.TIMER = ops.TIMER, None
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)

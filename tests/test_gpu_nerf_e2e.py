@@ -810,3 +810,47 @@ def test_reference_precision_f16_mode_meets_the_gates(dev, kind):
     out2 = render.render_rays(sd, o.to(dev), d.to(dev), **shade)
     assert (out2["rgb"].cpu() - ref[None]["rgb"]).abs().max() < 1e-5
     assert not torch.equal(out2["rgb"], out["rgb"])
+
+
+@pytest.mark.parametrize("kind,overlap", [("active", False), ("mcdropout", False), ("laplace", False), ("mcdropout", True)])
+def test_frame_path_scratch_arena_changes_nothing_and_memory_settles_at_once(dev, kind, overlap):
+    """NerfSceneDev.workspace (ops.Workspace): the per-launch-group temporaries of the frame path are views of one arena
+    instead of per-call allocations.  Same images bit for bit (several launch groups, the raw `density` of the ACTIVE
+    output included: it must be a copy, not a view of rows the next group overwrites), and from the SECOND frame on the
+    process asks the allocator for nothing new (without the arena the reserved memory of the 1080p K = 8 frame grew by
+    6 GiB in the fourth frame -- a hipMalloc inside a timed frame)."""
+    from uncertainty_nerf_gs_amd import render, synthetic
+    kw = {}
+    if kind == "mcdropout":
+        kw = dict(K=4, seed=5, p_drop=0.2)
+    t = synthetic.make_scene_tensors(seed=2, kind=kind, log2T=15, prop_log2T=13)
+    if kind == "laplace":
+        wsd, wsr = synthetic.laplace_weight_samples(t, seed=3, n_samples=20)
+        kw = dict(ws_density=wsd.to(dev), ws_rgb=wsr.to(dev))
+    cam = dict(fx=300.0, fy=300.0, cx=160.0, cy=128.0, H=256, W=320)
+    shade = dict(keep_density=True) if kind == "active" else {}
+    outs = []
+    for arena in (True, False):
+        sd = synthetic.scene_to_device(t, dev, **kw)
+        assert sd.workspace is not None
+        if not arena:
+            sd.workspace = None
+        sd.chunk_rays = 1 << 13
+        frames = []
+        for i in range(3):
+            out = render.render_camera(sd, synthetic.orbit_c2w(0.3 * i), rays_per_launch=1 << 14, overlap=overlap,
+                                       depth_seed=7, **cam, **shade)
+            frames.append({k: v.cpu() for k, v in out.items()})
+            del out
+            if arena and i == 0:
+                reserved, held = torch.cuda.memory_reserved(), sd.workspace.nbytes()
+        if arena:   # the arena is complete after one frame; what is left to the allocator is the frame's small outputs
+            assert held > 0 and sd.workspace.nbytes() == held
+            assert torch.cuda.memory_reserved() - reserved <= 64 << 20
+        outs.append(frames)
+    for fa, fb in zip(*outs):
+        assert set(fa) == set(fb)
+        for k in fa:
+            assert torch.equal(fa[k], fb[k]), k
+    if kind == "active":
+        assert outs[0][0]["density"].shape == (256, 320, 48) and outs[0][0]["density"].is_contiguous()

@@ -711,18 +711,57 @@ def pack_laplace_sets(ws_density: torch.Tensor, ws_rgb: torch.Tensor, device, ex
     return blob, torch.cat([head, B[:, :, brow].reshape(T, -1)], dim=1).contiguous()
 
 
+# ------------------------------------------------------- frame-path scratch -------------
+
+class Workspace:
+    """Scratch buffers of the frame path (render.render_rays / render_camera): the per-launch-group temporaries that never
+    leave it -- proposal densities, resampled bins, the field kernel's per-sample rows (6.4 GB per 2^20-ray group at K = 8).
+    Taken from torch's caching allocator per call they are the same requests every group, but the allocator's block
+    splitting needs several frames to settle: the FOURTH frame of a process asked hipMalloc for another 6 GiB
+    (memory_reserved 7.9 -> 13.9 GiB), which costs 0.4 ms on some boxes and 118 ms on others -- one 163 ms frame in the
+    timed five of a default bench run.  One flat buffer per tag, grown when a larger request arrives, handed out as views:
+    every use is ordered on the stream that runs the frame, and nothing that is returned to a caller aliases one.
+    UNERF_WORKSPACE=0: allocate per call instead (NerfSceneDev.workspace is then None)."""
+
+    def __init__(self):
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+
+    def get(self, tag: str, shape, device, dtype=torch.float32) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        key = (tag, dtype, str(device))
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < n:
+            self._bufs.pop(key, None)          # release the smaller buffer before asking for the larger one
+            buf = None
+            buf = torch.empty(max(n, 1), device=device, dtype=dtype)
+            self._bufs[key] = buf
+        return buf[:n].view(*shape)
+
+    def nbytes(self) -> int:
+        return sum(b.numel() * b.element_size() for b in self._bufs.values())
+
+
+def _scratch(workspace: Optional["Workspace"], tag: str, shape, device) -> torch.Tensor:
+    if workspace is None:
+        return torch.empty(*shape, device=device, dtype=torch.float32)
+    return workspace.get(tag, shape, device)
+
+
 # ------------------------------------------------------- proposal sampling -------------
 
 def proposal_density(origins, directions, sbins, net: DensityNetDev, near: float, far: float,
                      average_init_density: float, n: Optional[int] = None, ray_offset: int = 0,
-                     image_width: int = 0, spacing: int = 0) -> torch.Tensor:
+                     image_width: int = 0, spacing: int = 0, workspace: Optional[Workspace] = None) -> torch.Tensor:
     """sbins: [n+1] shared row or [R,n+1] per ray -> density [R,n].  image_width > 0: the rays are pixels
-    [ray_offset, ray_offset + R) of a row-major image (8x8-pixel-patch schedule, same results)."""
+    [ray_offset, ray_offset + R) of a row-major image (8x8-pixel-patch schedule, same results).
+    workspace: the result is a view of that scratch arena (valid until the next call with it)."""
     lib = _l.load()
     R = origins.shape[0]
     stride = 0 if sbins.dim() == 1 else sbins.shape[1]
     n = sbins.shape[-1] - 1 if n is None else n
-    out = torch.empty(R, n, device=origins.device, dtype=torch.float32)
+    out = _scratch(workspace, f"prop_density_{n}", (R, n), origins.device)
     cs = net.cstruct()
     with _ctx(origins.device):
         _run(f"proposal_density_{n}", lambda: lib.unerf_proposal_density(_p(origins), _p(directions), _p(sbins), stride, R, n, near, far,
@@ -734,13 +773,13 @@ def proposal_density(origins, directions, sbins, net: DensityNetDev, near: float
 def weights_pdf_resample(density, sbins, u, near: float, far: float, histogram_padding: float = 0.01,
                          eps: float = 1e-5, want_prop_depth: bool = True, want_weights: bool = False,
                          clip_minmax: Optional[torch.Tensor] = None, ray_offset: int = 0, chunk_rays: int = 1 << 15,
-                         spacing: int = 0):
-    """-> (new sbins [R,m+1], prop_depth [R,1] | None, weights [R,n] | None)"""
+                         spacing: int = 0, workspace: Optional[Workspace] = None):
+    """-> (new sbins [R,m+1], prop_depth [R,1] | None, weights [R,n] | None); workspace: the new bins are a view of it"""
     lib = _l.load()
     R, n = density.shape
     m = u.numel() - 1
     stride = 0 if sbins.dim() == 1 else sbins.shape[1]
-    out = torch.empty(R, m + 1, device=density.device, dtype=torch.float32)
+    out = _scratch(workspace, f"pdf_bins_{m}", (R, m + 1), density.device)
     pd = torch.empty(R, 1, device=density.device, dtype=torch.float32) if want_prop_depth else None
     w = torch.empty(R, n, device=density.device, dtype=torch.float32) if want_weights else None
     with _ctx(density.device):
@@ -788,13 +827,14 @@ def supports_packed(field: "FieldDev") -> bool:
 def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0,
               features: Optional[torch.Tensor] = None, image_width: int = 0, euclidean_bins: bool = False,
               sample_major: bool = False, spacing: int = 0, nonfinite_flag: Optional[torch.Tensor] = None,
-              packed: bool = False):
+              packed: bool = False, workspace: Optional[Workspace] = None):
     """-> density [B,R,S], rgb [B,R,S,3], aux, aux2 (see include/unerf.h).  image_width > 0 tells the kernel that
     rays [ray_offset, ray_offset+R) are consecutive pixels of a row-major image (8x4-pixel tiles: same results).
     euclidean_bins: `sbins` holds Euclidean bin edges (a caller-made RaySamples) instead of spacing-domain bins.
     sample_major: the outputs are planes density [B,S,R], rgb [B,S,3,R], aux [S,R] (composite_*_planes read them).
     packed (ACTIVE / MCDROPOUT, ray-major): -> None, rows [B,R,S,4] = (sigma, r, g, b), aux, None -- one 16-byte store
-    per sample; composite_var / composite_moments take the rows as `rgb` with density=None."""
+    per sample; composite_var / composite_moments take the rows as `rgb` with density=None.
+    workspace: the four outputs are views of that scratch arena (valid until the next call with it)."""
     if euclidean_bins:
         near = -1.0
     lib = _l.load()
@@ -803,19 +843,15 @@ def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: flo
     dev = origins.device
     if packed and (sample_major or not supports_packed(field)):
         raise _l.UnerfError("field_fwd: packed rows are written by the ACTIVE / MCDROPOUT kernels in the ray-major layout only")
+    new = lambda tag, *shape: _scratch(workspace, "field_" + tag, shape, dev)
+    has_aux = field.mode != _l.FIELD_MCDROPOUT
     if sample_major:
-        density = torch.empty(B, S, R, device=dev, dtype=torch.float32)
-        rgb = torch.empty(B, S, 3, R, device=dev, dtype=torch.float32)
-        aux = torch.empty(S, R, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
+        density, rgb, aux = new("density", B, S, R), new("rgb", B, S, 3, R), (new("aux", S, R) if has_aux else None)
     elif packed:
-        density = None
-        rgb = torch.empty(B, R, S, 4, device=dev, dtype=torch.float32)
-        aux = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
+        density, rgb, aux = None, new("rgb", B, R, S, 4), (new("aux", R, S) if has_aux else None)
     else:
-        density = torch.empty(B, R, S, device=dev, dtype=torch.float32)
-        rgb = torch.empty(B, R, S, 3, device=dev, dtype=torch.float32)
-        aux = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode != _l.FIELD_MCDROPOUT else None
-    aux2 = torch.empty(R, S, device=dev, dtype=torch.float32) if field.mode == _l.FIELD_LAPLACE else None
+        density, rgb, aux = new("density", B, R, S), new("rgb", B, R, S, 3), (new("aux", R, S) if has_aux else None)
+    aux2 = new("aux2", R, S) if field.mode == _l.FIELD_LAPLACE else None
     cs = field.cstruct()
     cs.image_width = int(image_width)
     cs.sample_major = 1 if sample_major else 0

@@ -71,6 +71,9 @@ class NerfSceneDev:
     overflow_rerenders: int = 0      # how many launch groups that has happened to (diagnostic)
     # field outputs as packed (sigma, r, g, b) rows (include/unerf.h: packed_out)
     packed_out: bool = field(default_factory=lambda: os.environ.get("UNERF_PACKED_OUT", "1") != "0")
+    # scratch arena of the frame path's per-launch-group temporaries (ops.Workspace; UNERF_WORKSPACE=0: per-call allocations)
+    workspace: Optional[ops.Workspace] = field(
+        default_factory=lambda: ops.Workspace() if os.environ.get("UNERF_WORKSPACE", "1") != "0" else None)
     _const: Dict[str, torch.Tensor] = field(default_factory=dict)
 
     @property
@@ -126,8 +129,9 @@ class OverflowGuard:
 
 def sample_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Tensor, clip: Optional[torch.Tensor],
                 ray_offset: int = 0, want_prop_depth: bool = True, image_width: int = 0,
-                init_bins: Optional[torch.Tensor] = None):
+                init_bins: Optional[torch.Tensor] = None, workspace: Optional[ops.Workspace] = None):
     """ProposalNetworkSampler at eval.  -> (final spacing bins [R,S+1], [prop_depth_0, prop_depth_1])
+    workspace (the frame path only): the bins are a view of that scratch arena, not a tensor of their own
     init_bins [R, num_prop[0]+1]: per-ray first-level bins (a bundle with its own nears / fars: `crop_bins`), else
     the shared uniform row"""
     sb = scene.const("bins", scene.num_prop[0]) if init_bins is None else init_bins
@@ -136,13 +140,13 @@ def sample_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Te
     for lvl in range(n_iter):
         dens = ops.proposal_density(origins, directions, sb, scene.props[lvl], scene.near, scene.far,
                                     scene.prop_average_init_density, ray_offset=ray_offset, image_width=image_width,
-                                    spacing=scene.spacing)
+                                    spacing=scene.spacing, workspace=workspace)
         m = scene.num_prop[lvl + 1] if lvl + 1 < n_iter else scene.num_nerf
         last = lvl + 1 == n_iter
         sb, pd, _ = ops.weights_pdf_resample(dens, sb, scene.const("u", m), scene.near, scene.far,
                                              want_prop_depth=want_prop_depth,
                                              clip_minmax=clip if last else None, ray_offset=ray_offset,
-                                             chunk_rays=scene.chunk_rays, spacing=scene.spacing)
+                                             chunk_rays=scene.chunk_rays, spacing=scene.spacing, workspace=workspace)
         prop_depths.append(pd)
     return sb, prop_depths
 
@@ -173,10 +177,12 @@ def crop_bins(scene: NerfSceneDev, origins, directions, obb=None, nears=None, fa
 
 
 def sampling_stage(scene: NerfSceneDev, origins, directions, clip, ray_offset: int, image_width: int = 0,
-                   init_bins: Optional[torch.Tensor] = None):
-    """-> (final spacing bins, prop depths, feature planes | None)"""
+                   init_bins: Optional[torch.Tensor] = None, scratch: bool = True):
+    """-> (final spacing bins, prop depths, feature planes | None); the frame path's stage: its temporaries live in
+    scene.workspace.  scratch=False (render_camera(overlap=True)): tensors of their own -- there the bins of group g are
+    still being read by the shading stream while this stage runs for group g + 1"""
     sb, prop_depths = sample_rays(scene, origins, directions, clip, ray_offset, image_width=image_width,
-                                  init_bins=init_bins)
+                                  init_bins=init_bins, workspace=scene.workspace if scratch else None)
     feats = (ops.field_gather(origins, directions, sb, scene.field, scene.near, scene.far, spacing=scene.spacing)
              if _uses_split(scene) else None)
     return sb, prop_depths, feats
@@ -195,7 +201,7 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
     packed = scene.packed_out and not planes and ops.supports_packed(f)
     density, rgb, aux, aux2 = ops.field_fwd(origins, directions, sb, f, scene.near, scene.far, ray_offset, features=feats,
                                             image_width=image_width, sample_major=planes, spacing=scene.spacing,
-                                            nonfinite_flag=nonfinite_flag, packed=packed)
+                                            nonfinite_flag=nonfinite_flag, packed=packed, workspace=scene.workspace)
     kw = dict(clip_minmax=clip, ray_offset=ray_offset, chunk_rays=scene.chunk_rays, spacing=scene.spacing,
               background=scene.background, nonfinite_flag=nonfinite_flag)
     res: Dict[str, torch.Tensor] = {}
@@ -208,7 +214,9 @@ def shading_stage(scene: NerfSceneDev, origins, directions, sb, prop_depths, fea
         res["rgb_std"] = res["rgb_var"].sqrt()
         res["depth_std"] = res["depth_var"].sqrt()
         if keep_density:   # the reference returns density [R,48,1] (activenerfacto_model.py:115,122)
-            res["density"] = rgb[0][..., 0] if packed else (density[0].t().contiguous() if planes else density[0])
+            # (a copy: the kernel's rows live in scene.workspace and the next launch group overwrites them)
+            res["density"] = (rgb[0][..., 0] if packed else (density[0].t() if planes else density[0])).clone(
+                memory_format=torch.contiguous_format)
     elif f.mode == _l.FIELD_MCDROPOUT:
         if planes and f.K >= 2:
             mean, var = ops.composite_moments_planes(density, rgb, sb, scene.near, scene.far, **kw)
@@ -309,7 +317,7 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
                 with torch.cuda.stream(s_samp):
                     o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start), distortion=distortion)
                     sb, pds, feats = sampling_stage(scene, o, d, clip, start, image_width=W,
-                                                    init_bins=crop_bins(scene, o, d, obb))
+                                                    init_bins=crop_bins(scene, o, d, obb), scratch=False)
                     ev = torch.cuda.Event()
                     ev.record(s_samp)
                     for t in (o, d, sb, feats, *pds):   # handed to the other stream: keep the allocator honest
