@@ -216,45 +216,71 @@ __device__ __forceinline__ void unerf_hash_corners(float px, float py, float pz,
 // row ride one packed fp32 pair (v_pk_mul_f32 / v_pk_add_f32 round each half exactly like the scalar
 // op): 21 packed instructions per level.  Left as scalar code the SLP vectoriser paired (f0*ox, f3*mx)
 // instead and spent a half-wasted horizontal v_pk_add plus ~25 register moves per level.
+// FUSED (the proposal kernels, UNERF_PROP_BLEND_FMA): each lerp as fma(a, o, b * (1 - o)) -- one rounding fewer than torch's
+// mul, mul, add, two instructions instead of three: 14 per level.  The proposal kernels are VALU-issue bound and the blend
+// was 37 % of their instructions: first proposal pass 6.78 -> 6.49 ms per frame, second 3.12 -> 3.08
+// (profiles/r4_exp_blend_fma_*.json).  unerf_hashgrid_fwd (whose outputs are the reference's bits) and the field kernels
+// keep torch's order.  UNERF_FIELD_BLEND_FMA=1 builds the field kernels with the fused form too (-1.1 % K-pass, -1.7 %
+// ACTIVE) -- NOT shippable: the split-f16 kernels of that build return different values from run to run in the columns
+// 16..31 of a few tiles per launch (every other build and kernel is bit-reproducible, tests/test_gpu_repeatability.py);
+// the cause was not found (not the inline assembly, not the MFMA register form, not the scheduler strategy: DESIGN.md 4.5).
+#ifndef UNERF_PROP_BLEND_FMA
+#define UNERF_PROP_BLEND_FMA 1
+#endif
+#ifndef UNERF_FIELD_BLEND_FMA
+#define UNERF_FIELD_BLEND_FMA 0
+#endif
 typedef float unerf_v2f __attribute__((ext_vector_type(2)));
+template <bool FUSED = false>
+__device__ __forceinline__ unerf_v2f unerf_lerp2(unerf_v2f a, unerf_v2f b, float o, float m) {
+    if (FUSED) return __builtin_elementwise_fma(a, unerf_v2f{o, o}, b * m);
+    return a * o + b * m;
+}
+template <bool FUSED = false>
+__device__ __forceinline__ float unerf_lerp1(float a, float b, float o, float m) {
+    if (FUSED) return __builtin_fmaf(a, o, b * m);
+    return a * o + b * m;
+}
+template <bool FUSED = false>
 __device__ __forceinline__ float2 unerf_blend8(const float2 (&f)[8], float ox, float oy, float oz) {
     const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
     unerf_v2f v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = unerf_v2f{f[k].x, f[k].y};
-    unerf_v2f f03 = v[0] * ox + v[3] * mx;
-    unerf_v2f f12 = v[1] * ox + v[2] * mx;
-    unerf_v2f f56 = v[5] * ox + v[6] * mx;
-    unerf_v2f f47 = v[4] * ox + v[7] * mx;
-    unerf_v2f f0312 = f03 * oy + f12 * my;
-    unerf_v2f f4756 = f47 * oy + f56 * my;
-    unerf_v2f r = f0312 * oz + f4756 * mz;
+    unerf_v2f f03 = unerf_lerp2<FUSED>(v[0], v[3], ox, mx);
+    unerf_v2f f12 = unerf_lerp2<FUSED>(v[1], v[2], ox, mx);
+    unerf_v2f f56 = unerf_lerp2<FUSED>(v[5], v[6], ox, mx);
+    unerf_v2f f47 = unerf_lerp2<FUSED>(v[4], v[7], ox, mx);
+    unerf_v2f f0312 = unerf_lerp2<FUSED>(f03, f12, oy, my);
+    unerf_v2f f4756 = unerf_lerp2<FUSED>(f47, f56, oy, my);
+    unerf_v2f r = unerf_lerp2<FUSED>(f0312, f4756, oz, mz);
     return make_float2(r.x, r.y);
 }
 
 // Scalar statement of the same blend (identical roundings) for the MFMA field kernels, which are bound
 // by the gather rather than by VALU issue: the packed form's aligned register pairs cost them ~18 VGPRs
 // and with that the third wave per SIMD.
+template <bool FUSED = false>
 __device__ __forceinline__ float2 unerf_blend8_scalar(const float2 (&f)[8], float ox, float oy, float oz) {
     float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
     float2 r;
     {
-        float f03 = f[0].x * ox + f[3].x * mx;
-        float f12 = f[1].x * ox + f[2].x * mx;
-        float f56 = f[5].x * ox + f[6].x * mx;
-        float f47 = f[4].x * ox + f[7].x * mx;
-        float f0312 = f03 * oy + f12 * my;
-        float f4756 = f47 * oy + f56 * my;
-        r.x = f0312 * oz + f4756 * mz;
+        float f03 = unerf_lerp1<FUSED>(f[0].x, f[3].x, ox, mx);
+        float f12 = unerf_lerp1<FUSED>(f[1].x, f[2].x, ox, mx);
+        float f56 = unerf_lerp1<FUSED>(f[5].x, f[6].x, ox, mx);
+        float f47 = unerf_lerp1<FUSED>(f[4].x, f[7].x, ox, mx);
+        float f0312 = unerf_lerp1<FUSED>(f03, f12, oy, my);
+        float f4756 = unerf_lerp1<FUSED>(f47, f56, oy, my);
+        r.x = unerf_lerp1<FUSED>(f0312, f4756, oz, mz);
     }
     {
-        float f03 = f[0].y * ox + f[3].y * mx;
-        float f12 = f[1].y * ox + f[2].y * mx;
-        float f56 = f[5].y * ox + f[6].y * mx;
-        float f47 = f[4].y * ox + f[7].y * mx;
-        float f0312 = f03 * oy + f12 * my;
-        float f4756 = f47 * oy + f56 * my;
-        r.y = f0312 * oz + f4756 * mz;
+        float f03 = unerf_lerp1<FUSED>(f[0].y, f[3].y, ox, mx);
+        float f12 = unerf_lerp1<FUSED>(f[1].y, f[2].y, ox, mx);
+        float f56 = unerf_lerp1<FUSED>(f[5].y, f[6].y, ox, mx);
+        float f47 = unerf_lerp1<FUSED>(f[4].y, f[7].y, ox, mx);
+        float f0312 = unerf_lerp1<FUSED>(f03, f12, oy, my);
+        float f4756 = unerf_lerp1<FUSED>(f47, f56, oy, my);
+        r.y = unerf_lerp1<FUSED>(f0312, f4756, oz, mz);
     }
     return r;
 }
@@ -270,7 +296,7 @@ __device__ __forceinline__ void unerf_fetch_corners(const float2* __restrict__ l
     for (int k = 0; k < 8; ++k) f[k] = *reinterpret_cast<const float2*>(base + off[k]);
 }
 
-template <bool EXACT_CEIL = false>
+template <bool EXACT_CEIL = false, bool FUSED = false>
 __device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lvl, float px, float py, float pz,
                                                    float scale, uint32_t mask) {
     uint32_t off[8];
@@ -278,12 +304,13 @@ __device__ __forceinline__ float2 unerf_hash_level(const float2* __restrict__ lv
     unerf_hash_corners<false, EXACT_CEIL>(px, py, pz, scale, mask, off, ox, oy, oz);
     float2 f[8];
     unerf_fetch_corners(lvl, off, f);
-    return unerf_blend8(f, ox, oy, oz);
+    return unerf_blend8<FUSED>(f, ox, oy, oz);
 }
 
 // Dense re-indexed level (see unerf_density_net in include/unerf.h): cell (x,y,z) holds
 // { table[hash(x,y,z)], table[hash(x+1,y,z)] }, so the floor-x and ceil-x corners of one (y,z) edge
 // arrive in a single 16-byte load.  Same values, same blend order as unerf_hash_level.
+template <bool FUSED = false>
 __device__ __forceinline__ float2 unerf_dense_level(const float4* __restrict__ cells, int dim, float px, float py,
                                                     float pz, float scale) {
     float sx = px * scale, sy = py * scale, sz = pz * scale;
@@ -312,7 +339,7 @@ __device__ __forceinline__ float2 unerf_dense_level(const float4* __restrict__ c
     f[4] = make_float2(pcf.z, pcf.w);
     f[6] = make_float2(pff.x, pff.y);
     f[5] = make_float2(pff.z, pff.w);
-    return unerf_blend8(f, ox, oy, oz);
+    return unerf_blend8<FUSED>(f, ox, oy, oz);
 }
 
 // ---- one level of a tiny-cuda-nn HashGrid (include/unerf.h: unerf_tcnn_level) ----------------------

@@ -538,11 +538,11 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
         if (a.net.tcnn_levels) {  // uniform: tcnn-layout grid
             f = unerf_tcnn_level_feat(reinterpret_cast<const float2*>(a.net.table), a.net.tcnn_levels[l], px, py, pz);
         } else if (l < a.net.n_dense) {  // wave-uniform: coarse level with a dense, x-paired copy
-            f = unerf_dense_level(reinterpret_cast<const float4*>(a.net.dense) + a.net.dense_off[l], a.net.dense_dim[l],
+            f = unerf_dense_level<(UNERF_PROP_BLEND_FMA != 0)>(reinterpret_cast<const float4*>(a.net.dense) + a.net.dense_off[l], a.net.dense_dim[l],
                                   px, py, pz, a.net.scalings[l]);
         } else {
             const float2* lvl = reinterpret_cast<const float2*>(a.net.table) + ((size_t)l << a.net.log2T);
-            f = unerf_hash_level(lvl, px, py, pz, a.net.scalings[l], mask);
+            f = unerf_hash_level<false, (UNERF_PROP_BLEND_FMA != 0)>(lvl, px, py, pz, a.net.scalings[l], mask);
         }
         feat[2 * l] = f.x;
         feat[2 * l + 1] = f.y;
@@ -639,11 +639,11 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
             if (a.net.tcnn_levels) {  // uniform: tcnn-layout grid
                 f = unerf_tcnn_level_feat(reinterpret_cast<const float2*>(a.net.table), a.net.tcnn_levels[l], px, py, pz);
             } else if (l < a.net.n_dense) {  // wave-uniform: coarse level with a dense, x-paired copy
-                f = unerf_dense_level(reinterpret_cast<const float4*>(a.net.dense) + a.net.dense_off[l], a.net.dense_dim[l],
+                f = unerf_dense_level<(UNERF_PROP_BLEND_FMA != 0)>(reinterpret_cast<const float4*>(a.net.dense) + a.net.dense_off[l], a.net.dense_dim[l],
                                       px, py, pz, a.net.scalings[l]);
             } else {
                 const float2* lvl = reinterpret_cast<const float2*>(a.net.table) + ((size_t)l << a.net.log2T);
-                f = unerf_hash_level(lvl, px, py, pz, a.net.scalings[l], mask);
+                f = unerf_hash_level<false, (UNERF_PROP_BLEND_FMA != 0)>(lvl, px, py, pz, a.net.scalings[l], mask);
             }
             feat[2 * l] = f.x;
             feat[2 * l + 1] = f.y;
@@ -1483,8 +1483,8 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
             float2 c8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
-            float2 f = PACKED ? unerf_blend8(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2])
-                              : unerf_blend8_scalar(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+            float2 f = PACKED ? unerf_blend8<(UNERF_FIELD_BLEND_FMA != 0)>(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2])
+                              : unerf_blend8_scalar<(UNERF_FIELD_BLEND_FMA != 0)>(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
             feat[2 * (4 * hb + q)] = f.x;
             feat[2 * (4 * hb + q) + 1] = f.y;
         }
