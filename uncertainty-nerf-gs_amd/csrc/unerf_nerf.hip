@@ -1722,14 +1722,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // convert (the kernels are VALU-issue-bound once the matrix work is on the f16 pipe).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void mf16_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-    const f16x2 hh = {(_Float16)x0, (_Float16)x1};
-    hi = __builtin_bit_cast(uint32_t, hh);
-    uint32_t l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
-    lo = l;
-}
 // F1 (every helper below, and the kernels): the REFERENCE-PRECISION form, `precision = "f16"` / unerf_field_params.f16_single.
 // One f16 product per MAC with fp32 accumulation: operands rounded to f16 once (v_cvt_pk_f16_f32 for the activations,
 // the hi halves of the packed weights), no lo halves anywhere -- the arithmetic of torch.autocast(float16) Linear layers
@@ -1741,15 +1733,30 @@ __device__ __forceinline__ void mf16_split8(const float (&x)[8], f16x8& hi, f16x
     u32x4 hv, lv;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        if (F1) {
-            const f16x2 hh = {(_Float16)x[2 * p], (_Float16)x[2 * p + 1]};
-            hv[p] = lv[p] = __builtin_bit_cast(uint32_t, hh);   // lo is never read in this form
-        } else {
-            uint32_t hq, lq;
-            mf16_split2(x[2 * p], x[2 * p + 1], hq, lq);
-            hv[p] = hq;
-            lv[p] = lq;
-        }
+        const f16x2 hh = {(_Float16)x[2 * p], (_Float16)x[2 * p + 1]};
+        hv[p] = lv[p] = __builtin_bit_cast(uint32_t, hh);   // F1: lo is never read in this form
+    }
+    if (!F1) {
+        // The eight residuals of a k-step operand in ONE assembly statement that ends in two wait states.  An MFMA must not
+        // read a VGPR within two wait states of a VALU write to it (and a VALU instruction not within one of a half-register
+        // write); the compiler places those for the instructions it knows, and does not look inside inline assembly: written
+        // as one statement per instruction (rounds 2 - 4) the listing had MFMAs ONE instruction behind the v_fma_mixhi_f16
+        // that completes their B operand.  No run of the test suite ever differed because of it -- the other wave of the
+        // SIMD usually separates the two -- but nothing guaranteed that.
+        uint32_t l0, l1, l2, l3;
+        asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "s_nop 1"
+            : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+            : "v"(hv[0]), "v"(hv[1]), "v"(hv[2]), "v"(hv[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
+              "v"(x[6]), "v"(x[7]));
+        lv[0] = l0; lv[1] = l1; lv[2] = l2; lv[3] = l3;
     }
     hi = __builtin_bit_cast(f16x8, hv);
     lo = __builtin_bit_cast(f16x8, lv);
