@@ -105,3 +105,30 @@ def test_a_rank_count_that_contradicts_gpus_is_refused():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
                        timeout=300)
     assert p.returncode == 2 and "WORLD_SIZE=4" in p.stderr
+
+
+def test_parity_record_is_zero_for_identical_frames_and_well_conditioned():
+    """bench.parity_record on CPU tensors: identical frames give zero deltas; a perturbation of rgb_std at the level the f16
+    kernels differ from the oracle moves the gated AUSE (target error follows the uncertainty) far less than the AUSE against
+    the tests' uninformative target -- the reason the gate reads the first (tests/tools/ause_conditioning.py)."""
+    import importlib.util
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g = torch.Generator().manual_seed(0)
+    n = 8192
+    ref = {"rgb": torch.rand(n, 3, generator=g) * 0.5 + 0.2, "rgb_std": 0.002 + 0.007 * torch.rand(n, 1, generator=g) ** 3,
+           "accumulation": torch.ones(n, 1), "depth": 1.0 + torch.rand(n, 1, generator=g)}
+    ids = np.arange(n, dtype=np.int64)
+    same = bench.parity_record({k: v.clone() for k, v in ref.items()}, ids, ref, "f16")
+    assert same["rays"] == n and same["d_psnr"] == 0 and same["d_ause_mse"] == 0 and same["inside_gates"] is True
+    assert same["d_ause_mse_uninformative_target"]["max"] == 0 and same["median_depth_pixels_off_1e-3"] == 0
+    got = {k: v.clone() for k, v in ref.items()}
+    got["rgb_std"] = (ref["rgb_std"] + (torch.rand(n, 1, generator=g) - 0.5) * 1.2e-5).clamp(min=0)
+    got["rgb"] = ref["rgb"] + (torch.rand(n, 3, generator=g) - 0.5) * 2e-5
+    rec = bench.parity_record(got, ids, ref, "f16")
+    assert rec["inside_gates"] is True and rec["d_psnr"] < 1e-4
+    assert rec["d_ause_mse"] < rec["d_ause_mse_uninformative_target"]["mean"]
+    assert 0 < rec["ause_mse_oracle"] < 0.6
