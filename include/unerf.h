@@ -38,7 +38,7 @@ extern "C" {
 const char* unerf_last_error(void);
 /* Library/ABI version (major*1000+minor).  A binding built against this header must find exactly UNERF_ABI_VERSION
  * (struct layouts and argument lists change with it; uncertainty-nerf-gs_amd/lib.py::load checks). */
-#define UNERF_ABI_VERSION 1300
+#define UNERF_ABI_VERSION 1400
 int unerf_version(void);
 
 /* Spacing function of the proposal sampler's initial sampler, passed behind every (near_plane, far_plane) pair:
@@ -138,6 +138,15 @@ typedef struct {
  * out_idx (may be NULL) [N,L,8] int32 = absolute row indices in corner order k = 0..7. */
 int unerf_hashgrid_fwd_tcnn(const float* xyz, const float* params, const unerf_tcnn_level* levels_host, int64_t N,
                             int L, float* out, int32_t* out_idx, void* stream);
+/* The same lookup the way tiny-cuda-nn computes it when built with TCNN_HALF_PRECISION (its default on every GPU the
+ * reference targets; kernel_grid in include/tiny-cuda-nn/encodings/grid.h with T = __half) -- what the reference's
+ * HashEncoding(implementation="tcnn") call sites above return: params_half = the parameter vector cast to half
+ * ([rows] half2, round to nearest even); positions and the three interpolation weights in fp32 as above; per corner
+ * k = 0..7 the fp32 weight product ((w_x w_y) w_z) is rounded to half and result = fma(half weight, row, result) is a
+ * HALF fused multiply-add per feature (__hfma2), result starting at 0.  out [N,2L] fp32 holding the half values (rows are
+ * those of unerf_hashgrid_fwd_tcnn's out_idx). */
+int unerf_hashgrid_fwd_tcnn_half(const float* xyz, const void* params_half, const unerf_tcnn_level* levels_host, int64_t N,
+                                 int L, float* out, void* stream);
 
 /* hash grid + small MLP (torch nn.Linear weights pre-transposed to [in][out]). */
 typedef struct {
@@ -167,6 +176,10 @@ typedef struct {
        SceneContraction(inf) followed by (x + 2) / 4.  aabb = {min xyz, max xyz}. */
     int use_aabb;
     float aabb[6];
+    /* tcnn_levels only: 1 = `table` points at the HALF copy of the parameter vector ([rows] half2, 4 bytes per row) and
+       the level is interpolated in tiny-cuda-nn's own half arithmetic (see unerf_hashgrid_fwd_tcnn_half); the features
+       then enter the fp32 MLP as the half values they are.  0: fp32 rows, fp32 blend. */
+    int grid_half;
 } unerf_density_net;
 
 /* -------------------------------------------------- proposal density --
@@ -329,6 +342,13 @@ typedef struct {
        row is one dwordx4 store, and unerf_composite_var / unerf_composite_moments read it back with one 16-byte load
        (pass density = NULL and the packed rows as rgb).  Same values either way. */
     int packed_out;
+    /* tcnn_levels only: 1 = `table` points at the HALF copy of the main grid's parameter vector ([rows] half2) and the
+       lookup runs in tiny-cuda-nn's own half arithmetic (unerf_hashgrid_fwd_tcnn_half) -- what
+       HashEncoding(implementation="tcnn"), the reference's default (models/activenerfacto/activenerfacto_field.py:89,
+       140-147; mcdropout_fields.py:78, 115-122; laplace_field.py:91, 129-136), hands to the MLP.  The f16 matrix kernels
+       take the packed half features as their layer-0 operands without a conversion; 4 bytes per gathered corner
+       instead of 8.  0: fp32 rows and blend (a tcnn built without TCNN_HALF_PRECISION). */
+    int grid_half;
 } unerf_field_params;
 #define UNERF_DROP_TRUNK 1
 #define UNERF_DROP_HEAD0 2

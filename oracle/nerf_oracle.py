@@ -146,6 +146,51 @@ def tcnn_hash_encode(x: torch.Tensor, params: torch.Tensor, levels) -> torch.Ten
     return out.reshape(N, 2 * L)
 
 
+def _round_f16_of_sum(p: np.ndarray, c: np.ndarray) -> np.ndarray:
+    """round_to_nearest_even_f16(p + c) for float64 arrays whose EXACT sum may need more than 53 bits (p: a 22-bit product of
+    two halves, c: a half).  TwoSum gives s = fl64(p + c) and the exact error e; rounding s to f16 directly is wrong only
+    when s sits exactly on the midpoint of two neighbouring halves and e != 0, where the exact sum is off the midpoint on
+    e's side -- there the neighbour of s on that side is rounded instead."""
+    s = p + c
+    bb = s - p
+    e = (p - (s - bb)) + (c - bb)
+    with np.errstate(over="ignore"):
+        h = s.astype(np.float16)
+        up = np.nextafter(s, np.inf).astype(np.float16)
+        dn = np.nextafter(s, -np.inf).astype(np.float16)
+    tie = (up != dn) & (e != 0)
+    return np.where(tie & (e > 0), up, np.where(tie & (e < 0), dn, h))
+
+
+def tcnn_hash_encode_half(x: torch.Tensor, params: torch.Tensor, levels) -> torch.Tensor:
+    """tiny-cuda-nn's `kernel_grid` (include/tiny-cuda-nn/encodings/grid.h, HEAD -- the reference pins no version,
+    README.md:21) in the precision tcnn is built with on every GPU the reference targets (TCNN_HALF_PRECISION, T = __half),
+    i.e. what HashEncoding(implementation="tcnn") returns [UPSTREAM-RECALL]:
+      * the grid is the HALF copy of the fp32 master parameters (`params` is cast to T before the forward pass);
+      * pos_fract: pos = fmaf(scale, x, 0.5f); cell = floorf(pos); w = pos - cell  -- fp32, as tcnn_hash_indices;
+      * per corner idx = 0..7: weight = 1.f; for dim in x, y, z: weight *= (idx >> dim & 1) ? w[dim] : 1 - w[dim]  (fp32),
+        result = fma((T)weight, grid_val, result)  -- a half-precision fused multiply-add per feature (__hfma2), result
+        starting at zero, corners in index order;
+      * the encoded position is stored as T.
+    -> [N, 2L] float32 holding the half values, level-major.  Every rounding above is reproduced exactly (the hfma through
+    _round_f16_of_sum), so a kernel doing the same arithmetic matches bit for bit."""
+    rows, w = tcnn_hash_indices(x, levels)
+    tab = params.detach().reshape(-1, 2).to(torch.float32).numpy().astype(np.float16).astype(np.float64)
+    rows_np, w_np = rows.numpy(), w.numpy().astype(np.float32)
+    N, L = x.shape[0], len(levels)
+    res = np.zeros((N, L, 2), dtype=np.float64)
+    one = np.float32(1.0)
+    for k in range(8):
+        wk = np.ones((N, L), dtype=np.float32)
+        for d in range(3):
+            wd = w_np[..., d]
+            wk = (wk * (wd if (k >> d) & 1 else (one - wd))).astype(np.float32)
+        wh = wk.astype(np.float16).astype(np.float64)
+        val = tab[rows_np[..., k]]                                  # [N, L, 2]
+        res = _round_f16_of_sum(wh[..., None] * val, res).astype(np.float64)
+    return torch.from_numpy(res.astype(np.float32).reshape(N, 2 * L))
+
+
 def unpack_tcnn_mlp(params: torch.Tensor, in_dim: int, width: int, n_hidden_layers: int, out_dim: int):
     """tcnn FullyFusedMLP parameter vector -> torch-layout [out,in] weight matrices (no biases).
     Layout: first layer [width, pad16(in_dim)], (n_hidden_layers - 1) x [width, width], last [pad16(out_dim), width],
@@ -410,9 +455,12 @@ class GridMLP:
     biases: List[torch.Tensor]
     tcnn_levels: Optional[list] = None   # set: `table` is a tcnn-layout parameter vector (tcnn_grid_levels)
     aabb: Optional[torch.Tensor] = None  # [2,3]: scene-box normalisation instead of the contraction
+    grid_half: bool = False              # tcnn layout only: tcnn's own half-precision arithmetic (tcnn_hash_encode_half)
 
 
 def grid_encode(x: torch.Tensor, g: "GridMLP") -> torch.Tensor:
+    if g.tcnn_levels is not None and g.grid_half:
+        return tcnn_hash_encode_half(x, g.table, g.tcnn_levels)
     if g.tcnn_levels is not None:
         return tcnn_hash_encode(x, g.table, g.tcnn_levels)
     return hash_encode(x, g.table, g.scalings, g.log2_T)
@@ -1020,7 +1068,8 @@ def scene_from_tensors(t: dict) -> NerfScene:
             ws.append(d["w1"])
             bs.append(d["b1"])
         return GridMLP(d["table"], d["scalings"], int(d["log2T"]), ws, bs, tcnn_levels=d.get("tcnn_levels"),
-                       aabb=t.get("aabb"))   # scene box [2,3]: disable_scene_contraction
+                       aabb=t.get("aabb"),   # scene box [2,3]: disable_scene_contraction
+                       grid_half=d.get("tcnn_levels") is not None and t.get("grid_precision", "f32") == "f16")
 
     f = t["field"]
     lap = t["kind"] == "laplace"

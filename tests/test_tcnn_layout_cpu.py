@@ -98,3 +98,43 @@ def test_tcnn_oracle_lookup_properties():
     assert idx.shape == (500, 5, 8) and w.shape == (500, 5, 3)
     for l, (_, res, off, size, dense) in enumerate(lv):
         assert (idx[:, l] >= off).all() and (idx[:, l] < off + size).all()
+
+
+def test_half_fma_rounding_of_the_oracle_is_exact():
+    """oracle._round_f16_of_sum = round-to-nearest-even-f16(p + c) for p a product of two halves: checked against exact
+    rational arithmetic, including sums whose exact value needs more than 53 bits and constructed ties"""
+    from fractions import Fraction
+    import numpy as np
+    from oracle.nerf_oracle import _round_f16_of_sum
+    rng = np.random.default_rng(0)
+
+    def halves(n, lo, hi):
+        m, e, s = rng.integers(0, 2048, n), rng.integers(lo, hi, n), rng.choice([-1, 1], n)
+        return (s * m * np.exp2(e.astype(np.float64) - 10)).astype(np.float16)
+
+    n = 4000
+    w, v, c = np.abs(halves(n, -24, 0)), halves(n, -24, 15), halves(n, -24, 15)
+    got = _round_f16_of_sum(w.astype(np.float64) * v.astype(np.float64), c.astype(np.float64))
+    for i in range(n):
+        fr = Fraction(float(w[i])) * Fraction(float(v[i])) + Fraction(float(c[i]))
+        if abs(fr) > 65000:
+            continue
+        h = np.float16(float(fr))
+        best = min((x for x in (h, np.nextafter(h, np.float16(np.inf)), np.nextafter(h, np.float16(-np.inf))) if np.isfinite(x)),
+                   key=lambda x: (abs(Fraction(float(x)) - fr), int(np.float16(x).view(np.uint16)) & 1))
+        assert best == got[i], (w[i], v[i], c[i], best, got[i])
+    # a product exactly on a half midpoint, nudged by an addend below the float64 resolution of the sum
+    p = np.array([1.0 + 2.0 ** -11] * 2)
+    assert list(_round_f16_of_sum(p, np.array([2.0 ** -24, -2.0 ** -24]))) == [np.float16(1.0 + 2.0 ** -10), np.float16(1.0)]
+
+
+def test_tcnn_half_encode_is_the_fp32_encode_to_half_precision():
+    import math
+    import torch
+    from oracle import nerf_oracle as O
+    lv = O.tcnn_grid_levels(8, 16, math.exp((math.log(512) - math.log(16)) / 7), 12)
+    g = torch.Generator().manual_seed(1)
+    table = torch.rand(lv[-1][2] + lv[-1][3], 2, generator=g) * 2 - 1
+    x = torch.rand(500, 3, generator=g)
+    h, f = O.tcnn_hash_encode_half(x, table, lv), O.tcnn_hash_encode(x, table, lv)
+    assert torch.equal(h, h.half().float()) and (h - f).abs().max() < 4e-3 and (h - f).abs().max() > 1e-5

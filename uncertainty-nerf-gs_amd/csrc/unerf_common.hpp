@@ -391,11 +391,38 @@ __device__ __forceinline__ float2 unerf_tcnn_blend(const float2 (&f)[8], float w
     }
     return make_float2(r.x, r.y);
 }
-// Corner BYTE offsets (8-byte rows, level offset included) off the table base for the persistent field kernels:
+// tcnn's OWN arithmetic (kernel_grid of tiny-cuda-nn's encodings/grid.h with T = __half, the precision tcnn is built with
+// on the GPUs the reference targets; twin: oracle tcnn_hash_encode_half): the table is the HALF copy of the fp32 master
+// parameters, one 4-byte half2 row per corner; per corner the fp32 weight product above is rounded to half and
+// result = fma((T)weight, row, result) runs as a half-precision fused multiply-add per feature (__hfma2 ->
+// v_pk_fma_f16), result starting at zero, corners in index order.  -> the level's two features as one packed half2.
+typedef _Float16 unerf_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t unerf_tcnn_blend_half(const uint32_t (&rows)[8], float wx, float wy, float wz) {
+    const float mx = 1.f - wx, my = 1.f - wy, mz = 1.f - wz;
+    const float wxy[4] = {mx * my, wx * my, mx * wy, wx * wy};
+    unerf_h2 r = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        // two corner weights per v_cvt_pk_f16_f32 (round to nearest even, as __float2half_rn); each packed fma then
+        // takes its weight from one half of the pair
+        const unerf_v2f w2 = {wxy[k & 3] * ((k & 4) ? wz : mz), wxy[(k + 1) & 3] * ((k & 4) ? wz : mz)};
+        const unerf_h2 wh = __builtin_convertvector(w2, unerf_h2);
+        r = __builtin_elementwise_fma(unerf_h2{wh.x, wh.x}, __builtin_bit_cast(unerf_h2, rows[k]), r);
+        r = __builtin_elementwise_fma(unerf_h2{wh.y, wh.y}, __builtin_bit_cast(unerf_h2, rows[k + 1]), r);
+    }
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float2 unerf_h2_to_float2(uint32_t packed) {
+    const unerf_h2 h = __builtin_bit_cast(unerf_h2, packed);
+    return make_float2((float)h.x, (float)h.y);
+}
+// Corner BYTE offsets (level offset included) off the table base for the persistent field kernels:
 // a uniform (SGPR) base + 32-bit lane offset per load instead of 64-bit address arithmetic per corner; the level
 // record arrives as five scalars (staged in LDS by the caller).  Same rows as unerf_tcnn_corners.  Needs the
-// table below 2^32 bytes and, on dense levels, res^2 * (res + 1) < 2^24.
-__device__ __forceinline__ void unerf_tcnn_offsets(float scale, uint32_t res, uint32_t off8, uint32_t size,
+// table below 2^32 bytes and, on dense levels, res^2 * (res + 1) < 2^24.  RS = log2 of the row size in bytes:
+// 3 (fp32 rows of two features), 2 (half2 rows); off_b = the level's byte offset (lv.offset << RS).
+template <int RS = 3>
+__device__ __forceinline__ void unerf_tcnn_offsets(float scale, uint32_t res, uint32_t off_b, uint32_t size,
                                                    uint32_t dense, float px, float py, float pz, uint32_t (&off)[8],
                                                    float& wx, float& wy, float& wz) {
     const float fx = fmaf(scale, px, 0.5f), fy = fmaf(scale, py, 0.5f), fz = fmaf(scale, pz, 0.5f);
@@ -404,6 +431,7 @@ __device__ __forceinline__ void unerf_tcnn_offsets(float scale, uint32_t res, ui
     wy = fy - gy;
     wz = fz - gz;
     const uint32_t x0 = (uint32_t)(int)gx, y0 = (uint32_t)(int)gy, z0 = (uint32_t)(int)gz;
+    constexpr uint32_t ROW = 1u << RS;
     if (dense) {
         const uint32_t r2 = __umul24(res, res);
         const uint32_t b00 = x0 + __umul24(y0, res) + __umul24(z0, r2);
@@ -413,22 +441,22 @@ __device__ __forceinline__ void unerf_tcnn_offsets(float scale, uint32_t res, ui
             for (int k = 0; k < 8; ++k) {
                 uint32_t i = b[k >> 1] + (uint32_t)(k & 1);
                 i = min(i, i - size);   // i >= size ? i - size : i  (the difference wraps to a huge value when i < size)
-                off[k] = off8 + (i << 3);
+                off[k] = off_b + (i << RS);
             }
-        } else {  // one base offset + uniform steps (+8 rides in the load's immediate offset)
-            const uint32_t o00 = off8 + (b00 << 3), r8 = res << 3, r28 = r2 << 3;
+        } else {  // one base offset + uniform steps (+ROW rides in the load's immediate offset)
+            const uint32_t o00 = off_b + (b00 << RS), r8 = res << RS, r28 = r2 << RS;
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                off[k] = o00 + ((k & 1) ? 8u : 0u) + ((k & 2) ? r8 : 0u) + ((k & 4) ? r28 : 0u);
+                off[k] = o00 + ((k & 1) ? ROW : 0u) + ((k & 2) ? r8 : 0u) + ((k & 4) ? r28 : 0u);
         }
     } else {
-        const uint32_t m8 = (size - 1u) << 3, P1 = 2654435761u << 3, P2 = 805459861u << 3;
-        const uint32_t hx0 = x0 << 3, hx1 = hx0 + 8u;
+        const uint32_t m8 = (size - 1u) << RS, P1 = 2654435761u << RS, P2 = 805459861u << RS;
+        const uint32_t hx0 = x0 << RS, hx1 = hx0 + ROW;
         const uint32_t hy0 = y0 * P1, hz0 = z0 * P2, hy1 = hy0 + P1, hz1 = hz0 + P2;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t hx = (k & 1) ? hx1 : hx0, hy = (k & 2) ? hy1 : hy0, hz = (k & 4) ? hz1 : hz0;
-            off[k] = off8 + ((hx ^ hy ^ hz) & m8);
+            off[k] = off_b + ((hx ^ hy ^ hz) & m8);
         }
     }
 }
@@ -459,10 +487,41 @@ __device__ __forceinline__ float2 unerf_tcnn_level_feat(const float2* __restrict
         }
     }
     uint32_t off[8];
-    unerf_tcnn_offsets(lv.scale, lv.res, lv.offset << 3, lv.size, lv.dense, px, py, pz, off, wx, wy, wz);
+    unerf_tcnn_offsets<3>(lv.scale, lv.res, lv.offset << 3, lv.size, lv.dense, px, py, pz, off, wx, wy, wz);
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = *reinterpret_cast<const float2*>(base + off[k]);
     return unerf_tcnn_blend(f, wx, wy, wz);
+}
+// the same level of a HALF table (4-byte half2 rows), tcnn's half arithmetic -> the two features as floats holding
+// the half values.  Dense levels away from the wrap: the x-neighbours of an edge are one 8-byte load (4-byte aligned).
+__device__ __forceinline__ float2 unerf_tcnn_level_feat_half(const void* __restrict__ params, const unerf_tcnn_level& lv,
+                                                             float px, float py, float pz) {
+    const char* base = reinterpret_cast<const char*>(params);
+    uint32_t rows[8];
+    float wx, wy, wz;
+    if (lv.dense) {
+        const float fx = fmaf(lv.scale, px, 0.5f), fy = fmaf(lv.scale, py, 0.5f), fz = fmaf(lv.scale, pz, 0.5f);
+        const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+        const uint32_t x0 = (uint32_t)(int)gx, y0 = (uint32_t)(int)gy, z0 = (uint32_t)(int)gz;
+        const uint32_t r2 = __umul24(lv.res, lv.res);
+        const uint32_t b00 = x0 + __umul24(y0, lv.res) + __umul24(z0, r2);
+        if (!__any(b00 + lv.res + r2 + 1u >= lv.size)) {
+            struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
+            const uint32_t o00 = (lv.offset + b00) << 2, r4 = lv.res << 2, r24 = r2 << 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const Pair v = *reinterpret_cast<const Pair*>(base + (o00 + ((e & 1) ? r4 : 0u) + ((e & 2) ? r24 : 0u)));
+                rows[2 * e] = v.a;
+                rows[2 * e + 1] = v.b;
+            }
+            return unerf_h2_to_float2(unerf_tcnn_blend_half(rows, fx - gx, fy - gy, fz - gz));
+        }
+    }
+    uint32_t off[8];
+    unerf_tcnn_offsets<2>(lv.scale, lv.res, lv.offset << 2, lv.size, lv.dense, px, py, pz, off, wx, wy, wz);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rows[k] = *reinterpret_cast<const uint32_t*>(base + off[k]);
+    return unerf_h2_to_float2(unerf_tcnn_blend_half(rows, wx, wy, wz));
 }
 
 // ---- real SH, 4 levels (components_from_spherical_harmonics) -------------------------

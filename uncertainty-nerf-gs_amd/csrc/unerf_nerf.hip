@@ -452,21 +452,57 @@ __global__ __launch_bounds__(256) void hashgrid_tcnn_kernel(const float* __restr
     }
 }
 
+static int unerf_tcnn_levels_from_host(TcnnLevels& lv, const unerf_tcnn_level* levels_host, int L, const char* what) {
+    for (int l = 0; l < L; ++l) {
+        lv.v[l] = levels_host[l];
+        UNERF_REQUIRE(lv.v[l].res >= 2 && lv.v[l].size >= 8 && (lv.v[l].dense || (lv.v[l].size & (lv.v[l].size - 1)) == 0),
+                      "%s: level %d: res=%u size=%u (hashed levels need a power-of-two size)", what, l,
+                      lv.v[l].res, lv.v[l].size);
+    }
+    return UNERF_OK;
+}
+
 extern "C" int unerf_hashgrid_fwd_tcnn(const float* xyz, const float* params, const unerf_tcnn_level* levels_host,
                                        int64_t N, int L, float* out, int32_t* out_idx, void* stream) {
     UNERF_REQUIRE(L >= 1 && L <= 32 && N >= 0, "hashgrid_fwd_tcnn: bad L=%d", L);
     if (N == 0) return UNERF_OK;
     UNERF_REQUIRE(xyz && params && levels_host && out, "hashgrid_fwd_tcnn: null pointer");
     TcnnLevels lv;
-    for (int l = 0; l < L; ++l) {
-        lv.v[l] = levels_host[l];
-        UNERF_REQUIRE(lv.v[l].res >= 2 && lv.v[l].size >= 8 && (lv.v[l].dense || (lv.v[l].size & (lv.v[l].size - 1)) == 0),
-                      "hashgrid_fwd_tcnn: level %d: res=%u size=%u (hashed levels need a power-of-two size)", l,
-                      lv.v[l].res, lv.v[l].size);
-    }
+    if (int rc = unerf_tcnn_levels_from_host(lv, levels_host, L, "hashgrid_fwd_tcnn")) return rc;
     hipLaunchKernelGGL(hashgrid_tcnn_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, xyz, params,
                        lv, N, L, out, out_idx);
     return unerf_check_launch("hashgrid_fwd_tcnn");
+}
+
+// the same lookup in tcnn's own half arithmetic: params_half = the half copy of the parameter vector, [rows] half2
+__global__ __launch_bounds__(256) void hashgrid_tcnn_half_kernel(const float* __restrict__ xyz,
+                                                                 const void* __restrict__ params_half, TcnnLevels lv, int64_t N,
+                                                                 int L, float* __restrict__ out) {
+    int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float px = xyz[n * 3 + 0], py = xyz[n * 3 + 1], pz = xyz[n * 3 + 2];
+    for (int l = 0; l < L; ++l) {
+        uint32_t rows[8], c8[8];
+        float wx, wy, wz;
+        unerf_tcnn_corners(lv.v[l], px, py, pz, rows, wx, wy, wz);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c8[k] = reinterpret_cast<const uint32_t*>(params_half)[rows[k]];
+        const float2 r = unerf_h2_to_float2(unerf_tcnn_blend_half(c8, wx, wy, wz));
+        out[n * (2 * L) + 2 * l + 0] = r.x;
+        out[n * (2 * L) + 2 * l + 1] = r.y;
+    }
+}
+
+extern "C" int unerf_hashgrid_fwd_tcnn_half(const float* xyz, const void* params_half, const unerf_tcnn_level* levels_host,
+                                            int64_t N, int L, float* out, void* stream) {
+    UNERF_REQUIRE(L >= 1 && L <= 32 && N >= 0, "hashgrid_fwd_tcnn_half: bad L=%d", L);
+    if (N == 0) return UNERF_OK;
+    UNERF_REQUIRE(xyz && params_half && levels_host && out, "hashgrid_fwd_tcnn_half: null pointer");
+    TcnnLevels lv;
+    if (int rc = unerf_tcnn_levels_from_host(lv, levels_host, L, "hashgrid_fwd_tcnn_half")) return rc;
+    hipLaunchKernelGGL(hashgrid_tcnn_half_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, xyz,
+                       params_half, lv, N, L, out);
+    return unerf_check_launch("hashgrid_fwd_tcnn_half");
 }
 
 // ======================================================================================
@@ -535,7 +571,9 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         float2 f;
-        if (a.net.tcnn_levels) {  // uniform: tcnn-layout grid
+        if (a.net.tcnn_levels && a.net.grid_half) {  // uniform: tcnn layout, half2 rows, tcnn's half arithmetic
+            f = unerf_tcnn_level_feat_half(a.net.table, a.net.tcnn_levels[l], px, py, pz);
+        } else if (a.net.tcnn_levels) {  // uniform: tcnn-layout grid
             f = unerf_tcnn_level_feat(reinterpret_cast<const float2*>(a.net.table), a.net.tcnn_levels[l], px, py, pz);
         } else if (l < a.net.n_dense) {  // wave-uniform: coarse level with a dense, x-paired copy
             f = unerf_dense_level<(UNERF_PROP_BLEND_FMA != 0)>(reinterpret_cast<const float4*>(a.net.dense) + a.net.dense_off[l], a.net.dense_dim[l],
@@ -636,7 +674,9 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             float2 f;
-            if (a.net.tcnn_levels) {  // uniform: tcnn-layout grid
+            if (a.net.tcnn_levels && a.net.grid_half) {  // uniform: tcnn layout, half2 rows, tcnn's half arithmetic
+                f = unerf_tcnn_level_feat_half(a.net.table, a.net.tcnn_levels[l], px, py, pz);
+            } else if (a.net.tcnn_levels) {  // uniform: tcnn-layout grid
                 f = unerf_tcnn_level_feat(reinterpret_cast<const float2*>(a.net.table), a.net.tcnn_levels[l], px, py, pz);
             } else if (l < a.net.n_dense) {  // wave-uniform: coarse level with a dense, x-paired copy
                 f = unerf_dense_level<(UNERF_PROP_BLEND_FMA != 0)>(reinterpret_cast<const float4*>(a.net.dense) + a.net.dense_off[l], a.net.dense_dim[l],
@@ -1185,7 +1225,9 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
 #pragma unroll 4
     for (int l = 0; l < 16; ++l) {
         float2 f;
-        if (a.p.tcnn_levels) {
+        if (a.p.tcnn_levels && a.p.grid_half) {   // uniform
+            f = unerf_tcnn_level_feat_half(a.p.table, a.p.tcnn_levels[l], px, py, pz);
+        } else if (a.p.tcnn_levels) {
             f = unerf_tcnn_level_feat(reinterpret_cast<const float2*>(a.p.table), a.p.tcnn_levels[l], px, py, pz);
         } else {
             const float2* lvl = reinterpret_cast<const float2*>(a.p.table) + ((size_t)l << a.p.log2T);
@@ -1417,21 +1459,60 @@ __device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], 
 // byte offset, size, dense): read per lane from the device array they were 40 vector loads per tile (the level
 // index differs between the wave's halves, and loads after stores in the tile loop cannot be scalar).
 #define MF_TL_WORDS 80
+template <int RS = 3>   // log2 of the row size in bytes: 3 = fp32 rows, 2 = half2 rows (grid_half)
 __device__ __forceinline__ void mf_stage_tcnn_levels(const FieldArgs& a, uint32_t* tl) {
     if (threadIdx.x < 16) {
         const unerf_tcnn_level lv = a.p.tcnn_levels[threadIdx.x];
         tl[threadIdx.x] = __float_as_uint(lv.scale);
         tl[16 + threadIdx.x] = lv.res;
-        tl[32 + threadIdx.x] = lv.offset << 3;
+        tl[32 + threadIdx.x] = lv.offset << RS;
         tl[48 + threadIdx.x] = lv.size;
         tl[64 + threadIdx.x] = lv.dense;
     }
 }
 
-template <bool PACKED, bool TCNN>
+// TCNN: 0 = nerfstudio's torch HashEncoding, 1 = tcnn layout on fp32 rows, 2 = tcnn layout in tcnn's own half arithmetic
+// (unerf_field_params.grid_half: half2 rows, unerf_tcnn_blend_half).  TCNN == 2 also hands back the features as they
+// come out of the blend -- `packed`[4 hb + q] = level 8 h + 4 hb + q as one half2 = operand quad [4 st .. 4 st + 3] of
+// layer 0's k-step st: the f16 matrix kernels take them as they are (the floats returned hold the same values).
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+template <bool PACKED, int TCNN>
 __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, float py, float pz, int h, uint32_t mask,
-                                                  const uint32_t* tl = nullptr) {
+                                                  const uint32_t* tl = nullptr, u32x8* packed = nullptr) {
     f32x16 feat;
+    if (TCNN == 2) {
+        const char* tbase = reinterpret_cast<const char*>(a.p.table);
+        u32x8 pk;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            uint32_t cd[32];
+            float wf[12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int lev = 8 * h + 4 * hb + q;
+                uint32_t off[8];
+                unerf_tcnn_offsets<2>(__uint_as_float(tl[lev]), tl[16 + lev], tl[32 + lev], tl[48 + lev], tl[64 + lev], px, py, pz,
+                                      off, wf[3 * q], wf[3 * q + 1], wf[3 * q + 2]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cd[8 * q + k] = *reinterpret_cast<const uint32_t*>(tbase + off[k]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t c8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
+                const uint32_t f = unerf_tcnn_blend_half(c8, wf[3 * q], wf[3 * q + 1], wf[3 * q + 2]);
+                pk[4 * hb + q] = f;
+                const float2 ff = unerf_h2_to_float2(f);
+                feat[2 * (4 * hb + q)] = ff.x;
+                feat[2 * (4 * hb + q) + 1] = ff.y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (packed) *packed = pk;
+        return feat;
+    }
     if (TCNN) {  // tcnn-layout grid: same batching (4 levels = 32 corner rows in flight), tcnn indexing + blend
         const char* tbase = reinterpret_cast<const char*>(a.p.table);
 #pragma unroll
@@ -1442,8 +1523,8 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
             for (int q = 0; q < 4; ++q) {
                 const int lev = 8 * h + 4 * hb + q;
                 uint32_t off[8];
-                unerf_tcnn_offsets(__uint_as_float(tl[lev]), tl[16 + lev], tl[32 + lev], tl[48 + lev], tl[64 + lev], px, py, pz,
-                                   off, wf[3 * q], wf[3 * q + 1], wf[3 * q + 2]);
+                unerf_tcnn_offsets<3>(__uint_as_float(tl[lev]), tl[16 + lev], tl[32 + lev], tl[48 + lev], tl[64 + lev], px, py, pz,
+                                      off, wf[3 * q], wf[3 * q + 1], wf[3 * q + 2]);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) cd[8 * q + k] = *reinterpret_cast<const float2*>(tbase + off[k]);
             }
@@ -1493,11 +1574,11 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
     return feat;
 }
 
-template <int MODE, bool FEAT_IN, bool TCNN = false>
+template <int MODE, bool FEAT_IN, int TCNN = 0>
 // ACTIVE is bound by the gather (texture-address unit): three waves per SIMD (<= 168 VGPRs) hide more of
 // its latency than two (measured 21.7 vs 23.7 ms/frame when a 176-VGPR build lost the third wave); the
 // K-pass mode needs the registers instead.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && !TCNN) ? 3 : 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && TCNN != 1) ? 3 : 2)))
 void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
@@ -1506,7 +1587,7 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
     __shared__ uint32_t s_tl[TCNN ? MF_TL_WORDS : 1];
-    if (TCNN) mf_stage_tcnn_levels(a, s_tl);
+    if (TCNN) mf_stage_tcnn_levels<(TCNN == 2 ? 2 : 3)>(a, s_tl);
     __syncthreads();
     // wave index as a scalar: the tile walk and its divisions then run on the scalar unit
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1800,7 +1881,9 @@ __device__ __forceinline__ f32x16 mf16_mac(const float* lds, int slab, int lane,
 // two row blocks against one B operand, the two accumulator chains interleaved: an MFMA whose SrcC is the result of
 // the MFMA right before it issues 16 cycles late (benchmarks/mfma_data_probe.hip: 48 instead of 32 cycles per
 // instruction in a single dependent chain), an independent MFMA in between hides that
-template <bool F1 = false>
+// LOZ: the activations are half values already (tcnn's half grid features): their lo residual is zero and the W_hi x lo
+// product is dropped
+template <bool F1 = false, bool LOZ = false>
 __device__ __forceinline__ void mf16_mac2(const float* lds, int slab_a, int slab_b, int lane, const f16x8& bhi, const f16x8& blo,
                                           f32x16& o0, f32x16& o1) {
     const f16x8 ahi0 = *reinterpret_cast<const f16x8*>(lds + slab_a * 512 + lane * 4);
@@ -1814,10 +1897,23 @@ __device__ __forceinline__ void mf16_mac2(const float* lds, int slab_a, int slab
     const f16x8 alo1 = *reinterpret_cast<const f16x8*>(lds + slab_b * 512 + 256 + lane * 4);
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo0, bhi, o0, 0, 0, 0);
     o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo1, bhi, o1, 0, 0, 0);
-    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi0, blo, o0, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1, blo, o1, 0, 0, 0);
+    if (!LOZ) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi0, blo, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1, blo, o1, 0, 0, 0);
+    }
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi0, bhi, o0, 0, 0, 0);
     o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1, bhi, o1, 0, 0, 0);
+}
+// layer 0's operand quad of k-step st: split (or, F1, rounded) from the fp32 features, or -- TCNN == 2 -- the packed half
+// features of mf_gather_feats as they are (no conversion, no residual: mf16_mac2<F1, true>)
+template <int TCNN, bool F1>
+__device__ __forceinline__ void mf16_feat_operand(const f32x16& feat, const u32x8& pk, int st, f16x8& bhi, f16x8& blo) {
+    if (TCNN == 2) {
+        const u32x4 q = {pk[4 * st], pk[4 * st + 1], pk[4 * st + 2], pk[4 * st + 3]};
+        bhi = blo = __builtin_bit_cast(f16x8, q);
+    } else {
+        mf16_split<F1>(feat, st, bhi, blo);
+    }
 }
 // Folded slab (ops.pack_field_mfma16: fold_trunk) of a layer with <= 16 output rows: the slab's second operand holds
 // rows 0..15 = W_hi and rows 16..31 = W_lo, so one MFMA against the hi halves of the activations produces W_hi a_hi in
@@ -1874,10 +1970,10 @@ __device__ __forceinline__ void mf16_apply_masks(f16x8& hi, f16x8& lo, const uin
 // they cost that kernel 50 VGPRs and 84 bytes of scratch (K = 8 field kernel 50 -> 55.6 ms).
 // DROP: masks are generated (MCDROPOUT with K > 0 and p > 0).  A compile-time flag: as a run-time (uniform) flag every
 // k-step of the masked layers carried a branch and the operand quads were copied to merge the two paths.
-template <int MODE, bool TCNN, bool SITES = false, bool DROP = false, bool F1 = false>
+template <int MODE, int TCNN, bool SITES = false, bool DROP = false, bool F1 = false>
 // (the single-product K-pass kernel at 3 waves per SIMD -- 168 VGPRs, 96 B of scratch, trunk operands re-read from LDS --
 // was measured and lost: 4.84 vs 3.89 ms per launch, same box, profiles/r3_exp_f16_single_occ3.json)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && !TCNN) ? 3 : 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == UNERF_FIELD_ACTIVE && TCNN != 1) ? 3 : 2)))
 void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
@@ -1886,7 +1982,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
     __shared__ uint32_t s_tl[TCNN ? MF_TL_WORDS : 1];
-    if (TCNN) mf_stage_tcnn_levels(a, s_tl);
+    if (TCNN) mf_stage_tcnn_levels<(TCNN == 2 ? 2 : 3)>(a, s_tl);
     __syncthreads();
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane_c & 31, h = lane_c >> 5;
@@ -1907,7 +2003,8 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         float px = ts.px, py = ts.py, pz = ts.pz;
         const float sel = unerf_normalize_position(px, py, pz, a.box);
         // packed fp32x2 blend: this kernel has the registers for it (123 VGPRs without) in every mode
-        const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
+        u32x8 feat_pk;
+        const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl, &feat_pk);
 
         // colour layer 0, SH half (pass-invariant): components 8h..8h+7 of this lane half, one k-step
         f32x16 csh0 = mf16_bias(lds, 3, h), csh1 = mf16_bias(lds, 4, h);
@@ -1938,8 +2035,8 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 f16x8 bhi, blo;
-                mf16_split<F1>(feat, st, bhi, blo);
-                mf16_mac2<F1>(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hid0, hid1);
+                mf16_feat_operand<TCNN, F1>(feat, feat_pk, st, bhi, blo);
+                mf16_mac2<F1, TCNN == 2>(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hid0, hid1);
             }
             hid0 = mf_relu(hid0);
             hid1 = mf_relu(hid1);
@@ -2227,7 +2324,7 @@ __device__ __forceinline__ float mf_half_dot(const float* __restrict__ w, int h,
 // CAPTURE = the deterministic (is_inference=False) forward for GGN fitting: ws_density / ws_rgb hold the MEAN
 // last layers, density = exp(.) * selector (laplace_field.py:317-345), rgb = sigmoid(.), and the inputs of the
 // two last layers (base_mlp output, colour hidden) are written to [N][64] planes a.aux / a.aux2.
-template <bool CAPTURE, bool TCNN = false>
+template <bool CAPTURE, int TCNN = 0>
 __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
@@ -2236,7 +2333,7 @@ __global__ __launch_bounds__(256) void field_kernel_mfma_laplace(FieldArgs a, ui
         for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
     }
     __shared__ uint32_t s_tl[TCNN ? MF_TL_WORDS : 1];
-    if (TCNN) mf_stage_tcnn_levels(a, s_tl);
+    if (TCNN) mf_stage_tcnn_levels<(TCNN == 2 ? 2 : 3)>(a, s_tl);
     __syncthreads();
     // wave index as a scalar: the tile walk and its divisions then run on the scalar unit
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2505,7 +2602,7 @@ __device__ __forceinline__ void mf16_lap_stream(const float* __restrict__ lap, c
     }
 }
 
-template <bool TCNN, bool F1 = false>
+template <int TCNN, bool F1 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCNN) ? 3 : 2))) void field_kernel_mfma16_laplace(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     extern __shared__ float lds[];
     {
@@ -2519,7 +2616,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
     // 16 round trips to L2 per tile.  Each wave brings its tile's 512 words in with two 16-byte loads per lane while the
     // hash grid is gathered, parks them in LDS, and the blocks read them back with ds_read_b128.
     __shared__ float s_lbias[UNERF_LAP_BIAS_LDS && UNERF_LAP_PREFETCH >= 2 ? 4 : 1][UNERF_LAP_BIAS_LDS && UNERF_LAP_PREFETCH >= 2 ? 512 : 4];
-    if (TCNN) mf_stage_tcnn_levels(a, s_tl);
+    if (TCNN) mf_stage_tcnn_levels<(TCNN == 2 ? 2 : 3)>(a, s_tl);
     __syncthreads();
     const int lane_c = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane_c & 31, h = lane_c >> 5;
@@ -2546,7 +2643,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
             lb0 = lbsrc[0];
             lb1 = lbsrc[1];
         }
-        const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl);
+        u32x8 feat_pk;
+        const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl, &feat_pk);
         if (BIAS_LDS) {   // (the previous tile's heads are done with the buffer: a wave's LDS operations execute in order)
             float4* dst = reinterpret_cast<float4*>(s_lbias[wv]) + lane_c * 2;
             dst[0] = lb0;
@@ -2562,8 +2660,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((F1 && !TCN
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             f16x8 bhi, blo;
-            mf16_split<F1>(feat, st, bhi, blo);
-            mf16_mac2<F1>(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hb0, hb1);
+            mf16_feat_operand<TCNN, F1>(feat, feat_pk, st, bhi, blo);
+            mf16_mac2<F1, TCNN == 2>(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hb0, hb1);
         }
         // the 64 base outputs feed both mlp_hidden (geo) and the sampled density rows: split them once
         f16x8 xhi[4], xlo[4];
@@ -2774,6 +2872,7 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                   "field_fwd: pre-gathered features are consumed by the MFMA kernel only (ACTIVE/MCDROPOUT with mfma_blob)");
     UNERF_REQUIRE(p->tcnn_levels || (p->log2T >= 1 && p->log2T <= 24), "field_fwd: bad log2T=%d", p->log2T);
     UNERF_REQUIRE(!(p->tcnn_levels && features), "field_fwd: pre-gathered feature planes are built for the torch-layout grid only");
+    UNERF_REQUIRE(!p->grid_half || p->tcnn_levels, "field_fwd: grid_half (half2 rows, tcnn's half arithmetic) needs a tcnn-layout grid");
     UNERF_REQUIRE(R >= 0 && S >= 1, "field_fwd: bad R/S");
     UNERF_REQUIRE(!(near_plane < 0.f && features), "field_fwd: Euclidean bins (near_plane < 0) cannot be combined with pre-gathered features");
     UNERF_REQUIRE((uint64_t)(ray_offset + R) * (uint64_t)S < (1ull << 32),
@@ -2804,7 +2903,7 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     a.drop_scale = 1.f / (1.f - p->p_drop);
     dim3 grid(blocks_for(R * (int64_t)S, 64)), block(64);
     hipStream_t st = (hipStream_t)stream;
-    const bool tc = p->tcnn_levels != nullptr;
+    const int tc = p->tcnn_levels ? (p->grid_half ? 2 : 1) : 0;   // the TCNN template argument of the matrix kernels
     const bool f1 = p->f16_single != 0;
     UNERF_REQUIRE(!f1 || (p->mfma16_blob && !features && (p->mode != UNERF_FIELD_LAPLACE || (p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS))),
                   "field_fwd: f16_single needs mfma16_blob (and lap16_blob with n_lap <= 128 for LAPLACE), without pre-gathered features");
@@ -2812,14 +2911,17 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
             if (p->mfma16_blob && !features && f1) {
-                if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, true, false, false, true>, MF_LDS_F16, a, st);
+                if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 2, false, false, true>, MF_LDS_F16, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 1, false, false, true>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, false, false, false, true>, MF_LDS_F16, a, st);
             } else if (p->mfma16_blob && !features) {
-                if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, true>, MF_LDS_F16, a, st);
+                if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 2>, MF_LDS_F16, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 1>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob) {
                 if (features) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_ACTIVE, true>, MF_LDS_FP32, a, st);
-                else if (tc) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_ACTIVE, false, true>, MF_LDS_FP32, a, st);
+                else if (tc == 2) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_ACTIVE, false, 2>, MF_LDS_FP32, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_ACTIVE, false, 1>, MF_LDS_FP32, a, st);
                 else launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_ACTIVE, false>, MF_LDS_FP32, a, st);
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_ACTIVE>), grid, block, 64 * 64 * 4, st, a);
@@ -2838,23 +2940,30 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
             } else if (p->mfma16_blob && !features && f1) {
                 const bool head0 = a.drop_on && a.drop_sites != (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1);   // non-default sites
-                if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, true, true, true>, MF_LDS_F16, a, st);
+                if (tc == 2 && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, true, true, true>, MF_LDS_F16, a, st);
+                else if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, true, true, true>, MF_LDS_F16, a, st);
                 else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true, true>, MF_LDS_F16, a, st);
-                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, false, true, true>, MF_LDS_F16, a, st);
+                else if (tc == 2 && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, false, true, true>, MF_LDS_F16, a, st);
+                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, false, true, true>, MF_LDS_F16, a, st);
                 else if (a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, true, true>, MF_LDS_F16, a, st);
-                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, false, false, true>, MF_LDS_F16, a, st);
+                else if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, false, false, true>, MF_LDS_F16, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, false, false, true>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, false, true>, MF_LDS_F16, a, st);
             } else if (p->mfma16_blob && !features) {
                 const bool head0 = a.drop_on && a.drop_sites != (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1);   // non-default sites
-                if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, true, true>, MF_LDS_F16, a, st);
+                if (tc == 2 && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, true, true>, MF_LDS_F16, a, st);
+                else if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, true, true>, MF_LDS_F16, a, st);
                 else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true>, MF_LDS_F16, a, st);
-                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true, false, true>, MF_LDS_F16, a, st);
+                else if (tc == 2 && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, false, true>, MF_LDS_F16, a, st);
+                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, false, true>, MF_LDS_F16, a, st);
                 else if (a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, true>, MF_LDS_F16, a, st);
-                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, true>, MF_LDS_F16, a, st);
+                else if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2>, MF_LDS_F16, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob) {
                 if (features) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_MCDROPOUT, true>, MF_LDS_FP32, a, st);
-                else if (tc) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, true>, MF_LDS_FP32, a, st);
+                else if (tc == 2) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, 2>, MF_LDS_FP32, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false, 1>, MF_LDS_FP32, a, st);
                 else launch_matrix_kernel(field_kernel_mfma<UNERF_FIELD_MCDROPOUT, false>, MF_LDS_FP32, a, st);
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
@@ -2876,13 +2985,16 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                 a.p.image_width = 0;
             }
             if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS && f1) {
-                if (tc) launch_matrix_kernel(field_kernel_mfma16_laplace<true, true>, MF_LDS_F16, a, st);
+                if (tc == 2) launch_matrix_kernel(field_kernel_mfma16_laplace<2, true>, MF_LDS_F16, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16_laplace<1, true>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16_laplace<false, true>, MF_LDS_F16, a, st);
             } else if (p->mfma16_blob && p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS) {
-                if (tc) launch_matrix_kernel(field_kernel_mfma16_laplace<true>, MF_LDS_F16, a, st);
+                if (tc == 2) launch_matrix_kernel(field_kernel_mfma16_laplace<2>, MF_LDS_F16, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16_laplace<1>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16_laplace<false>, MF_LDS_F16, a, st);
             } else if (p->mfma_blob && p->lap_blob && p->n_lap <= 32 * LAP_BLOCKS) {
-                if (tc) launch_matrix_kernel(field_kernel_mfma_laplace<false, true>, MF_LDS_FP32, a, st);
+                if (tc == 2) launch_matrix_kernel(field_kernel_mfma_laplace<false, 2>, MF_LDS_FP32, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma_laplace<false, 1>, MF_LDS_FP32, a, st);
                 else launch_matrix_kernel(field_kernel_mfma_laplace<false>, MF_LDS_FP32, a, st);
             } else {
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_LAPLACE>), grid, block, 64 * 64 * 4, st, a);
@@ -3048,7 +3160,8 @@ extern "C" int unerf_laplace_ggn_diag(const float* origins, const float* directi
     a.keep_hi = 0; a.keep_pk = 0; a.drop_on = 0; a.drop_sites = 0; a.drop_scale = 1.f;
     a.box = make_norm_box(p->use_aabb, p->aabb);
     a.p.image_width = 0;   // 1-D tiles
-    if (p->tcnn_levels) launch_matrix_kernel(field_kernel_mfma_laplace<true, true>, MF_LDS_FP32, a, st);
+    if (p->tcnn_levels && p->grid_half) launch_matrix_kernel(field_kernel_mfma_laplace<true, 2>, MF_LDS_FP32, a, st);
+    else if (p->tcnn_levels) launch_matrix_kernel(field_kernel_mfma_laplace<true, 1>, MF_LDS_FP32, a, st);
     else launch_matrix_kernel(field_kernel_mfma_laplace<true>, MF_LDS_FP32, a, st);
     GgnArgs g;
     g.sbins = sbins; g.R = R; g.S = S; g.s_near = a.s_near; g.s_far = a.s_far; g.lin = a.lin;

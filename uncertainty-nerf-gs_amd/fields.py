@@ -111,7 +111,11 @@ class HashEncoding(nn.Module):
     """nerfstudio HashEncoding.  implementation="torch": parameter `hash_table` [L*T, F] (every level hashed).
     implementation="tcnn": parameter `tcnn_encoding.params`, the flat fp32 vector of a tiny-cuda-nn HashGrid
     (dense coarse levels, +0.5 cell shift; include/unerf.h: unerf_tcnn_level) -- the layout the reference's
-    default configuration trains with (activenerfacto_field.py:89)."""
+    default configuration trains with (activenerfacto_field.py:89).
+    grid_precision (tcnn only): "f16" (default) = the device copy of the parameters is half and the lookup runs in
+    tiny-cuda-nn's own half arithmetic (unerf_field_params.grid_half) -- what tcnn computes on every GPU the reference
+    targets; "f32" = fp32 rows and blend (a tcnn built without TCNN_HALF_PRECISION).  The parameter itself stays the
+    fp32 master vector either way (checkpoints load unchanged)."""
 
     def __init__(self, num_levels=16, min_res=16, max_res=1024, log2_hashmap_size=19, features_per_level=2,
                  hash_init_scale=0.001, implementation="torch"):
@@ -121,6 +125,7 @@ class HashEncoding(nn.Module):
         self.num_levels, self.log2_hashmap_size, self.implementation = num_levels, log2_hashmap_size, implementation
         self.register_buffer("scalings", hash_scalings(num_levels, min_res, max_res), persistent=False)
         self.tcnn_levels = None
+        self.grid_precision = "f16" if implementation == "tcnn" else "f32"
         if implementation == "tcnn":
             import math
             growth = math.exp((math.log(max_res) - math.log(min_res)) / (num_levels - 1)) if num_levels > 1 else 1.0
@@ -236,7 +241,8 @@ class HashMLPDensityField(nn.Module, _FieldBuffers):
     def to_device(self, device) -> ops.DensityNetDev:
         (w0, b0), (w1, b1) = self.mlp_base.mlp.linear_layers()
         return ops.DensityNetDev.from_torch(self.encoding.table, self.encoding.scalings, self.encoding.log2_hashmap_size,
-                                            w0, b0, w1, b1, device, tcnn_levels=self.encoding.tcnn_levels)
+                                            w0, b0, w1, b1, device, tcnn_levels=self.encoding.tcnn_levels,
+                                            grid_precision=self.encoding.grid_precision)
 
     # -- Field-level calls (nerfstudio HashMLPDensityField.get_density / Field.density_fn) on the proposal kernel --
     _dev: Optional[ops.DensityNetDev] = None
@@ -290,7 +296,8 @@ class _NerfactoFieldBase(nn.Module, _FieldBuffers):
 
     def _grid_kw(self, grid: HashEncoding):
         """tcnn layout of the grid + tcnn's SphericalHarmonics convention (it maps the (d+1)/2 input back to [-1,1])"""
-        return {"tcnn_levels": grid.tcnn_levels, "sh_remap": 1 if self.implementation == "tcnn" else 0}
+        return {"tcnn_levels": grid.tcnn_levels, "sh_remap": 1 if self.implementation == "tcnn" else 0,
+                "grid_precision": grid.grid_precision}
 
     def eval_appearance(self) -> torch.Tensor:
         """constant eval embedding: mean of the table or zeros (laplace_field.py:386-398)"""

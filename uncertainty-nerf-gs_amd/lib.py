@@ -88,7 +88,7 @@ class DensityNet(C.Structure):
         ("table", C.c_void_p), ("scalings", C.c_void_p), ("L", C.c_int), ("log2T", C.c_int),
         ("w0t", C.c_void_p), ("b0", C.c_void_p), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("hidden", C.c_int),
         ("dense", C.c_void_p), ("n_dense", C.c_int), ("dense_off", C.c_int * 8), ("dense_dim", C.c_int * 8),
-        ("tcnn_levels", C.c_void_p), ("use_aabb", C.c_int), ("aabb", C.c_float * 6),
+        ("tcnn_levels", C.c_void_p), ("use_aabb", C.c_int), ("aabb", C.c_float * 6), ("grid_half", C.c_int),
     ]
 
 
@@ -109,10 +109,11 @@ class FieldParams(C.Structure):
         ("aabb", C.c_float * 6), ("f16_single", C.c_int), ("overflow_flag", C.c_void_p),
         ("h0_full_t", C.c_void_p), ("hb0_raw", C.c_void_p), ("app_embed", C.c_void_p),
         ("lap_chunk_rays", C.c_int), ("lap_sets", C.c_int), ("n_lap_rgb", C.c_int), ("packed_out", C.c_int),
+        ("grid_half", C.c_int),
     ]
 
 
-ABI_VERSION = 1300                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
+ABI_VERSION = 1400                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
 SPACING_PIECEWISE, SPACING_UNIFORM = 0, 1         # include/unerf.h: UNERF_SPACING_*
 BG_LAST_SAMPLE, BG_NONE, BG_COLOR = 0, 1, 2       # include/unerf.h: UNERF_BG_*
@@ -134,6 +135,7 @@ SIGNATURES = {
     "unerf_ray_planes_bins": (_i, [_vp, _vp, _i64, _f, _f, _i, _vp, _i, _vp, _vp]),
     "unerf_hashgrid_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "unerf_hashgrid_fwd_tcnn": (_i, [_vp, _vp, C.POINTER(TcnnLevel), _i64, _i, _vp, _vp, _vp]),
+    "unerf_hashgrid_fwd_tcnn_half": (_i, [_vp, _vp, C.POINTER(TcnnLevel), _i64, _i, _vp, _vp]),
     "unerf_proposal_density": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _i, C.POINTER(DensityNet), _f, _vp, _i64, _i, _vp]),
     "unerf_weights_pdf_resample": (_i, [_vp, _vp, _i64, _i64, _i, _f, _f, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp,
                                         _i64, _i64, _vp]),

@@ -197,6 +197,21 @@ def hashgrid_fwd_tcnn(xyz: torch.Tensor, params: torch.Tensor, levels, return_in
     return (out, idx) if return_indices else out
 
 
+def hashgrid_fwd_tcnn_half(xyz: torch.Tensor, params: torch.Tensor, levels) -> torch.Tensor:
+    """tcnn-layout lookup in tcnn's own half arithmetic (include/unerf.h: unerf_hashgrid_fwd_tcnn_half).  params: the
+    fp32 master vector (cast to half here, round to nearest even, as tcnn does before its forward pass) or a half tensor.
+    -> [N, 2L] fp32 holding the half features"""
+    lib = _l.load()
+    N, L = xyz.shape[0], len(levels)
+    ph = params.detach().reshape(-1, 2).to(torch.float16).contiguous()
+    out = torch.empty(N, 2 * L, device=xyz.device, dtype=torch.float32)
+    lv = tcnn_levels_ctypes(levels)
+    with _ctx(xyz.device):
+        _run("hashgrid_fwd_tcnn_half", lambda: lib.unerf_hashgrid_fwd_tcnn_half(_p(xyz, name="xyz"), _p(ph, torch.float16, "params"),
+                                                                               lv, N, L, _p(out), _stream()))
+    return out
+
+
 # --------------------------------------------------------- parameter packs --------------
 
 _HASH_P1, _HASH_P2 = 2654435761, 805459861
@@ -258,14 +273,21 @@ class DensityNetDev:
     use_dense: bool = True
     tcnn_levels: Optional[torch.Tensor] = None   # device records: `table` is then a tcnn-layout parameter vector
     aabb: Optional[Tuple[float, ...]] = None     # 6 floats: scene-box normalisation instead of the contraction
+    # tcnn layout only: "f16" = `table` is the HALF copy of the parameters ([rows, 2] float16) and the lookup runs in
+    # tcnn's own half arithmetic (unerf_density_net.grid_half); "f32" = fp32 rows and blend
+    grid_precision: str = "f32"
 
     @classmethod
-    def from_torch(cls, table, scalings, log2T, w0, b0, w1, b1, device, tcnn_levels=None):
+    def from_torch(cls, table, scalings, log2T, w0, b0, w1, b1, device, tcnn_levels=None, grid_precision="f32"):
         f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        if grid_precision not in ("f32", "f16") or (grid_precision == "f16" and tcnn_levels is None):
+            raise _l.UnerfError(f"grid_precision={grid_precision!r}: 'f32', or 'f16' with a tcnn-layout grid")
         if tcnn_levels is not None:
             sc = torch.zeros(len(tcnn_levels))
-            return cls(f(table.reshape(-1, 2)), f(sc), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
-                       tcnn_levels=tcnn_levels_tensor(tcnn_levels, device))
+            tab = table.detach().reshape(-1, 2)
+            tab = tab.to(device=device, dtype=torch.float16).contiguous() if grid_precision == "f16" else f(tab)
+            return cls(tab, f(sc), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
+                       tcnn_levels=tcnn_levels_tensor(tcnn_levels, device), grid_precision=grid_precision)
         dense, offs, dims = build_dense_pairs(table, scalings.detach().cpu(), int(log2T),
                                               max_level_bytes=int(os.environ.get("UNERF_DENSE_LEVEL_BYTES", DENSE_LEVEL_BYTES)))
         return cls(f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
@@ -275,10 +297,12 @@ class DensityNetDev:
         nd = len(self.dense_off) if (self.use_dense and self.dense is not None and self.tcnn_levels is None) else 0
         offs = (C.c_int * 8)(*(list(self.dense_off[:nd]) + [0] * (8 - nd)))
         dims = (C.c_int * 8)(*(list(self.dense_dim[:nd]) + [0] * (8 - nd)))
-        return _l.DensityNet(_p(self.table), _p(self.scalings), self.scalings.numel(), self.log2T, _p(self.w0t),
+        half = self.grid_precision == "f16"
+        return _l.DensityNet(_p(self.table, torch.float16 if half else torch.float32, "table"), _p(self.scalings),
+                             self.scalings.numel(), self.log2T, _p(self.w0t),
                              _p(self.b0), _p(self.w1t), _p(self.b1), self.b0.numel(),
                              _p(self.dense) if nd else None, nd, offs, dims, _p(self.tcnn_levels, torch.int32),
-                             0 if self.aabb is None else 1, _aabb6(self.aabb))
+                             0 if self.aabb is None else 1, _aabb6(self.aabb), 1 if half else 0)
 
 
 @dataclass
@@ -335,11 +359,18 @@ class FieldDev:
     h0_full_t: Optional[torch.Tensor] = None
     hb0_raw: Optional[torch.Tensor] = None
     app_embed: Optional[torch.Tensor] = None
+    # tcnn layout only: "f16" = `table` is the HALF copy of the parameters ([rows, 2] float16) and the lookup runs in
+    # tcnn's own half arithmetic (unerf_field_params.grid_half) -- what the reference's default implementation="tcnn"
+    # computes; "f32" = fp32 rows and blend (also the only form of the torch layout)
+    grid_precision: str = "f32"
 
     @classmethod
     def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device,
                    tcnn_levels=None, **kw):
         f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        gp = kw.get("grid_precision", "f32")
+        if gp not in ("f32", "f16") or (gp == "f16" and tcnn_levels is None):
+            raise _l.UnerfError(f"grid_precision={gp!r}: 'f32', or 'f16' with a tcnn-layout grid")
         if tcnn_levels is not None:
             table, scalings = table.reshape(-1, 2), torch.zeros(len(tcnn_levels))
             kw["tcnn_levels"] = tcnn_levels_tensor(tcnn_levels, device)
@@ -372,7 +403,8 @@ class FieldDev:
             kw["packed_lap_softplus"] = int(bool(kw.get("lap_softplus", 0)))
         if kw.get("ws_density") is not None:
             kw["ws_density"], kw["ws_rgb"] = f(kw["ws_density"]), f(kw["ws_rgb"])
-        return cls(mode, f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
+        tab = table.detach().to(device=device, dtype=torch.float16).contiguous() if gp == "f16" else f(table)
+        return cls(mode, tab, f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
                    f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
                    mfma_blob=blob, lap_blob=lap_blob, h0_full_t=f(h0.t()), hb0_raw=f(head_b[0]), app_embed=f(appearance),
                    **kw)
@@ -407,8 +439,11 @@ class FieldDev:
                                 "lack) the log2(e) factor of the other activation; rebuild the FieldDev")
         if use16 and self.packed_mode >= 0 and (self.packed_mode == _l.FIELD_MCDROPOUT) != (self.mode == _l.FIELD_MCDROPOUT):
             raise _l.UnerfError("FieldDev: mfma16_blob was laid out for another mode; rebuild the FieldDev (from_torch)")
-        return _l.FieldParams(
-            self.mode, _p(self.table), _p(self.scalings), self.scalings.numel(), self.log2T,
+        half = self.grid_precision == "f16"
+        if half and self.tcnn_levels is None:
+            raise _l.UnerfError("FieldDev.grid_precision='f16' needs a tcnn-layout grid (tcnn_levels)")
+        cs = _l.FieldParams(
+            self.mode, _p(self.table, torch.float16 if half else torch.float32, "table"), _p(self.scalings), self.scalings.numel(), self.log2T,
             _p(self.w0t), _p(self.b0), _p(self.w1t), _p(self.b1), self.b1.numel(),
             _p(self.h0t), _p(self.hb0), _p(self.h1t), _p(self.hb1), _p(self.h2t), _p(self.hb2),
             self.average_init_density, self.beta_min, self.sh_remap, self.K, self.seed & 0xFFFFFFFF, self.p_drop,
@@ -423,6 +458,8 @@ class FieldDev:
             int(self.lap_chunk_rays) if (self.ws_density is not None and self.ws_density.dim() == 3) else 0,
             self.ws_density.shape[0] if (self.ws_density is not None and self.ws_density.dim() == 3) else 1,
             0 if self.ws_rgb is None else self.ws_rgb.shape[-2])
+        cs.grid_half = 1 if half else 0
+        return cs
 
 
 # ---- MFMA operand packing for field_kernel_mfma (csrc/unerf_nerf.hip) -------------------------

@@ -52,7 +52,7 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
                        max_res: int = 2048, table_scale: float = 0.5, density_gain: float = 16.0,
                        density_bias: float = -2.0, color_gain: float = 4.0, beta_gain: float = 12.0,
                        grid: str = "torch", sharp: bool = False, overflow_units: Tuple[int, ...] = (),
-                       head_overflow_units: Tuple[int, ...] = ()) -> Dict:
+                       head_overflow_units: Tuple[int, ...] = (), color_contrast: float = 1.0) -> Dict:
     """Random-init nerfacto-shaped scene.  Tables U(-1,1)*table_scale; Linear layers
     Kaiming-uniform like nn.Linear; the density row is gained up so accumulation, depth and the
     variances vary over the image instead of saturating.
@@ -60,6 +60,11 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
     sharp: magnitudes of a TRAINED field instead of a fresh one -- density logits spanning about +-12 (opaque surfaces
     next to empty space: densities from e^-12 to e^12), colour-head activations of the order 1e3 (first hidden layer
     scaled up, the next layer's weights scaled down to match), proposal logits likewise.
+    color_contrast: the last colour layer scaled by this factor.  At 1 the colour logits stay within about +-0.3 -- a
+    grey image (rgb 0.47 .. 0.59) whose MC-dropout / Laplace rgb_std all lies within a factor of four (0.007 .. 0.03 at
+    K = 8); at 10 the image spans 0.02 .. 1.0 with saturated and unsaturated regions and rgb_std 0.04 .. 0.34, the dynamic
+    range of a trained model's output (and a ranking by variance that a 1e-5 perturbation does not reshuffle:
+    tests/tools/ause_conditioning.py).
     overflow_units: trunk hidden units whose pre-activations reach past 65504 -- beyond the f16 operand range of the
     f16 matrix kernels -- on ~9 % of the samples (first-layer rows of +-5e4, inside the weight limit the packer checks);
     their outgoing weights are 1e-6-small, so in fp32 arithmetic they move the outputs by less than 1.
@@ -116,6 +121,8 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
         f["head_w"][1] = f["head_w"][1] * 2.5e-4
         for p in props:
             p["w1"][0] *= 3.0
+    if color_contrast != 1.0:
+        f["head_w"][2] = f["head_w"][2] * color_contrast
     for u in overflow_units:
         f["w0"][u] = torch.sign(f["w0"][u]) * 5e4
         f["b0"][u] = 0.0
@@ -134,14 +141,18 @@ _MODE = {"active": _l.FIELD_ACTIVE, "mcdropout": _l.FIELD_MCDROPOUT, "laplace": 
 
 
 def scene_to_device(t: Dict, device, **field_kw) -> NerfSceneDev:
+    """t["grid_precision"] = "f16" (tcnn-layout scenes only): half tables + tcnn's half interpolation in the main field and
+    the proposal networks -- the oracle reads the same key (scene_from_tensors)"""
     f = t["field"]
+    gp = t.get("grid_precision", "f32")
     fd = ops.FieldDev.from_torch(_MODE[t["kind"]], f["table"], f["scalings"], f["log2T"], f["w0"], f["b0"], f["w1"],
                                  f["b1"], f["head_w"], f["head_b"], f["appearance"], device,
                                  average_init_density=float(f["average_init_density"]),
                                  beta_min=float(f["beta_min"]), tcnn_levels=f.get("tcnn_levels"),
-                                 sh_remap=int(bool(f.get("sh_remap", False))), **field_kw)
+                                 sh_remap=int(bool(f.get("sh_remap", False))),
+                                 **({"grid_precision": gp} if gp != "f32" else {}), **field_kw)
     props = [ops.DensityNetDev.from_torch(p["table"], p["scalings"], p["log2T"], p["w0"], p["b0"], p["w1"], p["b1"],
-                                          device, tcnn_levels=p.get("tcnn_levels")) for p in t["props"]]
+                                          device, tcnn_levels=p.get("tcnn_levels"), grid_precision=gp) for p in t["props"]]
     if t.get("aabb") is not None:   # disable_scene_contraction: scene-box normalisation in every network
         box = tuple(float(v) for v in t["aabb"].reshape(-1))
         fd.aabb = box
