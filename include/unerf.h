@@ -355,6 +355,7 @@ typedef struct {
 #define UNERF_DROP_HEAD1 4
 #define UNERF_DROP_HEADIN 8
 #define UNERF_MFMA_BLOB_FLOATS 10660
+#define UNERF_MFMA16_BLOB_FLOATS 11684   /* mfma16_blob: + the 64 -> 3 colour layer as four f16 operand slabs (f16_single) */
 #define UNERF_LAP_BLOB_FLOATS 33280
 
 /* outputs: B = max(K,1) passes

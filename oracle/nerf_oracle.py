@@ -589,35 +589,51 @@ def mc_base(seed: int, pass_idx: int, sample_idx: np.ndarray) -> np.ndarray:
         return _hash32(_hash32(sample_idx.astype(np.uint32)) + key)
 
 
+MASK_LCG_A, MASK_LCG_C = np.uint32(25173), np.uint32(13849)
+
+
 def _mask_step(x: np.ndarray) -> np.ndarray:
-    """twin of unerf_mask_step: x = rotr(x, 22) * 65 (mod 2^32)"""
+    """twin of unerf_mask_step: each 16-bit half steps as x -> 25173 x + 13849 (mod 2^16)"""
     x = x.astype(np.uint32)
     with np.errstate(over="ignore"):
-        y = (x >> np.uint32(22)) | (x << np.uint32(10))
-        x = y + (y << np.uint32(6))
-    return x
+        lo = ((x & np.uint32(0xFFFF)) * MASK_LCG_A + MASK_LCG_C) & np.uint32(0xFFFF)
+        hi = ((x >> np.uint32(16)) * MASK_LCG_A + MASK_LCG_C) & np.uint32(0xFFFF)
+    return (lo | (hi << np.uint32(16))).astype(np.uint32)
+
+
+def _mask_word0(seed: int, sample_idx: np.ndarray, stream: int, n_pairs: int) -> np.ndarray:
+    """[N, n_pairs] pass-0 mask words (twin of unerf_mc_pre / unerf_mc_base_h / unerf_mask_word0): pair j takes the base
+    b_h = hash32(hash32(sample) + key + h GOLDEN) of h = bit 1 of j and the odd 24-bit constants of (stream, j & ~2):
+    w = (b_h & 0xFFFFFF) A + (b_h >> 8) B  (mod 2^32)."""
+    with np.errstate(over="ignore"):
+        key = _hash32(np.array([seed], dtype=np.uint32))
+        pre = _hash32(sample_idx.astype(np.uint32)) + key
+        b = np.stack([_hash32(pre + np.uint32(h) * GOLDEN) for h in (0, 1)], axis=0)            # [2, N]
+        j = np.arange(n_pairs, dtype=np.uint32)
+        jc = j & ~np.uint32(2)
+        A = (_hash32(np.uint32(0xA5A50000) + np.uint32(64 * stream) + jc) & np.uint32(0xFFFFFE)) | np.uint32(1)
+        B = (_hash32(np.uint32(0x5A5A0000) + np.uint32(64 * stream) + jc) & np.uint32(0xFFFFFE)) | np.uint32(1)
+        bb = b[(j >> np.uint32(1)) & np.uint32(1)].T                                               # [N, n_pairs]
+        w = (bb & np.uint32(0xFFFFFF)) * A[None, :] + (bb >> np.uint32(8)) * B[None, :]
+    return w.astype(np.uint32)
 
 
 def mc_keep_mask(seed: int, pass_idx: int, sample_idx: np.ndarray, stream: int, n_units: int,
                  p_drop: float) -> np.ndarray:
-    """[N, n_units] bool keep-mask.  stream 0 = density trunk, 1 = colour head.
-    Mask word of unit pair j: pass 0 = hash32(base0 + (32*stream + j + 1)*GOLDEN) with
-    base0 = mc_base(seed, 0, sample) (0 -> GOLDEN); pass k = _mask_step of pass k-1.
+    """[N, n_units] bool keep-mask.  stream 0 = density trunk, 1 = last colour layer, 2 = second colour layer, 3 = the
+    head's inputs.  Mask word of unit pair j: pass 0 = _mask_word0 (a multilinear hash of the sample's base hash), pass
+    k = _mask_step of pass k-1 (a 16-bit LCG per half).
     Low 16 bits -> unit 2j, high 16 bits -> unit 2j+1; keep iff the half read as a signed 16-bit number is below
     round((1-p)*65536) - 32768, i.e. iff (u16 ^ 0x8000) < round((1-p)*65536); p = 0 keeps every unit.
     (twin of unerf_mask_word0 / unerf_mask_step / unerf_keep_lo / unerf_keep_hi in csrc/unerf_common.hpp)"""
     assert n_units % 2 == 0 and n_units <= 64
     thr = np.uint32(int(round((1.0 - p_drop) * 65536.0)))
-    base = mc_base(seed, 0, sample_idx)[:, None]
-    j = np.arange(n_units // 2, dtype=np.uint32)[None, :]
-    with np.errstate(over="ignore"):
-        r = _hash32(base + (np.uint32(stream * 32) + j + np.uint32(1)) * GOLDEN)
-    r = np.where(r == 0, GOLDEN, r).astype(np.uint32)
+    r = _mask_word0(seed, sample_idx, stream, n_units // 2)
     for _ in range(pass_idx):
         r = _mask_step(r)
     lo = ((r & np.uint32(0xFFFF)) ^ np.uint32(0x8000)) < thr
     hi = ((r >> np.uint32(16)) ^ np.uint32(0x8000)) < thr
-    return np.stack([lo, hi], axis=-1).reshape(base.shape[0], n_units)
+    return np.stack([lo, hi], axis=-1).reshape(r.shape[0], n_units)
 
 
 def _xorshift32(x: np.ndarray) -> np.ndarray:

@@ -168,6 +168,13 @@ def test_dropout_mask_generator_statistics():
             assert corr(keeps[k][:, 1::2], keeps[m][:, 0::2]) < tol * 1.5, (k, m)
     assert corr(keeps[:, :, 0::2], keeps[:, :, 1::2]) < tol                             # the two halves of a word
     assert corr(keeps[:, :, :-2], keeps[:, :, 2:]) < tol                                # neighbouring words
+    # every pair of the 64 units of a sample (pass 0: the words are multilinear hashes of ONE base hash per lane half)
+    k0 = keeps[0].astype(np.float64)
+    k0 -= k0.mean(axis=0)
+    c = (k0.T @ k0) / n / np.outer(k0.std(axis=0), k0.std(axis=0))
+    np.fill_diagonal(c, 0.0)
+    assert np.abs(c).max() < 5.0 / np.sqrt(n)
+    assert np.abs(keeps.mean(axis=(0, 1)) - 0.8).max() < 5.0 * 0.4 / np.sqrt(n * K)        # every unit's own keep rate
     cnt = keeps[:8].sum(axis=0).reshape(-1)
     hist = np.bincount(cnt, minlength=9) / N
     binom = np.array([comb(8, i) * 0.8 ** i * 0.2 ** (8 - i) for i in range(9)])

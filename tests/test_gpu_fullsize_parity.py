@@ -75,3 +75,55 @@ def test_full_size_frame_matches_the_oracle_on_sampled_rays(dev, method, precisi
     if "depth_std" in ref:
         _img_close(got["depth_std"][~off], ref["depth_std"][~off], 1e-5, 2e-2 if method == "mcdropout" else 5e-3,
                    "depth_std (rays with equal medians)", max_bad_frac=1e-2)
+
+
+@pytest.mark.parametrize("method", ["mcdropout", "active"])
+def test_full_size_trained_like_frame_in_the_reference_arithmetic(dev, method):
+    """The headline precision where f16 is hard, at the BASELINE size: the full-table 1080p frame of the TRAINED-LIKE scene
+    (make_scene_tensors(sharp=True): density logits +-12, colour-head activations ~1e3) rendered at "f16" -- the
+    arithmetic of the bench headline, of nerfacto-mcdropout and of tcnn-configured active-nerfacto models -- against BOTH
+    oracles on the same 4,096 sampled rays: the autocast(float16)-emulating one (what the reference computes:
+    mcdropout_models.py:86-92) and the fp32 one, gates on the informative target (oracle/targets.py; the plain-target
+    numbers and the two oracles' own gap on it go to the parity report).  No overflow re-render on this scene."""
+    from uncertainty_nerf_gs_amd import render, synthetic
+    from oracle import targets
+    from test_gpu_nerf_e2e import _report
+    kw, okw = {}, {}
+    if method == "mcdropout":
+        kw = dict(K=8, seed=1234, p_drop=0.2)
+        okw = dict(K=8, mc_seed=1234, p_drop=0.2)
+    t = synthetic.make_scene_tensors(seed=0, kind=method, sharp=True)
+    sd = synthetic.scene_to_device(t, dev, **kw)
+    sd.field.precision = "f16"
+    cam, c2w = dict(synthetic.CAMERA_1080P), synthetic.orbit_c2w(0.0)
+    out = render.render_camera(sd, c2w, depth_seed=7, **cam)
+    assert sd.overflow_rerenders == 0
+    H, W = cam["H"], cam["W"]
+    total = H * W
+    ids = SF.ray_runs(total, N_RUNS, RUN)
+    o, d, _ = O.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W)
+    sc = O.scene_from_tensors(t)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))
+    try:
+        diag, diag16 = {}, {}
+        ref = SF.reference_rays(method, sc, o.reshape(-1, 3), d.reshape(-1, 3), ids, diagnostics=diag, **okw)
+        ref16 = SF.reference_rays(method, sc, o.reshape(-1, 3), d.reshape(-1, 3), ids, diagnostics=diag16, autocast=torch.float16, **okw)
+    finally:
+        torch.set_num_threads(threads)
+    sel = torch.from_numpy(ids).to(dev)
+    got = {k: v.view(total, -1)[sel].cpu() for k, v in out.items()}
+    v = lambda x: x.view(N_RUNS, RUN, -1)
+    vd = lambda dct: {k: v(x) for k, x in dct.items()}
+    tie = 1e-2   # densities up to e^12 (test_gpu_trained_like)
+    rec16 = _gates(f"fullsize-trained-like-{method}-f16-vs-autocast", v(got["rgb"]), v(got["rgb_std"]), v(ref16["rgb"]), v(ref16["rgb_std"]),
+                   out=vd(got), ref=vd(ref16), diag=diag16, precision="f16", tie_margin=tie, ref_name="autocast(float16) oracle")
+    rec = _gates(f"fullsize-trained-like-{method}-f16", v(got["rgb"]), v(got["rgb_std"]), v(ref["rgb"]), v(ref["rgb_std"]),
+                 out=vd(got), ref=vd(ref), diag=diag, precision="f16", tie_margin=tie)
+    _img_close(got["rgb"], ref16["rgb"], 2e-4, 0, "rgb vs the autocast(fp16) oracle")
+    _img_close(got["rgb"], ref["rgb"], 2e-4, 0, "rgb vs the fp32 oracle")
+    _img_close(got["accumulation"], ref["accumulation"], 6e-4, 0, "accumulation", max_bad_frac=5e-3)   # densities up to e^12
+    gap = targets.gate_deltas(v(ref16["rgb"]), v(ref16["rgb_std"]), v(ref["rgb"]), v(ref["rgb_std"]), targets.gt_image_plain(v(ref["rgb"])))
+    _report(f"fullsize-trained-like-{method}-oracle-gap-plain-target",
+            {"d_psnr": gap["d_psnr"], "d_ause_mse": gap["d_ause_mse"], "build_vs_fp32_d_ause_mse": rec["d_ause_mse_plain"],
+             "build_vs_autocast_d_ause_mse": rec16["d_ause_mse_plain"]})

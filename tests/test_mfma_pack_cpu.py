@@ -227,9 +227,10 @@ def test_split_f16_slabs_reproduce_the_mlp():
     w0, b0, w1, b1 = rnd(64, 32), rnd(64), rnd(17, 64), rnd(17)
     h0, hb0, h1, hb1, h2, hb2 = rnd(64, 31), rnd(64), rnd(64, 64), rnd(64), rnd(3, 64), rnd(3)
     blob = ops.pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2)
-    assert blob.numel() == ops.MFMA_BLOB_FLOATS
+    assert blob.numel() == ops.MFMA16_BLOB_FLOATS == 11684          # include/unerf.h: UNERF_MFMA16_BLOB_FLOATS
     # the tail (bias rows, rgb layer) is the fp32 blob's tail
-    assert torch.equal(blob[ops.MFMA_BIAS_OFF:], ops.pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2)[ops.MFMA_BIAS_OFF:])
+    assert torch.equal(blob[ops.MFMA_BIAS_OFF:ops.MFMA_BLOB_FLOATS],
+                       ops.pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2)[ops.MFMA_BIAS_OFF:])
     sl = _slabs16(blob, ops.MF16_SLABS)
     bias = blob[ops.MFMA_BIAS_OFF:ops.MFMA_H2_OFF].numpy().astype(np.float64).reshape(7, 2, 16)
     binit = lambda k: np.stack([bias[k, H_, r] for r in range(16)])
@@ -269,6 +270,18 @@ def test_split_f16_slabs_reproduce_the_mlp():
     np.testing.assert_allclose(trunk[:, :17], t_ref.numpy(), rtol=0, atol=3e-6)
     assert np.all(trunk[:, 17:] == 0)
     np.testing.assert_allclose(hidden2, x.numpy(), rtol=0, atol=5e-6)
+    # the 64 -> 3 colour layer of the "f16" form: four single-operand (hi only) slabs behind the fp32 tail, rows 0..2
+    c2 = blob[ops.MFMA_BLOB_FLOATS:].contiguous().view(torch.int16).view(torch.float16).view(4, 64, 8).to(torch.float64).numpy()
+    o4 = np.zeros((16, 64))
+    dr = [np.maximum(a, 0) for a in d]
+    for st in range(4):
+        o4 = mfma16(c2[st], _regs(dr[st >> 1], st & 1), o4)
+    rgb_pre = np.zeros((32, 32))
+    for r in range(16):
+        rgb_pre[j, unit(r, H_)] = o4[r]
+    ref = F.linear(torch.from_numpy(hidden2), h2.to(torch.float16).double()).numpy()     # f16-rounded weights, no bias
+    np.testing.assert_allclose(rgb_pre[:, :3], ref, rtol=0, atol=1e-9)
+    assert np.all(rgb_pre[:, 3:] == 0)
 
 
 def test_folded_trunk_slabs_give_both_weight_halves_from_one_mfma():

@@ -66,5 +66,56 @@ def main():
     print(json.dumps(out))
 
 
+def oracle_gap(cache_dir="/tmp"):
+    """--oracle-gap: |dPSNR| / |dAUSE| between the REFERENCE'S OWN TWO ARITHMETICS -- the oracle in fp32 and the oracle under
+    the autocast(float16) the reference forces at eval (mcdropout_models.py:86-92) -- on 16 strided 1024-ray chunks of
+    bench.py's 1080p frame (full tables), for mc-dropout K = 8 and active-nerfacto, random-init and trained-like scene, on
+    the plain and on the informative target (oracle/targets.py), over 8 target noise seeds.  CPU only (~10 minutes on 8
+    cores; oracle outputs are cached in `cache_dir`).  -> profiles/r5_exp_ause_oracle_gap.json"""
+    import conftest  # noqa: F401
+    from oracle import nerf_oracle as O, sampled_frame as SF, targets
+    from uncertainty_nerf_gs_amd import synthetic
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    cam = dict(synthetic.CAMERA_1080P)
+    c2w = synthetic.orbit_c2w(2 * math.pi * 6 / 24)
+    o, d, _ = O.generate_rays(c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["H"], cam["W"])
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    chunk, n_chunks = 1024, 16
+    stride = max(1, o.shape[0] // 64 // chunk) * chunk
+    ids = (np.arange(n_chunks, dtype=np.int64)[:, None] * stride * (64 // n_chunks) + np.arange(chunk, dtype=np.int64)[None]).reshape(-1)
+    rows = []
+    for kind in ("mcdropout", "active"):
+        for sharp in (True, False):
+            f = os.path.join(cache_dir, f"oracles_{kind}_{int(sharp)}.pt")
+            if os.path.exists(f):
+                both = torch.load(f, weights_only=False)
+                a, b = both["fp32"], both["ac16"]
+            else:
+                sc = O.scene_from_tensors(synthetic.make_scene_tensors(seed=0, kind=kind, sharp=sharp))
+                kw = dict(K=8, mc_seed=1234, p_drop=0.2) if kind == "mcdropout" else {}
+                a = SF.reference_rays(kind, sc, o, d, ids, step=chunk, **kw)
+                b = SF.reference_rays(kind, sc, o, d, ids, step=chunk, autocast=torch.float16, **kw)
+                torch.save({"fp32": a, "ac16": b, "ids": ids}, f)
+            for n in (4096, 16384):
+                sel = slice(0, n) if n == 16384 else torch.arange(0, 16384, 4)
+                ra, sa, rb, sb = a["rgb"][sel], a["rgb_std"][sel], b["rgb"][sel], b["rgb_std"][sel]
+                row = {"method": kind, "scene": "trained-like" if sharp else "random-init", "rays": n,
+                       "max_abs_rgb": float((ra - rb).abs().max()), "max_abs_rgb_std": float((sa - sb).abs().max()),
+                       "rgb_std_quantiles_1_50_99": [float(x) for x in torch.quantile(sa.flatten(), torch.tensor([.01, .5, .99]))]}
+                for name, mk in (("plain", lambda s_: targets.gt_image_plain(ra, s_)), ("informative", lambda s_: targets.gt_image_informative(ra, sa, s_))):
+                    recs = [targets.gate_deltas(rb, sb, ra, sa, mk(seed), err_types=("mse", "mae")) for seed in range(123, 131)]
+                    row[name] = {"ause_mse": float(np.mean([r["ause_mse_ref"] for r in recs])),
+                                 "d_psnr_max": float(np.max([r["d_psnr"] for r in recs])),
+                                 **{f"d_ause_{et}": {"seed_123": recs[0][f"d_ause_{et}"], "mean": float(np.mean([r[f"d_ause_{et}"] for r in recs])),
+                                                     "max": float(np.max([r[f"d_ause_{et}"] for r in recs]))} for et in ("mse", "mae")}}
+                rows.append(row)
+                print(json.dumps(row), file=sys.stderr)
+    print(json.dumps({"what": "fp32 oracle vs autocast(float16) oracle -- the reference's two arithmetics -- through the north-star "
+                              "gate quantities, 8 target seeds; gates: |dPSNR| <= 1e-4 dB, |dAUSE| <= 1e-3", "rows": rows}, indent=1))
+
+
 if __name__ == "__main__":
-    main()
+    if "--oracle-gap" in sys.argv:
+        oracle_gap()
+    else:
+        main()

@@ -25,7 +25,7 @@ int unerf_check_launch(const char* what);
 // ---- counter-based RNG (twin: oracle/nerf_oracle.py::_hash32 / mc_keep_mask) --------
 #define UNERF_GOLDEN 0x9E3779B9u
 
-__host__ __device__ __forceinline__ uint32_t unerf_hash32(uint32_t x) {
+__host__ __device__ __forceinline__ constexpr uint32_t unerf_hash32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x21F0AAADu;
     x ^= x >> 15;
@@ -39,38 +39,59 @@ __host__ __device__ __forceinline__ uint32_t unerf_mc_key(uint32_t seed, uint32_
 __host__ __device__ __forceinline__ uint32_t unerf_mc_base(uint32_t key, uint32_t sample_idx) {
     return unerf_hash32(unerf_hash32(sample_idx) + key);
 }
-// MC-dropout mask words.  Unit pair j of stream s (0 = density trunk, 1 = colour head) of one sample:
-//   pass 0 : w = hash32(base0 + (32 s + j + 1) * GOLDEN), base0 = mc_base(mc_key(seed, 0), sample)  (0 -> GOLDEN)
-//   pass k : w = mask_step(w of pass k-1)
-// low 16 bits gate unit 2j, high 16 bits unit 2j+1: a unit is kept iff its half, read as a SIGNED 16-bit number,
-// is below thr_s = round((1-p) 65536) - 32768 (the same event as "unsigned half ^ 0x8000 < round((1-p) 65536)",
-// i.e. a relabelling of uniform bits).  The signed form lets the split-f16 kernels build the AND mask of a
-// packed f16 pair in two packed instructions (saturating v_pk_sub_i16, v_pk_ashrrev_i16 15).  The full hash (two
-// quarter-rate integer multiplies) is paid once per sample; every further pass costs two instructions per word --
-// the K-pass kernel is VALU-issue-bound (twin: oracle mc_keep_mask).
-__host__ __device__ __forceinline__ uint32_t unerf_mask_word0(uint32_t base0, uint32_t stream_id, uint32_t j) {
-    uint32_t w = unerf_hash32(base0 + (stream_id * 32u + j + 1u) * UNERF_GOLDEN);
-    return w ? w : UNERF_GOLDEN;
+// MC-dropout mask words (round 5 definition; twin: oracle/nerf_oracle.py::mc_keep_mask).  Unit pair j (units 2j, 2j + 1)
+// of stream s (0 = density trunk, 1 = last colour layer, 2 = second colour layer, 3 = the head's inputs) of one sample:
+//   b_h    = hash32(hash32(sample) + key + h GOLDEN),  h = bit 1 of j       (unerf_mc_base_h: the full hash -- two
+//            quarter-rate multiplies -- is paid ONCE per lane of the matrix kernels: a lane holds the pairs of one h)
+//   pass 0 : w = (b_h & 0xFFFFFF) A(s, j & ~2) + (b_h >> 8) B(s, j & ~2)  mod 2^32, A / B odd 24-bit constants
+//            (a multilinear hash of the two overlapping 24-bit windows of b_h: v_mul_u32_u24 + v_mad_u32_u24, both
+//            full rate, the constants compile-time literals in the unrolled kernels)
+//   pass k : each 16-bit half steps as the LCG x -> 25173 x + 13849 mod 2^16 (one v_pk_mad_u16 for the word)
+// low half gates unit 2j, high half unit 2j+1: a unit is kept iff its half, read as a SIGNED 16-bit number, is below
+// thr_s = round((1-p) 65536) - 32768 (the same event as "unsigned half ^ 0x8000 < round((1-p) 65536)").  The signed form
+// lets the f16 kernels build the AND mask of a packed f16 pair in two packed instructions (saturating v_pk_sub_i16,
+// v_pk_ashrrev_i16 15).
+// Why this form: the K-pass kernel is VALU-issue-bound and rounds 1 - 4 spent 8 instructions per word on pass 0 (a full
+// hash32 with two quarter-rate v_mul_lo_u32: ~56 issue cycles x 32 words per lane = one MC pass' worth of time per tile)
+// plus a zero test, and two per word and pass on the step (rotate + shift-add); now 2 - 3 and 1.  Only <= K - 1 LCG
+// steps are ever taken from a hashed start; tests/test_golden_cpu.py checks keep rate, independence between ALL pairs of
+// K = 10 passes (same unit, either half), between the halves, between neighbouring words and between all pairs of units
+// of a sample, and the Binomial(8, 1 - p) count of keeps, on 4 M units per pass.
+__host__ __device__ __forceinline__ uint32_t unerf_mc_pre(uint32_t key, uint32_t sample_idx) {
+    return unerf_hash32(sample_idx) + key;
 }
-// One step of a mask word: x = rotr(x, 22) * 65 -- a bijection of the 32-bit words (rotation, odd multiplier; 0 is
-// a fixed point and mask_word0 never returns it), two instructions (v_alignbit_b32, v_lshl_add_u32) against four
-// for the x*8193 / x ^= x>>17 / x*33 step used in round 1 and six for xorshift32.  The rotation feeds the high
-// bits back into the low half, the multiply carries the low bits up.  Only <= K - 1 steps are ever taken from a
-// hashed start; tests/test_golden_cpu.py checks keep rate, independence between ALL pairs of passes (same unit,
-// either half), between the halves and between neighbouring words, and the Binomial(K, 1 - p) count of keeps
-// over 4 M words ((rotation, shift) = (22, 6) came out of a search over all 2-instruction rotate-multiply steps,
-// /benchmarks/mask_step_search.py).
+__host__ __device__ __forceinline__ uint32_t unerf_mc_base_h(uint32_t pre, uint32_t h) {
+    return unerf_hash32(pre + h * UNERF_GOLDEN);
+}
+__host__ __device__ __forceinline__ constexpr uint32_t unerf_mask_mul_a(uint32_t stream_id, uint32_t jc) {
+    return (unerf_hash32(0xA5A50000u + 64u * stream_id + jc) & 0xFFFFFEu) | 1u;
+}
+__host__ __device__ __forceinline__ constexpr uint32_t unerf_mask_mul_b(uint32_t stream_id, uint32_t jc) {
+    return (unerf_hash32(0x5A5A0000u + 64u * stream_id + jc) & 0xFFFFFEu) | 1u;
+}
+// b_h must be the base of h = (j >> 1) & 1
+__host__ __device__ __forceinline__ uint32_t unerf_mask_word0(uint32_t b_h, uint32_t stream_id, uint32_t j) {
+    const uint32_t jc = j & ~2u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(b_h, unerf_mask_mul_a(stream_id, jc)) + __umul24(b_h >> 8, unerf_mask_mul_b(stream_id, jc));
+#else
+    return (b_h & 0xFFFFFFu) * unerf_mask_mul_a(stream_id, jc) + (b_h >> 8) * unerf_mask_mul_b(stream_id, jc);
+#endif
+}
+#define UNERF_MASK_LCG_A 25173u   // 0x6255 = 1 mod 4, increment odd: full period 2^16 per half
+#define UNERF_MASK_LCG_C 13849u
 __host__ __device__ __forceinline__ uint32_t unerf_mask_step(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t y = __builtin_amdgcn_alignbit(x, x, 22);
-    uint32_t r = y + (y << 6);
-    // opaque to the optimiser: it otherwise recomputes the stepped word as y * 65 with a quarter-rate v_mul_lo_u32
-    // next to the v_lshl_add_u32 that updates the state (seen in the K-pass kernel: 16 multiplies per pass)
-    asm("" : "+v"(r));
-    return r;
+    typedef unsigned short unerf_u16x2 __attribute__((ext_vector_type(2)));
+    unerf_u16x2 v = __builtin_bit_cast(unerf_u16x2, x);
+    const unerf_u16x2 a = {(unsigned short)UNERF_MASK_LCG_A, (unsigned short)UNERF_MASK_LCG_A};
+    const unerf_u16x2 c = {(unsigned short)UNERF_MASK_LCG_C, (unsigned short)UNERF_MASK_LCG_C};
+    v = v * a + c;   // v_pk_mad_u16
+    return __builtin_bit_cast(uint32_t, v);
 #else
-    const uint32_t y = (x >> 22) | (x << 10);
-    return y + (y << 6);
+    const uint32_t lo = ((x & 0xFFFFu) * UNERF_MASK_LCG_A + UNERF_MASK_LCG_C) & 0xFFFFu;
+    const uint32_t hi = ((x >> 16) * UNERF_MASK_LCG_A + UNERF_MASK_LCG_C) & 0xFFFFu;
+    return lo | (hi << 16);
 #endif
 }
 // keep tests for one word on a scalar path: thr_hi = thr_s << 16 (a signed 32-bit number with zero low half).

@@ -833,19 +833,38 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
     // chunk instead of one per ray (2 M same-address L2 reads per frame made this kernel 3.5 ms).
     int64_t cur_chunk = -1;
     unsigned int cmin = 0x7F800000u, cmax = 0u;
+    // One shared row of bin edges (sstride == 0: the 256 initial bins): its Euclidean edges are the same for every ray,
+    // so each wave converts them ONCE per block into its own LDS row (one conversion = an IEEE division, ~15
+    // instructions; per ray that was EPL + 1 of them per lane) and the raw row is staged once as well.  Same values.
+    __shared__ float s_eu[4][PDF_MAXN + 4];
+    const bool shared_row = a.sstride == 0;
+    if (shared_row) {
+        for (int k = lane; k <= n; k += 64) {
+            const float b = a.sbins[k];
+            s_sb[wv][k] = b;
+            s_eu[wv][k] = unerf_s2e(b, a.s_near, a.s_far, a.lin);
+        }
+    }
     for (int it = 0; it < PDF_RAYS_PER_BLOCK / 4; ++it) {
     int64_t r = (int64_t)blockIdx.x * PDF_RAYS_PER_BLOCK + it * 4 + wv;
     const bool ray_ok = r < a.R;
     if (!ray_ok) r = a.R - 1;  // keep the wave alive for the block barrier at the end
     wave_lds_sync();           // previous ray's LDS rows are free again
-    const float* sb = a.sbins + r * a.sstride;
-    for (int k = lane; k <= n; k += 64) s_sb[wv][k] = sb[k];
+    if (!shared_row) {
+        const float* sb = a.sbins + r * a.sstride;
+        for (int k = lane; k <= n; k += 64) s_sb[wv][k] = sb[k];
+    }
     wave_lds_sync();
 
     float eu[EPL + 1], w[EPL], dd[EPL];
     const int k0 = lane * EPL;
+    if (shared_row) {
 #pragma unroll
-    for (int e = 0; e <= EPL; ++e) eu[e] = unerf_s2e(s_sb[wv][min(k0 + e, n)], a.s_near, a.s_far, a.lin);
+        for (int e = 0; e <= EPL; ++e) eu[e] = s_eu[wv][min(k0 + e, n)];
+    } else {
+#pragma unroll
+        for (int e = 0; e <= EPL; ++e) eu[e] = unerf_s2e(s_sb[wv][min(k0 + e, n)], a.s_near, a.s_far, a.lin);
+    }
     float lsum = 0.f, lexcl[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
@@ -937,8 +956,10 @@ __global__ __launch_bounds__(256) void pdf_kernel(PdfArgs a) {
     if (a.clip) {
         wave_lds_sync();
         if (ray_ok) {  // wave-uniform
-            float f0 = unerf_s2e(s_nb[wv][0], a.s_near, a.s_far, a.lin), f1 = unerf_s2e(s_nb[wv][1], a.s_near, a.s_far, a.lin);
-            float l0 = unerf_s2e(s_nb[wv][nb - 2], a.s_near, a.s_far, a.lin), l1 = unerf_s2e(s_nb[wv][nb - 1], a.s_near, a.s_far, a.lin);
+            // the four edges (first two, last two) converted by lanes 0..3 at once, one conversion stream instead of four
+            const int ei = (lane & 2) ? nb - 2 + (lane & 1) : (lane & 1);
+            const float ev = unerf_s2e(s_nb[wv][ei], a.s_near, a.s_far, a.lin);
+            const float f0 = __shfl(ev, 0, 64), f1 = __shfl(ev, 1, 64), l0 = __shfl(ev, 2, 64), l1 = __shfl(ev, 3, 64);
             float first = (f0 + f1) / 2.f, last = (l0 + l1) / 2.f;
             const int64_t chunk = (a.ray_offset + r) / a.chunk_rays;
             if (chunk != cur_chunk) {
@@ -1173,12 +1194,13 @@ __device__ __forceinline__ void dense_lds(const float* __restrict__ Wt, const fl
 // low half of word j, unit 2j + 1 the high half)
 template <int OUT, int IN = 64>
 __device__ __forceinline__ void dense_lds_dropout(const float* __restrict__ Wt, const float* __restrict__ b,
-                                                  const float* act, int lane, uint32_t base0, int pass,
+                                                  const float* act, int lane, uint32_t pre, int pass,
                                                   uint32_t stream_id, int32_t thr_hi, float scale, float (&acc)[OUT]) {
 #pragma unroll
     for (int o = 0; o < OUT; ++o) acc[o] = b[o];
+    const uint32_t bh[2] = {unerf_mc_base_h(pre, 0u), unerf_mc_base_h(pre, 1u)};
     for (int j = 0; j < (IN + 1) / 2; ++j) {
-        uint32_t rnd = unerf_mask_word0(base0, stream_id, (uint32_t)j);
+        uint32_t rnd = unerf_mask_word0(bh[(j >> 1) & 1], stream_id, (uint32_t)j);
         for (int q = 0; q < pass; ++q) rnd = unerf_mask_step(rnd);
         float x0 = act[(2 * j) * 64 + lane];
         x0 = unerf_keep_lo(rnd, thr_hi) ? x0 * scale : 0.f;
@@ -1283,7 +1305,7 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
         const int passes = a.p.K > 0 ? a.p.K : 1;
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         for (int k = 0; k < passes; ++k) {
-            const uint32_t base = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
+            const uint32_t base = unerf_mc_pre(unerf_mc_key(a.p.seed, 0u), sidx);   // dense_lds_dropout derives both half bases
             float o1[16];
             if (a.drop_sites & UNERF_DROP_TRUNK) dense_lds_dropout<16>(a.p.w1t, a.p.b1, A, lane, base, k, 0u, a.keep_hi, a.drop_scale, o1);
             else dense_lds<64, 16>(a.p.w1t, a.p.b1, A, lane, o1);
@@ -1421,12 +1443,15 @@ __device__ __forceinline__ f32x16 mf_slab(const float* lds, int frag0, int lane,
 }
 // inverted dropout on one accumulator block (units 32*blk + row(r,h)).  Register pairs (r, r+1) are
 // units (u, u+1) = one mask word; the lane keeps its 8 words per block in `st` across the passes.
-__device__ __forceinline__ void mf_mask_init(uint32_t (&st)[8], int blk, int h, uint32_t base0, uint32_t stream_id) {
+// (base_h: unerf_mc_base_h of THIS lane half h -- bit 1 of the pair index u >> 1 is h, and the word constants are taken at
+// that bit cleared, so they are compile-time literals)
+__device__ __forceinline__ void mf_mask_init(uint32_t (&st)[8], int blk, int h, uint32_t base_h, uint32_t stream_id) {
+    (void)h;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int r = 2 * q;
-        uint32_t u = 32u * blk + (r & 3) + 8 * (r >> 2) + 4 * h;
-        st[q] = unerf_mask_word0(base0, stream_id, u >> 1);
+        const uint32_t u0 = 32u * blk + (r & 3) + 8 * (r >> 2);   // the unit at h = 0; + 4 h: bit 1 of the pair index
+        st[q] = unerf_mask_word0(base_h, stream_id, u0 >> 1);
     }
 }
 __device__ __forceinline__ void mf_mask_step(uint32_t (&st)[8]) {
@@ -1435,8 +1460,8 @@ __device__ __forceinline__ void mf_mask_step(uint32_t (&st)[8]) {
 }
 // the eight words of one block at pass k, recomputed from the sample's base hash (k chained steps): used only by the
 // non-default dropout site UNERF_DROP_HEAD0, which therefore costs the default configuration no registers
-__device__ __forceinline__ void mf_mask_words_at(uint32_t (&st)[8], int blk, int h, uint32_t base0, uint32_t stream_id, int k) {
-    mf_mask_init(st, blk, h, base0, stream_id);
+__device__ __forceinline__ void mf_mask_words_at(uint32_t (&st)[8], int blk, int h, uint32_t base_h, uint32_t stream_id, int k) {
+    mf_mask_init(st, blk, h, base_h, stream_id);
     for (int q = 0; q < k; ++q) mf_mask_step(st);
 }
 __device__ __forceinline__ f32x16 mf_dropout(f32x16 v, const uint32_t (&st)[8], int32_t thr_hi, float scale) {
@@ -1660,7 +1685,7 @@ void field_kernel_mfma(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         const bool drop = (MODE == UNERF_FIELD_MCDROPOUT) && a.drop_on;
         const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
         uint32_t mk0[8], mk1[8], mk2[8], mk3[8];  // this lane's mask words: trunk blk 0/1, head blk 0/1
-        const uint32_t base0 = drop ? unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx) : 0u;
+        const uint32_t base0 = drop ? unerf_mc_base_h(unerf_mc_pre(unerf_mc_key(a.p.seed, 0u), sidx), (uint32_t)h) : 0u;   // this lane half's
         if (drop) {
             mf_mask_init(mk0, 0, h, base0, 0u);
             mf_mask_init(mk1, 1, h, base0, 0u);
@@ -1979,7 +2004,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
     {
         const float4* src = reinterpret_cast<const float4*>(a.p.mfma16_blob);
         float4* dst = reinterpret_cast<float4*>(lds);
-        for (int i = threadIdx.x; i < UNERF_MFMA_BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (F1 ? UNERF_MFMA16_BLOB_FLOATS : UNERF_MFMA_BLOB_FLOATS) / 4; i += 256) dst[i] = src[i];
     }
     __shared__ uint32_t s_tl[TCNN ? MF_TL_WORDS : 1];
     if (TCNN) mf_stage_tcnn_levels<(TCNN == 2 ? 2 : 3)>(a, s_tl);
@@ -2065,7 +2090,7 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         const bool drop_trunk = SITES ? (drop && (a.drop_sites & UNERF_DROP_TRUNK)) : drop;
         const bool drop_head1 = SITES ? (drop && (a.drop_sites & UNERF_DROP_HEAD1)) : drop;
         if (drop) {
-            const uint32_t base0 = unerf_mc_base(unerf_mc_key(a.p.seed, 0u), sidx);
+            const uint32_t base0 = unerf_mc_base_h(unerf_mc_pre(unerf_mc_key(a.p.seed, 0u), sidx), (uint32_t)h);   // this lane half's
             if (SITES) base0_h0 = base0;
             mf_mask_init(mk0, 0, h, base0, 0u);
             mf_mask_init(mk1, 1, h, base0, 0u);
@@ -2151,7 +2176,35 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             // launch, but the f16 rounding of the last layer's operands moved one MC-dropout AUSE figure past its 1e-3
             // gate; profiles/r3_exp_f16_rgb_on_mfma.json, DESIGN.md 4.5.  The colour layer stays fp32 in every form.)
             float o[3];
-            {
+            if constexpr (F1) {
+                // colour 2: 64 -> 3 as four more k-steps on the matrix pipe (rows 0..2 of one 32-row block; slabs behind the
+                // fp32 tail of the blob), its operands = the hidden units rounded to f16 -- which is what the reference's
+                // Linear computes under its forced autocast (mcdropout_models.py:86-92: f16 inputs and weights, fp32
+                // accumulate) and what tcnn's FullyFusedMLP does.  ReLU and the dropout masks ride on the packed halves like
+                // the trunk's: convert 0.5 + ReLU 0.5 + mask 1.5 instructions per unit instead of ReLU 1 + compare 1 +
+                // select 1 on the fp32 accumulators, and 4 MFMAs (128 issue cycles) instead of 48 packed FMAs + the half
+                // exchange.  (Round 3 measured this form at -5 % and dropped it over ONE AUSE figure at 1.04e-3 -- a gate
+                // that the reference's own two arithmetics miss by more on that target)
+                __builtin_amdgcn_s_setprio(1);
+                f32x16 o4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o4[r] = 0.f;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    f16x8 bhi, blo;
+                    mf16_split_relu(st < 2 ? d0 : d1, st & 1, bhi);
+                    blo = bhi;
+                    if (drop_head1) mf16_apply_masks<true>(bhi, blo, st < 2 ? mk2 : mk3, st & 1, a.keep_pk);
+                    const f16x8 aw = *reinterpret_cast<const f16x8*>(lds + UNERF_MFMA_BLOB_FLOATS + st * 256 + lane * 4);
+                    o4 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, bhi, o4, 0, 0, 0);
+                }
+                // rows 0..2 = registers 0..2 of the h = 0 half: one v_permlane32_swap each hands them to both halves
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o4[c]), __float_as_uint(o4[c]), false, false);
+                    o[c] = __uint_as_float(sw[0]) + lds[MF_H2_OFF + 192 + c];
+                }
+            } else {
             if (!F1) f1_bad |= d0[0] != d0[0];
             d0 = mf_relu(d0);
             d1 = mf_relu(d1);
@@ -2850,6 +2903,7 @@ static int mfma_grid_for(Kern kernel, int64_t num_tiles, size_t lds_bytes) {
 // one persistent matrix-kernel launch: tile map from the image_width hint, LDS = the operand blob
 #define MF_LDS_FP32 ((size_t)UNERF_MFMA_BLOB_FLOATS * 4)
 #define MF_LDS_F16 MF_LDS_FP32
+#define MF_LDS_F16S ((size_t)UNERF_MFMA16_BLOB_FLOATS * 4)   // the "f16" form of field_kernel_mfma16: + the colour-2 slabs
 template <typename Kern>
 static void launch_matrix_kernel(Kern kernel, size_t lds_bytes, FieldArgs& a, hipStream_t st) {
     const int64_t tiles = make_tiles(a, a.p.image_width);
@@ -2911,9 +2965,9 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");
             if (p->mfma16_blob && !features && f1) {
-                if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 2, false, false, true>, MF_LDS_F16, a, st);
-                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 1, false, false, true>, MF_LDS_F16, a, st);
-                else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, false, false, false, true>, MF_LDS_F16, a, st);
+                if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 2, false, false, true>, MF_LDS_F16S, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 1, false, false, true>, MF_LDS_F16S, a, st);
+                else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, false, false, false, true>, MF_LDS_F16S, a, st);
             } else if (p->mfma16_blob && !features) {
                 if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 2>, MF_LDS_F16, a, st);
                 else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_ACTIVE, 1>, MF_LDS_F16, a, st);
@@ -2940,23 +2994,23 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
                 hipLaunchKernelGGL((field_kernel<UNERF_FIELD_MCDROPOUT>), grid, block, 2 * 64 * 64 * 4, st, a);
             } else if (p->mfma16_blob && !features && f1) {
                 const bool head0 = a.drop_on && a.drop_sites != (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1);   // non-default sites
-                if (tc == 2 && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, true, true, true>, MF_LDS_F16, a, st);
-                else if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, true, true, true>, MF_LDS_F16, a, st);
-                else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true, true>, MF_LDS_F16, a, st);
-                else if (tc == 2 && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, false, true, true>, MF_LDS_F16, a, st);
-                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, false, true, true>, MF_LDS_F16, a, st);
-                else if (a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, true, true>, MF_LDS_F16, a, st);
-                else if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, false, false, true>, MF_LDS_F16, a, st);
-                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, false, false, true>, MF_LDS_F16, a, st);
-                else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, false, true>, MF_LDS_F16, a, st);
+                if (tc == 2 && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, true, true, true>, MF_LDS_F16S, a, st);
+                else if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, true, true, true>, MF_LDS_F16S, a, st);
+                else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true, true>, MF_LDS_F16S, a, st);
+                else if (tc == 2 && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, false, true, true>, MF_LDS_F16S, a, st);
+                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, false, true, true>, MF_LDS_F16S, a, st);
+                else if (a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, true, true>, MF_LDS_F16S, a, st);
+                else if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, false, false, true>, MF_LDS_F16S, a, st);
+                else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, false, false, true>, MF_LDS_F16S, a, st);
+                else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, false, true>, MF_LDS_F16S, a, st);
             } else if (p->mfma16_blob && !features) {
                 const bool head0 = a.drop_on && a.drop_sites != (UNERF_DROP_TRUNK | UNERF_DROP_HEAD1);   // non-default sites
-                if (tc == 2 && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, true, true>, MF_LDS_F16, a, st);
-                else if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, true, true>, MF_LDS_F16, a, st);
-                else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true>, MF_LDS_F16, a, st);
-                else if (tc == 2 && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, false, true>, MF_LDS_F16, a, st);
-                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, false, true>, MF_LDS_F16, a, st);
-                else if (a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, true>, MF_LDS_F16, a, st);
+                if (tc == 2 && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, true, true>, MF_LDS_F16S, a, st);
+                else if (tc && head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, true, true>, MF_LDS_F16S, a, st);
+                else if (head0) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, true, true>, MF_LDS_F16S, a, st);
+                else if (tc == 2 && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2, false, true>, MF_LDS_F16S, a, st);
+                else if (tc && a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1, false, true>, MF_LDS_F16S, a, st);
+                else if (a.drop_on) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false, false, true>, MF_LDS_F16S, a, st);
                 else if (tc == 2) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 2>, MF_LDS_F16, a, st);
                 else if (tc) launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, 1>, MF_LDS_F16, a, st);
                 else launch_matrix_kernel(field_kernel_mfma16<UNERF_FIELD_MCDROPOUT, false>, MF_LDS_F16, a, st);

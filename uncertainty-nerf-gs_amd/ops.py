@@ -474,6 +474,7 @@ MFMA_FRAGS = 160            # L0: 32, trunk-out: 32, colour-0: 32, colour-1: 64
 MFMA_BIAS_OFF = MFMA_FRAGS * 64
 MFMA_H2_OFF = MFMA_BIAS_OFF + 7 * 32
 MFMA_BLOB_FLOATS = MFMA_H2_OFF + 2 * 2 * 3 * 16 + 4
+MFMA16_BLOB_FLOATS = MFMA_BLOB_FLOATS + 4 * 64 * 8 // 2     # include/unerf.h: UNERF_MFMA16_BLOB_FLOATS
 
 
 def _mfma_unit(r, h):
@@ -541,6 +542,10 @@ def pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit: i
 F16_OPERAND_LIMIT = 6.0e4  # |operand| must stay below f16 max (65504) for the hi half to be finite
 MF16_SLABS = 20            # L0: 4 (step, block), trunk-out: 4 steps, colour-0: 4 (geo|SH, block), colour-1: 8
 MF16_SLAB_FLOATS = 512     # 64 lanes x 8 halves x (hi, lo) = 2 KiB
+# the 64 -> 3 colour layer as four MORE single-operand slabs (hi halves only, [step][lane][8 halves], rows 0..2 = r, g, b,
+# rows 3..31 zero) behind the fp32 tail: read by the "f16" form only (unerf_field_params.f16_single), which runs that layer
+# on the matrix pipe too
+# (offset MFMA_BLOB_FLOATS, MFMA16_BLOB_FLOATS - MFMA_BLOB_FLOATS floats)
 
 
 def _mf16_unit(s, g, e):
@@ -602,9 +607,18 @@ def pack_field_mfma16(w0, b0, w1, b1, h0, hb0, h1, hb1, h2, hb2, geo_first_unit:
     frag = torch.stack([hi, lo], dim=1).contiguous()      # [slab][hi|lo][lane][8]
     head = frag.view(torch.int16).reshape(-1).view(torch.float32)
     assert head.numel() == MF16_SLABS * MF16_SLAB_FLOATS == MFMA_BIAS_OFF
-    tail = pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2 * (float(drop_scale) if drop_sites & 4 else 1.0), hb2,
-                           geo_first_unit)[MFMA_BIAS_OFF:]
-    return torch.cat([head, tail])
+    h2s = h2 * (float(drop_scale) if drop_sites & 4 else 1.0)
+    tail = pack_field_mfma(w0, b0, w1, b1, h0, hb0, h1, hb1, h2s, hb2, geo_first_unit)[MFMA_BIAS_OFF:]
+    if float(h2s.abs().max()) >= F16_OPERAND_LIMIT:
+        return None
+    c2 = torch.zeros(4, 64, 8)                            # colour-2: rows 0..2 of a 32-row block, accumulator order
+    h2p = torch.zeros(32, 64)
+    h2p[:3] = h2s
+    for s in range(4):
+        c2[s] = h2p[row, 32 * (s >> 1) + _mf16_unit(s & 1, g, e)]
+    c2f = c2.to(torch.float16).contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+    assert c2f.numel() == MFMA16_BLOB_FLOATS - MFMA_BLOB_FLOATS
+    return torch.cat([head, tail, c2f])
 
 
 # sampled last layers of the Laplace field as MFMA A fragments: rows = weight samples (padded to 128
