@@ -157,7 +157,8 @@ typedef struct {
     const float* b0;         /* [hidden] */
     const float* w1t;        /* [hidden][1] */
     const float* b1;         /* [1] */
-    int hidden;              /* 16 (nerfacto proposal nets) or 64 */
+    int hidden;              /* 16 (nerfacto proposal nets) or 64; 0 = use_linear=True (HashMLPDensityField's single
+                                Linear on the grid features: w1t [2L] and b1 are that layer, w0t / b0 unused) */
     /* Optional dense re-indexing of the first n_dense (coarse) levels, n_dense <= 8 (0 = none).  Level l
        then has (dense_dim[l])^3 cells, dense_dim = scalings[l]+1, stored x-fastest from cell offset
        dense_off[l] in `dense` as float4 = { table[hash(x,y,z)], table[hash(x+1,y,z)] }: the same values the
@@ -349,6 +350,17 @@ typedef struct {
        take the packed half features as their layer-0 operands without a conversion; 4 bytes per gathered corner
        instead of 8.  0: fp32 rows and blend (a tcnn built without TCNN_HALF_PRECISION). */
     int grid_half;
+    /* Network widths, 0 = nerfacto's (hidden 64, hidden_color 64, geo_dim 15, feat_per_level 2, app_dim 32).  The reference
+       forwards hidden_dim, hidden_dim_color, features_per_level and appearance_embed_dim from its model configs to the
+       field (models/activenerfacto/activenerfacto_model.py:63-77, models/mcdropout/mcdropout_models.py:66-80,
+       models/laplace/laplace_model.py:169-186); the field classes also take geo_feat_dim.  Any other combination (and
+       L != 16) runs the ANY-WIDTH kernel: one lane per sample, every width a run-time loop -- correct, 10-20 x slower than
+       the matrix kernels, plain ray-major outputs only (no packed_out / sample_major / feature planes), features_per_level
+       4 on the torch-layout grid only (table rows of 4 floats).  Shapes then: w0t [L F][hidden], w1t [hidden][out1] with
+       out1 = geo_dim + 2 (ACTIVE) / + 1 (MCDROPOUT) / + 0 (LAPLACE), h0t [16 + geo_dim][hidden_color], h1t
+       [hidden_color][hidden_color], h2t [hidden_color][3], ws_density [..][hidden + 1], ws_rgb [..][3 hidden_color + 3],
+       h0_full_t [16 + geo_dim + app_dim][hidden_color], app_embed [app_dim].  A dropout site has at most 128 units. */
+    int hidden, hidden_color, geo_dim, feat_per_level, app_dim;
 } unerf_field_params;
 #define UNERF_DROP_TRUNK 1
 #define UNERF_DROP_HEAD0 2

@@ -626,7 +626,7 @@ def mc_keep_mask(seed: int, pass_idx: int, sample_idx: np.ndarray, stream: int, 
     Low 16 bits -> unit 2j, high 16 bits -> unit 2j+1; keep iff the half read as a signed 16-bit number is below
     round((1-p)*65536) - 32768, i.e. iff (u16 ^ 0x8000) < round((1-p)*65536); p = 0 keeps every unit.
     (twin of unerf_mask_word0 / unerf_mask_step / unerf_keep_lo / unerf_keep_hi in csrc/unerf_common.hpp)"""
-    assert n_units % 2 == 0 and n_units <= 64
+    assert n_units % 2 == 0 and n_units <= 128     # 64 pairs per stream: the word constants are indexed 64 stream + pair
     thr = np.uint32(int(round((1.0 - p_drop) * 65536.0)))
     r = _mask_word0(seed, sample_idx, stream, n_units // 2)
     for _ in range(pass_idx):
@@ -972,10 +972,13 @@ def mcdropout_outputs(scene: NerfScene, origins, directions, K: int, seed: int, 
     for k in range(K):
         # drop_sites bits: 1 trunk (mask stream 0), 2 head hidden-0 (stream 2), 4 head hidden-1 (stream 1),
         # 8 head inputs (stream 3, 63 of its 64 units)
-        kt = torch.from_numpy(mc_keep_mask(seed, k, sidx, 0, 64, p_drop)) if drop_sites & 1 else None
-        kh0 = torch.from_numpy(mc_keep_mask(seed, k, sidx, 2, 64, p_drop)) if drop_sites & 2 else None
-        kh = torch.from_numpy(mc_keep_mask(seed, k, sidx, 1, 64, p_drop)) if drop_sites & 4 else None
-        kin = torch.from_numpy(mc_keep_mask(seed, k, sidx, 3, 64, p_drop)[:, :63]) if drop_sites & 8 else None
+        fp = scene.field
+        nH, nHC, nIN = fp.grid.weights[0].shape[0], fp.head_w[1].shape[0], fp.head_w[0].shape[1]   # 64, 64, 63 for nerfacto
+        ev = lambda n: n + (n & 1)                                                                 # words gate unit PAIRS
+        kt = torch.from_numpy(mc_keep_mask(seed, k, sidx, 0, ev(nH), p_drop)[:, :nH]) if drop_sites & 1 else None
+        kh0 = torch.from_numpy(mc_keep_mask(seed, k, sidx, 2, ev(nHC), p_drop)[:, :nHC]) if drop_sites & 2 else None
+        kh = torch.from_numpy(mc_keep_mask(seed, k, sidx, 1, ev(nHC), p_drop)[:, :nHC]) if drop_sites & 4 else None
+        kin = torch.from_numpy(mc_keep_mask(seed, k, sidx, 3, ev(nIN), p_drop)[:, :nIN]) if drop_sites & 8 else None
         density, rgb = mcdropout_field(origins, directions, eb, scene.field, kt, kh, p_drop, keep_head0=kh0, autocast=autocast,
                                        keep_in=kin)
         outs.append(nerfacto_pass_outputs(scene, origins, directions, eb, wl, bl, density, rgb, nears, fars, passes))
@@ -1079,7 +1082,10 @@ def ensemble_aggregate(outputs_list: List[Dict[str, torch.Tensor]]) -> Dict[str,
 def scene_from_tensors(t: dict) -> NerfScene:
     """Build the oracle-side scene from the same weight dict the device path is built from."""
     def grid(d):
-        ws, bs = [d["w0"]], [d["b0"]]
+        if d.get("w0") is None:      # use_linear=True proposal network: one Linear on the grid features
+            ws, bs = [], []
+        else:
+            ws, bs = [d["w0"]], [d["b0"]]
         if "w1" in d and d.get("w1") is not None and not d.get("_laplace", False):
             ws.append(d["w1"])
             bs.append(d["b1"])
@@ -1093,7 +1099,8 @@ def scene_from_tensors(t: dict) -> NerfScene:
     fd["_laplace"] = lap
     fp = FieldParams(grid=grid(fd), head_w=list(f["head_w"]), head_b=list(f["head_b"]), appearance=f["appearance"],
                      average_init_density=float(f.get("average_init_density", 1.0)),
-                     beta_min=float(f.get("beta_min", 0.01)), sh_remap=bool(f.get("sh_remap", False)))
+                     beta_min=float(f.get("beta_min", 0.01)), sh_remap=bool(f.get("sh_remap", False)),
+                     geo_feat_dim=int(f["w1"].shape[0]) - {"active": 2, "mcdropout": 1, "laplace": 0}[t["kind"]])
     if lap:
         fp.hidden_w, fp.hidden_b = f["w1"], f["b1"]
         fp.density_w, fp.density_b = f["density_w"], f["density_b"]

@@ -588,12 +588,19 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
     const float* __restrict__ w0t = a.net.w0t;
     const float* __restrict__ b0 = a.net.b0;
     const float* __restrict__ w1t = a.net.w1t;
+    float o = a.net.b1[0];
+    if constexpr (HID == 0) {
+        // use_linear=True (HashMLPDensityField: `self.linear = nn.Linear(encoding.get_out_dim(), 1)` straight on the grid
+        // features, no hidden layer): w1t = that layer's 2L weights
+#pragma unroll
+        for (int k = 0; k < 2 * L; ++k) o = fmaf(feat[k], w1t[k], o);
+    } else {
     // two hidden units per v_pk_fma_f32 (each half is an IEEE fma, same bits as fmaf): the kernel is
     // VALU-issue-bound, and the MLP was a third of its instructions.  Weights arrive as SGPR pairs.
     static_assert(HID % 2 == 0, "hidden width must be even");
     const unerf_v2f* __restrict__ w0p = reinterpret_cast<const unerf_v2f*>(w0t);
     const unerf_v2f* __restrict__ b0p = reinterpret_cast<const unerf_v2f*>(b0);
-    unerf_v2f h2[HID / 2];
+    unerf_v2f h2[HID / 2 + 1];
 #pragma unroll
     for (int j = 0; j < HID / 2; ++j) h2[j] = b0p[j];
 #pragma unroll
@@ -602,11 +609,11 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
 #pragma unroll
         for (int j = 0; j < HID / 2; ++j) h2[j] = __builtin_elementwise_fma(fk, w0p[k * (HID / 2) + j], h2[j]);
     }
-    float o = a.net.b1[0];
 #pragma unroll
     for (int j = 0; j < HID / 2; ++j) {  // ReLU as an integer max on the bit pattern (one op, see mf_relu)
         o = fmaf(__int_as_float(max(__float_as_int(h2[j].x), 0)), w1t[2 * j], o);
         o = fmaf(__int_as_float(max(__float_as_int(h2[j].y), 0)), w1t[2 * j + 1], o);
+    }
     }
     a.out[idx] = a.avg * unerf_exp(o) * sel;
 }
@@ -689,10 +696,15 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
             feat[2 * l + 1] = f.y;
         }
         const float* __restrict__ w1t = a.net.w1t;
+        float o = a.net.b1[0];
+        if constexpr (HID == 0) {   // use_linear=True: one Linear on the grid features (see prop_density_kernel)
+#pragma unroll
+            for (int k = 0; k < 2 * L; ++k) o = fmaf(feat[k], w1t[k], o);
+        } else {
         static_assert(HID % 2 == 0, "hidden width must be even");
         const unerf_v2f* __restrict__ w0p = reinterpret_cast<const unerf_v2f*>(a.net.w0t);
         const unerf_v2f* __restrict__ b0p = reinterpret_cast<const unerf_v2f*>(a.net.b0);
-        unerf_v2f h2[HID / 2];
+        unerf_v2f h2[HID / 2 + 1];
 #pragma unroll
         for (int j = 0; j < HID / 2; ++j) h2[j] = b0p[j];
 #pragma unroll
@@ -701,7 +713,6 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
 #pragma unroll
             for (int j = 0; j < HID / 2; ++j) h2[j] = __builtin_elementwise_fma(fk, w0p[k * (HID / 2) + j], h2[j]);
         }
-        float o = a.net.b1[0];
         // [probe:prop-mlp-out begin]  (benchmarks/probe_source.py rewrites the marked span in COPIES of this file)
 #pragma unroll
         for (int j = 0; j < HID / 2; ++j) {
@@ -709,6 +720,7 @@ __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
             o = fmaf(__int_as_float(max(__float_as_int(h2[j].y), 0)), w1t[2 * j + 1], o);
         }
         // [probe:prop-mlp-out end]
+        }
         dens = a.avg * unerf_exp(o) * sel;
     }
     if (a.vec4) {  // uniform: n % 4 == 0 and a 16-byte aligned output: the ray's 4 densities leave as one store
@@ -726,7 +738,7 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
                                       const unerf_density_net* net, float average_init_density, float* density_out,
                                       int64_t ray_offset, int image_width, void* stream) {
     UNERF_REQUIRE(net && (R == 0 || (origins && directions && sbins && density_out)), "proposal_density: null pointer");
-    UNERF_REQUIRE(net->table && (net->scalings || net->tcnn_levels) && net->w0t && net->b0 && net->w1t && net->b1,
+    UNERF_REQUIRE(net->table && (net->scalings || net->tcnn_levels) && (net->hidden == 0 || (net->w0t && net->b0)) && net->w1t && net->b1,
                   "proposal_density: null pointer inside unerf_density_net");
     UNERF_REQUIRE(R >= 0 && n >= 1, "proposal_density: bad R/n");
     UNERF_REQUIRE(sbins_stride == 0 || sbins_stride >= n + 1, "proposal_density: sbins_stride %lld < n+1",
@@ -768,8 +780,10 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
     else if (net->L == 5 && net->hidden == 64) { UNERF_PROP_LAUNCH(5, 64); }
     else if (net->L == 8 && net->hidden == 64) { UNERF_PROP_LAUNCH(8, 64); }
     else if (net->L == 8 && net->hidden == 16) { UNERF_PROP_LAUNCH(8, 16); }
+    else if (net->L == 5 && net->hidden == 0) { UNERF_PROP_LAUNCH(5, 0); }   // use_linear=True
+    else if (net->L == 8 && net->hidden == 0) { UNERF_PROP_LAUNCH(8, 0); }
     else {
-        unerf_set_error("proposal_density: unsupported (L=%d, hidden=%d); built: (5,16) (5,64) (8,16) (8,64)", net->L,
+        unerf_set_error("proposal_density: unsupported (L=%d, hidden=%d); built: (5,16) (5,64) (8,16) (8,64) (5,0) (8,0)", net->L,
                         net->hidden);
         return UNERF_ERR_ARG;
     }
@@ -1397,6 +1411,200 @@ __global__ __launch_bounds__(64) void field_kernel(FieldArgs a) {
             a.rgb[n * 3 + 0] = m1[0];
             a.rgb[n * 3 + 1] = m1[1];
             a.rgb[n * 3 + 2] = m1[2];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// 5a'. ANY-WIDTH field (the slow path).  The reference forwards hidden_dim, hidden_dim_color, features_per_level and
+// appearance_embed_dim from the model config to the field (activenerfacto_model.py:63-77, mcdropout_models.py:66-80,
+// laplace_model.py:169-186) and the field class takes geo_feat_dim; the matrix kernels and field_kernel above are
+// built for nerfacto's 64 / 64 / 2 / 15.  This kernel takes every width at run time (unerf_field_params.hidden, ...):
+// one lane per sample, activations in LDS as [unit][lane], weights through the scalar cache, eight outputs per sweep
+// of a layer's inputs.  Same arithmetic definitions (mask words, SH, activations) as field_kernel -- roughly 10-20 x the
+// time of the matrix kernels: a configuration that is kept CORRECT, and says so once (ops.py warns).
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ void dense_any(const float* __restrict__ Wt, const float* __restrict__ b, const float* in,
+                                          float* out, int IN, int OUT, int lane, bool relu) {
+    for (int o0 = 0; o0 < OUT; o0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = o0 + j < OUT ? b[o0 + j] : 0.f;
+        for (int i = 0; i < IN; ++i) {
+            const float x = in[i * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (o0 + j < OUT) acc[j] = fmaf(x, Wt[i * OUT + o0 + j], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (o0 + j < OUT) out[(o0 + j) * 64 + lane] = relu ? fmaxf(acc[j], 0.f) : acc[j];
+    }
+}
+// inverted dropout of `n` units: dst = keep ? src * scale : 0 (dst may be src)
+__device__ __forceinline__ void mask_any(const float* src, float* dst, int n, int lane, uint32_t pre, int pass,
+                                         uint32_t stream_id, int32_t thr_hi, float scale) {
+    const uint32_t bh[2] = {unerf_mc_base_h(pre, 0u), unerf_mc_base_h(pre, 1u)};
+    for (int j = 0; 2 * j < n; ++j) {
+        uint32_t rnd = unerf_mask_word0(bh[(j >> 1) & 1], stream_id, (uint32_t)j);
+        for (int q = 0; q < pass; ++q) rnd = unerf_mask_step(rnd);
+        dst[(2 * j) * 64 + lane] = unerf_keep_lo(rnd, thr_hi) ? src[(2 * j) * 64 + lane] * scale : 0.f;
+        if (2 * j + 1 < n) dst[(2 * j + 1) * 64 + lane] = unerf_keep_hi(rnd, thr_hi) ? src[(2 * j + 1) * 64 + lane] * scale : 0.f;
+    }
+}
+// one level of the torch-layout grid with FOUR features per row (16-byte rows): the same corners and lerp order
+__device__ __forceinline__ void unerf_hash_level4(const float4* __restrict__ lvl, float px, float py, float pz, float scale,
+                                                  uint32_t mask, float (&f4)[4]) {
+    uint32_t off[8];
+    float ox, oy, oz;
+    unerf_hash_corners<false, false>(px, py, pz, scale, mask, off, ox, oy, oz);
+    float2 lo[8], hi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4 v = lvl[off[k] >> 3];
+        lo[k] = make_float2(v.x, v.y);
+        hi[k] = make_float2(v.z, v.w);
+    }
+    const float2 a = unerf_blend8(lo, ox, oy, oz), c = unerf_blend8(hi, ox, oy, oz);
+    f4[0] = a.x; f4[1] = a.y; f4[2] = c.x; f4[3] = c.y;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void field_kernel_generic(FieldArgs a, int rows) {
+    extern __shared__ float lds[];
+    float* A = lds;                       // hidden trunk units (pass-invariant)
+    float* B = lds + (size_t)rows * 64;   // ping
+    float* Cb = B + (size_t)rows * 64;    // head input [SH16 | geo | (appearance)]
+    float* D = Cb + (size_t)rows * 64;    // pong / trunk output
+    const int lane = threadIdx.x;
+    const int H = a.p.hidden, HC = a.p.hidden_color, G = a.p.geo_dim, F = a.p.feat_per_level, L = a.p.L, AD = a.p.app_dim;
+    const int IN0 = L * F, OUT1 = a.p.out1, INC = 16 + G;
+    const int64_t N = a.R * (int64_t)a.S;
+    int64_t n = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = n < N;
+    if (!valid) n = N - 1;
+    const int64_t r = n / a.S;
+    const int s = (int)(n - r * a.S);
+    const float* sb = a.sbins + r * (a.S + 1);
+    const float t = field_bin_edge(a, sb[s]) + field_bin_edge(a, sb[s + 1]);
+    const float dxr = a.dirs[r * 3 + 0], dyr = a.dirs[r * 3 + 1], dzr = a.dirs[r * 3 + 2];
+    float px = a.origins[r * 3 + 0] + dxr * t / 2.f;
+    float py = a.origins[r * 3 + 1] + dyr * t / 2.f;
+    float pz = a.origins[r * 3 + 2] + dzr * t / 2.f;
+    const float sel = unerf_normalize_position(px, py, pz, a.box);
+    const uint32_t mask = (1u << a.p.log2T) - 1u;
+    for (int l = 0; l < L; ++l) {   // grid features -> B rows 0..IN0-1
+        if (F == 4) {
+            float f4[4];
+            unerf_hash_level4(reinterpret_cast<const float4*>(a.p.table) + ((size_t)l << a.p.log2T), px, py, pz, a.p.scalings[l], mask, f4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) B[(4 * l + e) * 64 + lane] = f4[e];
+        } else {
+            float2 f;
+            if (a.p.tcnn_levels && a.p.grid_half) f = unerf_tcnn_level_feat_half(a.p.table, a.p.tcnn_levels[l], px, py, pz);
+            else if (a.p.tcnn_levels) f = unerf_tcnn_level_feat(reinterpret_cast<const float2*>(a.p.table), a.p.tcnn_levels[l], px, py, pz);
+            else f = unerf_hash_level(reinterpret_cast<const float2*>(a.p.table) + ((size_t)l << a.p.log2T), px, py, pz, a.p.scalings[l], mask);
+            B[(2 * l) * 64 + lane] = f.x;
+            B[(2 * l + 1) * 64 + lane] = f.y;
+        }
+    }
+    float sh[16];
+    {
+        float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
+        if (a.p.sh_remap) {
+            ux = ux * 2.f - 1.f;
+            uy = uy * 2.f - 1.f;
+            uz = uz * 2.f - 1.f;
+        }
+        unerf_sh16(ux, uy, uz, sh);
+    }
+    dense_any(a.p.w0t, a.p.b0, B, A, IN0, H, lane, MODE != UNERF_FIELD_LAPLACE);   // LAPLACE: bare Linear (utils.py:22-23)
+    if constexpr (MODE == UNERF_FIELD_LAPLACE) {
+        dense_any(a.p.w1t, a.p.b1, A, D, H, G, lane, false);                       // mlp_hidden: the geo features
+        const int nl = a.p.n_lap, nr = a.p.n_lap_rgb;
+        const size_t set = a.p.lap_chunk_rays ? (size_t)fastdiv(a.chunk0 + (uint32_t)r, a.div_chunk) : 0;
+        float mu = 0.f, mu2 = 0.f;
+        for (int q = 0; q < nl; ++q) {
+            const float* __restrict__ w = a.p.ws_density + (set * nl + (size_t)q) * (size_t)(H + 1);
+            float pre = 0.f;
+            for (int i = 0; i < H; ++i) pre = fmaf(A[i * 64 + lane], w[i], pre);
+            pre += w[H];
+            const float pred = a.p.lap_softplus ? unerf_softplus(pre) : expf(pre);
+            mu += pred;
+            mu2 += pred * pred;
+        }
+        mu /= (float)nl;
+        mu2 /= (float)nl;
+        const float var_d = a.p.lap_mask_density ? 0.f : mu2 - mu * mu;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Cb[e * 64 + lane] = sh[e];
+        for (int g = 0; g < G; ++g) Cb[(16 + g) * 64 + lane] = D[g * 64 + lane];
+        dense_any(a.p.h0t, a.p.hb0, Cb, B, INC, HC, lane, true);
+        dense_any(a.p.h1t, a.p.hb1, B, D, HC, HC, lane, true);
+        float m1[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
+        for (int q = 0; q < nr; ++q) {
+            const float* __restrict__ w = a.p.ws_rgb + (set * nr + (size_t)q) * (size_t)(3 * HC + 3);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float pre = 0.f;
+                for (int i = 0; i < HC; ++i) pre = fmaf(D[i * 64 + lane], w[c * HC + i], pre);
+                pre += w[3 * HC + c];
+                const float pred = unerf_sigmoid(pre);
+                m1[c] += pred;
+                m2[c] += pred * pred;
+            }
+        }
+        float vsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            m1[c] /= (float)nr;
+            m2[c] /= (float)nr;
+            vsum += fmaxf(m2[c] - m1[c] * m1[c], 0.f);
+        }
+        if (valid) {
+            a.density[n] = a.p.lap_mask_density ? mu * sel : mu;
+            a.aux[n] = var_d;
+            a.aux2[n] = vsum / 3.f;
+            a.rgb[n * 3 + 0] = m1[0];
+            a.rgb[n * 3 + 1] = m1[1];
+            a.rgb[n * 3 + 2] = m1[2];
+        }
+        return;
+    } else {
+        const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
+        const uint32_t sidx = (uint32_t)((uint64_t)a.ray_offset * (uint64_t)a.S + (uint64_t)n);
+        const uint32_t pre = unerf_mc_pre(unerf_mc_key(a.p.seed, 0u), sidx);
+        for (int k = 0; k < passes; ++k) {
+            const float* src = A;
+            if (a.drop_sites & UNERF_DROP_TRUNK) {
+                mask_any(A, B, H, lane, pre, k, 0u, a.keep_hi, a.drop_scale);
+                src = B;
+            }
+            dense_any(a.p.w1t, a.p.b1, src, D, H, OUT1, lane, false);
+            const float density = a.p.average_init_density * expf(D[lane]) * sel;
+            const float beta = MODE == UNERF_FIELD_ACTIVE ? unerf_softplus(D[(G + 1) * 64 + lane]) + a.p.beta_min : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Cb[e * 64 + lane] = sh[e];
+            for (int g = 0; g < G; ++g) Cb[(16 + g) * 64 + lane] = D[(1 + g) * 64 + lane];
+            if (a.drop_sites & UNERF_DROP_HEADIN) {   // Dropout on the head's inputs: the appearance block unfolded
+                for (int e = 0; e < AD; ++e) Cb[(INC + e) * 64 + lane] = a.p.app_embed[e];
+                mask_any(Cb, Cb, INC + AD, lane, pre, k, 3u, a.keep_hi, a.drop_scale);
+                dense_any(a.p.h0_full_t, a.p.hb0_raw, Cb, B, INC + AD, HC, lane, true);
+            } else {
+                dense_any(a.p.h0t, a.p.hb0, Cb, B, INC, HC, lane, true);
+            }
+            if (a.drop_sites & UNERF_DROP_HEAD0) mask_any(B, B, HC, lane, pre, k, 2u, a.keep_hi, a.drop_scale);
+            dense_any(a.p.h1t, a.p.hb1, B, D, HC, HC, lane, true);
+            if (a.drop_sites & UNERF_DROP_HEAD1) mask_any(D, D, HC, lane, pre, k, 1u, a.keep_hi, a.drop_scale);
+            dense_any(a.p.h2t, a.p.hb2, D, B, HC, 3, lane, false);
+            if (valid) {
+                const int64_t q = (int64_t)k * N + n;
+                a.density[q] = density;
+                a.rgb[q * 3 + 0] = unerf_sigmoid(B[lane]);
+                a.rgb[q * 3 + 1] = unerf_sigmoid(B[64 + lane]);
+                a.rgb[q * 3 + 2] = unerf_sigmoid(B[128 + lane]);
+                if (MODE == UNERF_FIELD_ACTIVE) a.aux[n] = beta;
+            }
         }
     }
 }
@@ -2921,7 +3129,20 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     UNERF_REQUIRE(p->table && (p->scalings || p->tcnn_levels) && p->w0t && p->b0 && p->w1t && p->b1 && p->h0t &&
                       p->hb0 && p->h1t && p->hb1 && p->h2t && p->hb2,
                   "field_fwd: null weight pointer");
-    UNERF_REQUIRE(p->L == 16, "field_fwd: L=%d (only the nerfacto 16-level grid is built)", p->L);
+    // any-width slow path (field_kernel_generic): widths given and different from nerfacto's 64 / 64 / 15 / 2 (or L != 16)
+    const int gH = p->hidden ? p->hidden : 64, gHC = p->hidden_color ? p->hidden_color : 64, gG = p->geo_dim ? p->geo_dim : 15;
+    const int gF = p->feat_per_level ? p->feat_per_level : 2, gAD = p->app_dim ? p->app_dim : 32;
+    const bool headin_site = p->mode == UNERF_FIELD_MCDROPOUT && (p->drop_sites & UNERF_DROP_HEADIN);
+    const bool generic = gH != 64 || gHC != 64 || gG != 15 || gF != 2 || p->L != 16 || (gAD != 32 && headin_site);
+    UNERF_REQUIRE(generic || p->L == 16, "field_fwd: L=%d", p->L);
+    if (generic) {
+        UNERF_REQUIRE(p->L >= 1 && p->L <= 32 && (gF == 2 || gF == 4) && gH >= 1 && gH <= 256 && gHC >= 1 && gHC <= 256 && gG >= 0 && gG <= 64,
+                      "field_fwd: widths outside the any-width kernel's range (L=%d F=%d hidden=%d hidden_color=%d geo=%d)", p->L, gF, gH, gHC, gG);
+        UNERF_REQUIRE(gF == 2 || !p->tcnn_levels, "field_fwd: features_per_level = 4 is built for the torch-layout grid");
+        UNERF_REQUIRE(!features && !p->sample_major && !p->packed_out, "field_fwd: the any-width kernel writes the plain ray-major layout only");
+        UNERF_REQUIRE(p->mode != UNERF_FIELD_MCDROPOUT || (gH <= 128 && gHC <= 128 && (!headin_site || 16 + gG + gAD <= 128)),
+                      "field_fwd: a dropout site has at most 128 units (mask stream layout)");
+    }
     UNERF_REQUIRE(!features || (p->mfma_blob && p->mode != UNERF_FIELD_LAPLACE),
                   "field_fwd: pre-gathered features are consumed by the MFMA kernel only (ACTIVE/MCDROPOUT with mfma_blob)");
     UNERF_REQUIRE(p->tcnn_levels || (p->log2T >= 1 && p->log2T <= 24), "field_fwd: bad log2T=%d", p->log2T);
@@ -2961,6 +3182,44 @@ extern "C" int unerf_field_fwd(const float* origins, const float* directions, co
     const bool f1 = p->f16_single != 0;
     UNERF_REQUIRE(!f1 || (p->mfma16_blob && !features && (p->mode != UNERF_FIELD_LAPLACE || (p->lap16_blob && p->n_lap <= 32 * LAP_BLOCKS))),
                   "field_fwd: f16_single needs mfma16_blob (and lap16_blob with n_lap <= 128 for LAPLACE), without pre-gathered features");
+    if (generic) {
+        a.p.hidden = gH; a.p.hidden_color = gHC; a.p.geo_dim = gG; a.p.feat_per_level = gF; a.p.app_dim = gAD;
+        int rows = p->L * gF;
+        for (int v : {gH, gHC, 16 + gG + gAD, 1 + gG + 1}) rows = v > rows ? v : rows;
+        const size_t lds_bytes = (size_t)rows * 64 * 4 * 4;
+        UNERF_REQUIRE(lds_bytes <= 160 * 1024, "field_fwd: %zu bytes of LDS for the any-width kernel", lds_bytes);
+        const int want1 = p->mode == UNERF_FIELD_ACTIVE ? gG + 2 : (p->mode == UNERF_FIELD_MCDROPOUT ? gG + 1 : gG);
+        UNERF_REQUIRE(p->out1 == want1, "field_fwd: out1=%d, expected %d for geo_dim=%d in this mode", p->out1, want1, gG);
+        if (a.drop_sites & UNERF_DROP_HEADIN)
+            UNERF_REQUIRE(p->h0_full_t && p->hb0_raw && p->app_embed, "field_fwd MCDROPOUT: UNERF_DROP_HEADIN needs h0_full_t / hb0_raw / app_embed");
+#define UNERF_GENERIC_LAUNCH(MODE_)                                                                                      \
+    do {                                                                                                                 \
+        if (lds_bytes > 64 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(field_kernel_generic<MODE_>),                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                       \
+        hipLaunchKernelGGL((field_kernel_generic<MODE_>), grid, block, lds_bytes, st, a, rows);                          \
+    } while (0)
+        switch (p->mode) {
+            case UNERF_FIELD_ACTIVE:
+                UNERF_REQUIRE(aux, "field_fwd ACTIVE: aux (beta) must be non-null");
+                UNERF_GENERIC_LAUNCH(UNERF_FIELD_ACTIVE);
+                break;
+            case UNERF_FIELD_MCDROPOUT:
+                UNERF_REQUIRE(p->K >= 0 && p->p_drop >= 0.f && p->p_drop < 1.f, "field_fwd MCDROPOUT: bad K/p_drop");
+                UNERF_GENERIC_LAUNCH(UNERF_FIELD_MCDROPOUT);
+                break;
+            case UNERF_FIELD_LAPLACE:
+                UNERF_REQUIRE(aux && aux2 && p->ws_density && p->ws_rgb && p->n_lap >= 1, "field_fwd LAPLACE: need aux, aux2, ws_density, ws_rgb, n_lap>=1");
+                UNERF_REQUIRE(p->lap_chunk_rays == 0 || (ray_offset + R - 1) / p->lap_chunk_rays < p->lap_sets, "field_fwd LAPLACE: rays reach past the sample sets");
+                UNERF_GENERIC_LAUNCH(UNERF_FIELD_LAPLACE);
+                break;
+            default:
+                unerf_set_error("field_fwd: unknown mode %d", p->mode);
+                return UNERF_ERR_ARG;
+        }
+#undef UNERF_GENERIC_LAUNCH
+        return unerf_check_launch("field_fwd (any-width kernel)");
+    }
     switch (p->mode) {
         case UNERF_FIELD_ACTIVE:
             UNERF_REQUIRE(p->out1 == 17 && aux, "field_fwd ACTIVE: out1 must be 17 and aux (beta) non-null");

@@ -120,8 +120,11 @@ class HashEncoding(nn.Module):
     def __init__(self, num_levels=16, min_res=16, max_res=1024, log2_hashmap_size=19, features_per_level=2,
                  hash_init_scale=0.001, implementation="torch"):
         super().__init__()
-        assert features_per_level == 2, "the HIP kernels are built for F=2"
         assert implementation in ("torch", "tcnn")
+        if features_per_level not in (2, 4) or (features_per_level == 4 and implementation == "tcnn"):
+            raise ValueError(f"features_per_level={features_per_level} ({implementation}): 2, or 4 on the torch-layout grid "
+                             "(any-width kernel, include/unerf.h)")
+        self.features_per_level = features_per_level
         self.num_levels, self.log2_hashmap_size, self.implementation = num_levels, log2_hashmap_size, implementation
         self.register_buffer("scalings", hash_scalings(num_levels, min_res, max_res), persistent=False)
         self.tcnn_levels = None
@@ -141,7 +144,7 @@ class HashEncoding(nn.Module):
         return self.tcnn_encoding.params if self.implementation == "tcnn" else self.hash_table
 
     def get_out_dim(self) -> int:
-        return self.num_levels * 2
+        return self.num_levels * self.features_per_level
 
 
 class MLP(nn.Module):
@@ -227,19 +230,28 @@ class HashMLPDensityField(nn.Module, _FieldBuffers):
                  average_init_density=1.0, implementation="torch", use_linear=False, **_unused):
         super().__init__()
         assert num_layers == 2, "proposal kernels are built for Linear-ReLU-Linear"
-        if use_linear:
-            raise NotImplementedError("use_linear=True proposal networks (grid + one Linear) are not built")
+        self.use_linear = bool(use_linear)
         self.average_init_density = average_init_density
         self._register_field_buffers(aabb, max_res, num_levels, log2_hashmap_size)
-        self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, 2, num_layers, hidden_dim, 1,
-                                            implementation=implementation)
-
-    @property
-    def encoding(self) -> "HashEncoding":
-        return self.mlp_base.encoder
+        if use_linear:
+            # [UPSTREAM density_fields.py] use_linear=True: `self.encoding = HashEncoding(...)` and
+            # `self.linear = nn.Linear(encoding.get_out_dim(), 1)` straight on the grid features, no hidden layer
+            # (keys encoding.*, linear.{weight,bias}); unerf_density_net.hidden = 0
+            self.encoding = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, 2, implementation=implementation)
+            self.linear = nn.Linear(self.encoding.get_out_dim(), 1)
+        else:
+            self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, 2, num_layers, hidden_dim, 1,
+                                                implementation=implementation)
+            # `encoding`: the grid, under the same attribute name in both forms -- here a plain reference (NOT a second
+            # registration: the state dict keeps the one set of mlp_base.* keys)
+            object.__setattr__(self, "encoding", self.mlp_base.encoder)
 
     def to_device(self, device) -> ops.DensityNetDev:
-        (w0, b0), (w1, b1) = self.mlp_base.mlp.linear_layers()
+        if self.use_linear:
+            w0 = b0 = None
+            w1, b1 = self.linear.weight, self.linear.bias
+        else:
+            (w0, b0), (w1, b1) = self.mlp_base.mlp.linear_layers()
         return ops.DensityNetDev.from_torch(self.encoding.table, self.encoding.scalings, self.encoding.log2_hashmap_size,
                                             w0, b0, w1, b1, device, tcnn_levels=self.encoding.tcnn_levels,
                                             grid_precision=self.encoding.grid_precision)
@@ -287,7 +299,6 @@ class _NerfactoFieldBase(nn.Module, _FieldBuffers):
         super().__init__()
         assert implementation in ("torch", "tcnn")
         self.implementation = implementation
-        assert geo_feat_dim == 15 and appearance_embedding_dim == 32, "kernels are built for the nerfacto widths"
         self.geo_feat_dim = geo_feat_dim
         self.appearance_embedding_dim = appearance_embedding_dim
         self.use_average_appearance_embedding = use_average_appearance_embedding
@@ -349,7 +360,7 @@ class ActiveNerfactoField(_NerfactoFieldBase):
                  spatial_distortion=None, implementation="torch", beta_min=0.01, **_unused):
         super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
                          implementation)
-        assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        assert (num_layers, num_layers_color) == (2, 3), "depths other than nerfacto's (2-layer trunk, 3-layer head) are not built"
         self._register_field_buffers(aabb, max_res, num_levels, log2_hashmap_size)
         self.beta_min = beta_min
         self.mlp_base_grid = HashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
@@ -384,7 +395,7 @@ class NerfactoMCDropoutField(_NerfactoFieldBase):
                  rgb_dropout_layers: Optional[List[int]] = None, density_dropout_layers=True, **_unused):
         super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
                          implementation)
-        assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        assert (num_layers, num_layers_color) == (2, 3), "depths other than nerfacto's (2-layer trunk, 3-layer head) are not built"
         rgb_dropout_layers = [-1] if rgb_dropout_layers is None else list(rgb_dropout_layers)
         # create_mlp (utils.py:6-43) puts a Dropout in front of Linear i for every i in dropout_layers; -1 and
         # num_layers - 1 both mean "in front of the last Linear".  The trunk's hidden layer (density_dropout_layers) and
@@ -455,7 +466,7 @@ class NerfactoField(_NerfactoFieldBase):
                  spatial_distortion=None, implementation="torch", average_init_density=1.0, **_unused):
         super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
                          implementation)
-        assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        assert (num_layers, num_layers_color) == (2, 3), "depths other than nerfacto's (2-layer trunk, 3-layer head) are not built"
         self._register_field_buffers(aabb, max_res, num_levels, log2_hashmap_size)
         self.average_init_density = average_init_density
         self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
@@ -485,7 +496,7 @@ class NerfactoLaplaceField(_NerfactoFieldBase):
                  spatial_distortion=None, implementation="torch", density_activation="trunc_exp", **_unused):
         super().__init__(num_images, geo_feat_dim, appearance_embedding_dim, use_average_appearance_embedding,
                          implementation)
-        assert (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        assert (num_layers, num_layers_color) == (2, 3), "depths other than nerfacto's (2-layer trunk, 3-layer head) are not built"
         if density_activation not in ("trunc_exp", "softplus"):        # laplace_model.py:151
             raise ValueError(f"density_activation={density_activation!r}: expected 'trunc_exp' or 'softplus'")
         self.density_activation = density_activation

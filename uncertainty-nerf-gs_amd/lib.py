@@ -110,6 +110,7 @@ class FieldParams(C.Structure):
         ("h0_full_t", C.c_void_p), ("hb0_raw", C.c_void_p), ("app_embed", C.c_void_p),
         ("lap_chunk_rays", C.c_int), ("lap_sets", C.c_int), ("n_lap_rgb", C.c_int), ("packed_out", C.c_int),
         ("grid_half", C.c_int),
+        ("hidden", C.c_int), ("hidden_color", C.c_int), ("geo_dim", C.c_int), ("feat_per_level", C.c_int), ("app_dim", C.c_int),
     ]
 
 

@@ -312,7 +312,7 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
         self.proposal_networks = nn.ModuleList([
             F.HashMLPDensityField(hidden_dim=a["hidden_dim"], num_levels=a["num_levels"], max_res=a["max_res"],
                                   log2_hashmap_size=a["log2_hashmap_size"],
-                                  average_init_density=c.average_init_density,
+                                  average_init_density=c.average_init_density, use_linear=bool(a.get("use_linear", False)),
                                   implementation=c.implementation) for a in c.proposal_net_args_list])
         self.field = self._make_field()
 

@@ -282,15 +282,19 @@ class DensityNetDev:
         f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         if grid_precision not in ("f32", "f16") or (grid_precision == "f16" and tcnn_levels is None):
             raise _l.UnerfError(f"grid_precision={grid_precision!r}: 'f32', or 'f16' with a tcnn-layout grid")
+        if w0 is None:   # use_linear=True: one Linear on the grid features (unerf_density_net.hidden = 0)
+            w0t, b0d = torch.zeros(0, device=device), torch.zeros(0, device=device)
+        else:
+            w0t, b0d = f(w0.t()), f(b0)
         if tcnn_levels is not None:
             sc = torch.zeros(len(tcnn_levels))
             tab = table.detach().reshape(-1, 2)
             tab = tab.to(device=device, dtype=torch.float16).contiguous() if grid_precision == "f16" else f(tab)
-            return cls(tab, f(sc), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
+            return cls(tab, f(sc), int(log2T), w0t, b0d, f(w1.t()), f(b1),
                        tcnn_levels=tcnn_levels_tensor(tcnn_levels, device), grid_precision=grid_precision)
         dense, offs, dims = build_dense_pairs(table, scalings.detach().cpu(), int(log2T),
                                               max_level_bytes=int(os.environ.get("UNERF_DENSE_LEVEL_BYTES", DENSE_LEVEL_BYTES)))
-        return cls(f(table), f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
+        return cls(f(table), f(scalings), int(log2T), w0t, b0d, f(w1.t()), f(b1),
                    None if dense is None else f(dense), tuple(offs), tuple(dims))
 
     def cstruct(self) -> _l.DensityNet:
@@ -298,11 +302,25 @@ class DensityNetDev:
         offs = (C.c_int * 8)(*(list(self.dense_off[:nd]) + [0] * (8 - nd)))
         dims = (C.c_int * 8)(*(list(self.dense_dim[:nd]) + [0] * (8 - nd)))
         half = self.grid_precision == "f16"
+        lin = self.b0.numel() == 0
         return _l.DensityNet(_p(self.table, torch.float16 if half else torch.float32, "table"), _p(self.scalings),
-                             self.scalings.numel(), self.log2T, _p(self.w0t),
-                             _p(self.b0), _p(self.w1t), _p(self.b1), self.b0.numel(),
+                             self.scalings.numel(), self.log2T, None if lin else _p(self.w0t),
+                             None if lin else _p(self.b0), _p(self.w1t), _p(self.b1), self.b0.numel(),
                              _p(self.dense) if nd else None, nd, offs, dims, _p(self.tcnn_levels, torch.int32),
                              0 if self.aabb is None else 1, _aabb6(self.aabb), 1 if half else 0)
+
+
+_warned_any_width = set()
+
+
+def _warn_any_width(H, HC, G, Fp, L):
+    key = (H, HC, G, Fp, L)
+    if key not in _warned_any_width:
+        _warned_any_width.add(key)
+        import warnings
+        warnings.warn(f"libunerf: field widths hidden={H}, hidden_color={HC}, geo_feat_dim={G}, features_per_level={Fp}, "
+                      f"num_levels={L} differ from nerfacto's 64 / 64 / 15 / 2 / 16: rendering with the any-width kernel "
+                      "(correct, 10-20 x slower than the matrix kernels)", stacklevel=3)
 
 
 @dataclass
@@ -363,6 +381,16 @@ class FieldDev:
     # tcnn's own half arithmetic (unerf_field_params.grid_half) -- what the reference's default implementation="tcnn"
     # computes; "f32" = fp32 rows and blend (also the only form of the torch layout)
     grid_precision: str = "f32"
+    # widths other than nerfacto's 64 / 64 / 15 / 2 / (32): the any-width kernel (0 = the defaults; include/unerf.h)
+    hidden: int = 0
+    hidden_color: int = 0
+    geo_dim: int = 0
+    feat_per_level: int = 0
+    app_dim: int = 0
+
+    @property
+    def any_width(self) -> bool:
+        return bool(self.hidden)     # from_torch sets all five together
 
     @classmethod
     def from_torch(cls, mode, table, scalings, log2T, w0, b0, w1, b1, head_w, head_b, appearance, device,
@@ -375,24 +403,39 @@ class FieldDev:
             table, scalings = table.reshape(-1, 2), torch.zeros(len(tcnn_levels))
             kw["tcnn_levels"] = tcnn_levels_tensor(tcnn_levels, device)
         h0 = head_w[0].detach().to(torch.float32).contiguous()
+        lap = mode == _l.FIELD_LAPLACE
+        # widths (include/unerf.h: unerf_field_params.hidden ...): anything but nerfacto's runs the any-width kernel
+        H, HC, AD = int(w0.shape[0]), int(head_w[1].shape[0]), int(appearance.numel())
+        G = int(w1.shape[0]) - (0 if lap else (2 if mode == _l.FIELD_ACTIVE else 1))
+        Fp = int(table.shape[-1]) if tcnn_levels is None else 2
+        L = int(scalings.numel())
+        if h0.shape != (HC, 16 + G + AD) or w1.shape[1] != H or w0.shape[1] != L * Fp or head_w[2].shape != (3, HC):
+            raise _l.UnerfError(f"FieldDev: inconsistent layer shapes (trunk {tuple(w0.shape)} -> {tuple(w1.shape)}, head "
+                                f"{tuple(h0.shape)} / {tuple(head_w[1].shape)} / {tuple(head_w[2].shape)}, appearance {AD}, grid {L} x {Fp})")
+        headin = mode == _l.FIELD_MCDROPOUT and bool(int(kw.get("drop_sites", 0)) & _l.DROP_HEADIN)
+        generic = (H, HC, G, Fp, L) != (64, 64, 15, 2, 16) or (AD != 32 and headin)
+        if generic:
+            _warn_any_width(H, HC, G, Fp, L)
+            kw.update(hidden=H, hidden_color=HC, geo_dim=G, feat_per_level=Fp, app_dim=AD)
         # appearance block folded into the bias; accumulated in float64 so the result does not depend on the
         # memory layout the weights arrived in (a strided view takes a different CPU matmul path)
-        hb0 = (head_b[0].detach().double() + h0[:, 31:].double() @ appearance.detach().double()).to(torch.float32)
-        lap = mode == _l.FIELD_LAPLACE
-        blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
-                                 geo_first_unit=0 if lap else 1))
+        hb0 = (head_b[0].detach().double() + h0[:, 16 + G:].double() @ appearance.detach().double()).to(torch.float32)
         kw["packed_drop_scale"] = cls._drop_scale(mode, int(kw.get("K", 0)), float(kw.get("p_drop", 0.2)))
         kw["packed_drop_sites"] = cls._sites(int(kw.get("drop_sites", 0)))
-        blob16 = pack_field_mfma16(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
-                                   geo_first_unit=0 if lap else 1, drop_scale=kw["packed_drop_scale"],
-                                   drop_sites=kw["packed_drop_sites"],
-                                   fold_trunk=mode == _l.FIELD_MCDROPOUT and bool(_l.load().unerf_build_flags() & _l.BUILD_TRUNK_FOLD))
+        blob = blob16 = None
+        if not generic:
+            blob = f(pack_field_mfma(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
+                                     geo_first_unit=0 if lap else 1))
+            blob16 = pack_field_mfma16(w0, b0, w1, b1, h0[:, :31], hb0, head_w[1], head_b[1], head_w[2], head_b[2],
+                                       geo_first_unit=0 if lap else 1, drop_scale=kw["packed_drop_scale"],
+                                       drop_sites=kw["packed_drop_sites"],
+                                       fold_trunk=mode == _l.FIELD_MCDROPOUT and bool(_l.load().unerf_build_flags() & _l.BUILD_TRUNK_FOLD))
         kw["packed_mode"] = mode
         kw["mfma16_blob"] = None if blob16 is None else f(blob16)   # None (weights beyond the f16 range): exact kernels
         lap_blob = None
         if lap and kw.get("ws_density") is not None and kw["ws_density"].dim() == 3 and not kw.get("lap_chunk_rays"):
             raise _l.UnerfError("FieldDev: stacked Laplace sample sets [sets, n, P] need lap_chunk_rays (rays per set)")
-        if lap and kw.get("ws_density") is not None and max(kw["ws_density"].shape[-2], kw["ws_rgb"].shape[-2]) <= 32 * LAP_BLOCKS:
+        if lap and not generic and kw.get("ws_density") is not None and max(kw["ws_density"].shape[-2], kw["ws_rgb"].shape[-2]) <= 32 * LAP_BLOCKS:
             wsd, wsr = kw["ws_density"], kw["ws_rgb"]
             stacked = wsd.dim() == 3
             lap_blob, lap16 = pack_laplace_sets(wsd if stacked else wsd[None], wsr if stacked else wsr[None], device,
@@ -405,7 +448,7 @@ class FieldDev:
             kw["ws_density"], kw["ws_rgb"] = f(kw["ws_density"]), f(kw["ws_rgb"])
         tab = table.detach().to(device=device, dtype=torch.float16).contiguous() if gp == "f16" else f(table)
         return cls(mode, tab, f(scalings), int(log2T), f(w0.t()), f(b0), f(w1.t()), f(b1),
-                   f(h0[:, :31].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
+                   f(h0[:, :16 + G].t()), f(hb0), f(head_w[1].t()), f(head_b[1]), f(head_w[2].t()), f(head_b[2]),
                    mfma_blob=blob, lap_blob=lap_blob, h0_full_t=f(h0.t()), hb0_raw=f(head_b[0]), app_embed=f(appearance),
                    **kw)
 
@@ -419,6 +462,8 @@ class FieldDev:
         return drop_sites if drop_sites else (_l.DROP_TRUNK | _l.DROP_HEAD1)
 
     def cstruct(self) -> _l.FieldParams:
+        if self.any_width and self.precision == "f16":
+            raise _l.UnerfError("FieldDev.precision='f16': the any-width kernel computes in fp32 (use 'f16x2' or 'fp32')")
         if self.precision not in ("f16x2", "fp32", "f16"):
             raise _l.UnerfError(f"FieldDev.precision={self.precision!r}: expected 'f16x2', 'fp32' or 'f16'")
         h16 = self.precision in ("f16x2", "f16")
@@ -459,6 +504,8 @@ class FieldDev:
             self.ws_density.shape[0] if (self.ws_density is not None and self.ws_density.dim() == 3) else 1,
             0 if self.ws_rgb is None else self.ws_rgb.shape[-2])
         cs.grid_half = 1 if half else 0
+        cs.hidden, cs.hidden_color, cs.geo_dim = int(self.hidden), int(self.hidden_color), int(self.geo_dim)
+        cs.feat_per_level, cs.app_dim = int(self.feat_per_level), int(self.app_dim)
         return cs
 
 
@@ -872,7 +919,7 @@ def supports_planes(field: FieldDev) -> bool:
 
 def supports_packed(field: "FieldDev") -> bool:
     """unerf_field_params.packed_out: the ACTIVE / MCDROPOUT kernels can leave one 16-byte row per sample"""
-    return field.mode in (_l.FIELD_ACTIVE, _l.FIELD_MCDROPOUT)
+    return field.mode in (_l.FIELD_ACTIVE, _l.FIELD_MCDROPOUT) and not field.any_width
 
 
 def field_fwd(origins, directions, sbins, field: FieldDev, near: float, far: float, ray_offset: int = 0,

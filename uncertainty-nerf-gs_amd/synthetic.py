@@ -32,9 +32,9 @@ def _linear(gen, out_dim, in_dim):
     return w, b
 
 
-def _grid(gen, num_levels, min_res, max_res, log2T, table_scale):
+def _grid(gen, num_levels, min_res, max_res, log2T, table_scale, features=2):
     T = 1 << log2T
-    table = (torch.rand(num_levels * T, 2, generator=gen) * 2 - 1) * table_scale
+    table = (torch.rand(num_levels * T, features, generator=gen) * 2 - 1) * table_scale
     return {"table": table, "scalings": hash_scalings(num_levels, min_res, max_res), "log2T": log2T}
 
 
@@ -52,7 +52,9 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
                        max_res: int = 2048, table_scale: float = 0.5, density_gain: float = 16.0,
                        density_bias: float = -2.0, color_gain: float = 4.0, beta_gain: float = 12.0,
                        grid: str = "torch", sharp: bool = False, overflow_units: Tuple[int, ...] = (),
-                       head_overflow_units: Tuple[int, ...] = (), color_contrast: float = 1.0) -> Dict:
+                       head_overflow_units: Tuple[int, ...] = (), color_contrast: float = 1.0, hidden_dim: int = 64,
+                       hidden_dim_color: int = 64, geo_feat_dim: int = 15, features_per_level: int = 2,
+                       appearance_dim: int = 32, prop_linear: bool = False) -> Dict:
     """Random-init nerfacto-shaped scene.  Tables U(-1,1)*table_scale; Linear layers
     Kaiming-uniform like nn.Linear; the density row is gained up so accumulation, depth and the
     variances vary over the image instead of saturating.
@@ -75,37 +77,46 @@ def make_scene_tensors(seed: int = 0, kind: str = "active", log2T: int = 19, pro
     assert kind in ("active", "mcdropout", "laplace") and grid in ("torch", "tcnn")
     gen = torch.Generator().manual_seed(seed)
     make_grid = _grid_tcnn if grid == "tcnn" else _grid
-    f = make_grid(gen, 16, 16, max_res, log2T, table_scale)
+    # hidden_dim / hidden_dim_color / geo_feat_dim / features_per_level / appearance_dim: the widths the reference's model
+    # configs forward to the field; anything but 64 / 64 / 15 / 2 runs the any-width kernel.  prop_linear: use_linear=True
+    # proposal networks (one Linear on the grid features)
+    f = make_grid(gen, 16, 16, max_res, log2T, table_scale) if features_per_level == 2 else \
+        _grid(gen, 16, 16, max_res, log2T, table_scale, features_per_level)
+    assert features_per_level == 2 or grid == "torch"
     f["sh_remap"] = grid == "tcnn"   # tcnn's SphericalHarmonics encoding maps (d+1)/2 back to [-1,1]
-    f["w0"], f["b0"] = _linear(gen, 64, 32)
-    out1 = {"active": 17, "mcdropout": 16, "laplace": 15}[kind]
-    f["w1"], f["b1"] = _linear(gen, out1, 64)
+    f["w0"], f["b0"] = _linear(gen, hidden_dim, 16 * features_per_level)
+    out1 = geo_feat_dim + {"active": 2, "mcdropout": 1, "laplace": 0}[kind]
+    f["w1"], f["b1"] = _linear(gen, out1, hidden_dim)
     head_w, head_b = [], []
-    for i, o in ((63, 64), (64, 64), (64, 3)):
+    for i, o in ((16 + geo_feat_dim + appearance_dim, hidden_dim_color), (hidden_dim_color, hidden_dim_color), (hidden_dim_color, 3)):
         w, b = _linear(gen, o, i)
         head_w.append(w * (color_gain if o == 3 else 1.0))
         head_b.append(b)
     f["head_w"], f["head_b"] = head_w, head_b
-    f["appearance"] = torch.randn(32, generator=gen) * 0.1
+    f["appearance"] = torch.randn(appearance_dim, generator=gen) * 0.1
     f["average_init_density"] = 1.0
     f["beta_min"] = 0.01
     if kind == "laplace":
         f["w1"] = f["w1"] * color_gain
-        dw, db = _linear(gen, 1, 64)
+        dw, db = _linear(gen, 1, hidden_dim)
         f["density_w"] = dw * (density_gain / 4)
         f["density_b"] = db * 0 + density_bias
     else:
         f["w1"][0] *= density_gain
-        f["w1"][1:16] *= color_gain
+        f["w1"][1:1 + geo_feat_dim] *= color_gain
         f["b1"][0] = density_bias
         if kind == "active":
-            f["w1"][16] *= beta_gain  # learned-variance logit: give the variance image dynamic range
-            f["b1"][16] = -2.0
+            f["w1"][1 + geo_feat_dim] *= beta_gain  # learned-variance logit: give the variance image dynamic range
+            f["b1"][1 + geo_feat_dim] = -2.0
     props = []
     for mr in (128, 256):
         p = make_grid(gen, 5, 16, mr, prop_log2T, table_scale)
-        p["w0"], p["b0"] = _linear(gen, 16, 10)
-        p["w1"], p["b1"] = _linear(gen, 1, 16)
+        if prop_linear:
+            p["w0"] = p["b0"] = None
+            p["w1"], p["b1"] = _linear(gen, 1, 10)
+        else:
+            p["w0"], p["b0"] = _linear(gen, 16, 10)
+            p["w1"], p["b1"] = _linear(gen, 1, 16)
         p["w1"][0] *= density_gain
         p["b1"][0] = density_bias + math.log(100.0)  # proposal nets carry average_init_density = 0.01
         props.append(p)
