@@ -192,6 +192,38 @@ def test_laplace_model_draws_fresh_last_layer_samples_in_every_eval_chunk(dev):
         one = model.get_outputs_for_camera_unc(cam, n_samples=50, generator=torch.Generator().manual_seed(9))
     assert torch.allclose(one["rgb"].reshape(-1, 3)[:128], out["rgb"].reshape(-1, 3)[:128], atol=1e-6)   # chunk 0: the same draw
     assert float((one["rgb_std"] - out["rgb_std"]).abs().max()) > 1e-4
+    # a chunk size that is not a multiple of 32 cannot carry per-chunk sets (a kernel tile is 32 rays): it
+    # renders with one set for the frame -- what "camera" does -- and says so, instead of refusing the frame
+    model.resample = "chunk"
+    cfg.eval_num_rays_per_chunk = 100
+    model.invalidate()
+    with torch.cuda.device(dev), pytest.warns(UserWarning, match="not a multiple of 32"):
+        odd = model.get_outputs_for_camera_unc(cam, n_samples=50, generator=torch.Generator().manual_seed(9))
+    assert torch.allclose(odd["rgb_std"], one["rgb_std"], atol=2e-6)     # (expected_depth clips per chunk: not compared)
+    # ... and the scratch arena of the frame path survives the two invalidate() calls of every *_unc frame
+    ws = model.device_scene().workspace
+    if ws is not None:
+        held = ws.nbytes()
+        with torch.cuda.device(dev):
+            model.get_outputs_for_camera_unc(cam, n_samples=50, generator=torch.Generator().manual_seed(9))
+        assert model.device_scene().workspace is ws and ws.nbytes() == held > 0
+        model.release()
+        assert ws.nbytes() == 0 and model._dev_scene is None
+
+
+def test_splat_counts_in_flight_keep_their_own_values(dev):
+    """ops.SplatCount: several counts started before any is awaited -- pipelined frames, ensemble members --
+    each read their own number (a ring of pinned words, wait() caches its value), in any order and repeatedly"""
+    from uncertainty_nerf_gs_amd import lib as L, ops
+    hits = [torch.full((1000 + 37 * i,), i + 1, dtype=torch.int32, device=dev) for i in range(ops.SplatCount.RING)]
+    counts = [ops.SplatCount(h) for h in hits]
+    want = [int(h.sum()) for h in hits]
+    assert [c.wait() for c in reversed(counts)] == list(reversed(want))
+    assert [c.wait() for c in counts] == want                         # again: cached
+    more = [ops.SplatCount(h) for h in hits]                          # the ring wraps: the awaited words are free
+    with pytest.raises(L.UnerfError, match="without wait"):
+        ops.SplatCount(hits[0])                                       # ... a ninth unawaited one is refused
+    assert [c.wait() for c in more] == want and [c.wait() for c in counts] == want
 
 
 def test_laplace_model_deterministic_density_matches_oracle(dev):

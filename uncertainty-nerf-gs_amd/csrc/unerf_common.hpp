@@ -254,8 +254,17 @@ __device__ __forceinline__ void unerf_hash_corners(float px, float py, float pz,
 typedef float unerf_v2f __attribute__((ext_vector_type(2)));
 template <bool FUSED = false>
 __device__ __forceinline__ unerf_v2f unerf_lerp2(unerf_v2f a, unerf_v2f b, float o, float m) {
+#if UNERF_FIELD_BLEND_FMA == 7
+    // experiment: the scalar weights as REAL register pairs, both halves written -- no packed operand
+    // whose upper half is an undefined register the allocator may hand to another live value
+    unerf_v2f oo = {o, o}, mm = {m, m};
+    asm volatile("" : "+v"(oo), "+v"(mm));
+    if (FUSED) return __builtin_elementwise_fma(a, oo, b * mm);
+    return a * oo + b * mm;
+#else
     if (FUSED) return __builtin_elementwise_fma(a, unerf_v2f{o, o}, b * m);
     return a * o + b * m;
+#endif
 }
 template <bool FUSED = false>
 __device__ __forceinline__ float unerf_lerp1(float a, float b, float o, float m) {

@@ -1797,8 +1797,17 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
             float2 c8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
-            float2 f = PACKED ? unerf_blend8<(UNERF_FIELD_BLEND_FMA != 0)>(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2])
+            // UNERF_FIELD_BLEND_FMA (experiments; 0 ships): 1 = fused lerps, 2 = fused lerps in the SCALAR form
+            // in every kernel (no v_pk_fma_f32 in the blend), 3 = as 1 with two wait states behind every level's blend
+            float2 f = (PACKED && UNERF_FIELD_BLEND_FMA != 2) ? unerf_blend8<(UNERF_FIELD_BLEND_FMA != 0)>(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2])
                               : unerf_blend8_scalar<(UNERF_FIELD_BLEND_FMA != 0)>(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
+#if UNERF_FIELD_BLEND_FMA == 3
+            asm volatile("s_nop 1" : "+v"(f.x), "+v"(f.y));
+#elif UNERF_FIELD_BLEND_FMA == 4
+            asm volatile("s_nop 0" : "+v"(f.x), "+v"(f.y));
+#elif UNERF_FIELD_BLEND_FMA == 5
+            asm volatile("" : "+v"(f.x), "+v"(f.y));
+#endif
             feat[2 * (4 * hb + q)] = f.x;
             feat[2 * (4 * hb + q) + 1] = f.y;
         }

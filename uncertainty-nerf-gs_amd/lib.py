@@ -20,8 +20,17 @@ SOURCES = ["unerf_nerf.hip", "unerf_splat.hip"]
 # -amdgpu-mfma-vgpr-form: gfx950 has one unified register file; let the MFMAs write their accumulators to
 # ordinary VGPRs so ReLU / dropout / the next layer's B operand read them without v_accvgpr_read copies
 # (97 copies per tile in the K-pass kernel, which is VALU-issue-bound; rocprof r1_04).
+# -fno-slp-vectorize: the one KNOWN trigger of run-to-run differences in the split-f16 field kernels is code the SLP
+# vectoriser makes (packed v_pk_mul_f32 forms of the position x scale products in front of the hash): the fused-blend
+# experiment build (UNERF_FIELD_BLEND_FMA=1) differs from launch to launch with it and repeats bit for bit without it
+# (profiles/r5_exp_blend_defect.jsonl).  The shipped sources never showed the defect, but the flag costs
+# nothing (same frame times, same bits: every hot loop is written on explicit 2-vectors) and removes the trigger class.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
-               "-mllvm", "-amdgpu-mfma-vgpr-form"]
+               "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+# The compiler the kernels' hazard placement (hand-placed wait states inside inline assembly, the internal
+# -amdgpu-mfma-vgpr-form switch) was validated with: tests/test_gpu_repeatability.py on MI355X.  Another version builds,
+# with a warning -- rerun that test before trusting it.
+VALIDATED_HIPCC = "HIP version: 7.2"
 
 
 class UnerfError(RuntimeError):
@@ -62,6 +71,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             if not force and fresh():   # another rank built it while we waited
                 return LIB_PATH
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+            if VALIDATED_HIPCC not in ver:
+                import warnings
+                warnings.warn(f"libunerf: building with {ver.splitlines()[0] if ver else hipcc!r}; the kernels were validated with "
+                              f"'{VALIDATED_HIPCC}*' (run tests/test_gpu_repeatability.py on the GPU before trusting this build)")
             tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
             cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
             if verbose:

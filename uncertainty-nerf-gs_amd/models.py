@@ -360,6 +360,10 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
                 want = "fp32"       # weights beyond the f16 range (or a VALU-only layout): the exact kernels
             fd.precision = want
             self._dev_scene = self._build_scene(device, fd)
+            kept = getattr(self, "_kept_workspace", None)
+            if kept is not None and self._dev_scene.workspace is not None:
+                self._dev_scene.workspace = kept     # the scratch arena survives a rebuild of the parameter copies
+            self._kept_workspace = None
         return self._dev_scene
 
     def _build_scene(self, device, fd) -> NerfSceneDev:
@@ -381,7 +385,19 @@ class _NerfactoBase(nn.Module, _ImageMetrics):
             chunk_rays=c.eval_num_rays_per_chunk, **self._sampler_opts())
 
     def invalidate(self):
-        """call after changing weights or eval-time knobs (mc_samples, GGN, ...)"""
+        """call after changing weights or eval-time knobs (mc_samples, GGN, ...).  The device copies of the parameters are
+        rebuilt on the next render; the frame path's scratch arena (ops.Workspace, GBs at 1080p) is carried over -- a
+        Laplace *_unc call invalidates twice per frame.  release() drops it too."""
+        if self._dev_scene is not None and self._dev_scene.workspace is not None:
+            self._kept_workspace = self._dev_scene.workspace
+        self._dev_scene = None
+
+    def release(self):
+        """free the device copies AND the scratch arena (a model that will not render again soon)"""
+        for ws in (getattr(self, "_kept_workspace", None), None if self._dev_scene is None else self._dev_scene.workspace):
+            if ws is not None:
+                ws.release()
+        self._kept_workspace = None
         self._dev_scene = None
 
     def _begin_render(self, scene: NerfSceneDev) -> None:
@@ -607,9 +623,13 @@ class NerfactoLaplaceModel(_NerfactoBase):
             _, cam = _camera_args(camera)
             chunk = int(self.config.eval_num_rays_per_chunk)
             if chunk <= 0 or chunk % 32:
-                raise ValueError(f"eval_num_rays_per_chunk={chunk}: per-chunk Laplace samples need a multiple of 32 rays per "
-                                 "chunk (a kernel tile is 32 rays); use such a chunk size or model.resample = 'camera'")
-            n_sets = -(-(cam["H"] * cam["W"]) // chunk)
+                # a kernel tile is 32 rays and must not straddle two sample sets: such a chunk size renders with ONE set
+                # for the frame (what every chunk size did before per-chunk sets existed) instead of failing
+                import warnings
+                warnings.warn(f"eval_num_rays_per_chunk={chunk} is not a multiple of 32: per-chunk Laplace sample sets need "
+                              "that; rendering this frame with one set (model.resample = 'camera')")
+            else:
+                n_sets = -(-(cam["H"] * cam["W"]) // chunk)
         self._ws = self.field.sample_last_layers(n_samples=n_samples, prior_prec=prior_prec, eps=eps, generator=generator,
                                                  deterministic_density=use_deterministic_density, n_sets=n_sets)
         self._deterministic_density = bool(use_deterministic_density)

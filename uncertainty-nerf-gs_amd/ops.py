@@ -840,6 +840,16 @@ class Workspace:
     def nbytes(self) -> int:
         return sum(b.numel() * b.element_size() for b in self._bufs.values())
 
+    def release(self) -> None:
+        """drop every buffer (scene teardown; a scene that is rebuilt keeps its arena instead: models.invalidate()).
+        A buffer that a side stream may still be reading (render_camera(overlap=True) shades on its own stream) is
+        handed back to the allocator with that stream recorded on it."""
+        cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        for b in self._bufs.values():
+            if b.is_cuda and cur is not None:
+                b.record_stream(cur)
+        self._bufs.clear()
+
 
 def _scratch(workspace: Optional["Workspace"], tag: str, shape, device) -> torch.Tensor:
     if workspace is None:
@@ -1204,7 +1214,13 @@ class SplatCount:
     device idling through a full stream synchronisation and the launch latency of everything behind it."""
 
     _side: Dict = {}
-    _pinned: Dict = {}      # one pinned int32 per device and side stream, reused by every frame
+    # A small RING of pinned int32 words per device: a count may be started and awaited later (pipelined frames, ensemble
+    # members, threads), so two can be in flight; each takes the next word, and wait() caches its value on first return --
+    # a word is reused only RING counts later (a count still unawaited by then is refused: it would read another's value)
+    RING = 8
+    _pinned: Dict = {}
+    _next: Dict = {}
+    _owner: Dict = {}
 
     def __init__(self, num_tiles_hit: torch.Tensor):
         lib = _l.load()
@@ -1220,10 +1236,19 @@ class SplatCount:
                 SplatCount._side[key] = torch.cuda.Stream(device=self.dev)
             side = SplatCount._side[key]
             if key not in SplatCount._pinned:
-                SplatCount._pinned[key] = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            # (frames of one device run one after the other on the side stream: the previous frame's wait() has returned
-            # before this copy is queued, so the word is free)
-            self._host = SplatCount._pinned[key]
+                SplatCount._pinned[key] = torch.empty(SplatCount.RING, dtype=torch.int32, pin_memory=True)
+                SplatCount._next[key], SplatCount._owner[key] = 0, [None] * SplatCount.RING
+            slot = SplatCount._next[key]
+            prev = SplatCount._owner[key][slot]
+            prev = prev() if prev is not None else None
+            if prev is not None and prev._value is None:
+                raise _l.UnerfError(f"SplatCount: {SplatCount.RING} counts started on this device without wait(): await them "
+                                    "before starting more")
+            import weakref
+            SplatCount._owner[key][slot] = weakref.ref(self)
+            SplatCount._next[key] = (slot + 1) % SplatCount.RING
+            self._value: Optional[int] = None
+            self._host = SplatCount._pinned[key][slot:slot + 1]
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -1235,8 +1260,10 @@ class SplatCount:
             self._ws0 = ws0     # keeps the scan's scratch alive until the count is known
 
     def wait(self) -> int:
-        self._done.synchronize()
-        return int(self._host[0])
+        if self._value is None:
+            self._done.synchronize()
+            self._value = int(self._host[0])
+        return self._value
 
 
 def splat_bin_sort(xys, depths, radii, num_tiles_hit, H: int, W: int, block_width: int = 16,
