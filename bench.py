@@ -42,9 +42,9 @@ FP32_PEAK_TFLOPS = 157.3       # fp32 vector = fp32-input MFMA peak (the exact-f
 F16_PEAK_TFLOPS = 2500.0       # dense f16/bf16 MFMA peak (the split-f16 field kernels issue 3 f16 products per fp32 MAC)
 
 # algorithmic work per ray (SURVEY.md 8d / DESIGN.md "Kernels"): bytes the algorithm must touch
-def _alg(kind, K):
+def _alg(kind, K, row_bytes=8):
     S0, S1, S = 256, 96, 48
-    corner = 8 * 8  # 8 corners x (2 x fp32)
+    corner = 8 * row_bytes  # 8 corners x one table row: 2 x fp32, or half2 (tcnn grids in tcnn's half arithmetic)
     passes = max(K, 1)
     mlp_shared = 2 * 32 * 64
     mlp_tail = {"active": 2 * 64 * 17, "mcdropout": 2 * 64 * 16, "laplace": 2 * 64 * 15}[kind] + 2 * 63 * 64 + 2 * 64 * 64
@@ -102,10 +102,19 @@ def _issue_profile(method, K):
 # on every run, frame 1 of the five default steps 163 ms on a box that had parsed more JSON before (step_wall_ms of those runs;
 # with the long-lived objects frozen, or the collector off, no frame of 2 x 400 exceeded 47.1 ms).  freeze() moves what exists
 # after the warm-up into the permanent generation: the collector keeps running, on the young objects only.  No work is skipped.
-def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check=True, want_cpu=True, precision=None):
-    """One NeRF method through the whole frame path; returns the record (headline fields + roofline + cpu_baseline)."""
+def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check=True, want_cpu=True, precision=None,
+             grid=None, grid_precision=None):
+    """One NeRF method through the whole frame path; returns the record (headline fields + roofline + cpu_baseline).
+    grid / grid_precision (default: args): "tcnn" = the tiny-cuda-nn table layout the reference's default
+    implementation trains with, "f16" = in tcnn's own half arithmetic (half2 rows)."""
     from uncertainty_nerf_gs_amd import ops, render, synthetic
-    t = synthetic.make_scene_tensors(seed=0, kind=method)   # full nerfacto shape: 16x2^19x2 + 2 x 5x2^17x2
+    grid = grid or args.grid
+    grid_precision = grid_precision or (args.grid_precision or ("f16" if grid == "tcnn" else "f32"))
+    t = synthetic.make_scene_tensors(seed=0, kind=method, grid=grid)   # full nerfacto shape: 16x2^19x2 + 2 x 5x2^17x2
+    if grid == "tcnn":
+        t["grid_precision"] = grid_precision
+    row_bytes = 4 if (grid == "tcnn" and grid_precision == "f16") else 8
+    grid_tag = "" if grid == "torch" else ("_tcnn" if grid_precision == "f16" else "_tcnn32")
     kw = {}
     if method == "mcdropout":
         kw = dict(K=K, seed=1234, p_drop=0.2)
@@ -192,7 +201,11 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     single = scene.field.precision == "f16"
     rec["workload"] = (f"{method}-nerfacto {W}x{H} render with variance" + (f", K={K} MC-dropout passes" if K else "")
                        + (", 100 last-layer Laplace samples" if method == "laplace" else "")
-                       + (", density [H,W,48] kept" if method == "active" else ""))
+                       + (", density [H,W,48] kept" if method == "active" else "")
+                       + ("" if grid == "torch" else (", tcnn-layout tables in tcnn's half arithmetic (half2 rows)" if row_bytes == 4
+                                                      else ", tcnn-layout tables, fp32 rows")))
+    rec["hash_grid"] = ("16x2^19x2 fp32 (nerfstudio torch layout)" if grid == "torch" else
+                        f"tcnn layout, 16 levels up to 2^19 rows, {'half2' if row_bytes == 4 else 'fp32x2'} rows")
     rec["dense_layers"] = ("fp32 operands split into two f16 halves, 3 products on v_mfma_f32_32x32x16_f16, "
                            "fp32 accumulate (fp32-equivalent, DESIGN.md 4.2)" if split else
                            "f16 operands (one product per MAC on v_mfma_f32_32x32x16_f16), fp32 accumulate: the reference's eval "
@@ -202,7 +215,7 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     if rank != 0:
         return rec
     ksum = timer.summary()
-    alg = _alg(method, K)
+    alg = _alg(method, K, row_bytes)
     dom = max(ksum, key=lambda k: ksum[k]["total_ms"])
     rays_per_launch = H * W * steps / ksum[dom]["launches"]
     avg_s = ksum[dom]["avg_ms"] * 1e-3
@@ -231,7 +244,7 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
                              "algorithmic_bytes_per_ray x rays_per_launch) over the live launch duration; `traffic` = the bytes "
                              "that actually cross the fabric (PMC).  The tables are cache resident and the kernel is bound by "
                              "instruction issue, not by this roof: issue_roofline"})
-    prof = _issue_profile(method + ("_f16" if single else ""), K) if dom == "field_fwd" and (split or single) else None
+    prof = _issue_profile(method + ("_f16" if single else "") + grid_tag, K) if dom == "field_fwd" and (split or single) else None
     roof["issue_roofline"] = None
     if prof is not None:
         # the roof that binds: instruction issue (VALU + MFMA share one pipe per SIMD).  achieved = issue cycles the
@@ -261,7 +274,7 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     roof["algorithmic_bytes_per_ray"] = a["bytes"]
     roof["algorithmic_flops_per_ray"] = a["flops"]
     roof["traffic"] = None
-    tfile = os.path.join(ROOT, "profiles", f"traffic_{method}{'_f16' if single else ''}.json")
+    tfile = os.path.join(ROOT, "profiles", f"traffic_{method}{'_f16' if single else ''}{grid_tag}.json")
     if os.path.exists(tfile):  # HBM-side bytes from committed rocprofv3 --pmc passes of this command
         tj = json.load(open(tfile))
         tk = tj.get("kernels", {}).get(dom)
@@ -352,6 +365,11 @@ def main():
                          "precision); f16x2 = split-f16 (fp32-equivalent); fp32 = exact fp32-input MFMA.  Default: what the "
                          "reference computes the method in -- f16 for mcdropout (forced autocast) and active (tcnn), f16x2 for "
                          "laplace (`.float()` Linears)")
+    ap.add_argument("--grid", default="torch", choices=["torch", "tcnn"],
+                    help="table layout: nerfstudio's torch HashEncoding (the BASELINE's synthetic recipe) or tiny-cuda-nn's "
+                         "(implementation=\"tcnn\", the reference's default)")
+    ap.add_argument("--grid-precision", default=None, choices=["f32", "f16"],
+                    help="tcnn layout only: f16 (default) = half2 rows + tcnn's half interpolation, f32 = fp32 rows")
     ap.add_argument("--exact-fp32", action="store_true",
                     help="dense layers on the exact fp32-input MFMA kernels instead of the split-f16 ones")
     ap.add_argument("--no-exact-check", action="store_true",
@@ -418,14 +436,18 @@ def main():
             # one f16 product per MAC, fp32 accumulate = torch.autocast(float16), forced by mcdropout_models.py:86-92
             # (mcdropout_f32eq: the headline's workload in the fp32-equivalent split-f16 form, round 3's headline)
             other = "f16x2" if rec["precision"] == "f16" else "f16"
-            for name, m, kk, prec in ((f"mcdropout_{'f32eq' if other == 'f16x2' else 'f16'}", "mcdropout", K, other),
-                                      ("active", "active", 0, None), ("laplace", "laplace", 0, None)):
-                r = run_nerf(args, m, kk, 3, 2, rank, world, dev, dist, exact_check=False, want_cpu=False, precision=prec)
+            # mcdropout_tcnn: the headline's workload on the table layout and in the grid arithmetic the reference's DEFAULT
+            # implementation="tcnn" computes (half2 rows: 4 B per gathered corner, its own algorithmic_bytes_per_ray)
+            for name, m, kk, prec, gr in ((f"mcdropout_{'f32eq' if other == 'f16x2' else 'f16'}", "mcdropout", K, other, None),
+                                          ("mcdropout_tcnn", "mcdropout", K, "f16", "tcnn"),
+                                          ("active", "active", 0, None, None), ("laplace", "laplace", 0, None, None)):
+                r = run_nerf(args, m, kk, 3, 2, rank, world, dev, dist, exact_check=False, want_cpu=False, precision=prec, grid=gr)
                 subs[name] = {"value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 2,
                               "workload": r["workload"], "per_kernel_ms_per_frame": r["roofline"]["per_kernel_ms_per_frame"],
-                              "dtype": DTYPE_OF[r["precision"]], "dense_layers": r["dense_layers"],
+                              "dtype": DTYPE_OF[r["precision"]], "dense_layers": r["dense_layers"], "hash_grid": r["hash_grid"],
                               "roofline": {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
-                                                                             "avg_launch_ms", "traffic", "issue_roofline")}}
+                                                                             "avg_launch_ms", "traffic", "issue_roofline",
+                                                                             "algorithmic_bytes_per_ray")}}
             sp = bench_splat(args, rank, world, dev, dist, 5, 2)
             subs["splat"] = {"value": sp["value"], "unit": sp["unit"], "ms_per_step": sp["ms_per_step"], "steps": 5, "warmup": 2,
                              "workload": sp["config"]["workload"],
@@ -440,7 +462,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF[rec["precision"]],
                 "data": "synthetic",
                 "config": {"workload": rec["workload"], "rays_per_step": H * W, "samples_per_ray": [256, 96, 48],
-                           "hash_grid": "16x2^19x2 fp32", "dense_layers": rec["dense_layers"],
+                           "hash_grid": rec["hash_grid"], "dense_layers": rec["dense_layers"],
                            "parallelism": f"views x{world}" if world > 1 else "single"},
                 "roofline": rec["roofline"], "cpu_baseline": rec["cpu_baseline"],
                 "parity_at_bench_size": rec["parity_at_bench_size"], "wider_arithmetic": rec["wider_arithmetic"],

@@ -22,6 +22,10 @@ margs() {  # profile id -> bench.py arguments
         mcdropout_f16) echo "--method mcdropout --precision f16" ;;
         active) echo "--method active --precision f16x2" ;;
         active_f16) echo "--method active --precision f16" ;;
+        # the headline's workload on tcnn-layout tables: half2 rows + tcnn's half interpolation (the reference's default
+        # implementation), and fp32 rows (FETCH_SIZE before / after)
+        mcdropout_f16_tcnn) echo "--method mcdropout --precision f16 --grid tcnn --grid-precision f16" ;;
+        mcdropout_f16_tcnn32) echo "--method mcdropout --precision f16 --grid tcnn --grid-precision f32" ;;
         *) echo "--method $1" ;;
     esac
 }
@@ -45,7 +49,8 @@ pmc() {  # method, set name, counters...
     [ -n "$f" ] && python3 "$ROOT/benchmarks/summarize_pmc.py" reduce "$f" "$DST/${TAG}_${m}_pmc_$name.csv"
 }
 
-ALL="active active_f16 mcdropout mcdropout_f16 laplace splat"
+# ONLY="id id ..." restricts the collection (a supplementary run for profile ids added later)
+ALL=${ONLY:-"active active_f16 mcdropout mcdropout_f16 mcdropout_f16_tcnn mcdropout_f16_tcnn32 laplace splat"}
 for m in $ALL; do stats $m; done
 for m in $ALL; do
     pmc $m fetch FETCH_SIZE
@@ -54,9 +59,11 @@ done
 for m in $ALL; do
     pmc $m sq SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
 done
+if [ -z "${ONLY:-}" ]; then
 pmc splat lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAVES
 pmc active ta TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
 pmc active tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+fi
 python3 "$ROOT/benchmarks/summarize_pmc.py" summary "$DST" "$TAG"
 # the default line (what the driver runs), outside the profiler
 cd "$ROOT" && python3 bench.py > "$DST/${TAG}_default_bench.json" 2> "$OUT/default_bench.err"

@@ -38,11 +38,14 @@ def reduce(src, dst):
 
 # the dominant field kernel of a method = the first kernel name with one of these prefixes (template arguments after the
 # prefix -- tcnn / sites / drop flags -- vary with the round)
-FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, false, false, false, false", "field_kernel_mfma<0, false"),
-                 "active_f16": ("field_kernel_mfma16<0, false, false, false, true",),
-                 "mcdropout": ("field_kernel_mfma16<1, false, false, true, false", "field_kernel_mfma16<1, false", "field_kernel_mfma<1, false"),
-                 "mcdropout_f16": ("field_kernel_mfma16<1, false, false, true, true",),
-                 "laplace": ("field_kernel_mfma16_laplace<false, false", "field_kernel_mfma16_laplace<false"),
+FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, 0, false, false, false", "field_kernel_mfma16<0, false, false, false, false", "field_kernel_mfma<0, false"),
+                 "active_f16": ("field_kernel_mfma16<0, 0, false, false, true", "field_kernel_mfma16<0, false, false, false, true"),
+                 "mcdropout": ("field_kernel_mfma16<1, 0, false, true, false", "field_kernel_mfma16<1, false, false, true, false",
+                               "field_kernel_mfma16<1, false", "field_kernel_mfma<1, false"),
+                 "mcdropout_f16": ("field_kernel_mfma16<1, 0, false, true, true", "field_kernel_mfma16<1, false, false, true, true"),
+                 "mcdropout_f16_tcnn": ("field_kernel_mfma16<1, 2, false, true, true",),      # tcnn layout, half2 rows
+                 "mcdropout_f16_tcnn32": ("field_kernel_mfma16<1, 1, false, true, true",),    # tcnn layout, fp32 rows
+                 "laplace": ("field_kernel_mfma16_laplace<0, false", "field_kernel_mfma16_laplace<false, false", "field_kernel_mfma16_laplace<false"),
                  "splat": ("raster_kernel<5",)}
 # the kernels of one unerf_splat_bin_sort call (substrings of the short names)
 SORT_KERNELS = ("depth_keys_kernel", "sorted_counts_kernel", "map_intersects_kernel", "tile_hist_kernel", "tile_colsum_kernel",
@@ -50,7 +53,7 @@ SORT_KERNELS = ("depth_keys_kernel", "sorted_counts_kernel", "map_intersects_ker
                 "merge_sort", "radix_sort", "onesweep", "scan_config", "lookback_scan")
 # further kernels of a profile that get their own issue_<name>.json (same definition)
 EXTRA_ISSUE = {"laplace": {"lap_depth": ("lap_depth_kernel<3",)}, "splat": {"splat_raster1": ("raster_kernel<1",)}}
-K_OF = {"mcdropout": 8, "mcdropout_f16": 8}
+K_OF = {"mcdropout": 8, "mcdropout_f16": 8, "mcdropout_f16_tcnn": 8, "mcdropout_f16_tcnn32": 8}
 FRAME_RAYS = 1920 * 1080      # bench.py's frame
 PMC_FRAMES = 2                # collect_profiles.sh pmc(): --steps 1 --warmup 1
 
@@ -76,10 +79,10 @@ def _source_digest():
 
 def summary(d, tag):
     digest = _source_digest()
-    for method in ("active", "active_f16", "mcdropout", "mcdropout_f16", "laplace", "splat"):
+    for method in ("active", "active_f16", "mcdropout", "mcdropout_f16", "mcdropout_f16_tcnn", "mcdropout_f16_tcnn32", "laplace", "splat"):
         kernels = defaultdict(dict)
         for fn in sorted(os.listdir(d)):
-            m = re.match(rf"{tag}_{method}_pmc_(\w+)\.csv$", fn)
+            m = re.match(rf"{tag}_{method}_pmc_(fetch|write|sq|lds|ta|tcc)\.csv$", fn)
             if not m:
                 continue
             with open(os.path.join(d, fn), newline="") as f:

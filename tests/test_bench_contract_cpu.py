@@ -70,7 +70,11 @@ def test_committed_bench_line_has_every_contract_field():
         assert pb["d_ause_mse_uninformative_target"]["seeds"] == 8 and pb["d_ause_mse_uninformative_target"]["max"] < 5e-3
     assert len(d["step_wall_ms"]) == d["steps"] and abs(sum(d["step_wall_ms"]) / d["steps"] - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
     subs = d["sub_records"]
-    assert set(subs) == {"ensemble", "mcdropout_f32eq", "active", "laplace", "splat"}
+    assert set(subs) - {"mcdropout_tcnn"} == {"ensemble", "mcdropout_f32eq", "active", "laplace", "splat"}
+    if "mcdropout_tcnn" in subs:   # round 5: the headline's workload on tcnn-layout HALF tables (4 B per gathered corner)
+        tc = subs["mcdropout_tcnn"]
+        assert "half2" in tc["hash_grid"] and "K=8" in tc["workload"] and tc["dtype"].startswith("f16")
+        assert tc["roofline"]["algorithmic_bytes_per_ray"] == d["roofline"]["algorithmic_bytes_per_ray"] - 48 * 16 * 8 * 4
     for k, v in subs.items():
         assert v["value"] > 0 and v["ms_per_step"] > 0, k
         if k != "ensemble":
