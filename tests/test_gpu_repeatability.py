@@ -11,11 +11,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind,precisions", [("active", ("f16", "f16x2", "fp32")), ("mcdropout", ("f16", "f16x2", "fp32")),
-                                             ("laplace", ("f16x2", "fp32"))])
-def test_full_size_frames_repeat_bit_for_bit(dev, kind, precisions):
+@pytest.mark.parametrize("kind,precisions,grid", [("active", ("f16", "f16x2", "fp32"), "torch"), ("mcdropout", ("f16", "f16x2", "fp32"), "torch"),
+                                                  ("laplace", ("f16x2", "fp32"), "torch"),
+                                                  # round 5: the TCNN = 2 kernel instances (tcnn layout, half2 rows, half blend)
+                                                  ("active", ("f16", "f16x2"), "tcnn-half"), ("mcdropout", ("f16", "f16x2"), "tcnn-half"),
+                                                  ("laplace", ("f16x2",), "tcnn-half")])
+def test_full_size_frames_repeat_bit_for_bit(dev, kind, precisions, grid):
     from uncertainty_nerf_gs_amd import render, synthetic
-    t = synthetic.make_scene_tensors(seed=0, kind=kind)
+    t = synthetic.make_scene_tensors(seed=0, kind=kind, grid="tcnn" if grid == "tcnn-half" else "torch")
+    if grid == "tcnn-half":
+        t["grid_precision"] = "f16"
     kw = dict(K=8, seed=1234, p_drop=0.2) if kind == "mcdropout" else {}
     if kind == "laplace":
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)

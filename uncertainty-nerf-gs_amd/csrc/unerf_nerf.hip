@@ -1816,6 +1816,63 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
     return feat;
 }
 
+// The same lookup as a ROLLING stream (torch layout, packed blend): four batches of two levels (16 corner rows each); the
+// loads of batch b + 1 are issued BEFORE batch b is blended, and `filler` -- work that does not depend on the grid (the
+// direction encoding and its two MFMAs) -- runs behind the first two batches' loads.  mf_gather_feats asks for 32 rows,
+// blends them all, and only then asks for the next 32: between the two bursts the wave has nothing in flight, and at
+// the start of a tile it sits through a full memory round trip with the SH arithmetic already behind it.  Same 64
+// data registers (two 16-row buffers), same values: every level is blended exactly as before.
+// MEASURED AND NOT ADOPTED (profiles/r5_exp_gather_pipe_ab.txt): K-pass "f16" field 24.9 -> 25.5 ms per frame,
+// ACTIVE "f16" 9.82 -> 10.0, ACTIVE split 12.2 -> 12.9 (its 168-register budget spills 40 B) -- the K-pass kernel issues on
+// 0.93 of its cycles (nothing to hide latency under), and the ACTIVE kernels pay for the second address set with their third
+// wave's registers.  UNERF_GATHER_PIPE=1 builds it.
+#ifndef UNERF_GATHER_PIPE
+#define UNERF_GATHER_PIPE 0
+#endif
+template <typename Filler>
+__device__ __forceinline__ f32x16 mf_gather_feats_pipe(const FieldArgs& a, float px, float py, float pz, int h, uint32_t mask,
+                                                       Filler&& filler) {
+    f32x16 feat;
+    const char* tbase = reinterpret_cast<const char*>(a.p.table);
+    float2 cd[2][16];
+    float of[2][6];
+    auto issue = [&](int b, int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int lev = 8 * h + 2 * b + q;
+            uint32_t off[8];
+            unerf_hash_corners<true>(px, py, pz, a.p.scalings[lev], mask, off, of[buf][3 * q], of[buf][3 * q + 1], of[buf][3 * q + 2],
+                                     (uint32_t)lev << (a.p.log2T + 3));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cd[buf][8 * q + k] = *reinterpret_cast<const float2*>(tbase + off[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto blend = [&](int b, int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float2 c8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c8[k] = cd[buf][8 * q + k];
+            const float2 f = unerf_blend8<(UNERF_FIELD_BLEND_FMA != 0)>(c8, of[buf][3 * q], of[buf][3 * q + 1], of[buf][3 * q + 2]);
+            feat[2 * (2 * b + q)] = f.x;
+            feat[2 * (2 * b + q) + 1] = f.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    issue(0, 0);
+    issue(1, 1);
+    filler();
+    __builtin_amdgcn_sched_barrier(0);
+    blend(0, 0);
+    issue(2, 0);
+    blend(1, 1);
+    issue(3, 1);
+    blend(2, 0);
+    blend(3, 1);
+    return feat;
+}
+
 template <int MODE, bool FEAT_IN, int TCNN = 0>
 // ACTIVE is bound by the gather (texture-address unit): three waves per SIMD (<= 168 VGPRs) hide more of
 // its latency than two (measured 21.7 vs 23.7 ms/frame when a 176-VGPR build lost the third wave); the
@@ -2245,12 +2302,10 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
         float px = ts.px, py = ts.py, pz = ts.pz;
         const float sel = unerf_normalize_position(px, py, pz, a.box);
         // packed fp32x2 blend: this kernel has the registers for it (123 VGPRs without) in every mode
-        u32x8 feat_pk;
-        const f32x16 feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl, &feat_pk);
-
-        // colour layer 0, SH half (pass-invariant): components 8h..8h+7 of this lane half, one k-step
+        // colour layer 0, SH half (pass-invariant): components 8h..8h+7 of this lane half, one k-step -- as a closure, so
+        // that the torch-layout kernels can run it behind the first grid loads of the tile (mf_gather_feats_pipe)
         f32x16 csh0 = mf16_bias(lds, 3, h), csh1 = mf16_bias(lds, 4, h);
-        {
+        auto sh_layer = [&]() {
             float sh[16];
             float ux = (dxr + 1.f) / 2.f, uy = (dyr + 1.f) / 2.f, uz = (dzr + 1.f) / 2.f;
             if (a.p.sh_remap) {
@@ -2267,6 +2322,14 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             f16x8 bhi, blo;
             mf16_split8<F1>(mine, bhi, blo);
             mf16_mac2<F1>(lds, 10, 11, lane, bhi, blo, csh0, csh1);
+        };
+        u32x8 feat_pk;
+        f32x16 feat;
+        if constexpr (TCNN == 0 && UNERF_GATHER_PIPE != 0) {
+            feat = mf_gather_feats_pipe(a, px, py, pz, h, mask, sh_layer);
+        } else {
+            feat = mf_gather_feats<true, TCNN>(a, px, py, pz, h, mask, s_tl, &feat_pk);
+            sh_layer();
         }
 
         // layer 0: 32 -> 64 (this half's 16 features = two k-steps), ReLU; the 64 hidden units are the trunk
