@@ -65,6 +65,8 @@ pmc active ta TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum T
 pmc active tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
 fi
 python3 "$ROOT/benchmarks/summarize_pmc.py" summary "$DST" "$TAG"
-# the default line (what the driver runs), outside the profiler
+# the default line (what the driver runs), outside the profiler -- with THIS run's traffic_* / issue_* profiles in place, so that
+# its roofline block reads counters of the sources it times (bench.py ignores profiles of another source digest)
+cp "$DST"/traffic_*.json "$DST"/issue_*.json "$ROOT/profiles/" 2>/dev/null
 cd "$ROOT" && python3 bench.py > "$DST/${TAG}_default_bench.json" 2> "$OUT/default_bench.err"
 ls -la "$DST"

@@ -2343,10 +2343,18 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 mf16_feat_operand<TCNN, F1>(feat, feat_pk, st, bhi, blo);
                 mf16_mac2<F1, TCNN == 2>(lds, 2 * st, 2 * st + 1, lane, bhi, blo, hid0, hid1);
             }
-            hid0 = mf_relu(hid0);
-            hid1 = mf_relu(hid1);
+            if constexpr (F1) {   // ReLU on the packed halves (relu(cvt(x)) = cvt(relu(x)): mf16_split_relu), half the instructions
 #pragma unroll
-            for (int st = 0; st < 4; ++st) mf16_split<F1>(st < 2 ? hid0 : hid1, st & 1, hhi[st], hlo[st]);
+                for (int st = 0; st < 4; ++st) {
+                    mf16_split_relu(st < 2 ? hid0 : hid1, st & 1, hhi[st]);
+                    hlo[st] = hhi[st];
+                }
+            } else {
+                hid0 = mf_relu(hid0);
+                hid1 = mf_relu(hid1);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) mf16_split<F1>(st < 2 ? hid0 : hid1, st & 1, hhi[st], hlo[st]);
+            }
         }
 
         const int passes = (MODE == UNERF_FIELD_MCDROPOUT && a.p.K > 0) ? a.p.K : 1;
