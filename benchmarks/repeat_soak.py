@@ -9,8 +9,11 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 dev = torch.device("cuda:0")
 cam = dict(synthetic.CAMERA_1080P)
 rows = []
-for kind, precs in (("active", ("f16", "f16x2")), ("mcdropout", ("f16", "f16x2")), ("laplace", ("f16x2",))):
-    t = synthetic.make_scene_tensors(seed=0, kind=kind)
+for kind, precs, grid in (("active", ("f16", "f16x2"), "torch"), ("mcdropout", ("f16", "f16x2"), "torch"), ("laplace", ("f16x2",), "torch"),
+                          ("active", ("f16",), "tcnn-half"), ("mcdropout", ("f16", "f16x2"), "tcnn-half"), ("laplace", ("f16x2",), "tcnn-half")):
+    t = synthetic.make_scene_tensors(seed=0, kind=kind, grid="tcnn" if grid != "torch" else "torch")
+    if grid != "torch":
+        t["grid_precision"] = "f16"
     kw = dict(K=8, seed=1234, p_drop=0.2) if kind == "mcdropout" else {}
     if kind == "laplace":
         wsd, wsr = synthetic.laplace_weight_samples(t, seed=42, n_samples=100)
@@ -25,6 +28,6 @@ for kind, precs in (("active", ("f16", "f16x2")), ("mcdropout", ("f16", "f16x2")
                 ref = {k: v.clone() for k, v in out.items()}
                 continue
             bad += sum(int((ref[k] != out[k]).sum()) for k in ref)
-        rows.append({"method": kind, "precision": prec, "frames": N, "values_differing_from_first_frame": bad})
+        rows.append({"method": kind, "precision": prec, "grid": grid, "frames": N, "values_differing_from_first_frame": bad})
         print(json.dumps(rows[-1]))
     del sd

@@ -526,7 +526,7 @@ struct PropArgs {
     // a wave = the 64 pixels of the patch at ONE sample index.  Neighbouring pixels at equal depth sit in the
     // same one or two grid cells, so a gather instruction touches a handful of cache lines instead of the
     // ~20 of 64 consecutive samples along one ray (the proposal kernels saturate the texture-address unit).
-    uint32_t img_w, pcols, nsg;   // img_w = 0: linear schedule; nsg = ceil(n / 4) sample groups
+    uint32_t img_w, pcols, nsg, nblocks;   // img_w = 0: linear schedule; nsg = ceil(n / 4) sample groups; nblocks: workgroups of the patch schedule
     FastDiv div_nsg, div_pcols;
     int64_t g0, first_row;
     int vec4;   // prop_patch_kernel: n % 4 == 0 and density_out 16-byte aligned
@@ -625,12 +625,23 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
 // workgroup and storing one 16-byte vector per ray removes about half of the cache-line accesses of the 96-sample
 // pass (own sbins row per ray) and a quarter of the 256-sample pass (shared sbins).  Same arithmetic on
 // the same values: bit-identical to prop_density_kernel.
+#ifndef UNERF_PROP_XCD
+#define UNERF_PROP_XCD 0
+#endif
 template <int L, int HID>
 __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
     __shared__ float s_od[6][64];
     __shared__ float s_e[5][64];
     __shared__ float s_out[64][4];
-    const uint32_t patch = fastdiv(blockIdx.x, a.div_nsg), sg = blockIdx.x - patch * a.nsg;
+    // UNERF_PROP_XCD (experiment): every XCD takes a contiguous eighth of the (patch, sample group) list -- a band of the
+    // image -- instead of every eighth workgroup
+#if UNERF_PROP_XCD
+    const uint32_t per = (gridDim.x + 7u) >> 3, bid = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (bid >= a.nblocks) return;
+#else
+    const uint32_t bid = blockIdx.x;
+#endif
+    const uint32_t patch = fastdiv(bid, a.div_nsg), sg = bid - patch * a.nsg;
     const uint32_t band = fastdiv(patch, a.div_pcols), pc = patch - band * a.pcols;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t x = pc * 8u + (lane & 7u);
@@ -756,7 +767,7 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
     a.net = *net; a.avg = average_init_density; a.out = density_out;
     a.box = make_norm_box(net->use_aabb, net->aabb);
     a.fd = make_fastdiv((uint32_t)n); a.small = (R * (int64_t)n < (1ll << 31)) ? 1 : 0;
-    a.img_w = 0; a.pcols = 0; a.nsg = 0; a.div_nsg = a.div_pcols = make_fastdiv(1); a.g0 = 0; a.first_row = 0;
+    a.img_w = 0; a.pcols = 0; a.nsg = 0; a.nblocks = 0; a.div_nsg = a.div_pcols = make_fastdiv(1); a.g0 = 0; a.first_row = 0;
     a.vec4 = (n % 4 == 0 && ((uintptr_t)density_out & 15u) == 0) ? 1 : 0;
     dim3 grid(blocks_for(R * (int64_t)n, 256)), block(256);
     if (image_width >= 8 && R >= 8 * (int64_t)image_width && ray_offset >= 0) {  // at least one full 8-row band
@@ -767,7 +778,8 @@ extern "C" int unerf_proposal_density(const float* origins, const float* directi
             a.img_w = (uint32_t)image_width; a.pcols = (uint32_t)pcols; a.nsg = (uint32_t)nsg;
             a.div_nsg = make_fastdiv((uint32_t)nsg); a.div_pcols = make_fastdiv((uint32_t)pcols);
             a.g0 = ray_offset; a.first_row = band0 * 8;
-            grid = dim3((unsigned)blocks);
+            a.nblocks = (uint32_t)blocks;
+            grid = dim3((unsigned)(UNERF_PROP_XCD ? ((blocks + 7) / 8) * 8 : blocks));
         }
     }
     hipStream_t st = (hipStream_t)stream;

@@ -790,19 +790,35 @@ __global__ __launch_bounds__(256) void tile_apply_kernel(uint32_t* __restrict__ 
 // memory latency (four waves per CU: the 32-KB tables), so it works on four vectors per round and asks for the next
 // round's pairs before it ranks this round's.
 #define TS_VEC 4
+#ifndef UNERF_SPLAT_XCD
+#define UNERF_SPLAT_XCD 1
+#endif
 template <typename TKey>
 __global__ __launch_bounds__(64) void tile_scatter_kernel(const TKey* __restrict__ keys, const int32_t* __restrict__ vals,
                                                           int64_t I, int chunk, int T1, const uint32_t* __restrict__ table,
                                                           int32_t* __restrict__ out) {
     extern __shared__ uint32_t s_off[];
     const int lane = threadIdx.x;
+    // XCD-aware chunk order (UNERF_SPLAT_XCD): workgroups go to the 8 XCDs round-robin, and chunk c writes, for every tile,
+    // the slots right behind chunk c - 1's.  With chunk = blockIdx the eight chunks that fill one 64-byte line of a tile's
+    // list run on eight different XCDs, each of which holds the line partially written in its own L2 (WRITE_SIZE 7.6 x the
+    // payload, rocprofv3 r4_09).  Giving every XCD a CONTIGUOUS eighth of the chunks makes it the only writer of (almost)
+    // every line it touches, and its ~128 co-resident waves are exactly consecutive chunks: the line fills while it is
+    // still in that L2.  Same slots, same lists.
+#if UNERF_SPLAT_XCD
+    const int cpx = (int)(gridDim.x >> 3);      // the launcher rounds the grid up to 8 x ceil(nblk / 8) workgroups
+    const int cid = (int)(blockIdx.x & 7u) * cpx + (int)(blockIdx.x >> 3);
+    if ((int64_t)cid * chunk >= I) return;      // (the whole single-wave workgroup: a slot past the last chunk)
+#else
+    const int cid = (int)blockIdx.x;
+#endif
     {
-        const uint32_t* row = table + (size_t)blockIdx.x * T1;
+        const uint32_t* row = table + (size_t)cid * T1;
 #pragma unroll 8
         for (int t = lane; t < T1; t += 64) s_off[t] = row[t];
     }
     __syncthreads();
-    const int64_t k0 = (int64_t)blockIdx.x * chunk, k1 = (k0 + chunk < I) ? k0 + chunk : I;
+    const int64_t k0 = (int64_t)cid * chunk, k1 = (k0 + chunk < I) ? k0 + chunk : I;
     uint32_t key[TS_VEC], nkey[TS_VEC];
     int32_t id[TS_VEC], nid[TS_VEC];
     auto fetch = [&](int64_t k, uint32_t (&kk)[TS_VEC], int32_t (&ii)[TS_VEC]) {
@@ -883,8 +899,8 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, total, tp.T1, tiles, start, tile_bins);
         hipLaunchKernelGGL(tile_apply_kernel, dim3(blocks_for(tp.T1, 256), TS_SEG), dim3(256), 0, st, table, rps, tp.T1, segsum,
                            start);
-        hipLaunchKernelGGL((tile_scatter_kernel<TKey>), dim3(tp.nblk), dim3(64), lds, st, tk_in, v_in, I, tp.chunk, tp.T1, table,
-                           gaussian_ids_sorted);
+        hipLaunchKernelGGL((tile_scatter_kernel<TKey>), dim3(UNERF_SPLAT_XCD ? ((tp.nblk + 7) / 8) * 8 : tp.nblk), dim3(64), lds, st,
+                           tk_in, v_in, I, tp.chunk, tp.T1, table, gaussian_ids_sorted);
         if (isect_ids_sorted)
             hipLaunchKernelGGL(tile_isect_ids_kernel, dim3(blocks_for(I, 256)), dim3(256), 0, st, start, tp.T1,
                                gaussian_ids_sorted, depths, I, isect_ids_sorted);
@@ -1024,13 +1040,25 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
     __shared__ uint16_t s_list[4][256];
     const int bw = a.bw;
     const int tbx = (a.W + bw - 1) / bw;
-    const int tile = blockIdx.y * tbx + blockIdx.x;
+    // XCD-aware tile order (UNERF_SPLAT_XCD): every XCD rasterises a contiguous eighth of the row-major tile list -- a band of
+    // the image -- so the splats its tiles gather (neighbouring tiles share most of theirs) are looked up in ONE L2 instead
+    // of all eight.  Pure scheduling: a tile is computed exactly as before.
+#if UNERF_SPLAT_XCD
+    const int ntile = tbx * (int)gridDim.y;
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x), tpx = (ntile + 7) >> 3;
+    const int tile = (lin & 7) * tpx + (lin >> 3);
+    if ((lin >> 3) >= tpx || tile >= ntile) return;      // the launcher pads the grid to at least 8 x ceil(ntile / 8) workgroups
+    const int bx = tile % tbx, by = tile / tbx;
+#else
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int tile = by * tbx + bx;
+#endif
     const int tr = threadIdx.x;
     // 16-wide tiles: a wave owns one 8 x 8 quadrant (wave w: quadrant column w & 1, row w >> 1; lane l: pixel (l & 7,
     // l >> 3) of it); narrower tiles keep the row-major mapping (no culling there)
     const int ly = bw == 16 ? 8 * (tr >> 7) + ((tr & 63) >> 3) : tr / bw;
     const int lx = bw == 16 ? 8 * ((tr >> 6) & 1) + (tr & 7) : tr - (tr / bw) * bw;
-    const int i = blockIdx.y * bw + ly, j = blockIdx.x * bw + lx;
+    const int i = by * bw + ly, j = bx * bw + lx;
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const bool inside = (ly < bw) && (i < a.H) && (j < a.W);
     const int64_t p = (int64_t)i * a.W + j;
@@ -1040,7 +1068,7 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
     const int stop = (BOUNDED && inside) ? a.stop_idx[p] : 0;
     const bool cull = a.cull && bw == 16;                       // uniform: the quadrant geometry is the 16-wide tile's
     const int wv = __builtin_amdgcn_readfirstlane(tr >> 6), lane = tr & 63;
-    const float tile_x0 = (float)(blockIdx.x * bw), tile_y0 = (float)(blockIdx.y * bw);
+    const float tile_x0 = (float)(bx * bw), tile_y0 = (float)(by * bw);
     float T = 1.f;
     int cur_idx = 0;
     float pix[C];
@@ -1153,6 +1181,12 @@ extern "C" int unerf_splat_rasterize(const int32_t* gaussian_ids_sorted, const i
     a.final_idx = final_idx; a.stop_idx = stop_idx; a.cull = (flags & UNERF_RASTER_NO_CULL) ? 0 : 1;
     a.chan_max = reinterpret_cast<unsigned int*>(chan_max); a.max_ch = chan_max ? max_channel : -1;
     dim3 grid((W + block_width - 1) / block_width, (H + block_width - 1) / block_width), block(256);
+#if UNERF_SPLAT_XCD
+    {   // linear ids 0 .. 8 ceil(ntile / 8) - 1 must exist: one more grid column covers the padding (tby >= 1 workgroups more)
+        const unsigned ntile = grid.x * grid.y, need = ((ntile + 7u) / 8u) * 8u;
+        if (grid.x * grid.y < need) grid.x += 1;
+    }
+#endif
     hipStream_t st = (hipStream_t)stream;
 #define UNERF_RASTER_CASE(N)                                                                       \
     case N:                                                                                        \
