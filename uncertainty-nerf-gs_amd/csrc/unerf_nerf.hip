@@ -626,15 +626,16 @@ __global__ __launch_bounds__(256) void prop_density_kernel(PropArgs a) {
 // pass (own sbins row per ray) and a quarter of the 256-sample pass (shared sbins).  Same arithmetic on
 // the same values: bit-identical to prop_density_kernel.
 #ifndef UNERF_PROP_XCD
-#define UNERF_PROP_XCD 0
+#define UNERF_PROP_XCD 1
 #endif
 template <int L, int HID>
 __global__ __launch_bounds__(256) void prop_patch_kernel(PropArgs a) {
     __shared__ float s_od[6][64];
     __shared__ float s_e[5][64];
     __shared__ float s_out[64][4];
-    // UNERF_PROP_XCD (experiment): every XCD takes a contiguous eighth of the (patch, sample group) list -- a band of the
-    // image -- instead of every eighth workgroup
+    // XCD-aware order (UNERF_PROP_XCD): workgroups go to the 8 XCDs round-robin; every XCD takes a CONTIGUOUS
+    // eighth of the (patch, sample group) list -- a band of the image -- instead of every eighth workgroup, so the grid lines
+    // neighbouring patches share are fetched into one L2 instead of all eight.  Pure scheduling: same values per sample.
 #if UNERF_PROP_XCD
     const uint32_t per = (gridDim.x + 7u) >> 3, bid = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     if (bid >= a.nblocks) return;

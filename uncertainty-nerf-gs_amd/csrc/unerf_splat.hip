@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void tile_apply_kernel(uint32_t* __restrict__ 
 // round's pairs before it ranks this round's.
 #define TS_VEC 4
 #ifndef UNERF_SPLAT_XCD
-#define UNERF_SPLAT_XCD 1
+#define UNERF_SPLAT_XCD 0
 #endif
 template <typename TKey>
 __global__ __launch_bounds__(64) void tile_scatter_kernel(const TKey* __restrict__ keys, const int32_t* __restrict__ vals,
