@@ -282,10 +282,12 @@ def test_full_size_splat_frame_properties(dev):
 @pytest.mark.parametrize("N,H,W,tight", [(6000, 48, 64, False), (6000, 48, 64, True), (300000, 600, 800, True),
                                          (1_000_000, 1080, 1920, True), (1_000_000, 1080, 1920, False), (50, 1080, 1920, True)])
 def test_one_pass_tile_sort_gives_the_radix_sorts_lists(dev, N, H, W, tight, monkeypatch):
-    """unerf_splat_bin_sort's own tile sort (one LDS-digit scatter pass: 8,160 tile counters fit a wave's LDS) against
-    rocprim's two-pass radix sort of the same (tile, splat) pairs (UNERF_SPLAT_TILE_SORT=radix keeps that path for A/B
-    runs): gaussian_ids_sorted, tile_bins and the 64-bit isect ids are bit-identical -- at toy sizes, with box and tight
-    lists, at the BASELINE size (37 M / 20 M pairs, every one of the 1024 chunks busy) and with a handful of pairs."""
+    """unerf_splat_bin_sort's own tile sorts -- the default two-pass LSD sort (two digits of <= 7 bits, <= 128 write fronts
+    per wave; one pass when the image has <= 127 tiles: the 48 x 64 cases) and the one-pass LDS-digit sort it replaced
+    (UNERF_SPLAT_TILE_SORT=onepass: 8,160 tile counters in a wave's LDS) -- against rocprim's radix sort of the same
+    (tile, splat) pairs (UNERF_SPLAT_TILE_SORT=radix): gaussian_ids_sorted, tile_bins and the 64-bit isect ids are
+    bit-identical -- at toy sizes, with box and tight lists, at the BASELINE size (37 M / 20 M pairs) and with a handful of
+    pairs."""
     from uncertainty_nerf_gs_amd import ops, splat, synthetic
     gp = {k: v.to(dev) for k, v in synthetic.make_splat_tensors(seed=11, N=N).items()}
     if N <= 6000:
@@ -298,14 +300,46 @@ def test_one_pass_tile_sort_gives_the_radix_sorts_lists(dev, N, H, W, tight, mon
                            raw=True, opacity_logits=logits if tight else None)
     xys, depths, radii, conics, comp, tiles = pr[:6]
     tl = (conics, pr[7]) if tight else None
-    monkeypatch.delenv("UNERF_SPLAT_TILE_SORT", raising=False)
-    I, _, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, tight=tl)
     monkeypatch.setenv("UNERF_SPLAT_TILE_SORT", "radix")
     I2, _, keys2, gids2, bins2 = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, tight=tl)
-    assert I == I2 and I > 0
-    assert torch.equal(bins, bins2), "tile ranges"
-    assert torch.equal(gids, gids2), "depth-ordered splat ids of every tile"
-    assert torch.equal(keys, keys2), "(tile << 32 | depth bits) ids"
+    for which in (None, "onepass"):
+        if which is None:
+            monkeypatch.delenv("UNERF_SPLAT_TILE_SORT", raising=False)
+        else:
+            monkeypatch.setenv("UNERF_SPLAT_TILE_SORT", which)
+        I, _, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, tight=tl)
+        assert I == I2 and I > 0
+        assert torch.equal(bins, bins2), f"{which}: tile ranges"
+        assert torch.equal(gids, gids2), f"{which}: depth-ordered splat ids of every tile"
+        assert torch.equal(keys, keys2), f"{which}: (tile << 32 | depth bits) ids"
+
+
+@pytest.mark.parametrize("N,H,W", [(5000, 96, 128), (1_000_000, 1080, 1920), (1025, 64, 64), (3, 64, 64)])
+def test_depth_sort_is_rocprims(dev, N, H, W, monkeypatch):
+    """unerf_splat_bin_sort's own depth sort (four 8-bit LSD passes, one wave per 1,024 splats) against rocprim's stable
+    sort of the same (depth bits, index) pairs (UNERF_SPLAT_DEPTH_SORT=rocprim): the lists, the ranges and the 64-bit ids
+    are bit-identical -- with EQUAL depths in the set (a block of splats duplicated at the same position: stability decides
+    their order inside a tile) and culled splats (key 0xFFFFFFFF) in between."""
+    from uncertainty_nerf_gs_amd import ops, splat, synthetic
+    gp = {k: v.to(dev) for k, v in synthetic.make_splat_tensors(seed=5, N=N).items()}
+    if N >= 2000:
+        for k in ("means", "scales", "quats"):
+            gp[k][1000:2000] = gp[k][:1000]              # same centres, same shapes: equal depths, same tiles
+    if N <= 5000:
+        gp["scales"] = gp["scales"] + 1.0
+    c2w = synthetic.orbit_c2w(0.3, radius=2.5, height=0.4)
+    V = splat.viewmat_from_c2w(c2w)
+    f = 1111.0 * W / 1920
+    pr = ops.splat_project(gp["means"], gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], f, f, W / 2, H / 2, H, W, raw=True)
+    xys, depths, radii, conics, comp, tiles = pr[:6]
+    if N >= 2000:
+        assert torch.equal(depths[1000:2000], depths[:1000])
+    monkeypatch.setenv("UNERF_SPLAT_DEPTH_SORT", "rocprim")
+    I2, _, keys2, gids2, bins2 = ops.splat_bin_sort(xys, depths, radii, tiles, H, W)
+    monkeypatch.delenv("UNERF_SPLAT_DEPTH_SORT")
+    I, _, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W)
+    assert I == I2
+    assert torch.equal(bins, bins2) and torch.equal(gids, gids2) and torch.equal(keys, keys2)
 
 
 @pytest.mark.parametrize("C", [1, 5])

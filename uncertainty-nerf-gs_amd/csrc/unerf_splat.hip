@@ -4,6 +4,7 @@
 // Built with -ffp-contract=off: projection / tile boxes / sort keys are bit-exact against the
 // numpy oracle (oracle/splat_oracle.py) which performs the same fp32 operations in the same order.
 #include "unerf_common.hpp"
+#include <type_traits>
 
 #include <hipcub/hipcub.hpp>
 
@@ -467,6 +468,28 @@ static TileSortPlan tile_sort_plan(int64_t I, int tiles) {
     return p;
 }
 
+// ---- staged LSD radix passes (rs_* kernels below): the plan ---------------------------------------------------------------
+// One pass = per-chunk digit histogram -> prefix over chunks (per digit) -> scatter; a chunk is the M pairs ONE wave ranks,
+// stages in LDS in digit order and writes out as runs of consecutive slots (see rs_scatter_kernel for why).
+#define RS_M_TILE 2048      // pairs per wave, tile sort (u16 / u32 keys, <= 128 digits: runs of >= 16 slots per digit)
+#define RS_M_DEPTH 1024     // pairs per wave, depth sort (u32 keys, 256 digits: runs of 4)
+#define RS_CPW 4            // chunks per wave in the histogram kernel (a workgroup = 4 waves = 16 chunks)
+struct RsTilePlan {
+    int nchunk, b0, B0, B1, nhw;      // digit 0 = key & (B0 - 1), digit 1 = key >> b0 (< B1; B0, B1 powers of two <= 128)
+};
+static RsTilePlan rs_tile_plan(int64_t I, int T1) {
+    RsTilePlan p;
+    int bits = 1;
+    while ((1 << bits) < T1) ++bits;         // keys 0 .. T1 - 1 (the sentinel tile is T1 - 1)
+    p.b0 = bits <= 7 ? 0 : bits / 2;         // <= 128 keys: one pass on the whole key
+    p.B0 = 1 << p.b0;
+    p.B1 = 1 << (bits - p.b0);
+    p.nchunk = (int)((I + RS_M_TILE - 1) / RS_M_TILE);
+    if (p.nchunk < 1) p.nchunk = 1;
+    p.nhw = (p.nchunk + 4 * RS_CPW - 1) / (4 * RS_CPW);
+    return p;
+}
+
 static int tile_bits(int H, int W, int bw) {   // bits of the largest key: tiles - 1, and `tiles` itself (the sentinel)
     int64_t tiles = (int64_t)((W + bw - 1) / bw) * ((H + bw - 1) / bw);
     int b = 1;
@@ -488,7 +511,7 @@ static hipError_t depth_sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_t*
 }
 
 struct SortWs {
-    int64_t tmp, dkey_in, dkey_out, id_in, order, counts, cum, tkey_in, tkey_out, val_in, ts_table, ts_segsum, ts_start, total;
+    int64_t tmp, dkey_in, dkey_out, id_in, order, counts, cum, tkey_in, tkey_out, val_in, val_mid, ts_table, ts_segsum, ts_start, ds_table, ds_total, total;
 };
 static SortWs sort_ws_layout(int64_t N, int64_t I) {
     size_t scan_tmp = 0, sortN_tmp = 0, sortI_tmp = 0;
@@ -506,12 +529,16 @@ static SortWs sort_ws_layout(int64_t N, int64_t I) {
     w.tmp = take((int64_t)tmp);
     w.dkey_in = take(N * 4); w.dkey_out = take(N * 4); w.id_in = take(N * 4); w.order = take(N * 4);
     w.counts = take(N * 4); w.cum = take(N * 4);
-    w.tkey_in = take(I * 4); w.tkey_out = take(I * 4); w.val_in = take(I * 4);
+    w.tkey_in = take(I * 4); w.tkey_out = take(I * 4); w.val_in = take(I * 4); w.val_mid = take(I * 4);
     // the one-pass tile sort's tables, sized for the largest tile count it serves (the image size is not known here)
     const TileSortPlan tp = tile_sort_plan(I, TS_MAX_T1 - 1);
-    w.ts_table = take((int64_t)tp.rows * TS_MAX_T1 * 4);
+    const RsTilePlan lp = rs_tile_plan(I, TS_MAX_T1);     // the two-pass sort's tables: 2 x [128][nchunk] + [nhw][T1]
+    const int64_t onepass_bytes = (int64_t)tp.rows * TS_MAX_T1 * 4, lsd_bytes = ((int64_t)256 * lp.nchunk + (int64_t)lp.nhw * TS_MAX_T1) * 4;
+    w.ts_table = take(onepass_bytes > lsd_bytes ? onepass_bytes : lsd_bytes);
     w.ts_segsum = take((int64_t)TS_SEG * TS_MAX_T1 * 4);
     w.ts_start = take((int64_t)(2 * TS_MAX_T1 + 2) * 4);     // start [T1 + 1] + total [T1]
+    w.ds_table = take((int64_t)256 * ((N + RS_M_DEPTH - 1) / RS_M_DEPTH) * 4);     // the depth sort's [256][chunks] counters
+    w.ds_total = take(256 * 4);
     w.total = off + 1024;
     return w;
 }
@@ -856,6 +883,232 @@ __global__ __launch_bounds__(64) void tile_scatter_kernel(const TKey* __restrict
     }
 }
 
+// ---- staged LSD radix passes ---------------------------------------------------------------------------------------------
+// MI355X retires about 81 G isolated 4-byte stores per second, whatever the occupancy and wherever they land (246 us for
+// the 20 M ids of the bench frame, benchmarks/exp_scatter_store.hip; 132 / 77 / 53 / 38 us when 2 / 4 / 8 / 16 consecutive
+// lanes write consecutive dwords) -- which is where the one-pass tile sort's scatter sits (279 us: every lane of every
+// store on a cache line of its own, because a chunk of the depth-ordered stream holds ~1 pair per tile).  A stable sort by a
+// SMALL digit does not have that problem: with <= 128 digit values a wave's 2,048 pairs hold >= 16 per value, so the wave
+// ranks them, stages ids and keys in LDS in digit order and writes each digit's pairs as ONE run of consecutive slots.  Two
+// such passes (low digit, then high digit: LSD) sort by the 13-bit tile; four of them with 8-bit digits sort the 32-bit
+// depth keys.  Ranking: the lanes of a 64-pair vector that share a digit find each other with one ballot per digit bit (a
+// lane keeps the lanes that agree with it on every bit); the lowest takes the slots for all with one LDS atomic, the others
+// add their position among the peers -- stream order, i.e. stable.  Same lists as the one-pass sort, rocprim's radix sort
+// (tile) and rocprim's stable sort (depth), bit for bit (tests/test_gpu_splat.py).
+template <typename TKey, bool FULL>
+__global__ __launch_bounds__(256) void rs_hist_kernel(const TKey* __restrict__ keys, int64_t n, int chunk, int nchunk, uint32_t kmax,
+                                                      int shift, int B, int cpw, uint32_t* __restrict__ table, uint32_t* __restrict__ full) {
+    extern __shared__ uint32_t s_rs[];       // [4][256] digit counters, then FULL: [kmax + 1] whole-key counters of the workgroup
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t* dig = s_rs + wv * 256;
+    uint32_t* fh = s_rs + 1024;
+    if (FULL) {
+        for (uint32_t t = threadIdx.x; t <= kmax; t += 256) fh[t] = 0u;
+        __syncthreads();
+    }
+    const uint32_t dmask = (uint32_t)B - 1u;
+    constexpr int PER = 16 / (int)sizeof(TKey);
+    for (int cc = 0; cc < cpw; ++cc) {
+        const int c = ((int)blockIdx.x * 4 + wv) * cpw + cc;
+        if (c >= nchunk) break;                   // (uniform per wave)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dig[lane + 64 * i] = 0u;
+        const int64_t k0 = (int64_t)c * chunk, k1 = (k0 + chunk < n) ? k0 + chunk : n;
+        const int64_t nvec = (k1 - k0) / PER;
+        const uint4* kv = reinterpret_cast<const uint4*>(keys + k0);      // chunks are multiples of 256 keys: aligned
+        auto count = [&](uint32_t key) {
+            const uint32_t kq = key < kmax ? key : kmax;
+            atomicAdd(&dig[(kq >> shift) & dmask], 1u);
+            if (FULL) atomicAdd(&fh[kq], 1u);
+        };
+        for (int64_t v = lane; v < nvec; v += 64) {
+            const uint4 q = kv[v];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (sizeof(TKey) == 2) {
+                    count(w[i] & 0xFFFFu);
+                    count(w[i] >> 16);
+                } else {
+                    count(w[i]);
+                }
+            }
+        }
+        for (int64_t k = k0 + nvec * PER + lane; k < k1; k += 64) count((uint32_t)keys[k]);
+        // (one wave: the LDS executes its operations in program order, the reads below see every atomic above)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < B) table[(size_t)(lane + 64 * i) * nchunk + c] = dig[lane + 64 * i];
+    }
+    if (FULL) {
+        __syncthreads();
+        uint32_t* row = full + (size_t)blockIdx.x * (kmax + 1);
+        for (uint32_t t = threadIdx.x; t <= kmax; t += 256) row[t] = fh[t];
+    }
+}
+
+// column sums of the whole-key histogram rows, by row segment: seg[s][t] = sum of rows [s rps, (s + 1) rps) of column t
+__global__ __launch_bounds__(256) void rs_colsum_kernel(const uint32_t* __restrict__ full, int rows, int rps, int T1,
+                                                        uint32_t* __restrict__ seg) {
+    const int t = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
+    if (t >= T1) return;
+    const int r0 = sg * rps, r1 = (r0 + rps < rows) ? r0 + rps : rows;
+    uint32_t sum = 0u;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) sum += full[(size_t)r * T1 + t];
+    seg[(size_t)sg * T1 + t] = sum;
+}
+__global__ __launch_bounds__(256) void rs_segadd_kernel(const uint32_t* __restrict__ seg, int nseg, int T1, uint32_t* __restrict__ total) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T1) return;
+    uint32_t sum = 0u;
+    for (int s = 0; s < nseg; ++s) sum += seg[(size_t)s * T1 + t];
+    total[t] = sum;
+}
+
+// one workgroup per digit: exclusive prefix of its row over the chunks (in place) and the digit's total
+__global__ __launch_bounds__(1024) void rs_rowscan_kernel(uint32_t* __restrict__ table, int nchunk, uint32_t* __restrict__ dtotal) {
+    __shared__ uint32_t s_w[16];
+    uint32_t* row = table + (size_t)blockIdx.x * nchunk;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t carry = 0u;
+    for (int base = 0; base < nchunk; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const uint32_t x = i < nchunk ? row[i] : 0u;
+        uint32_t incl = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0u, all = 0u;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t t = s_w[w];
+            before += w < wv ? t : 0u;
+            all += t;
+        }
+        if (i < nchunk) row[i] = carry + before + incl - x;
+        carry += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dtotal[blockIdx.x] = carry;
+}
+
+// one wave per chunk of M pairs: rank, stage in LDS in digit order, write out digit run by digit run
+template <typename TKey, int M, bool KEYS_OUT>
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const TKey* __restrict__ keys, const int32_t* __restrict__ vals, int64_t n,
+                                                         int nchunk, uint32_t kmax, int shift, int B,
+                                                         const uint32_t* __restrict__ table, const uint32_t* __restrict__ dtotal,
+                                                         TKey* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+    // per wave: cur[256] | delta[256] | staged vals [M] | staged keys [M]
+    constexpr int WAVE_WORDS = 512 + M + (M * (int)sizeof(TKey) + 3) / 4;
+    extern __shared__ uint32_t s_rs[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = (int)blockIdx.x * 4 + wv;
+    if (c >= nchunk) return;
+    uint32_t* cur = s_rs + (size_t)wv * WAVE_WORDS;
+    uint32_t* delta = cur + 256;
+    int32_t* sval = reinterpret_cast<int32_t*>(delta + 256);
+    TKey* skey = reinterpret_cast<TKey*>(sval + M);
+    const uint32_t dmask = (uint32_t)B - 1u;
+    {   // lane l owns digits 4 l .. 4 l + 3.  For digit d: this chunk's pairs start at slot ls[d] of the staged order (prefix of
+        // the chunk's counts over the digits) and at gs[d] = (all pairs with a smaller digit) + (pairs with digit d in earlier
+        // chunks) of the output; the chunk's count is the difference of two neighbours of the prefix row
+        uint32_t tot[4], pre[4], cnt[4], tsum = 0u, csum = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = 4 * lane + i;
+            tot[i] = pre[i] = cnt[i] = 0u;
+            if (d < B) {
+                tot[i] = dtotal[d];
+                pre[i] = table[(size_t)d * nchunk + c];
+                cnt[i] = (c + 1 < nchunk ? table[(size_t)d * nchunk + c + 1] : tot[i]) - pre[i];
+            }
+            tsum += tot[i];
+            csum += cnt[i];
+        }
+        uint32_t ti = tsum, ci = csum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v0 = __shfl_up(ti, d, 64), v1 = __shfl_up(ci, d, 64);
+            if (lane >= d) { ti += v0; ci += v1; }
+        }
+        uint32_t gb = ti - tsum, lb = ci - csum;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cur[4 * lane + i] = lb;
+            delta[4 * lane + i] = gb + pre[i] - lb;
+            gb += tot[i];
+            lb += cnt[i];
+        }
+    }
+    const int64_t k0 = (int64_t)c * M;
+    const int m = (int)((n - k0 < M) ? n - k0 : M);       // pairs of this chunk
+    // every pair of the chunk is requested before the first is ranked (2 registers per vector: the ranking below is a chain
+    // of LDS round trips, a global load inside it would cost its whole latency once per vector)
+    constexpr int NV = M / 64;
+    uint32_t key[NV];
+    int32_t val[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int e = 64 * v + lane;
+        const int64_t ec = k0 + (e < m ? e : m - 1);       // clamped, not predicated
+        key[v] = (uint32_t)keys[ec];
+        val[v] = vals[ec];
+    }
+    // four vectors at a time, stage by stage: the ballots are independent VALU work, the four atomics go out back to back
+    // in vector order (the LDS executes a wave's operations in program order) and are collected by one wait, so are the
+    // four broadcasts
+#pragma unroll
+    for (int g = 0; g < NV; g += 4) {
+        uint32_t kq[4], d[4], rank[4], cntp[4], base[4];
+        int leader[4];
+        bool valid[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            valid[i] = 64 * (g + i) + lane < m;
+            kq[i] = key[g + i] < kmax ? key[g + i] : kmax;
+            d[i] = (kq[i] >> shift) & dmask;
+            uint64_t peers = __builtin_amdgcn_ballot_w64(valid[i]);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int32_t ext = (int32_t)(d[i] << (31 - b)) >> 31;      // 0 or -1
+                const uint64_t mk = __builtin_amdgcn_ballot_w64(ext != 0);
+                peers &= ~(mk ^ (uint64_t)(int64_t)ext);
+            }
+            rank[i] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            cntp[i] = (uint32_t)__builtin_popcountll(peers);
+            leader[i] = valid[i] ? __builtin_ctzll(peers) : lane;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)               // (every lane asks, all but the first of the peers for 0 slots: no branch)
+            base[i] = atomicAdd(&cur[d[i]], (valid[i] && rank[i] == 0u) ? cntp[i] : 0u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) base[i] = __shfl(base[i], leader[i], 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (valid[i]) {
+                sval[base[i] + rank[i]] = val[g + i];
+                skey[base[i] + rank[i]] = (TKey)kq[i];
+            }
+        }
+    }
+    // (one wave: the LDS executes its operations in program order)
+#pragma unroll 4
+    for (int j = 0; j < M / 64; ++j) {
+        const int slot = 64 * j + lane;
+        if (slot < m) {
+            const uint32_t kq = (uint32_t)skey[slot];
+            const uint32_t dst = delta[(kq >> shift) & dmask] + (uint32_t)slot;
+            if (KEYS_OUT) keys_out[dst] = (TKey)kq;
+            vals_out[dst] = sval[slot];
+        }
+    }
+}
+
 // the gsplat-style 64-bit ids of the sorted lists (on request only): the tile of entry i is found in the tile offsets
 __global__ __launch_bounds__(256) void tile_isect_ids_kernel(const uint32_t* __restrict__ start, int T1,
                                                              const int32_t* __restrict__ gids,
@@ -874,7 +1127,7 @@ __global__ __launch_bounds__(256) void tile_isect_ids_kernel(const uint32_t* __r
 template <typename TKey>
 static int bin_sort_impl(const float* xys, const float* depths, const int32_t* radii, const int32_t* order,
                          const int32_t* cum_sorted, const float* conics, const float* opac, int64_t N, int64_t I, int bw,
-                         int tbx, int tby, int bits, bool own_sort,
+                         int tbx, int tby, int bits, int own_sort,
                          int64_t* isect_ids_sorted, int32_t* gaussian_ids_sorted, int32_t* tile_bins, char* ws,
                          const SortWs& L, size_t tmp_bytes, hipStream_t st) {
     TKey* tk_in = reinterpret_cast<TKey*>(ws + L.tkey_in);
@@ -885,7 +1138,53 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
     int rc = unerf_check_launch("splat_bin_sort map");
     if (rc) return rc;
     const int tiles = tbx * tby;
-    if (own_sort) {   // the one-pass LDS-digit sort (above)
+    if (own_sort == 2) {   // two staged LSD passes (rs_* kernels above)
+        const int T1 = tiles + 1;
+        const RsTilePlan rp = rs_tile_plan(I, T1);
+        uint32_t* base = reinterpret_cast<uint32_t*>(ws + L.ts_table);
+        uint32_t* table0 = base;                                        // [B0][nchunk]
+        uint32_t* table1 = table0 + (size_t)128 * rp.nchunk;            // [B1][nchunk]
+        uint32_t* full = table1 + (size_t)128 * rp.nchunk;              // [nhw][T1]
+        uint32_t* dtotal = reinterpret_cast<uint32_t*>(ws + L.ts_segsum);      // [128] + [128]
+        uint32_t* total = dtotal + 256;                                 // [T1]
+        uint32_t* start = reinterpret_cast<uint32_t*>(ws + L.ts_start);
+        TKey* tk_mid = tk_out;
+        int32_t* v_mid = reinterpret_cast<int32_t*>(ws + L.val_mid);
+        const int sgrid = (rp.nchunk + 3) / 4;
+        const uint32_t kmax = (uint32_t)tiles;
+        const size_t lds_full = (1024 + (size_t)T1) * sizeof(uint32_t), lds_dig = 1024 * sizeof(uint32_t);
+        const size_t lds_sc = 4 * (512 + RS_M_TILE + (RS_M_TILE * sizeof(TKey) + 3) / 4) * sizeof(uint32_t);
+        if (rp.b0 == 0) {      // <= 128 keys: one pass
+            hipLaunchKernelGGL((rs_hist_kernel<TKey, true>), dim3(rp.nhw), dim3(256), lds_full, st, tk_in, I, RS_M_TILE, rp.nchunk, kmax, 0,
+                               rp.B1, RS_CPW, table1, full);
+            hipLaunchKernelGGL(rs_rowscan_kernel, dim3(rp.B1), dim3(1024), 0, st, table1, rp.nchunk, dtotal + 128);
+            hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, false>), dim3(sgrid), dim3(256), lds_sc, st, tk_in, v_in, I, rp.nchunk, kmax,
+                               0, rp.B1, table1, dtotal + 128, (TKey*)nullptr, gaussian_ids_sorted);
+        } else {
+            hipLaunchKernelGGL((rs_hist_kernel<TKey, true>), dim3(rp.nhw), dim3(256), lds_full, st, tk_in, I, RS_M_TILE, rp.nchunk, kmax, 0,
+                               rp.B0, RS_CPW, table0, full);
+            hipLaunchKernelGGL(rs_rowscan_kernel, dim3(rp.B0), dim3(1024), 0, st, table0, rp.nchunk, dtotal);
+            hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, true>), dim3(sgrid), dim3(256), lds_sc, st, tk_in, v_in, I, rp.nchunk, kmax,
+                               0, rp.B0, table0, dtotal, tk_mid, v_mid);
+            hipLaunchKernelGGL((rs_hist_kernel<TKey, false>), dim3(rp.nhw), dim3(256), lds_dig, st, tk_mid, I, RS_M_TILE, rp.nchunk, kmax,
+                               rp.b0, rp.B1, RS_CPW, table1, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(rs_rowscan_kernel, dim3(rp.B1), dim3(1024), 0, st, table1, rp.nchunk, dtotal + 128);
+            hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, false>), dim3(sgrid), dim3(256), lds_sc, st, tk_mid, v_mid, I, rp.nchunk,
+                               kmax, rp.b0, rp.B1, table1, dtotal + 128, (TKey*)nullptr, gaussian_ids_sorted);
+        }
+        // tile totals (column sums of the whole-key histograms) -> tile starts and the tile_bins
+        {   // (16 row segments summed in parallel, then added up per tile)
+            const int rps = (rp.nhw + 15) / 16;
+            hipLaunchKernelGGL(rs_colsum_kernel, dim3(blocks_for(T1, 256), 16), dim3(256), 0, st, full, rp.nhw, rps, T1, total + T1);
+            hipLaunchKernelGGL(rs_segadd_kernel, dim3(blocks_for(T1, 256)), dim3(256), 0, st, total + T1, 16, T1, total);
+        }
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, total, T1, tiles, start, tile_bins);
+        if (isect_ids_sorted)
+            hipLaunchKernelGGL(tile_isect_ids_kernel, dim3(blocks_for(I, 256)), dim3(256), 0, st, start, T1,
+                               gaussian_ids_sorted, depths, I, isect_ids_sorted);
+        return unerf_check_launch("splat_bin_sort two-pass tile sort");
+    }
+    if (own_sort == 1) {   // the one-pass LDS-digit sort (above)
         const TileSortPlan tp = tile_sort_plan(I, tiles);
         uint32_t* table = reinterpret_cast<uint32_t*>(ws + L.ts_table);
         uint32_t* segsum = reinterpret_cast<uint32_t*>(ws + L.ts_segsum);
@@ -944,11 +1243,38 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
     int32_t* counts = reinterpret_cast<int32_t*>(ws + L.counts);
     int32_t* cum_sorted = reinterpret_cast<int32_t*>(ws + L.cum);
     // 1. splats in depth order (stable: equal depths keep their index order)
-    hipLaunchKernelGGL(depth_keys_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, depths, radii, N, dk_in, id_in);
-    hipError_t e = depth_sort_pairs(ws + L.tmp, tmp_bytes, dk_in, dk_out, id_in, order, N, st);
-    if (e != hipSuccess) {
-        unerf_set_error("splat_bin_sort: depth sort: %s", hipGetErrorString(e));
-        return UNERF_ERR_HIP;
+    hipError_t e = hipSuccess;
+    const char* denv = getenv("UNERF_SPLAT_DEPTH_SORT");
+    if (denv && strcmp(denv, "rocprim") == 0) {      // rocprim's stable sort (kept for A/B runs and the identity test)
+        hipLaunchKernelGGL(depth_keys_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, depths, radii, N, dk_in, id_in);
+        e = depth_sort_pairs(ws + L.tmp, tmp_bytes, dk_in, dk_out, id_in, order, N, st);
+        if (e != hipSuccess) {
+            unerf_set_error("splat_bin_sort: depth sort: %s", hipGetErrorString(e));
+            return UNERF_ERR_HIP;
+        }
+    } else {      // four staged 8-bit LSD passes (rs_* kernels); the last one writes `order`
+        const int nchunk = (int)((N + RS_M_DEPTH - 1) / RS_M_DEPTH), grid = (nchunk + 3) / 4, hgrid = grid;
+        uint32_t* table = reinterpret_cast<uint32_t*>(ws + L.ds_table);
+        uint32_t* dtotal = reinterpret_cast<uint32_t*>(ws + L.ds_total);
+        const size_t lds_sc = 4 * (512 + 2 * RS_M_DEPTH) * sizeof(uint32_t), lds_dig = 1024 * sizeof(uint32_t);
+        hipLaunchKernelGGL(depth_keys_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, depths, radii, N, dk_out, order);
+        uint32_t* kin = dk_out; uint32_t* kout = dk_in;
+        int32_t* vin = order; int32_t* vout = id_in;
+        for (int p = 0; p < 4; ++p) {      // (dk_out, order) -> (dk_in, id_in) -> (dk_out, order) -> (dk_in, id_in) -> order
+            hipLaunchKernelGGL((rs_hist_kernel<uint32_t, false>), dim3(hgrid), dim3(256), lds_dig, st, kin, N, RS_M_DEPTH, nchunk, 0xFFFFFFFFu,
+                               8 * p, 256, 1, table, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(rs_rowscan_kernel, dim3(256), dim3(1024), 0, st, table, nchunk, dtotal);
+            if (p < 3)
+                hipLaunchKernelGGL((rs_scatter_kernel<uint32_t, RS_M_DEPTH, true>), dim3(grid), dim3(256), lds_sc, st, kin, vin, N, nchunk,
+                                   0xFFFFFFFFu, 8 * p, 256, table, dtotal, kout, vout);
+            else
+                hipLaunchKernelGGL((rs_scatter_kernel<uint32_t, RS_M_DEPTH, false>), dim3(grid), dim3(256), lds_sc, st, kin, vin, N, nchunk,
+                                   0xFFFFFFFFu, 8 * p, 256, table, dtotal, (uint32_t*)nullptr, order);
+            uint32_t* tk = kin; kin = kout; kout = tk;
+            int32_t* tv = vin; vin = vout; vout = tv;
+        }
+        int rc = unerf_check_launch("splat_bin_sort depth sort");
+        if (rc) return rc;
     }
     // 2. where each depth-ordered splat's intersections start
     hipLaunchKernelGGL(sorted_counts_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, order, radii, cum_tiles_hit, N,
@@ -963,7 +1289,8 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
     // radix sort otherwise or when UNERF_SPLAT_TILE_SORT=radix asks for it -- A/B timing), tile ranges + ids
     const int bits = tile_bits(H, W, block_width);      // (the sentinel tile `tbx * tby` included)
     const char* env = getenv("UNERF_SPLAT_TILE_SORT");
-    const bool own_sort = tbx * tby + 1 <= TS_MAX_T1 && !(env && strcmp(env, "radix") == 0);
+    int own_sort = 0;      // 0: rocprim radix sort, 1: one-pass LDS-digit sort, 2: two-pass LSD sort (default)
+    if (tbx * tby + 1 <= TS_MAX_T1 && !(env && strcmp(env, "radix") == 0)) own_sort = (env && strcmp(env, "onepass") == 0) ? 1 : 2;
     tmp_bytes = (size_t)(L.dkey_in - L.tmp);
     if (bits <= 16)
         return bin_sort_impl<uint16_t>(xys, depths, radii, order, cum_sorted, tight_conics, tight_opacities, N, I, block_width, tbx, tby, bits,
