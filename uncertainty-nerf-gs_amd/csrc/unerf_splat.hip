@@ -584,11 +584,14 @@ __global__ __launch_bounds__(256) void sorted_counts_kernel(const int32_t* __res
     counts[j] = radii[i] > 0 ? cum[i] - (i == 0 ? 0 : cum[i - 1]) : 0;
 }
 
-// 16 lanes per splat: lane t writes entries t, t+16, ... of the splat's row-major tile box, so a splat's run of
+// LPS lanes per splat (8: a tight list is ~20 tiles in ~5 rows on the 1 M-splat bench frame, and the per-splat set-up -- the
+// ellipse, a row range per lane, the scan -- is the same instruction stream whether 4 or 8 splats share the wave; 16 lanes per
+// splat spent 338 VALU instructions per wave on 4 splats: VALU-bound, 137 of 148 us, rocprofv3 r5).
+// Lane t writes entries t, t+LPS, ... of the splat's row-major tile box, so a splat's run of
 // (tile, id) pairs leaves as 32-B / 64-B segments instead of one thread trickling out 2-B and 4-B stores (an average
 // splat of the 1 M-splat bench scene covers 37 tiles).  Entry index = first + (ty - y0) * w + (tx - x0): the order a
 // serial row-major walk produces, which is gsplat's.
-template <typename TKey>
+template <typename TKey, int LPS>
 __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __restrict__ xys,
                                                              const int32_t* __restrict__ radii,
                                                              const int32_t* __restrict__ order,
@@ -596,8 +599,8 @@ __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __rest
                                                              int tbx, int tby, const float* __restrict__ conics,
                                                              const float* __restrict__ opac, TKey* __restrict__ tkeys,
                                                              int32_t* __restrict__ vals) {
-    const int l16 = threadIdx.x & 15;
-    const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & (LPS - 1);
+    const int64_t j = (int64_t)blockIdx.x * (256 / LPS) + threadIdx.x / LPS;
     if (j >= N) return;
     const int32_t i = order[j];
     if (radii[i] <= 0) return;
@@ -616,32 +619,32 @@ __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __rest
         // sort puts behind every real tile and tile_bins never covers: a wrong count costs pairs, never memory safety.
         const int64_t end = cum_sorted[j];
         const TKey sentinel = (TKey)(tbx * tby);
-        // 16 tile rows at a time, one per lane of the splat's 16-lane group; their widths are scanned inside the group and
+        // LPS tile rows at a time, one per lane of the splat's lane group; their widths are scanned inside the group and
         // the round's entries go out striped over the lanes like the box form below (a row is only ~5 tiles wide: a
         // lane-per-row or row-by-row emission leaves most lanes of every store idle -- 2.5 x the kernel time)
         const int nrows = y1 - y0;
         int64_t at = first;
-        for (int rb = 0; rb < nrows; rb += 16) {
+        for (int rb = 0; rb < nrows; rb += LPS) {
             int a0 = 0, a1 = 0;
             if (rb + l16 < nrows) tight_row(t, y0 + rb + l16, bw, x0, x1, a0, a1);
             const int wd = a1 - a0;
             int incl = wd;
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const int v = __shfl_up(incl, d, 16);
+            for (int d = 1; d < LPS; d <<= 1) {
+                const int v = __shfl_up(incl, d, LPS);
                 if (l16 >= d) incl += v;
             }
-            const int total = __shfl(incl, 15, 16), excl = incl - wd;
-            for (int e0 = 0; e0 < total; e0 += 16) {          // (uniform inside the group: every lane takes every shuffle)
+            const int total = __shfl(incl, LPS - 1, LPS), excl = incl - wd;
+            for (int e0 = 0; e0 < total; e0 += LPS) {          // (uniform inside the group: every lane takes every shuffle)
                 const int e = e0 + l16;
                 int r = 0;                                    // row of entry e: first lane whose inclusive sum exceeds e
 #pragma unroll
-                for (int step = 8; step >= 1; step >>= 1) {
-                    const int probe = __shfl(incl, r + step - 1, 16);
+                for (int step = LPS / 2; step >= 1; step >>= 1) {
+                    const int probe = __shfl(incl, r + step - 1, LPS);
                     if (probe <= e) r += step;
                 }
-                r = min(r, 15);
-                const int rex = __shfl(excl, r, 16), ra0 = __shfl(a0, r, 16);
+                r = min(r, LPS - 1);
+                const int rex = __shfl(excl, r, LPS), ra0 = __shfl(a0, r, LPS);
                 if (e < total && at + e < end) {
                     tkeys[at + e] = (TKey)((y0 + rb + r) * tbx + ra0 + (e - rex));
                     vals[at + e] = i;
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __rest
             }
             at += total;
         }
-        for (int64_t e = at + l16; e < end; e += 16) {        // never taken when the two counts agree
+        for (int64_t e = at + l16; e < end; e += LPS) {        // never taken when the two counts agree
             tkeys[e] = sentinel;
             vals[e] = i;
         }
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(256) void map_intersects_kernel(const float* __rest
     // row = floor(t / w) through the reciprocal, then made exact by one step either way (the estimate is within 1
     // for any box that fits an image)
     const float rw = 1.f / (float)w;
-    for (int t = l16; t < count; t += 16) {
+    for (int t = l16; t < count; t += LPS) {
         int row = (int)(((float)t + 0.5f) * rw);
         row -= (row * w > t) ? 1 : 0;
         row += ((row + 1) * w <= t) ? 1 : 0;
@@ -997,30 +1000,39 @@ __global__ __launch_bounds__(1024) void rs_rowscan_kernel(uint32_t* __restrict__
     if (threadIdx.x == 0) dtotal[blockIdx.x] = carry;
 }
 
-// one wave per chunk of M pairs: rank, stage in LDS in digit order, write out digit run by digit run
-template <typename TKey, int M, bool KEYS_OUT>
+// one wave per chunk of M pairs: rank, stage in LDS in digit order, write out digit run by digit run.  DMAX = digit values the
+// LDS tables are sized for (128: tile digits, 256: depth digits).
+// Ranking a 64-pair vector: every lane ORs its lane bit into its digit's 64-bit word (one LDS instruction), reads the word back
+// -- the lanes that share its digit -- and clears it; its slot is the digit's running position (read by all, advanced by the
+// first of the peers) plus the number of peers in lower lanes.  The LDS executes a wave's instructions in program order, so the
+// five of them need no wait on one another, and four vectors are in flight at a time.
+template <int M, int DMAX, typename TKey>
+struct RsLds {
+    static constexpr int WAVE_WORDS = 4 * DMAX + M + (M * (int)sizeof(TKey) + 3) / 4;     // cur | delta | peer words | vals | keys
+};
+template <typename TKey, int M, int DMAX, bool KEYS_OUT>
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const TKey* __restrict__ keys, const int32_t* __restrict__ vals, int64_t n,
                                                          int nchunk, uint32_t kmax, int shift, int B,
                                                          const uint32_t* __restrict__ table, const uint32_t* __restrict__ dtotal,
                                                          TKey* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
-    // per wave: cur[256] | delta[256] | staged vals [M] | staged keys [M]
-    constexpr int WAVE_WORDS = 512 + M + (M * (int)sizeof(TKey) + 3) / 4;
     extern __shared__ uint32_t s_rs[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = (int)blockIdx.x * 4 + wv;
+    const int c = (int)blockIdx.x * (int)(blockDim.x >> 6) + wv;      // (1 - 4 waves per workgroup: the launcher's choice)
     if (c >= nchunk) return;
-    uint32_t* cur = s_rs + (size_t)wv * WAVE_WORDS;
-    uint32_t* delta = cur + 256;
-    int32_t* sval = reinterpret_cast<int32_t*>(delta + 256);
+    uint32_t* cur = s_rs + (size_t)wv * RsLds<M, DMAX, TKey>::WAVE_WORDS;
+    uint32_t* delta = cur + DMAX;
+    uint32_t* pw = delta + DMAX;             // [DMAX][2]
+    int32_t* sval = reinterpret_cast<int32_t*>(pw + 2 * DMAX);
     TKey* skey = reinterpret_cast<TKey*>(sval + M);
     const uint32_t dmask = (uint32_t)B - 1u;
-    {   // lane l owns digits 4 l .. 4 l + 3.  For digit d: this chunk's pairs start at slot ls[d] of the staged order (prefix of
-        // the chunk's counts over the digits) and at gs[d] = (all pairs with a smaller digit) + (pairs with digit d in earlier
-        // chunks) of the output; the chunk's count is the difference of two neighbours of the prefix row
-        uint32_t tot[4], pre[4], cnt[4], tsum = 0u, csum = 0u;
+    constexpr int DPL = DMAX / 64;           // digits per lane in the prologue
+    {   // lane l owns digits DPL l .. DPL l + DPL - 1.  For digit d: this chunk's pairs start at slot ls[d] of the staged order
+        // (prefix of the chunk's counts over the digits) and at gs[d] = (all pairs with a smaller digit) + (pairs with digit d in
+        // earlier chunks) of the output; the chunk's count is the difference of two neighbours of the prefix row
+        uint32_t tot[DPL], pre[DPL], cnt[DPL], tsum = 0u, csum = 0u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int d = 4 * lane + i;
+        for (int i = 0; i < DPL; ++i) {
+            const int d = DPL * lane + i;
             tot[i] = pre[i] = cnt[i] = 0u;
             if (d < B) {
                 tot[i] = dtotal[d];
@@ -1038,9 +1050,12 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const TKey* __restrict_
         }
         uint32_t gb = ti - tsum, lb = ci - csum;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            cur[4 * lane + i] = lb;
-            delta[4 * lane + i] = gb + pre[i] - lb;
+        for (int i = 0; i < DPL; ++i) {
+            const int d = DPL * lane + i;
+            cur[d] = lb;
+            delta[d] = gb + pre[i] - lb;
+            pw[2 * d] = 0u;
+            pw[2 * d + 1] = 0u;
             gb += tot[i];
             lb += cnt[i];
         }
@@ -1059,35 +1074,28 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const TKey* __restrict_
         key[v] = (uint32_t)keys[ec];
         val[v] = vals[ec];
     }
-    // four vectors at a time, stage by stage: the ballots are independent VALU work, the four atomics go out back to back
-    // in vector order (the LDS executes a wave's operations in program order) and are collected by one wait, so are the
-    // four broadcasts
+    const uint32_t mybit = 1u << (lane & 31), half = (uint32_t)lane >> 5;
 #pragma unroll
     for (int g = 0; g < NV; g += 4) {
-        uint32_t kq[4], d[4], rank[4], cntp[4], base[4];
-        int leader[4];
+        uint32_t kq[4], d[4], base[4], rank[4];
+        uint2 peers[4];
         bool valid[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             valid[i] = 64 * (g + i) + lane < m;
             kq[i] = key[g + i] < kmax ? key[g + i] : kmax;
             d[i] = (kq[i] >> shift) & dmask;
-            uint64_t peers = __builtin_amdgcn_ballot_w64(valid[i]);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int32_t ext = (int32_t)(d[i] << (31 - b)) >> 31;      // 0 or -1
-                const uint64_t mk = __builtin_amdgcn_ballot_w64(ext != 0);
-                peers &= ~(mk ^ (uint64_t)(int64_t)ext);
-            }
-            rank[i] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-            cntp[i] = (uint32_t)__builtin_popcountll(peers);
-            leader[i] = valid[i] ? __builtin_ctzll(peers) : lane;
+            atomicOr(&pw[2 * d[i] + half], valid[i] ? mybit : 0u);
+            peers[i] = *reinterpret_cast<const uint2*>(&pw[2 * d[i]]);
+            *reinterpret_cast<uint2*>(&pw[2 * d[i]]) = make_uint2(0u, 0u);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)               // (every lane asks, all but the first of the peers for 0 slots: no branch)
-            base[i] = atomicAdd(&cur[d[i]], (valid[i] && rank[i] == 0u) ? cntp[i] : 0u);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) base[i] = __shfl(base[i], leader[i], 64);
+        for (int i = 0; i < 4; ++i) {
+            rank[i] = __builtin_amdgcn_mbcnt_hi(peers[i].y, __builtin_amdgcn_mbcnt_lo(peers[i].x, 0u));
+            const uint32_t cntp = (uint32_t)(__builtin_popcount(peers[i].x) + __builtin_popcount(peers[i].y));
+            base[i] = cur[d[i]];
+            atomicAdd(&cur[d[i]], (valid[i] && rank[i] == 0u) ? cntp : 0u);      // the first of the peers advances it for all
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (valid[i]) {
@@ -1133,7 +1141,12 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
     TKey* tk_in = reinterpret_cast<TKey*>(ws + L.tkey_in);
     TKey* tk_out = reinterpret_cast<TKey*>(ws + L.tkey_out);
     int32_t* v_in = reinterpret_cast<int32_t*>(ws + L.val_in);
-    hipLaunchKernelGGL((map_intersects_kernel<TKey>), dim3(blocks_for(N, 16)), dim3(256), 0, st, xys, radii, order,
+    // tight lists: 8 lanes per splat; gsplat's boxes (37 tiles per splat on the bench frame): 16
+    if (conics)
+        hipLaunchKernelGGL((map_intersects_kernel<TKey, 8>), dim3(blocks_for(N, 32)), dim3(256), 0, st, xys, radii, order,
+                           cum_sorted, N, bw, tbx, tby, conics, opac, tk_in, v_in);
+    else
+    hipLaunchKernelGGL((map_intersects_kernel<TKey, 16>), dim3(blocks_for(N, 16)), dim3(256), 0, st, xys, radii, order,
                        cum_sorted, N, bw, tbx, tby, conics, opac, tk_in, v_in);
     int rc = unerf_check_launch("splat_bin_sort map");
     if (rc) return rc;
@@ -1150,26 +1163,26 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
         uint32_t* start = reinterpret_cast<uint32_t*>(ws + L.ts_start);
         TKey* tk_mid = tk_out;
         int32_t* v_mid = reinterpret_cast<int32_t*>(ws + L.val_mid);
-        const int sgrid = (rp.nchunk + 3) / 4;
+        const int swpb = getenv("UNERF_RS_WPB") ? atoi(getenv("UNERF_RS_WPB")) : 1, sgrid = (rp.nchunk + swpb - 1) / swpb;
         const uint32_t kmax = (uint32_t)tiles;
         const size_t lds_full = (1024 + (size_t)T1) * sizeof(uint32_t), lds_dig = 1024 * sizeof(uint32_t);
-        const size_t lds_sc = 4 * (512 + RS_M_TILE + (RS_M_TILE * sizeof(TKey) + 3) / 4) * sizeof(uint32_t);
+        const size_t lds_sc = swpb * (size_t)RsLds<RS_M_TILE, 128, TKey>::WAVE_WORDS * sizeof(uint32_t);
         if (rp.b0 == 0) {      // <= 128 keys: one pass
             hipLaunchKernelGGL((rs_hist_kernel<TKey, true>), dim3(rp.nhw), dim3(256), lds_full, st, tk_in, I, RS_M_TILE, rp.nchunk, kmax, 0,
                                rp.B1, RS_CPW, table1, full);
             hipLaunchKernelGGL(rs_rowscan_kernel, dim3(rp.B1), dim3(1024), 0, st, table1, rp.nchunk, dtotal + 128);
-            hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, false>), dim3(sgrid), dim3(256), lds_sc, st, tk_in, v_in, I, rp.nchunk, kmax,
+            hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, 128, false>), dim3(sgrid), dim3(64 * swpb), lds_sc, st, tk_in, v_in, I, rp.nchunk, kmax,
                                0, rp.B1, table1, dtotal + 128, (TKey*)nullptr, gaussian_ids_sorted);
         } else {
             hipLaunchKernelGGL((rs_hist_kernel<TKey, true>), dim3(rp.nhw), dim3(256), lds_full, st, tk_in, I, RS_M_TILE, rp.nchunk, kmax, 0,
                                rp.B0, RS_CPW, table0, full);
             hipLaunchKernelGGL(rs_rowscan_kernel, dim3(rp.B0), dim3(1024), 0, st, table0, rp.nchunk, dtotal);
-            hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, true>), dim3(sgrid), dim3(256), lds_sc, st, tk_in, v_in, I, rp.nchunk, kmax,
+            hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, 128, true>), dim3(sgrid), dim3(64 * swpb), lds_sc, st, tk_in, v_in, I, rp.nchunk, kmax,
                                0, rp.B0, table0, dtotal, tk_mid, v_mid);
             hipLaunchKernelGGL((rs_hist_kernel<TKey, false>), dim3(rp.nhw), dim3(256), lds_dig, st, tk_mid, I, RS_M_TILE, rp.nchunk, kmax,
                                rp.b0, rp.B1, RS_CPW, table1, (uint32_t*)nullptr);
             hipLaunchKernelGGL(rs_rowscan_kernel, dim3(rp.B1), dim3(1024), 0, st, table1, rp.nchunk, dtotal + 128);
-            hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, false>), dim3(sgrid), dim3(256), lds_sc, st, tk_mid, v_mid, I, rp.nchunk,
+            hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, 128, false>), dim3(sgrid), dim3(64 * swpb), lds_sc, st, tk_mid, v_mid, I, rp.nchunk,
                                kmax, rp.b0, rp.B1, table1, dtotal + 128, (TKey*)nullptr, gaussian_ids_sorted);
         }
         // tile totals (column sums of the whole-key histograms) -> tile starts and the tile_bins
@@ -1256,7 +1269,7 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
         const int nchunk = (int)((N + RS_M_DEPTH - 1) / RS_M_DEPTH), grid = (nchunk + 3) / 4, hgrid = grid;
         uint32_t* table = reinterpret_cast<uint32_t*>(ws + L.ds_table);
         uint32_t* dtotal = reinterpret_cast<uint32_t*>(ws + L.ds_total);
-        const size_t lds_sc = 4 * (512 + 2 * RS_M_DEPTH) * sizeof(uint32_t), lds_dig = 1024 * sizeof(uint32_t);
+        const size_t lds_sc = 4 * (size_t)RsLds<RS_M_DEPTH, 256, uint32_t>::WAVE_WORDS * sizeof(uint32_t), lds_dig = 1024 * sizeof(uint32_t);
         hipLaunchKernelGGL(depth_keys_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, depths, radii, N, dk_out, order);
         uint32_t* kin = dk_out; uint32_t* kout = dk_in;
         int32_t* vin = order; int32_t* vout = id_in;
@@ -1265,10 +1278,10 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
                                8 * p, 256, 1, table, (uint32_t*)nullptr);
             hipLaunchKernelGGL(rs_rowscan_kernel, dim3(256), dim3(1024), 0, st, table, nchunk, dtotal);
             if (p < 3)
-                hipLaunchKernelGGL((rs_scatter_kernel<uint32_t, RS_M_DEPTH, true>), dim3(grid), dim3(256), lds_sc, st, kin, vin, N, nchunk,
+                hipLaunchKernelGGL((rs_scatter_kernel<uint32_t, RS_M_DEPTH, 256, true>), dim3(grid), dim3(256), lds_sc, st, kin, vin, N, nchunk,
                                    0xFFFFFFFFu, 8 * p, 256, table, dtotal, kout, vout);
             else
-                hipLaunchKernelGGL((rs_scatter_kernel<uint32_t, RS_M_DEPTH, false>), dim3(grid), dim3(256), lds_sc, st, kin, vin, N, nchunk,
+                hipLaunchKernelGGL((rs_scatter_kernel<uint32_t, RS_M_DEPTH, 256, false>), dim3(grid), dim3(256), lds_sc, st, kin, vin, N, nchunk,
                                    0xFFFFFFFFu, 8 * p, 256, table, dtotal, (uint32_t*)nullptr, order);
             uint32_t* tk = kin; kin = kout; kout = tk;
             int32_t* tv = vin; vin = vout; vout = tv;
