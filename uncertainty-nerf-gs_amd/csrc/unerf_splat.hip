@@ -450,7 +450,7 @@ extern "C" int unerf_splat_shade_inputs(int degree, const float* means3d, const 
 // ======================================================================================
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 #define TS_SEG 32          // one-pass tile sort (below): the prefix over chunks runs in 32 independent row segments
-#define TS_MAX_T1 16000    // tiles + 1 sentinel: the counters of one wave must fit 64 KB of LDS (beyond: rocprim)
+#define TS_MAX_T1 12000    // tiles + 1 sentinel: the whole-key counters + 16 waves' digit counters must fit 64 KB of LDS (beyond: rocprim)
 struct TileSortPlan {
     int chunk, nblk, rows, T1;
 };
@@ -473,7 +473,7 @@ static TileSortPlan tile_sort_plan(int64_t I, int tiles) {
 // stages in LDS in digit order and writes out as runs of consecutive slots (see rs_scatter_kernel for why).
 #define RS_M_TILE 2048      // pairs per wave, tile sort (u16 / u32 keys, <= 128 digits: runs of >= 16 slots per digit)
 #define RS_M_DEPTH 1024     // pairs per wave, depth sort (u32 keys, 256 digits: runs of 4)
-#define RS_CPW 4            // chunks per wave in the histogram kernel (a workgroup = 4 waves = 16 chunks)
+#define RS_CPW 1            // chunks per wave in the histogram kernels; the whole-key histogram's workgroup = 16 waves = 16 chunks
 struct RsTilePlan {
     int nchunk, b0, B0, B1, nhw;      // digit 0 = key & (B0 - 1), digit 1 = key >> b0 (< B1; B0, B1 powers of two <= 128)
 };
@@ -486,7 +486,7 @@ static RsTilePlan rs_tile_plan(int64_t I, int T1) {
     p.B1 = 1 << (bits - p.b0);
     p.nchunk = (int)((I + RS_M_TILE - 1) / RS_M_TILE);
     if (p.nchunk < 1) p.nchunk = 1;
-    p.nhw = (p.nchunk + 4 * RS_CPW - 1) / (4 * RS_CPW);
+    p.nhw = (p.nchunk + 15) / 16;
     return p;
 }
 
@@ -769,25 +769,38 @@ __global__ __launch_bounds__(256) void tile_segscan_kernel(uint32_t* __restrict_
 }
 
 // one workgroup: the exclusive prefix of the tile totals over the tiles -> start[t] (start[T1] = all pairs), and the
-// tile_bins the rasteriser reads
+// tile_bins the rasteriser reads.  A tile's total is the sum of NSEG partial rows total[s][t] (1: already summed).
+template <int NSEG>
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ total, int T1, int tiles,
                                                          uint32_t* __restrict__ start, int32_t* __restrict__ bins) {
-    __shared__ uint32_t s_part[1024];
+    extern __shared__ uint32_t s_tot[];      // [T1] tile totals, then [16] wave sums
+    uint32_t* s_w = s_tot + T1;
+    for (int t = threadIdx.x; t < T1; t += 1024) {      // (coalesced over the tiles, segment by segment)
+        uint32_t n = 0u;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) n += total[(size_t)sg * T1 + t];
+        s_tot[t] = n;
+    }
+    __syncthreads();
     const int per = (T1 + 1023) / 1024;
     const int t0 = threadIdx.x * per, t1 = (t0 + per < T1) ? t0 + per : T1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t mine = 0u;
-    for (int t = t0; t < t1; ++t) mine += total[t];
-    s_part[threadIdx.x] = mine;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {      // Hillis-Steele over the 1024 partial sums
-        const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
+    for (int t = t0; t < t1; ++t) mine += s_tot[t];
+    uint32_t incl = mine;      // inclusive scan of the 1,024 partial sums: inside each wave, then over the 16 waves
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
     }
-    uint32_t run = s_part[threadIdx.x] - mine;
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) before += w < wv ? s_w[w] : 0u;
+    uint32_t run = before + incl - mine;
     for (int t = t0; t < t1; ++t) {
-        const uint32_t n = total[t];
+        const uint32_t n = s_tot[t];
         start[t] = run;
         if (t < tiles) {      // an empty tile keeps the (0, 0) of gsplat's zero-filled tile_bins
             bins[t * 2] = n ? (int32_t)run : 0;
@@ -899,20 +912,20 @@ __global__ __launch_bounds__(64) void tile_scatter_kernel(const TKey* __restrict
 // add their position among the peers -- stream order, i.e. stable.  Same lists as the one-pass sort, rocprim's radix sort
 // (tile) and rocprim's stable sort (depth), bit for bit (tests/test_gpu_splat.py).
 template <typename TKey, bool FULL>
-__global__ __launch_bounds__(256) void rs_hist_kernel(const TKey* __restrict__ keys, int64_t n, int chunk, int nchunk, uint32_t kmax,
+__global__ __launch_bounds__(1024) void rs_hist_kernel(const TKey* __restrict__ keys, int64_t n, int chunk, int nchunk, uint32_t kmax,
                                                       int shift, int B, int cpw, uint32_t* __restrict__ table, uint32_t* __restrict__ full) {
-    extern __shared__ uint32_t s_rs[];       // [4][256] digit counters, then FULL: [kmax + 1] whole-key counters of the workgroup
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    extern __shared__ uint32_t s_rs[];       // [waves][256] digit counters, then FULL: [kmax + 1] whole-key counters of the workgroup
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = (int)(blockDim.x >> 6);
     uint32_t* dig = s_rs + wv * 256;
-    uint32_t* fh = s_rs + 1024;
+    uint32_t* fh = s_rs + wpb * 256;
     if (FULL) {
-        for (uint32_t t = threadIdx.x; t <= kmax; t += 256) fh[t] = 0u;
+        for (uint32_t t = threadIdx.x; t <= kmax; t += blockDim.x) fh[t] = 0u;
         __syncthreads();
     }
     const uint32_t dmask = (uint32_t)B - 1u;
     constexpr int PER = 16 / (int)sizeof(TKey);
     for (int cc = 0; cc < cpw; ++cc) {
-        const int c = ((int)blockIdx.x * 4 + wv) * cpw + cc;
+        const int c = ((int)blockIdx.x * wpb + wv) * cpw + cc;
         if (c >= nchunk) break;                   // (uniform per wave)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dig[lane + 64 * i] = 0u;
@@ -924,16 +937,26 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const TKey* __restrict__ k
             atomicAdd(&dig[(kq >> shift) & dmask], 1u);
             if (FULL) atomicAdd(&fh[kq], 1u);
         };
-        for (int64_t v = lane; v < nvec; v += 64) {
-            const uint4 q = kv[v];
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        for (int64_t v0 = 0; v0 < nvec; v0 += 256) {      // four 16-byte loads per lane in flight
+            uint4 q[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (sizeof(TKey) == 2) {
-                    count(w[i] & 0xFFFFu);
-                    count(w[i] >> 16);
-                } else {
-                    count(w[i]);
+            for (int u = 0; u < 4; ++u) {
+                const int64_t v = v0 + 64 * u + lane;
+                q[u] = kv[v < nvec ? v : nvec - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (v0 + 64 * u + lane < nvec) {
+                    const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (sizeof(TKey) == 2) {
+                            count(w[i] & 0xFFFFu);
+                            count(w[i] >> 16);
+                        } else {
+                            count(w[i]);
+                        }
+                    }
                 }
             }
         }
@@ -946,7 +969,7 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const TKey* __restrict__ k
     if (FULL) {
         __syncthreads();
         uint32_t* row = full + (size_t)blockIdx.x * (kmax + 1);
-        for (uint32_t t = threadIdx.x; t <= kmax; t += 256) row[t] = fh[t];
+        for (uint32_t t = threadIdx.x; t <= kmax; t += blockDim.x) row[t] = fh[t];
     }
 }
 
@@ -960,13 +983,6 @@ __global__ __launch_bounds__(256) void rs_colsum_kernel(const uint32_t* __restri
 #pragma unroll 8
     for (int r = r0; r < r1; ++r) sum += full[(size_t)r * T1 + t];
     seg[(size_t)sg * T1 + t] = sum;
-}
-__global__ __launch_bounds__(256) void rs_segadd_kernel(const uint32_t* __restrict__ seg, int nseg, int T1, uint32_t* __restrict__ total) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T1) return;
-    uint32_t sum = 0u;
-    for (int s = 0; s < nseg; ++s) sum += seg[(size_t)s * T1 + t];
-    total[t] = sum;
 }
 
 // one workgroup per digit: exclusive prefix of its row over the chunks (in place) and the digit's total
@@ -1010,11 +1026,15 @@ template <int M, int DMAX, typename TKey>
 struct RsLds {
     static constexpr int WAVE_WORDS = 4 * DMAX + M + (M * (int)sizeof(TKey) + 3) / 4;     // cur | delta | peer words | vals | keys
 };
-template <typename TKey, int M, int DMAX, bool KEYS_OUT>
+// COUNTS (the depth sort's last pass): also writes, in output order, how many tiles each splat hits -- num_tiles_hit recovered from
+// its inclusive scan, 0 for culled splats -- the gather a separate kernel used to make (21 us, waiting on three random reads per splat).
+template <typename TKey, int M, int DMAX, bool KEYS_OUT, bool COUNTS = false>
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const TKey* __restrict__ keys, const int32_t* __restrict__ vals, int64_t n,
                                                          int nchunk, uint32_t kmax, int shift, int B,
                                                          const uint32_t* __restrict__ table, const uint32_t* __restrict__ dtotal,
-                                                         TKey* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+                                                         TKey* __restrict__ keys_out, int32_t* __restrict__ vals_out,
+                                                         const int32_t* __restrict__ radii = nullptr, const int32_t* __restrict__ cum = nullptr,
+                                                         int32_t* __restrict__ counts_out = nullptr) {
     extern __shared__ uint32_t s_rs[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = (int)blockIdx.x * (int)(blockDim.x >> 6) + wv;      // (1 - 4 waves per workgroup: the launcher's choice)
@@ -1112,7 +1132,9 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const TKey* __restrict_
             const uint32_t kq = (uint32_t)skey[slot];
             const uint32_t dst = delta[(kq >> shift) & dmask] + (uint32_t)slot;
             if (KEYS_OUT) keys_out[dst] = (TKey)kq;
-            vals_out[dst] = sval[slot];
+            const int32_t i = sval[slot];
+            vals_out[dst] = i;
+            if (COUNTS) counts_out[dst] = radii[i] > 0 ? cum[i] - (i == 0 ? 0 : cum[i - 1]) : 0;
         }
     }
 }
@@ -1165,33 +1187,33 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
         int32_t* v_mid = reinterpret_cast<int32_t*>(ws + L.val_mid);
         const int swpb = getenv("UNERF_RS_WPB") ? atoi(getenv("UNERF_RS_WPB")) : 1, sgrid = (rp.nchunk + swpb - 1) / swpb;
         const uint32_t kmax = (uint32_t)tiles;
-        const size_t lds_full = (1024 + (size_t)T1) * sizeof(uint32_t), lds_dig = 1024 * sizeof(uint32_t);
+        const size_t lds_full = (16 * 256 + (size_t)T1) * sizeof(uint32_t), lds_dig = 1024 * sizeof(uint32_t);
+        const int hgrid = (rp.nchunk + 3) / 4;      // digit-only histogram: one chunk per wave, four waves per workgroup
         const size_t lds_sc = swpb * (size_t)RsLds<RS_M_TILE, 128, TKey>::WAVE_WORDS * sizeof(uint32_t);
         if (rp.b0 == 0) {      // <= 128 keys: one pass
-            hipLaunchKernelGGL((rs_hist_kernel<TKey, true>), dim3(rp.nhw), dim3(256), lds_full, st, tk_in, I, RS_M_TILE, rp.nchunk, kmax, 0,
-                               rp.B1, RS_CPW, table1, full);
+            hipLaunchKernelGGL((rs_hist_kernel<TKey, true>), dim3(rp.nhw), dim3(1024), lds_full, st, tk_in, I, RS_M_TILE, rp.nchunk, kmax, 0,
+                               rp.B1, 1, table1, full);
             hipLaunchKernelGGL(rs_rowscan_kernel, dim3(rp.B1), dim3(1024), 0, st, table1, rp.nchunk, dtotal + 128);
             hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, 128, false>), dim3(sgrid), dim3(64 * swpb), lds_sc, st, tk_in, v_in, I, rp.nchunk, kmax,
                                0, rp.B1, table1, dtotal + 128, (TKey*)nullptr, gaussian_ids_sorted);
         } else {
-            hipLaunchKernelGGL((rs_hist_kernel<TKey, true>), dim3(rp.nhw), dim3(256), lds_full, st, tk_in, I, RS_M_TILE, rp.nchunk, kmax, 0,
-                               rp.B0, RS_CPW, table0, full);
+            hipLaunchKernelGGL((rs_hist_kernel<TKey, true>), dim3(rp.nhw), dim3(1024), lds_full, st, tk_in, I, RS_M_TILE, rp.nchunk, kmax, 0,
+                               rp.B0, 1, table0, full);
             hipLaunchKernelGGL(rs_rowscan_kernel, dim3(rp.B0), dim3(1024), 0, st, table0, rp.nchunk, dtotal);
             hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, 128, true>), dim3(sgrid), dim3(64 * swpb), lds_sc, st, tk_in, v_in, I, rp.nchunk, kmax,
                                0, rp.B0, table0, dtotal, tk_mid, v_mid);
-            hipLaunchKernelGGL((rs_hist_kernel<TKey, false>), dim3(rp.nhw), dim3(256), lds_dig, st, tk_mid, I, RS_M_TILE, rp.nchunk, kmax,
-                               rp.b0, rp.B1, RS_CPW, table1, (uint32_t*)nullptr);
+            hipLaunchKernelGGL((rs_hist_kernel<TKey, false>), dim3(hgrid), dim3(256), lds_dig, st, tk_mid, I, RS_M_TILE, rp.nchunk, kmax,
+                               rp.b0, rp.B1, 1, table1, (uint32_t*)nullptr);
             hipLaunchKernelGGL(rs_rowscan_kernel, dim3(rp.B1), dim3(1024), 0, st, table1, rp.nchunk, dtotal + 128);
             hipLaunchKernelGGL((rs_scatter_kernel<TKey, RS_M_TILE, 128, false>), dim3(sgrid), dim3(64 * swpb), lds_sc, st, tk_mid, v_mid, I, rp.nchunk,
                                kmax, rp.b0, rp.B1, table1, dtotal + 128, (TKey*)nullptr, gaussian_ids_sorted);
         }
         // tile totals (column sums of the whole-key histograms) -> tile starts and the tile_bins
-        {   // (16 row segments summed in parallel, then added up per tile)
+        {   // (16 row segments summed in parallel; tile_scan_kernel adds them up per tile)
             const int rps = (rp.nhw + 15) / 16;
-            hipLaunchKernelGGL(rs_colsum_kernel, dim3(blocks_for(T1, 256), 16), dim3(256), 0, st, full, rp.nhw, rps, T1, total + T1);
-            hipLaunchKernelGGL(rs_segadd_kernel, dim3(blocks_for(T1, 256)), dim3(256), 0, st, total + T1, 16, T1, total);
+            hipLaunchKernelGGL(rs_colsum_kernel, dim3(blocks_for(T1, 256), 16), dim3(256), 0, st, full, rp.nhw, rps, T1, total);
         }
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, total, T1, tiles, start, tile_bins);
+        hipLaunchKernelGGL(tile_scan_kernel<16>, dim3(1), dim3(1024), ((size_t)T1 + 16) * sizeof(uint32_t), st, total, T1, tiles, start, tile_bins);
         if (isect_ids_sorted)
             hipLaunchKernelGGL(tile_isect_ids_kernel, dim3(blocks_for(I, 256)), dim3(256), 0, st, start, T1,
                                gaussian_ids_sorted, depths, I, isect_ids_sorted);
@@ -1208,7 +1230,7 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
         hipLaunchKernelGGL(tile_colsum_kernel, dim3(blocks_for(tp.T1, 256), TS_SEG), dim3(256), 0, st, table, rps, tp.T1, segsum);
         uint32_t* total = start + tp.T1 + 1;
         hipLaunchKernelGGL(tile_segscan_kernel, dim3(blocks_for(tp.T1, 256)), dim3(256), 0, st, segsum, tp.T1, total);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, total, tp.T1, tiles, start, tile_bins);
+        hipLaunchKernelGGL(tile_scan_kernel<1>, dim3(1), dim3(1024), ((size_t)tp.T1 + 16) * sizeof(uint32_t), st, total, tp.T1, tiles, start, tile_bins);
         hipLaunchKernelGGL(tile_apply_kernel, dim3(blocks_for(tp.T1, 256), TS_SEG), dim3(256), 0, st, table, rps, tp.T1, segsum,
                            start);
         hipLaunchKernelGGL((tile_scatter_kernel<TKey>), dim3(UNERF_SPLAT_XCD ? ((tp.nblk + 7) / 8) * 8 : tp.nblk), dim3(64), lds, st,
@@ -1281,8 +1303,8 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
                 hipLaunchKernelGGL((rs_scatter_kernel<uint32_t, RS_M_DEPTH, 256, true>), dim3(grid), dim3(256), lds_sc, st, kin, vin, N, nchunk,
                                    0xFFFFFFFFu, 8 * p, 256, table, dtotal, kout, vout);
             else
-                hipLaunchKernelGGL((rs_scatter_kernel<uint32_t, RS_M_DEPTH, 256, false>), dim3(grid), dim3(256), lds_sc, st, kin, vin, N, nchunk,
-                                   0xFFFFFFFFu, 8 * p, 256, table, dtotal, (uint32_t*)nullptr, order);
+                hipLaunchKernelGGL((rs_scatter_kernel<uint32_t, RS_M_DEPTH, 256, false, true>), dim3(grid), dim3(256), lds_sc, st, kin, vin, N, nchunk,
+                                   0xFFFFFFFFu, 8 * p, 256, table, dtotal, (uint32_t*)nullptr, order, radii, cum_tiles_hit, counts);
             uint32_t* tk = kin; kin = kout; kout = tk;
             int32_t* tv = vin; vin = vout; vout = tv;
         }
@@ -1290,8 +1312,9 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
         if (rc) return rc;
     }
     // 2. where each depth-ordered splat's intersections start
-    hipLaunchKernelGGL(sorted_counts_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, order, radii, cum_tiles_hit, N,
-                       counts);
+    if (denv && strcmp(denv, "rocprim") == 0)      // (the staged depth sort's last pass has written them)
+        hipLaunchKernelGGL(sorted_counts_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, order, radii, cum_tiles_hit, N,
+                           counts);
     tmp_bytes = (size_t)(L.dkey_in - L.tmp);
     e = hipcub::DeviceScan::InclusiveSum(ws + L.tmp, tmp_bytes, counts, cum_sorted, (int)N, st);
     if (e != hipSuccess) {
