@@ -619,17 +619,21 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
         # Bytes the bin-and-sort call REALLY moves, kernel by kernel (algorithmic: every array read or written once per
         # kernel that touches it), for the lists the frame actually sorts -- Is = num_intersects_sorted tight pairs:
         Is = n_isect_tight
-        merges = max(0, math.ceil(math.log2(max(N, 1) / 1024.0)))            # rocprim merge sort: block sort + merge passes
-        chunk = max(2048, -(-(-(-Is // 1024)) // 256) * 256)
-        rows = -(-(-(-Is // chunk)) // 32) * 32
+        # (unerf_splat.hip: four staged 8-bit LSD passes over the N depth keys, emission, two staged LSD passes over the pairs)
+        T1 = tiles + 1
+        nchunk_d, nchunk_t = -(-N // 1024), -(-Is // 2048)
+        nhw = -(-nchunk_t // 16)
         sort_parts = {
             "depth_keys (N x 16 B)": N * 16,
-            "depth sort: rocprim merge sort, (1 + merge passes) x 16 B per pair": N * 16 * (1 + merges),
-            "depth-ordered counts + scan (N x 28 B)": N * 28,
+            "depth sort: 4 x (histogram N x 4 B read; scatter N x 8 B read + N x 8 B written; 256 x chunks table written, scanned, read)":
+                4 * (N * 20 + 256 * nchunk_d * 4 * 4),
+            "depth-ordered counts (gather N x 12 B, N x 4 B written, inside the last depth pass) + their scan (N x 8 B)": N * 24,
             "emission: 40 B per splat read, 6 B per pair written": N * 40 + Is * 6,
-            "tile histogram: 2 B per pair read, chunk x tile table written": Is * 2 + rows * (tiles + 1) * 4,
-            "prefix over chunks and tiles: table read, read + written": rows * (tiles + 1) * 4 * 3,
-            "scatter: table + 6 B per pair read, 4 B per pair written": rows * (tiles + 1) * 4 + Is * 10,
+            "tile sort pass 1 (low digit): histogram 2 B per pair read + whole-key rows written; 6 B per pair read, 6 B written":
+                Is * 14 + nhw * T1 * 4 + 64 * nchunk_t * 4 * 4,
+            "tile sort pass 2 (high digit): histogram 2 B per pair read; 6 B per pair read, 4 B written":
+                Is * 12 + 128 * nchunk_t * 4 * 4,
+            "tile totals -> tile_bins: whole-key rows read, 16 partial rows written and read, bins written": nhw * T1 * 4 + 32 * T1 * 4 + T1 * 12,
         }
         sort_bytes = sum(sort_parts.values())
         # the frame's algorithmic bytes with the sort counted the same way (SURVEY 8d counted gsplat's 64-bit-key sort of
@@ -680,11 +684,11 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
                             if iss is not None else
                             {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": None if ach is None else ach / HBM_PEAK_GBS,
-                             "note": ("bin-and-sort = depth sort of the N splats (rocprim merge sort), emission of the "
-                                      "num_intersects_sorted (tile, id) pairs in depth order, and the own one-pass stable tile sort "
-                                      "(LDS histogram per chunk, prefix over chunks and tiles = tile_bins, single-wave scatter): "
+                             "note": ("bin-and-sort = depth sort of the N splats (four staged 8-bit LSD passes), emission of the "
+                                      "num_intersects_sorted (tile, id) pairs in depth order, and the stable tile sort (two staged LSD "
+                                      "passes: per-chunk digit histogram, prefix over chunks, rank + LDS staging + run-wise scatter): "
                                       "achieved = the bytes those kernels read and write (sort_bytes_by_kernel) over this call's "
-                                      "time.  Launch-latency and scattered-4-byte-store bound, not HBM bound (DESIGN.md 4.3)"
+                                      "time.  Launch-latency, VALU (emission) and store-request bound, not HBM bound (DESIGN.md 4.3)"
                                       if dom == "splat_bin_sort" else "algorithmic bytes of the dominant kernel")}),
                          "raster_roofline": raster,
                          "traffic": traffic, "avg_launch_ms": ksum[dom]["avg_ms"], "num_intersects": n_isect,

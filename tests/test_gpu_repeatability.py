@@ -43,7 +43,7 @@ def test_full_size_frames_repeat_bit_for_bit(dev, kind, precisions, grid):
 
 
 def test_full_size_splat_frames_repeat_bit_for_bit(dev):
-    """active-splatfacto, 1 M splats at 1080p: the depth sort, the one-pass tile sort (LDS atomics, run by run) and both
+    """active-splatfacto, 1 M splats at 1080p: the staged depth and tile sorts (LDS atomics, peer words, run-wise stores) and both
     rasteriser passes give the same bits every time."""
     import math
     from uncertainty_nerf_gs_amd import splat, synthetic
