@@ -312,14 +312,28 @@ struct ShadePack {
     int C;                         // row length: 4 = rgb + depth, 5 = rgb + beta + depth
 };
 
-template <bool SPLIT, bool PACK>
+// STAGE (SPLIT rows, degree 3, 16-byte aligned features_rest): the workgroup's 256 rows of 180 B are one contiguous 46-KB
+// block -- it is read with coalesced 16-byte loads into LDS and every thread takes its 45 floats from there (stride 45
+// words: conflict-free), instead of 12 loads per thread that touch 64 cache lines each (87 us for 208 MB: 2.4 TB/s).
+template <bool SPLIT, bool PACK, bool STAGE = false>
 __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float* __restrict__ means, float cxp,
                                                         float cyp, float czp, const float* __restrict__ coeffs,
                                                         const float* __restrict__ rest,
                                                         const float* __restrict__ log_unc, float beta_min, int64_t N,
                                                         float* __restrict__ colors, float* __restrict__ beta,
                                                         ShadePack pk) {
+    __shared__ float s_rest[STAGE ? 256 * 45 : 1];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (STAGE) {
+        const int64_t b0 = (int64_t)blockIdx.x * 256;
+        const int nb = (int)((N - b0 < 256) ? N - b0 : 256);
+        const float4* src = reinterpret_cast<const float4*>(rest + b0 * 45);     // (b0 * 180 B is a multiple of 16)
+        const int nq4 = nb * 45 / 4;
+#pragma unroll 4
+        for (int q = threadIdx.x; q < nq4; q += 256) reinterpret_cast<float4*>(s_rest)[q] = src[q];
+        for (int r = nq4 * 4 + (int)threadIdx.x; r < nb * 45; r += 256) s_rest[r] = rest[b0 * 45 + r];
+        __syncthreads();
+    }
     if (i >= N) return;
     const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
     const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
@@ -329,7 +343,12 @@ __global__ __launch_bounds__(256) void sh_colors_kernel(int degree, const float*
     // the splat's coefficient row (192 B, 16-byte aligned) as 16-byte loads: a thread-per-splat kernel reads with a
     // 192-B stride, so every load instruction touches 64 cache lines -- 12 of them instead of 46 dword loads
     float k[48];
-    if (SPLIT) {
+    if (SPLIT && STAGE) {
+        const float* dc = coeffs + i * 3;
+        k[0] = dc[0]; k[1] = dc[1]; k[2] = dc[2];
+#pragma unroll
+        for (int j = 0; j < 45; ++j) k[3 + j] = s_rest[threadIdx.x * 45 + j];
+    } else if (SPLIT) {
         const float* dc = coeffs + i * 3;
         k[0] = dc[0]; k[1] = dc[1]; k[2] = dc[2];
         // 180-byte rows are only 4-byte aligned: 11 x 16-byte + 1 x 4-byte unaligned-capable global loads
@@ -439,9 +458,15 @@ extern "C" int unerf_splat_shade_inputs(int degree, const float* means3d, const 
     ShadePack pk;
     pk.opacity_logits = opacity_logits; pk.compensation = compensation; pk.depths = depths; pk.opacities = opacities_out;
     pk.C = C;
-    hipLaunchKernelGGL((sh_colors_kernel<true, true>), dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
-                       means3d, cam_pos[0], cam_pos[1], cam_pos[2], features_dc, features_rest, log_unc, beta_min, N,
-                       rows_out, nullptr, pk);
+    if (degree >= 3 && ((uintptr_t)features_rest & 15u) == 0) {      // rows staged through LDS (see sh_colors_kernel)
+        hipLaunchKernelGGL((sh_colors_kernel<true, true, true>), dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
+                           means3d, cam_pos[0], cam_pos[1], cam_pos[2], features_dc, features_rest, log_unc, beta_min, N,
+                           rows_out, nullptr, pk);
+    } else {
+        hipLaunchKernelGGL((sh_colors_kernel<true, true>), dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, degree,
+                           means3d, cam_pos[0], cam_pos[1], cam_pos[2], features_dc, features_rest, log_unc, beta_min, N,
+                           rows_out, nullptr, pk);
+    }
     return unerf_check_launch("splat_shade_inputs");
 }
 
