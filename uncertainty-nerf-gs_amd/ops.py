@@ -1222,22 +1222,31 @@ class SplatCount:
     _next: Dict = {}
     _owner: Dict = {}
 
-    def __init__(self, num_tiles_hit: torch.Tensor):
+    _events: Dict = {}
+
+    def __init__(self, num_tiles_hit: torch.Tensor, defer_copy: bool = False):
+        """defer_copy: only the scan is queued (and the point behind it marked on the caller's stream); the caller queues its
+        independent kernels next and then calls start_copy() -- the host-side set-up of the side-stream copy (~50 us of
+        Python and HIP calls) then runs while those kernels execute instead of in front of them."""
         lib = _l.load()
         self.N, self.dev = num_tiles_hit.shape[0], num_tiles_hit.device
         self.cum = torch.empty(self.N, device=self.dev, dtype=torch.int32)
+        self._value: Optional[int] = None
+        self._copy_started = False
         with _ctx(self.dev):
             ws0 = torch.empty(int(lib.unerf_splat_sort_workspace_bytes(self.N, 0)), device=self.dev, dtype=torch.uint8)
             _run("splat_count", lambda: lib.unerf_splat_count_intersects(_p(num_tiles_hit, torch.int32), self.N,
                                                                          _p(self.cum, torch.int32), _p(ws0, torch.uint8),
                                                                          ws0.numel(), _stream()))
             key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+            self._key = key
             if key not in SplatCount._side:
                 SplatCount._side[key] = torch.cuda.Stream(device=self.dev)
-            side = SplatCount._side[key]
             if key not in SplatCount._pinned:
                 SplatCount._pinned[key] = torch.empty(SplatCount.RING, dtype=torch.int32, pin_memory=True)
                 SplatCount._next[key], SplatCount._owner[key] = 0, [None] * SplatCount.RING
+                # one (scan done, copy done) event pair per ring word, made once: an event is reusable once awaited
+                SplatCount._events[key] = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(SplatCount.RING)]
             slot = SplatCount._next[key]
             prev = SplatCount._owner[key][slot]
             prev = prev() if prev is not None else None
@@ -1247,20 +1256,29 @@ class SplatCount:
             import weakref
             SplatCount._owner[key][slot] = weakref.ref(self)
             SplatCount._next[key] = (slot + 1) % SplatCount.RING
-            self._value: Optional[int] = None
             self._host = SplatCount._pinned[key][slot:slot + 1]
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream())
+            self._ready, self._done = SplatCount._events[key][slot]
+            self._ready.record(torch.cuda.current_stream())
+            self._ws0 = ws0     # keeps the scan's scratch alive until the count is known
+        if not defer_copy:
+            self.start_copy()
+
+    def start_copy(self) -> None:
+        """queue the read-back of the count on the side stream (behind the scan only)"""
+        if self._copy_started:
+            return
+        self._copy_started = True
+        side = SplatCount._side[self._key]
+        with _ctx(self.dev):
             with torch.cuda.stream(side):
-                side.wait_event(ready)
+                side.wait_event(self._ready)
                 self._host.copy_(self.cum[-1:], non_blocking=True)
-                self._done = torch.cuda.Event()
                 self._done.record(side)
             self.cum.record_stream(side)
-            self._ws0 = ws0     # keeps the scan's scratch alive until the count is known
 
     def wait(self) -> int:
         if self._value is None:
+            self.start_copy()
             self._done.synchronize()
             self._value = int(self._host[0])
         return self._value

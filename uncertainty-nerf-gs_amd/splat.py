@@ -96,7 +96,7 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     opac = proj[7] if tight else None
     # the intersection count (the frame's one host read-back) starts its way to the host now and is awaited inside
     # splat_bin_sort; the SH colours do not depend on it and keep the GPU busy meanwhile
-    count = ops.SplatCount(tiles)
+    count = ops.SplatCount(tiles, defer_copy=True)
     if config_sh_degree is not None and config_sh_degree <= 0:
         sh_degree = -1                                     # kernel: colours = sigmoid(features_dc)
     # the reference concatenates features_dc and features_rest first (:242-243); the kernel reads them in place
@@ -107,6 +107,7 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
                                          None if plain else gp["log_uncertainties"].reshape(-1).contiguous(), beta_min,
                                          None if tight else logits,
                                          comp if rasterize_mode == "antialiased" else None, depths)
+    count.start_copy()      # (its host-side set-up runs under the SH kernel just queued)
     opac = opac if tight else opac2
     # (self.radii).sum() == 0 -> get_empty_outputs (:239-240).  A splat has a non-zero radius exactly when it hits at
     # least one tile, so "no intersections" is the same test and rides on the one host read-back of the frame
