@@ -147,7 +147,7 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     for i in range(warmup):
         out = frame(i)
     sync_all()
-    ops.TIMER = ops.KernelTimer()
+    ops.TIMER = ops.KernelTimer(prealloc=64 * steps)
     gc.freeze()   # see _timed_region_gc
     t0 = time.perf_counter()
     marks = []
@@ -584,7 +584,7 @@ def bench_splat(args, rank, world, dev, dist, steps, warmup):
     for i in range(warmup):
         out = frame(i)
     sync_all()
-    ops.TIMER = ops.KernelTimer()
+    ops.TIMER = ops.KernelTimer(prealloc=32 * steps)
     gc.freeze()   # _timed_region_gc
     t0 = time.perf_counter()
     for i in range(steps):

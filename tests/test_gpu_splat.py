@@ -280,7 +280,10 @@ def test_full_size_splat_frame_properties(dev):
 
 
 @pytest.mark.parametrize("N,H,W,tight", [(6000, 48, 64, False), (6000, 48, 64, True), (300000, 600, 800, True),
-                                         (1_000_000, 1080, 1920, True), (1_000_000, 1080, 1920, False), (50, 1080, 1920, True)])
+                                         (1_000_000, 1080, 1920, True), (1_000_000, 1080, 1920, False), (50, 1080, 1920, True),
+                                         (20000, 176, 176, False),       # 121 tiles: the single-pass form with ~1 M pairs
+                                         (20000, 192, 192, True),        # 144 tiles: two passes with a 1-bit high digit
+                                         (3000, 2000, 3000, True)])      # 23,500 tiles: beyond the own sorts (rocprim)
 def test_one_pass_tile_sort_gives_the_radix_sorts_lists(dev, N, H, W, tight, monkeypatch):
     """unerf_splat_bin_sort's own tile sorts -- the default two-pass LSD sort (two digits of <= 7 bits, <= 128 write fronts
     per wave; one pass when the image has <= 127 tiles: the 48 x 64 cases) and the one-pass LDS-digit sort it replaced

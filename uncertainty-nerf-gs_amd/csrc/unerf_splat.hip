@@ -1198,6 +1198,7 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
     int rc = unerf_check_launch("splat_bin_sort map");
     if (rc) return rc;
     const int tiles = tbx * tby;
+    if (sizeof(TKey) != 2) own_sort = 0;      // (the own sorts serve <= TS_MAX_T1 tiles: always 16-bit keys; their LDS images are sized for them)
     if (own_sort == 2) {   // two staged LSD passes (rs_* kernels above)
         const int T1 = tiles + 1;
         const RsTilePlan rp = rs_tile_plan(I, T1);

@@ -31,8 +31,11 @@ class KernelTimer:
     """Optional per-entry-point timing with HIP events recorded on the launch stream (torch's current
     stream is the stream handed to libunerf).  bench.py uses it for the roofline figure."""
 
-    def __init__(self):
+    def __init__(self, prealloc: int = 0):
         self.events = {}
+        # event pairs made up front (hipEventCreate is the expensive half of an instrumented call: inside a ~1 ms frame of
+        # ~15 entry points it showed); _run takes from here and falls back to making its own
+        self.pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(prealloc)]
 
     def summary(self):
         torch.cuda.synchronize()
@@ -51,7 +54,7 @@ def _run(name: str, rc_fn):
     if TIMER is None:
         _l.check(rc_fn(), name)
         return
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a, b = TIMER.pool.pop() if TIMER.pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     a.record()
     rc = rc_fn()
     b.record()
