@@ -31,3 +31,34 @@ for kind, precs, grid in (("active", ("f16", "f16x2"), "torch"), ("mcdropout", (
         rows.append({"method": kind, "precision": prec, "grid": grid, "frames": N, "values_differing_from_first_frame": bad})
         print(json.dumps(rows[-1]))
     del sd
+
+# active-splatfacto, 1 M splats: the frame (staged depth and tile sorts, both rasteriser passes) and the sorted lists themselves
+from uncertainty_nerf_gs_amd import ops, splat
+gp = {k: v.to(dev) for k, v in synthetic.make_splat_tensors(seed=7, N=1_000_000).items()}
+bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+c2w = synthetic.orbit_c2w(0.7, radius=2.5, height=0.5)
+H, W = cam["H"], cam["W"]
+ref, bad = None, 0
+for rep in range(4 * N):
+    out = splat.active_splatfacto_outputs(gp, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, bg)
+    out = {k: v for k, v in out.items() if v is not None}
+    if ref is None:
+        ref = {k: v.clone() for k, v in out.items()}
+        continue
+    bad += sum(int((ref[k] != out[k]).sum()) for k in ref)
+rows.append({"method": "active-splatfacto frame", "frames": 4 * N, "values_differing_from_first_frame": bad})
+print(json.dumps(rows[-1]))
+V = splat.viewmat_from_c2w(c2w)
+pr = ops.splat_project(gp["means"], gp["scales"].contiguous(), 1.0, gp["quats"].contiguous(), V[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"],
+                       H, W, raw=True, opacity_logits=gp["opacities"].reshape(-1).contiguous())
+xys, depths, radii, conics, comp, tiles = pr[:6]
+ref, bad = None, 0
+for rep in range(4 * N):
+    I, _, keys, gids, bins = ops.splat_bin_sort(xys, depths, radii, tiles, H, W, tight=(conics, pr[7]))
+    cur = (keys.clone(), gids.clone(), bins.clone())
+    if ref is None:
+        ref = cur
+        continue
+    bad += sum(int((a != b).sum()) for a, b in zip(ref, cur))
+rows.append({"method": "unerf_splat_bin_sort (ids, lists, ranges)", "pairs": int(I), "calls": 4 * N, "values_differing_from_first_call": bad})
+print(json.dumps(rows[-1]))
