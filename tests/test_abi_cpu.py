@@ -26,7 +26,7 @@ def test_header_symbols_all_bound_and_exported(lib):
 
 def test_version_and_error_string(lib):
     h = lib.load()
-    assert h.unerf_version() == lib.ABI_VERSION == 1400
+    assert h.unerf_version() == lib.ABI_VERSION == 1410
     assert h.unerf_build_flags() & lib.BUILD_TRUNK_FOLD          # the shipped build folds the K-pass trunk-out slabs
     assert isinstance(h.unerf_last_error(), bytes)
 

@@ -345,6 +345,35 @@ def test_depth_sort_is_rocprims(dev, N, H, W, monkeypatch):
     assert torch.equal(bins, bins2) and torch.equal(gids, gids2) and torch.equal(keys, keys2)
 
 
+def test_normalize_outputs_equals_the_torch_calls_it_replaces(dev):
+    """unerf_splat_normalize_outputs (one pass: depth normalisation + rgb clamp + accumulation + uncertainty^2, and for the
+    second pass sqrt of the normalised channel) against unerf_splat_alpha_normalize + torch.clamp / 1 - T / ** 2 / sqrt
+    (activesplatfacto_model.py:275, 319, 356, 359-367): same bits, NaN, inf, values above 1 and alpha = 0 pixels included."""
+    from uncertainty_nerf_gs_amd import ops
+    H, W = 37, 53
+    g = torch.Generator().manual_seed(3)
+    img = (torch.rand(H, W, 5, generator=g) * 1.6).to(dev)
+    img[0, 0, 1] = float("nan"); img[0, 1, 2] = float("inf"); img[1, 0, 0] = -0.25; img[2, 2, 3] = float("nan")
+    fT = torch.rand(H, W, generator=g).to(dev)
+    fT[3, :] = 1.0                                     # alpha = 0: the channel maximum goes in
+    mx = img[..., 4].max().reshape(1).clone()
+    want_img = img.clone()
+    ops.splat_alpha_normalize(want_img, 4, fT, max_ready=mx)
+    want = (torch.clamp(img[..., 0:3], max=1.0), (1.0 - fT)[..., None], img[..., 3:4] ** 2, want_img[..., 4:5].sqrt())
+    got_img = img.clone()
+    rgb, acc, sq, _ = ops.splat_normalize_outputs(got_img, 4, fT, mx, rgb=True, acc=True, sq_ch=3)
+    assert torch.equal(got_img.nan_to_num(-7.0), want_img.nan_to_num(-7.0))
+    for a, b, name in ((rgb, want[0], "rgb"), (acc, want[1], "accumulation"), (sq, want[2], "rgb_var")):
+        assert a.shape == b.shape and torch.equal(a.nan_to_num(-7.0), b.nan_to_num(-7.0)), name
+    assert bool(torch.isnan(rgb[0, 0, 1])) and float(rgb[0, 1, 2]) == 1.0 and float(rgb[1, 0, 0]) == -0.25
+    one = img[..., 4:5].clone().contiguous()           # second pass: a one-channel image, sqrt of the normalised value
+    want1 = one.clone()
+    mx1 = one.max().reshape(1).clone()
+    ops.splat_alpha_normalize(want1, 0, fT, max_ready=mx1)
+    _, _, _, rt = ops.splat_normalize_outputs(one, 0, fT, mx1, sqrt=True)
+    assert torch.equal(one, want1) and torch.equal(rt, want1.sqrt())
+
+
 @pytest.mark.parametrize("C", [1, 5])
 def test_wave_level_culling_and_bounded_pass_change_no_bit(dev, C):
     """the default schedule (a wave walks only the splats whose alpha >= 1/255 ellipse reaches its 8 x 8 quadrant of the tile) against

@@ -1650,6 +1650,47 @@ extern "C" int unerf_splat_alpha_normalize(float* img, int stride, int ch, const
     return unerf_check_launch("splat_alpha_normalize");
 }
 
+// the frame's per-pixel epilogue in one pass (unerf_splat_normalize_outputs): the alpha normalisation of channel ch as above
+// plus the elementwise outputs the reference forms with torch calls around it
+__global__ __launch_bounds__(256) void norm_outputs_kernel(float* __restrict__ img, int stride, int ch,
+                                                           const float* __restrict__ finalT, int64_t HW,
+                                                           const float* __restrict__ mx, float* __restrict__ rgb_out,
+                                                           float* __restrict__ acc_out, int sq_ch, float* __restrict__ sq_out,
+                                                           float* __restrict__ sqrt_out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float alpha = 1.f - finalT[i];
+    const float v = img[i * stride + ch];
+    const float nv = (alpha > 0.f) ? v / alpha : mx[0];
+    img[i * stride + ch] = nv;
+    if (rgb_out) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = img[i * stride + c];
+            rgb_out[i * 3 + c] = x > 1.f ? 1.f : x;      // torch.clamp(max=1): a NaN stays a NaN
+        }
+    }
+    if (acc_out) acc_out[i] = alpha;
+    if (sq_out) {
+        const float u = img[i * stride + sq_ch];
+        sq_out[i] = u * u;
+    }
+    if (sqrt_out) sqrt_out[i] = sqrtf(nv);
+}
+
+extern "C" int unerf_splat_normalize_outputs(float* img, int stride, int ch, const float* final_T, int64_t HW,
+                                             const float* scratch_max, float* rgb_out, float* acc_out, int sq_ch,
+                                             float* sq_out, float* sqrt_out, void* stream) {
+    UNERF_REQUIRE(img && final_T && scratch_max, "splat_normalize_outputs: null pointer");
+    UNERF_REQUIRE(stride >= 1 && ch >= 0 && ch < stride && HW >= 0, "splat_normalize_outputs: bad stride/ch");
+    UNERF_REQUIRE(!rgb_out || (stride >= 3 && ch >= 3), "splat_normalize_outputs: rgb_out needs channels 0..2 beside channel ch");
+    UNERF_REQUIRE(!sq_out || (sq_ch >= 0 && sq_ch < stride && sq_ch != ch), "splat_normalize_outputs: bad sq_ch");
+    if (HW == 0) return UNERF_OK;
+    hipLaunchKernelGGL(norm_outputs_kernel, dim3(blocks_for(HW, 256)), dim3(256), 0, (hipStream_t)stream, img, stride, ch, final_T, HW,
+                       scratch_max, rgb_out, acc_out, sq_ch, sq_out, sqrt_out);
+    return unerf_check_launch("splat_normalize_outputs");
+}
+
 __global__ __launch_bounds__(256) void depth_sqdiff_kernel(const float* __restrict__ xys,
                                                            const float* __restrict__ depths,
                                                            const float* __restrict__ dimg, int stride, int ch, int H,

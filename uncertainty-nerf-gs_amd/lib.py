@@ -128,7 +128,7 @@ class FieldParams(C.Structure):
     ]
 
 
-ABI_VERSION = 1400                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
+ABI_VERSION = 1410                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
 SPACING_PIECEWISE, SPACING_UNIFORM = 0, 1         # include/unerf.h: UNERF_SPACING_*
 BG_LAST_SAMPLE, BG_NONE, BG_COLOR = 0, 1, 2       # include/unerf.h: UNERF_BG_*
@@ -180,6 +180,7 @@ SIGNATURES = {
     "unerf_splat_rasterize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
                                    _vp]),
     "unerf_splat_alpha_normalize": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i, _vp]),
+    "unerf_splat_normalize_outputs": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "unerf_splat_depth_sqdiff": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _vp, _vp]),
 }
 

@@ -1349,6 +1349,25 @@ def splat_alpha_normalize(img: torch.Tensor, ch: int, final_T: torch.Tensor, max
                                                                               0 if max_ready is None else 1, _stream()))
 
 
+def splat_normalize_outputs(img: torch.Tensor, ch: int, final_T: torch.Tensor, max_ready: torch.Tensor, rgb: bool = False,
+                            acc: bool = False, sq_ch: Optional[int] = None, sqrt: bool = False):
+    """splat_alpha_normalize(img, ch, final_T, max_ready) + the frame's elementwise outputs in the same pass:
+    -> (rgb [H,W,3] = clamp(img[..., :3], max=1) | None, accumulation [H,W,1] = 1 - final_T | None,
+        img[..., sq_ch] ** 2 [H,W,1] | None, sqrt(normalised channel) [H,W,1] | None) -- the bits of the torch calls they replace"""
+    lib = _l.load()
+    H, W, Cn = img.shape
+    dev = img.device
+    rgb_o = torch.empty(H, W, 3, device=dev) if rgb else None
+    acc_o = torch.empty(H, W, 1, device=dev) if acc else None
+    sq_o = torch.empty(H, W, 1, device=dev) if sq_ch is not None else None
+    sqrt_o = torch.empty(H, W, 1, device=dev) if sqrt else None
+    with _ctx(dev):
+        _run("splat_alpha_normalize", lambda: lib.unerf_splat_normalize_outputs(
+            _p(img), Cn, ch, _p(final_T), H * W, _p(max_ready), _p(rgb_o), _p(acc_o), -1 if sq_ch is None else sq_ch, _p(sq_o), _p(sqrt_o),
+            _stream()))
+    return rgb_o, acc_o, sq_o, sqrt_o
+
+
 def splat_depth_sqdiff(xys, depths, depth_img: torch.Tensor, ch: int) -> torch.Tensor:
     lib = _l.load()
     H, W, Cn = depth_img.shape

@@ -126,19 +126,19 @@ def active_splatfacto_outputs(gp: Dict[str, torch.Tensor], c2w: torch.Tensor, fx
     bg, mx1, mx2 = scratch[:Cn], scratch[Cn:Cn + 1], scratch[Cn + 1:Cn + 2]
     if plain:
         img, fT, _ = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg, block_width, chan_max=(3, mx1))
-        ops.splat_alpha_normalize(img, 3, fT, max_ready=mx1)       # depth = where(alpha > 0, d / alpha, max(d))
-        return {"rgb": torch.clamp(img[..., 0:3], max=1.0), "depth": img[..., 3:4], "accumulation": (1.0 - fT)[..., None],
-                "background": background}
+        # depth = where(alpha > 0, d / alpha, max(d)), rgb clamp and accumulation in one pass over the pixels
+        rgb, alpha, _, _ = ops.splat_normalize_outputs(img, 3, fT, mx1, rgb=True, acc=True)
+        return {"rgb": rgb, "depth": img[..., 3:4], "accumulation": alpha, "background": background}
     img, fT, fidx = ops.splat_rasterize(gids, bins, xys, conics, cols, opac, H, W, bg, block_width, want_final_idx=True,
                                         chan_max=(4, mx1))
-    alpha = (1.0 - fT)[..., None]
-    ops.splat_alpha_normalize(img, 4, fT, max_ready=mx1)   # depth = where(alpha>0, d/alpha, max(d))   (:319)
+    # depth = where(alpha>0, d/alpha, max(d)) (:319) + clamp(rgb, max=1) (:275), 1 - final_T, uncertainty^2 in the same pass
+    rgb, alpha, rgb_var, _ = ops.splat_normalize_outputs(img, 4, fT, mx1, rgb=True, acc=True, sq_ch=3)
     sq = ops.splat_depth_sqdiff(xys, depths, img, 4)       # (z_i - depth[floor(xy_i)])^2            (:325-341)
     # same ids / bins / geometry / opacities as the first pass: every pixel stops at the index that pass ended on
     dv, fT2, _ = ops.splat_rasterize(gids, bins, xys, conics, sq[:, None], opac, H, W, None, block_width,
                                      stop_idx=fidx, chan_max=(0, mx2))
-    ops.splat_alpha_normalize(dv, 0, fT2, max_ready=mx2)   # (:356)
+    _, _, _, dstd = ops.splat_normalize_outputs(dv, 0, fT2, mx2, sqrt=True)   # (:356) + depth_std = sqrt(depth_var)
     unc = img[..., 3:4]
-    return {"rgb": torch.clamp(img[..., 0:3], max=1.0), "depth": img[..., 4:5], "accumulation": alpha,
-            "background": background, "uncertainty": unc, "rgb_var": unc ** 2, "rgb_std": unc,
-            "depth_var": dv, "depth_std": dv.sqrt()}
+    return {"rgb": rgb, "depth": img[..., 4:5], "accumulation": alpha,
+            "background": background, "uncertainty": unc, "rgb_var": rgb_var, "rgb_std": unc,
+            "depth_var": dv, "depth_std": dstd}
