@@ -17,7 +17,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    if any(k in n for k in ("tile_scatter", "rs_scatter", "rs_hist", "map_intersects", "sorted_counts")):
+    if any(k in n for k in ("tile_scatter", "rs_scatter", "rs_hist", "map_intersects", "sorted_counts", "raster_kernel")):
         acc[n.split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for n, c in acc.items():
     print(n, {k: round(sum(v) / len(v)) for k, v in c.items()})

@@ -936,6 +936,15 @@ __global__ __launch_bounds__(64) void tile_scatter_kernel(const TKey* __restrict
 // lane keeps the lanes that agree with it on every bit); the lowest takes the slots for all with one LDS atomic, the others
 // add their position among the peers -- stream order, i.e. stable.  Same lists as the one-pass sort, rocprim's radix sort
 // (tile) and rocprim's stable sort (depth), bit for bit (tests/test_gpu_splat.py).
+// One wave talks to itself through LDS in these kernels (lane A's atomic, lane B's read of the same word).  The LDS executes a
+// wave's instructions in program order, so no wait is needed -- this only tells the COMPILER that the accesses on either side
+// may not change places (wavefront-scope fences emit no instruction).
+__device__ __forceinline__ void rs_wave_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename TKey, bool FULL>
 __global__ __launch_bounds__(1024) void rs_hist_kernel(const TKey* __restrict__ keys, int64_t n, int chunk, int nchunk, uint32_t kmax,
                                                       int shift, int B, int cpw, uint32_t* __restrict__ table, uint32_t* __restrict__ full) {
@@ -986,7 +995,7 @@ __global__ __launch_bounds__(1024) void rs_hist_kernel(const TKey* __restrict__ 
             }
         }
         for (int64_t k = k0 + nvec * PER + lane; k < k1; k += 64) count((uint32_t)keys[k]);
-        // (one wave: the LDS executes its operations in program order, the reads below see every atomic above)
+        rs_wave_order();      // (the reads below see every atomic above)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (lane + 64 * i < B) table[(size_t)(lane + 64 * i) * nchunk + c] = dig[lane + 64 * i];
@@ -1104,6 +1113,7 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const TKey* __restrict_
             gb += tot[i];
             lb += cnt[i];
         }
+        rs_wave_order();
     }
     const int64_t k0 = (int64_t)c * M;
     const int m = (int)((n - k0 < M) ? n - k0 : M);       // pairs of this chunk
@@ -1131,6 +1141,7 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const TKey* __restrict_
             kq[i] = key[g + i] < kmax ? key[g + i] : kmax;
             d[i] = (kq[i] >> shift) & dmask;
             atomicOr(&pw[2 * d[i] + half], valid[i] ? mybit : 0u);
+            rs_wave_order();
             peers[i] = *reinterpret_cast<const uint2*>(&pw[2 * d[i]]);
             *reinterpret_cast<uint2*>(&pw[2 * d[i]]) = make_uint2(0u, 0u);
         }
@@ -1149,7 +1160,7 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const TKey* __restrict_
             }
         }
     }
-    // (one wave: the LDS executes its operations in program order)
+    rs_wave_order();      // the staged order is complete
 #pragma unroll 4
     for (int j = 0; j < M / 64; ++j) {
         const int slot = 64 * j + lane;
@@ -1211,7 +1222,7 @@ static int bin_sort_impl(const float* xys, const float* depths, const int32_t* r
         uint32_t* start = reinterpret_cast<uint32_t*>(ws + L.ts_start);
         TKey* tk_mid = tk_out;
         int32_t* v_mid = reinterpret_cast<int32_t*>(ws + L.val_mid);
-        const int swpb = getenv("UNERF_RS_WPB") ? atoi(getenv("UNERF_RS_WPB")) : 1, sgrid = (rp.nchunk + swpb - 1) / swpb;
+        const int swpb = 1, sgrid = (rp.nchunk + swpb - 1) / swpb;      // single-wave workgroups (1, 2 or 4 waves measured alike: 4.5.77)
         const uint32_t kmax = (uint32_t)tiles;
         const size_t lds_full = (16 * 256 + (size_t)T1) * sizeof(uint32_t), lds_dig = 1024 * sizeof(uint32_t);
         const int hgrid = (rp.nchunk + 3) / 4;      // digit-only histogram: one chunk per wave, four waves per workgroup
