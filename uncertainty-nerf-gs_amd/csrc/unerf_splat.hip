@@ -1433,9 +1433,9 @@ __device__ __forceinline__ uint32_t raster_quad_mask(float x, float y, float op,
 template <int C, bool BOUNDED>
 __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
     // one 16-byte + one 8-byte broadcast read per splat instead of six 4-byte ones
-    __shared__ float4 s_geo[256];  // x, y, opacity, conic a
-    __shared__ float2 s_bc[256];   // conic b, c
-    __shared__ float s_col[256 * C];
+    // one record per staged splat, REC4 16-byte words: [x, y, opacity, conic a | conic b, c, colour 0, 1 | colour 2 ...]
+    constexpr int REC4 = (6 + C + 3) / 4;
+    __shared__ float4 s_rec[256 * REC4];
     __shared__ uint8_t s_mask[256];
     __shared__ uint16_t s_list[4][256];
     const int bw = a.bw;
@@ -1483,19 +1483,21 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
             int g = a.ids[idx];
             const float x = a.xys[g * 2], y = a.xys[g * 2 + 1], op = a.opac[g];
             const float ca = a.conics[g * 3], cb = a.conics[g * 3 + 1], cc = a.conics[g * 3 + 2];
-            s_geo[tr] = make_float4(x, y, op, ca);
-            s_bc[tr] = make_float2(cb, cc);
-            // the colour row: 16-byte loads where it has the length (rows of C floats are 4-byte aligned only: the packed
-            // type makes them alignment-4 dwordx4 loads), dwords for the rest -- one + one for the 5-channel row
             struct __attribute__((packed, aligned(4))) Q4 { float x, y, z, w; };
             const float* crow = a.colors + (int64_t)g * C;
+            float rec[4 * REC4];
+            rec[0] = x; rec[1] = y; rec[2] = op; rec[3] = ca; rec[4] = cb; rec[5] = cc;
 #pragma unroll
             for (int c4 = 0; c4 + 4 <= C; c4 += 4) {
                 const Q4 q = *reinterpret_cast<const Q4*>(crow + c4);
-                s_col[tr * C + c4] = q.x; s_col[tr * C + c4 + 1] = q.y; s_col[tr * C + c4 + 2] = q.z; s_col[tr * C + c4 + 3] = q.w;
+                rec[6 + c4] = q.x; rec[7 + c4] = q.y; rec[8 + c4] = q.z; rec[9 + c4] = q.w;
             }
 #pragma unroll
-            for (int c = C & ~3; c < C; ++c) s_col[tr * C + c] = crow[c];
+            for (int c = C & ~3; c < C; ++c) rec[6 + c] = crow[c];
+#pragma unroll
+            for (int c = 6 + C; c < 4 * REC4; ++c) rec[c] = 0.f;
+#pragma unroll
+            for (int q = 0; q < REC4; ++q) s_rec[tr * REC4 + q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
             if (cull) s_mask[tr] = (uint8_t)raster_quad_mask(x, y, op, ca, cb, cc, tile_x0, tile_y0);
         }
         __syncthreads();
@@ -1514,29 +1516,56 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is read back by this wave only
             __builtin_amdgcn_wave_barrier();
         }
-        for (int k = 0; k < n_mine && !done; ++k) {
-            const int t = cull ? (int)s_list[wv][k] : k;
-            if (BOUNDED && start + t > stop) {   // past this pixel's last blended splat of the first pass
-                done = true;
-                break;
-            }
-            const float4 ge = s_geo[t];
-            const float2 bc = s_bc[t];
-            float dx = ge.x - px, dy = ge.y - py, op = ge.z;
-            float ca = ge.w, cb = bc.x, cc = bc.y;
-            float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-            float alpha = fminf(0.999f, op * __expf(-sigma));
-            if (sigma < 0.f || alpha < 1.f / 255.f) continue;
-            float nT = T * (1.f - alpha);
-            if (!BOUNDED && nT <= 1e-4f) {
-                done = true;
-                break;
-            }
-            float vis = alpha * T;
+        // Hand-pipelined walk, two splats per trip: the record of splat k + 1 and the list entries of k + 2, k + 3 are requested
+        // before splat k is blended, so no blend waits for an LDS round trip (the chain list entry -> record -> colours was three
+        // of them per visited splat, on the critical path of the tile's slowest quadrant).
+        struct Rec { float v[4 * REC4]; };
+        auto load_rec = [&](int t, Rec& r) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) pix[c] += s_col[t * C + c] * vis;
-            T = nT;
-            cur_idx = start + t;
+            for (int q = 0; q < REC4; ++q) {
+                const float4 w = s_rec[t * REC4 + q];
+                r.v[4 * q] = w.x; r.v[4 * q + 1] = w.y; r.v[4 * q + 2] = w.z; r.v[4 * q + 3] = w.w;
+            }
+        };
+        auto entry = [&](int k) { const int kk = k < n_mine ? k : n_mine - 1; return cull ? (int)s_list[wv][kk] : kk; };
+        auto blend = [&](const Rec& r, int t) {
+            if (!done) {
+                if (BOUNDED && start + t > stop) {   // past this pixel's last blended splat of the first pass
+                    done = true;
+                } else {
+                    float dx = r.v[0] - px, dy = r.v[1] - py, op = r.v[2];
+                    float ca = r.v[3], cb = r.v[4], cc = r.v[5];
+                    float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                    float alpha = fminf(0.999f, op * __expf(-sigma));
+                    if (!(sigma < 0.f || alpha < 1.f / 255.f)) {
+                        float nT = T * (1.f - alpha);
+                        if (!BOUNDED && nT <= 1e-4f) {
+                            done = true;
+                        } else {
+                            float vis = alpha * T;
+#pragma unroll
+                            for (int c = 0; c < C; ++c) pix[c] += r.v[6 + c] * vis;
+                            T = nT;
+                            cur_idx = start + t;
+                        }
+                    }
+                }
+            }
+        };
+        if (n_mine > 0) {
+            Rec ra, rb;
+            int ta = entry(0), tb = entry(1);
+            load_rec(ta, ra);
+            for (int k = 0; k < n_mine; k += 2) {
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;     // uniform: every pixel of this wave has finished
+                load_rec(tb, rb);
+                const int ta2 = entry(k + 2), tb2 = entry(k + 3);
+                blend(ra, ta);
+                load_rec(ta2, ra);
+                if (k + 1 < n_mine) blend(rb, tb);
+                ta = ta2;
+                tb = tb2;
+            }
         }
     }
     float vmax = 0.f;
