@@ -345,6 +345,21 @@ def test_depth_sort_is_rocprims(dev, N, H, W, monkeypatch):
     assert torch.equal(bins, bins2) and torch.equal(gids, gids2) and torch.equal(keys, keys2)
 
 
+@pytest.mark.parametrize("N", [1, 5, 1023, 1024, 1025, 4097, 1_000_003])
+def test_count_intersects_scan(dev, N, monkeypatch):
+    """unerf_splat_count_intersects' own two-launch inclusive scan (block sums, then every block behind the sum of the blocks
+    before it) against torch.cumsum and against hipcub's scan (UNERF_SPLAT_SCAN=rocprim), ragged sizes included"""
+    from uncertainty_nerf_gs_amd import ops
+    g = torch.Generator().manual_seed(N)
+    tiles = torch.randint(0, 60, (N,), generator=g, dtype=torch.int32).to(dev)
+    want = torch.cumsum(tiles.long(), 0).to(torch.int32)
+    c = ops.SplatCount(tiles)
+    assert c.wait() == int(want[-1]) and torch.equal(c.cum, want)
+    monkeypatch.setenv("UNERF_SPLAT_SCAN", "rocprim")
+    c2 = ops.SplatCount(tiles)
+    assert c2.wait() == int(want[-1]) and torch.equal(c2.cum, want)
+
+
 def test_normalize_outputs_equals_the_torch_calls_it_replaces(dev):
     """unerf_splat_normalize_outputs (one pass: depth normalisation + rgb clamp + accumulation + uncertainty^2, and for the
     second pass sqrt of the normalised channel) against unerf_splat_alpha_normalize + torch.clamp / 1 - T / ** 2 / sqrt

@@ -474,6 +474,7 @@ extern "C" int unerf_splat_shade_inputs(int degree, const float* means3d, const 
 // bin and sort (once per frame)
 // ======================================================================================
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+#define SCAN_BLOCK 1024    // own_inclusive_scan: elements per workgroup
 #define TS_SEG 32          // one-pass tile sort (below): the prefix over chunks runs in 32 independent row segments
 #define TS_MAX_T1 12000    // tiles + 1 sentinel: the whole-key counters + 16 waves' digit counters must fit 64 KB of LDS (beyond: rocprim)
 struct TileSortPlan {
@@ -548,6 +549,8 @@ static SortWs sort_ws_layout(int64_t N, int64_t I) {
     (void)hipGetLastError();
     size_t tmp = scan_tmp > sortN_tmp ? scan_tmp : sortN_tmp;
     tmp = tmp > sortI_tmp ? tmp : sortI_tmp;
+    const size_t own_scan = (size_t)((N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4;      // own_inclusive_scan's block sums
+    tmp = tmp > own_scan ? tmp : own_scan;
     SortWs w;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off += align256(bytes); return o; };
@@ -574,10 +577,78 @@ extern "C" int64_t unerf_splat_sort_workspace_bytes(int64_t N, int64_t I) {
     return sort_ws_layout(N, I).total;
 }
 
+// ---- inclusive scan of N int32 in two launches -------------------------------------------------------------------------------
+// (rocprim's look-back scan is three launches of 4 - 8 us for the 4 MB the frame scans twice: the tile counts in splat order and
+// again in depth order.)  Blocks of 1,024 elements: (1) block sums; (2) every block adds up the sums of the blocks before it
+// (at most N / 1024 values) and scans its own elements behind that.  Integer sums: the same numbers whatever the order.
+__global__ __launch_bounds__(256) void scan_sums_kernel(const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ bsum) {
+    __shared__ int32_t s_w[4];
+    const int64_t e0 = (int64_t)blockIdx.x * SCAN_BLOCK + 4 * threadIdx.x;
+    int32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v += (e0 + i < n) ? in[e0 + i] : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ bsum,
+                                                         int32_t* __restrict__ out) {
+    __shared__ int32_t s_w[4], s_p[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int32_t before = 0;      // sum of the earlier blocks' sums
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += bsum[b];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) before += __shfl_xor(before, m, 64);
+    const int64_t e0 = (int64_t)blockIdx.x * SCAN_BLOCK + 4 * threadIdx.x;
+    int32_t x[4], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = (e0 + i < n) ? in[e0 + i] : 0;
+        mine += x[i];
+    }
+    int32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    if (lane == 0) s_p[wv] = before;
+    __syncthreads();
+    int32_t run = s_p[0] + s_p[1] + s_p[2] + s_p[3] + incl - mine;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) run += w < wv ? s_w[w] : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        run += x[i];
+        if (e0 + i < n) out[e0 + i] = run;
+    }
+}
+
+// bsum: (n + 1023) / 1024 int32 of scratch
+static void own_inclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* bsum, hipStream_t st) {
+    const unsigned nb = blocks_for(n, SCAN_BLOCK);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, st, in, n, bsum);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, in, n, bsum, out);
+}
+static bool use_rocprim_scan() {
+    const char* env = getenv("UNERF_SPLAT_SCAN");
+    return env && strcmp(env, "rocprim") == 0;
+}
+
 extern "C" int unerf_splat_count_intersects(const int32_t* num_tiles_hit, int64_t N, int32_t* cum_tiles_hit,
                                             void* workspace, int64_t workspace_bytes, void* stream) {
     UNERF_REQUIRE(num_tiles_hit && cum_tiles_hit && workspace, "splat_count_intersects: null pointer");
     UNERF_REQUIRE(N >= 1 && N < (1ll << 31), "splat_count_intersects: bad N");
+    UNERF_REQUIRE(workspace_bytes >= (int64_t)blocks_for(N, SCAN_BLOCK) * 4, "splat_count_intersects: workspace %lld bytes too small",
+                  (long long)workspace_bytes);
+    if (!use_rocprim_scan()) {      // (UNERF_SPLAT_SCAN=rocprim: hipcub's scan, for A/B runs)
+        own_inclusive_scan(num_tiles_hit, cum_tiles_hit, N, reinterpret_cast<int32_t*>(workspace), (hipStream_t)stream);
+        return unerf_check_launch("splat_count_intersects");
+    }
     size_t tmp = (size_t)workspace_bytes;
     hipError_t e = hipcub::DeviceScan::InclusiveSum(workspace, tmp, num_tiles_hit, cum_tiles_hit, (int)N,
                                                     (hipStream_t)stream);
@@ -1353,10 +1424,14 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
         hipLaunchKernelGGL(sorted_counts_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, order, radii, cum_tiles_hit, N,
                            counts);
     tmp_bytes = (size_t)(L.dkey_in - L.tmp);
-    e = hipcub::DeviceScan::InclusiveSum(ws + L.tmp, tmp_bytes, counts, cum_sorted, (int)N, st);
-    if (e != hipSuccess) {
-        unerf_set_error("splat_bin_sort: scan: %s", hipGetErrorString(e));
-        return UNERF_ERR_HIP;
+    if (!use_rocprim_scan()) {
+        own_inclusive_scan(counts, cum_sorted, N, reinterpret_cast<int32_t*>(ws + L.tmp), st);
+    } else {
+        e = hipcub::DeviceScan::InclusiveSum(ws + L.tmp, tmp_bytes, counts, cum_sorted, (int)N, st);
+        if (e != hipSuccess) {
+            unerf_set_error("splat_bin_sort: scan: %s", hipGetErrorString(e));
+            return UNERF_ERR_HIP;
+        }
     }
     // 3. emit in depth order, stable sort by tile (one LDS-digit pass when the tile counters fit a wave's LDS, rocprim's
     // radix sort otherwise or when UNERF_SPLAT_TILE_SORT=radix asks for it -- A/B timing), tile ranges + ids
