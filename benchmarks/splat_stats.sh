@@ -9,7 +9,7 @@ python3 - "$f" <<PY
 import csv,sys
 tot = 0.0
 for r in list(csv.DictReader(open(sys.argv[1]))):
-    if any(k in r["Name"] for k in ("rs_","sorted_counts","depth_keys","tile_","map_inter","rocprim")):
+    if any(k in r["Name"] for k in ("rs_","sorted_counts","depth_keys","tile_","map_inter","rocprim","project_kernel","scan_")):
         per_frame = float(r["AverageNs"]) * int(r["Calls"]) / 6 / 1e3
         tot += per_frame
         print(r["Name"][:80].ljust(80), r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us; per frame", round(per_frame, 1))

@@ -132,30 +132,23 @@ template <bool RAW>
 __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.N) return;
-    // gsplat allocates every output zero-filled; culled splats keep zeros
-    a.radii[i] = 0;
-    a.tiles[i] = 0;
-    a.xys[i * 2] = 0.f;
-    a.xys[i * 2 + 1] = 0.f;
-    a.depths[i] = 0.f;
-    a.comp[i] = 0.f;
-    a.conics[i * 3] = 0.f;
-    a.conics[i * 3 + 1] = 0.f;
-    a.conics[i * 3 + 2] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) a.cov3d[i * 6 + k] = 0.f;
-    float opac = 0.f;
+    // gsplat allocates every output zero-filled and a culled splat keeps the zeros of whatever it had not reached yet.  Every
+    // output is held in a register (zero until computed) and stored ONCE at the end -- zero-filling the 15 dwords first and
+    // overwriting them for visible splats wrote the arrays twice (WRITE_SIZE 119 MB for 60 MB of outputs).
+    float o_xy[2] = {0.f, 0.f}, o_depth = 0.f, o_comp = 0.f, o_conic[3] = {0.f, 0.f, 0.f}, o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int o_radius = 0, o_tiles = 0;
+    float opac = 0.f, o_opac = 0.f;
     if (a.opl) {   // uniform.  sigmoid(opacities) (:256); "antialiased" multiplies the compensation in below (:252-254)
         opac = unerf_sigmoid(a.opl[i]);
-        a.opac_out[i] = a.antialiased ? 0.f : opac;
+        o_opac = a.antialiased ? 0.f : opac;
     }
-
+    auto per_splat = [&]() {
     const float p0 = a.means[i * 3], p1 = a.means[i * 3 + 1], p2 = a.means[i * 3 + 2];
     const float* V = a.V;
     float tx = ((V[0] * p0 + V[1] * p1) + V[2] * p2) + V[3];
     float ty = ((V[4] * p0 + V[5] * p1) + V[6] * p2) + V[7];
     float tz = ((V[8] * p0 + V[9] * p1) + V[10] * p2) + V[11];
-    if (tz <= a.clip) return;
+    if (tz <= a.clip) return;      // (leaves the lambda: the stores are below)
 
     // scale_rot_to_cov3d
     float qw = a.quats[i * 4], qx = a.quats[i * 4 + 1], qy = a.quats[i * 4 + 2], qz = a.quats[i * 4 + 3];
@@ -184,12 +177,7 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             Sg[r * 3 + c] = (M[r * 3] * M[c * 3] + M[r * 3 + 1] * M[c * 3 + 1]) + M[r * 3 + 2] * M[c * 3 + 2];
-    a.cov3d[i * 6 + 0] = Sg[0];
-    a.cov3d[i * 6 + 1] = Sg[1];
-    a.cov3d[i * 6 + 2] = Sg[2];
-    a.cov3d[i * 6 + 3] = Sg[4];
-    a.cov3d[i * 6 + 4] = Sg[5];
-    a.cov3d[i * 6 + 5] = Sg[8];
+    o_cov[0] = Sg[0]; o_cov[1] = Sg[1]; o_cov[2] = Sg[2]; o_cov[3] = Sg[4]; o_cov[4] = Sg[5]; o_cov[5] = Sg[8];
     // symmetric V from the 6 stored entries (as gsplat rebuilds it)
     float C3[9] = {Sg[0], Sg[1], Sg[2], Sg[1], Sg[4], Sg[5], Sg[2], Sg[5], Sg[8]};
 
@@ -222,9 +210,9 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
     // compute_cov2d_bounds
     if (det == 0.f) return;
     float inv_det = 1.f / det;
-    a.conics[i * 3 + 0] = cc * inv_det;
-    a.conics[i * 3 + 1] = -cb * inv_det;
-    a.conics[i * 3 + 2] = ca * inv_det;
+    o_conic[0] = cc * inv_det;
+    o_conic[1] = -cb * inv_det;
+    o_conic[2] = ca * inv_det;
     float bh = 0.5f * (ca + cc);
     float sq = sqrtf(fmaxf(0.1f, bh * bh - det));
     float v1 = bh + sq, v2 = bh - sq;
@@ -240,16 +228,29 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a) {
     if (a.opl) {
         if (a.antialiased) {
             opac = opac * comp;
-            a.opac_out[i] = opac;
+            o_opac = opac;
         }
         area = tight_count(tight_splat(u, v, opac, cc * inv_det, -cb * inv_det, ca * inv_det), a.bw, x0, y0, x1, y1);
     }
-    a.tiles[i] = area;
-    a.depths[i] = tz;
-    a.radii[i] = (int)radius;
-    a.xys[i * 2] = u;
-    a.xys[i * 2 + 1] = v;
-    a.comp[i] = comp;
+    o_tiles = area;
+    o_depth = tz;
+    o_radius = (int)radius;
+    o_xy[0] = u;
+    o_xy[1] = v;
+    o_comp = comp;
+    };
+    per_splat();
+    a.radii[i] = o_radius;
+    a.tiles[i] = o_tiles;
+    a.xys[i * 2] = o_xy[0];
+    a.xys[i * 2 + 1] = o_xy[1];
+    a.depths[i] = o_depth;
+    a.comp[i] = o_comp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.conics[i * 3 + c] = o_conic[c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a.cov3d[i * 6 + c] = o_cov[c];
+    if (a.opl) a.opac_out[i] = o_opac;
 }
 
 static int splat_project_impl(bool raw, const float* opacity_logits, int antialiased, float* opacities_out,
@@ -528,9 +529,11 @@ static int tile_bits(int H, int W, int bw) {   // bits of the largest key: tiles
 // tile id (13 bits at 1080p, 16-bit keys): two 6-byte-per-entry radix passes over the I intersections
 // instead of six 12-byte passes over 64-bit (tile | depth) keys.  Same final order, bit for bit: ties in
 // depth keep the splat-index order in both schemes.
-// (The depth sort stays on rocprim's default dispatch -- a merge sort up to 2^20 items, where a 1 M-splat scene sits.
-// Forcing Onesweep there is 137 us against 162 for the sort alone (benchmarks/exp_depth_sort.hip), and its histogram
-// kernel and per-pass hipMemsetAsync calls give the difference back inside the frame: measured net zero twice.)
+// (rocprim's default dispatch for the depth sort -- kept behind UNERF_SPLAT_DEPTH_SORT=rocprim -- is a merge sort up to 2^20
+// items, where a 1 M-splat scene sits; forcing its Onesweep there was 137 us against 162 for the sort alone
+// (benchmarks/exp_depth_sort.hip), net zero inside the frame.  The default is the four staged LSD passes of rs_scatter_kernel;
+// making the keys inside the first pass instead of in depth_keys_kernel was measured too: +8 us, its histogram loses the
+// 16-byte key loads.)
 static hipError_t depth_sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const int32_t* vin,
                                    int32_t* vout, int64_t n, hipStream_t st) {
     return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, st);
@@ -1433,8 +1436,9 @@ extern "C" int unerf_splat_bin_sort(const float* xys, const float* depths, const
             return UNERF_ERR_HIP;
         }
     }
-    // 3. emit in depth order, stable sort by tile (one LDS-digit pass when the tile counters fit a wave's LDS, rocprim's
-    // radix sort otherwise or when UNERF_SPLAT_TILE_SORT=radix asks for it -- A/B timing), tile ranges + ids
+    // 3. emit in depth order, stable sort by tile (two staged LSD passes when the image has <= TS_MAX_T1 - 1 tiles; rocprim's
+    // radix sort beyond that or when UNERF_SPLAT_TILE_SORT=radix asks for it, the round-4 one-pass sort with =onepass: A/B
+    // timing and the identity tests), tile ranges + ids
     const int bits = tile_bits(H, W, block_width);      // (the sentinel tile `tbx * tby` included)
     const char* env = getenv("UNERF_SPLAT_TILE_SORT");
     int own_sort = 0;      // 0: rocprim radix sort, 1: one-pass LDS-digit sort, 2: two-pass LSD sort (default)
