@@ -62,7 +62,7 @@ def _depth_gt(ref_depth):
 # below what the arithmetic explains, and are then compared as ties (the oracle's value on both sides).
 # What the arithmetic explains: scan order and the ~1e-6 sample-position differences between the two pipelines
 # (test_active_nerfacto_camera_parity) move a weight by delta x density x that difference -- measured worst margins of
-# differing medians over the whole suite (profiles/r5_12_parity_report.jsonl, 76 gated cases): 2.9e-4 in the fp32-equivalent
+# differing medians over the whole suite (profiles/r5_13_parity_report.jsonl, 76 gated cases): 2.9e-4 in the fp32-equivalent
 # arithmetics (mc-dropout at the BASELINE size: 8 chances per ray), 5.4e-4 at precision "f16" (half-grid mc-dropout).
 # TIE_MARGIN is that with a factor of ~1.8 (round 4 carried 1e-3 for every precision); the trained-like stress scene
 # (densities up to e^12: the same position difference moves a weight a thousand times further; measured worst 3.0e-3)
