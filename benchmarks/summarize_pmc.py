@@ -50,7 +50,7 @@ FIELD_KERNELS = {"active": ("field_kernel_mfma16<0, 0, false, false, false", "fi
 # the kernels of one unerf_splat_bin_sort call (substrings of the short names)
 SORT_KERNELS = ("depth_keys_kernel", "sorted_counts_kernel", "map_intersects_kernel", "tile_hist_kernel", "tile_colsum_kernel",
                 "tile_segscan_kernel", "tile_scan_kernel", "tile_apply_kernel", "tile_scatter_kernel", "tile_edges_kernel",
-                "rs_hist_kernel", "rs_rowscan_kernel", "rs_scatter_kernel", "rs_colsum_kernel",
+                "rs_hist_kernel", "rs_rowscan_kernel", "rs_scatter_kernel", "rs_colsum_kernel", "scan_sums_kernel", "scan_apply_kernel",
                 "merge_sort", "radix_sort", "onesweep", "scan_config", "lookback_scan")
 # further kernels of a profile that get their own issue_<name>.json (same definition)
 EXTRA_ISSUE = {"laplace": {"lap_depth": ("lap_depth_kernel<3",)}, "splat": {"splat_raster1": ("raster_kernel<1",)}}
