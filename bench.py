@@ -71,16 +71,20 @@ def _alg(kind, K, row_bytes=8):
 REFERENCE_PRECISION = {"mcdropout": "f16", "active": "f16", "laplace": "f16x2"}
 DTYPE_OF = {"f16": "f16 operands, f32 accumulate", "f16x2": "f32 (split-f16 operands, f32-equivalent)", "fp32": "f32"}
 STALE_PROFILES = []            # issue / traffic profiles under profiles/ that were taken from other kernel sources
+# shader cycles per wave64 instruction on one SIMD, measured by benchmarks/issue_sweep_probe.hip with s_memtime
+# (profiles/r6_issue_sweep.jsonl): a VALU instruction of the packed / converting / VOP3 kind 4.0 - 4.2 at 1 - 3 waves per
+# SIMD (plain VOP2 add / mul / and on registers: 2.1 at two waves, 1.4 at three); a v_mfma_f32_32x32x16_f16 holds the issue
+# for ~10 cycles and the matrix pipe for 32, and up to six VALU instructions ride in the remaining 22 for 0.25 - 0.5 each
+ISSUE_CYC_VALU, ISSUE_CYC_MFMA, MATRIX_CYC_MFMA = 4.0, 10.0, 32.0
 ISSUE_PEAK_GCYC = 1024 * 2.4   # 256 CUs x 4 SIMDs x 2.4 GHz peak engine clock: issue cycles per nanosecond x 1e9
 
 
 def _issue_profile(method, K):
     """Instruction-issue cycles of the field kernel per launch, from the committed rocprofv3 --pmc pass of this
-    command (profiles/issue_<method>.json, written by benchmarks/summarize_pmc.py): on gfx950 MFMA and VALU
-    instructions share one issue pipe per SIMD and never overlap (benchmarks/mfma_valu_overlap_probe.hip), so
-    4 cycles per VALU instruction + 32 per f16 MFMA, with the exact instruction counts SQ_INSTS_VALU / SQ_INSTS_MFMA,
-    is the work the instruction stream needs -- a property of the code (not of the clock it ran at), and a lower
-    bound (instructions that hold the pipe for two slots are counted as one)."""
+    command (profiles/issue_<method>.json, written by benchmarks/summarize_pmc.py): the exact instruction counts
+    SQ_INSTS_VALU / SQ_INSTS_MFMA.  They are priced in run_nerf with the constants benchmarks/issue_sweep_probe.hip measured
+    (ISSUE_CYC_VALU, ISSUE_CYC_MFMA, MATRIX_CYC_MFMA): the issue lane and the matrix lane of a SIMD run side by side, the
+    launch needs the larger of the two -- a property of the code, not of the clock it ran at."""
     f = os.path.join(ROOT, "profiles", f"issue_{method}.json")
     if not os.path.exists(f):
         return None
@@ -247,22 +251,34 @@ def run_nerf(args, method, K, steps, warmup, rank, world, dev, dist, exact_check
     prof = _issue_profile(method + ("_f16" if single else "") + grid_tag, K) if dom == "field_fwd" and (split or single) else None
     roof["issue_roofline"] = None
     if prof is not None:
-        # the roof that binds: instruction issue (VALU + MFMA share one pipe per SIMD).  achieved = issue cycles the
-        # launch's instruction stream needs (PMC, per launch of prof["rays_per_launch"] rays) / live launch duration;
-        # peak = every SIMD issuing every cycle at the peak engine clock.
-        cyc = prof["issue_cycles_per_launch"] * rays_per_launch / prof["rays_per_launch"]
+        # the roof that binds: instruction issue.  achieved = cycles the launch's instruction stream needs on the busier of
+        # a SIMD's two lanes (PMC instruction counts per launch of prof["rays_per_launch"] rays, probe prices) / live launch
+        # duration; peak = every SIMD busy every cycle at the peak engine clock.
+        sc = rays_per_launch / prof["rays_per_launch"]
+        lane_issue = (ISSUE_CYC_VALU * prof["valu_insts_per_launch"] + ISSUE_CYC_MFMA * prof["mfma_insts_per_launch"]) * sc
+        lane_matrix = MATRIX_CYC_MFMA * prof["mfma_insts_per_launch"] * sc
+        cyc = max(lane_issue, lane_matrix)
         ach = cyc / avg_s / 1e9
+        clock = prof.get("engine_clock_GHz_under_profiler")
         roof["issue_roofline"] = {
-            "bound": "valu-issue", "achieved": ach, "peak": ISSUE_PEAK_GCYC, "unit": "Gcycle/s", "frac": ach / ISSUE_PEAK_GCYC,
-            "note": "VALU and MFMA instructions share one issue pipe per SIMD on gfx950 and do not overlap "
-                    "(benchmarks/mfma_valu_overlap_probe.hip); achieved = (4 x VALU instructions + 32 x f16 MFMAs) of one "
-                    "launch, exact counts from the committed PMC pass, over the live launch time; peak = 1024 SIMDs x "
-                    "2.4 GHz.  The flat price of 4 cycles per VALU instruction is what packed / converting / integer-multiply "
-                    "/ SGPR-operand forms cost; plain fp32 add / mul / fma, and / xor / add_u32 and moves on VGPR operands "
-                    "issue in ~2.7 (profiles/r3_13_probe_valu_cost.jsonl), so for the part of the stream made of those the "
-                    "cycles needed -- and this fraction -- are an upper bound.  The engine clock under this load is 1.9-2.1 GHz, "
-                    "so ~0.85 is the practical ceiling; what the kernel leaves of it is latency of its dependent "
-                    "MFMA -> split -> MFMA chain at two waves per SIMD (DESIGN.md 4.5)",
+            "bound": "valu-issue" if lane_issue >= lane_matrix else "matrix-pipe", "achieved": ach, "peak": ISSUE_PEAK_GCYC,
+            "unit": "Gcycle/s", "frac": ach / ISSUE_PEAK_GCYC,
+            "frac_at_measured_clock": (ach / (1024 * clock)) if clock else None, "engine_clock_GHz_under_profiler": clock,
+            "issue_lane_Gcycles_per_launch": lane_issue / 1e9, "matrix_lane_Gcycles_per_launch": lane_matrix / 1e9,
+            "prices": {"valu": ISSUE_CYC_VALU, "mfma_issue": ISSUE_CYC_MFMA, "mfma_pipe": MATRIX_CYC_MFMA,
+                       "source": "benchmarks/issue_sweep_probe.hip, profiles/r6_issue_sweep.jsonl (s_memtime cycles, 1 - 3 waves per SIMD)"},
+            "note": "a SIMD has an issue lane (4 cycles per wave64 VALU instruction, ~10 per v_mfma_f32_32x32x16_f16) and a "
+                    "matrix lane (32 per MFMA) that run side by side: up to six VALU instructions per MFMA ride in its shadow. "
+                    "achieved = max(lane) of one launch, exact instruction counts from the committed PMC pass, over the live "
+                    "launch time; peak = 1024 SIMDs x 2.4 GHz; frac_at_measured_clock divides by the clock the kernel held "
+                    "under the profiler instead.  The VALU price is the packed / converting / VOP3 class' (what the pass loop is "
+                    "made of); plain VOP2 add / mul / and / xor on registers cost 2.1 at two waves per SIMD, so for their "
+                    "share of the stream (~25 % of the K-pass kernel's VALU count) the lane is over-estimated.  Rounds 2 - 5 "
+                    "priced 4 x VALU + 32 x MFMA as one lane ('no overlap', 0.79 for this kernel); that probe had 42 issue "
+                    "cycles of fillers in every 32-cycle gap.  What the kernel leaves of the roof is stall: the pass is one "
+                    "dependent chain (MFMA -> convert -> MFMA) and at two waves per SIMD both waves wait at once for part "
+                    "of it (DESIGN.md 4.4; placing the independent mask arithmetic in the MFMA shadows was built and "
+                    "measured: +0.6 %, docs/experiments.md 6.2)",
             "issue_source": prof["source"], "valu_insts_per_ray": prof["valu_insts_per_launch"] / prof["rays_per_launch"],
             "mfma_insts_per_ray": prof["mfma_insts_per_launch"] / prof["rays_per_launch"],
             "simd_busy_frac_under_profiler": prof.get("busy_frac")}
@@ -428,7 +444,7 @@ def main():
             ens = bench_ensemble(args, rank, world, dev, dist, 3, 1)
             torch.cuda.synchronize()
             if rank == 0:
-                subs = {"ensemble": {k: ens[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config")}}
+                subs = {"ensemble": {k: ens[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config", "exchange")}}
         if default_run and not args.no_sub_records and world == 1:
             # the other single-GPU configs of BASELINE.json, each with its own per-kernel times (fewer steps: the
             # default run must stay within minutes); the headline above is the north-star target config
@@ -543,9 +559,11 @@ def bench_ensemble(args, rank, world, dev, dist, steps, warmup):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out["rgb"]).all() and "rgb_std" in out
+    exchange = ensemble_exchange_record(pipe, cams[0], M, world, dev, dist, elapsed / steps * 1e3)
     del pipe, members
     torch.cuda.empty_cache()
     return {
+        "exchange": exchange,
         "metric": "Mrays/s (+var), Mip-NeRF360-shaped 1080p, M-member ensemble", "value": H * W * steps / elapsed / 1e6,
         "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -556,6 +574,58 @@ def bench_ensemble(args, rank, world, dev, dist, steps, warmup):
                                    if world > 1 else "single GPU: members rendered in sequence, moments on the device")},
         "roofline": None, "cpu_baseline": None,
     }
+
+
+def ensemble_exchange_record(pipe, cam, M, world, dev, dist, frame_ms):
+    """The distributed aggregation's stages timed one by one at THIS world size: pack -> all_to_all of
+    pixel slices -> exact two-pass moments -> all_gather of the reduced slices -> unpack (ensemble.aggregate_distributed,
+    HIP events on the stream, outside the timed region).  At world size 1 the two collectives are RCCL's self-copies, so
+    what this measures there is everything EXCEPT the fabric; the bytes each rank would send / receive at N = 8 and a
+    projection from them are written next to it and labelled as what they are -- no 2 - 8 GPU run exists."""
+    from uncertainty_nerf_gs_amd import ensemble
+    import torch.distributed as tdist
+    own_group = False
+    try:
+        if dist is None:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            own_group = True
+        outs = [m.get_outputs_for_camera(cam) for m in pipe.models]
+        st = {}
+        ensemble.aggregate_distributed(outs, stage_ms={})          # warm-up (communicator set-up, allocator)
+        for _ in range(3):
+            ensemble.aggregate_distributed(outs, stage_ms=st)
+        calls = st.pop("calls")
+        stages = {k: st[k] / calls for k in ("pack", "all_to_all", "moments", "all_gather", "unpack")}
+        img = st["packed_image_bytes_per_member"]
+        # N = 8, one member per GPU: every rank sends 7/8 of its packed image (1/8 to each peer, one xGMI link per peer) and
+        # receives 7 reduced slices of (mean, var) = 2 x 1/8 image each
+        n8_send, n8_recv = img * 7 // 8, 2 * img * 7 // 8
+        link = 64e9 * 0.7       # one direction of one xGMI link (153 GB/s both ways, MI355X_MICROARCH), 70 % assumed achievable
+        proj_ms = (n8_send / 7 / link + n8_recv / 7 / link) * 1e3
+        member_ms = frame_ms / max(len(pipe.models), 1)
+        ml = max(len(pipe.models), 1)
+        # a rank packs its own members and reduces P x (members per rank) pixel-members at every world size: scale both to 1
+        local = stages["pack"] / ml + stages["moments"] / ml + stages["unpack"]
+        return {"world_size": world, "members_on_this_rank": len(pipe.models), "stage_ms": stages,
+                "stage_ms_sum": sum(stages.values()), "packed_image_bytes_per_member": img,
+                "bytes_all_to_all_sent_per_rank": st["bytes_all_to_all_sent_per_rank"],
+                "bytes_all_gather_received_per_rank": st["bytes_all_gather_received_per_rank"],
+                "projection_8_gpus_UNMEASURED": {
+                    "assumes": "one member per GPU; each peer pair on its own xGMI link at 0.7 x 64 GB/s per direction; "
+                               "pack and moments scaled from this rank's members to one, unpack as measured",
+                    "all_to_all_bytes_sent_per_rank": n8_send, "all_gather_bytes_received_per_rank": n8_recv,
+                    "fabric_ms": proj_ms, "member_render_ms": member_ms,
+                    "frame_ms": member_ms + local + proj_ms,
+                    "speedup_over_one_gpu": frame_ms * (M / max(len(pipe.models), 1)) / (member_ms + local + proj_ms)}}
+    except Exception as e:  # noqa: BLE001 -- a record, not a gate: the ensemble line itself is already measured
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        if own_group:
+            tdist.destroy_process_group()
 
 
 def bench_splat(args, rank, world, dev, dist, steps, warmup):
@@ -751,9 +821,9 @@ def parity_record(got, ids, refs, precision):
     """One scene of `parity_at_bench_size`: the GPU frame (full tables, 1080p, the bench's launch groups) against the oracle
     outputs for `ids` -- refs = {"fp32": ..., "autocast16": ... (precision "f16" only)} -- through the north-star gate
     quantities on the tests' targets (oracle/targets.py, the same functions tests/test_gpu_nerf_e2e._gates calls): the
-    informative target is gated; the plain one is recorded over 8 noise seeds, next to what the two oracles differ by on the
-    same seeds (`reference_arithmetics_gap`: no implementation of the reference's f16 arithmetic can be closer to its fp32
-    semantics than the reference itself)."""
+    informative target carries the absolute gates; the plain one is gated over 8 noise seeds RELATIVE to what the two oracles
+    differ by on the same seeds (`plain_gate`, `reference_arithmetics_gap`: no implementation of the reference's f16
+    arithmetic can be closer to its fp32 semantics than the reference itself)."""
     from oracle import targets
     sel = torch.from_numpy(ids).to(got["rgb"].device)
     pick = lambda k: got[k].reshape(-1, got[k].shape[-1])[sel].cpu()
@@ -775,6 +845,13 @@ def parity_record(got, ids, refs, precision):
            "oracle": "torch-CPU (oracle/sampled_frame.py), same pose, same mask / depth-draw counters", "vs": {}}
     for name, ref in refs.items():
         r = against(ref["rgb"], ref["rgb_std"], rgb, std)
+        # the plain target, gated relative to what it resolves (oracle/targets.plain_gate): against the oracle of the build's
+        # own arithmetic the floor is the two oracles' gap (2.5 x), otherwise noise of the build's RMS difference (3 x)
+        other = None
+        if name == "autocast16" and "fp32" in refs:
+            other = (refs["fp32"]["rgb"], refs["fp32"]["rgb_std"])
+        r["plain_gate"] = targets.plain_gate(rgb, std, ref["rgb"], ref["rgb_std"], other=other, err_types=("mse",))
+        r["inside_gates"] = bool(r["inside_gates"] and r["plain_gate"]["ok"])
         r["max_abs_accumulation"] = float((pick("accumulation") - ref["accumulation"]).abs().max())
         dd = (pick("depth") - ref["depth"]).abs() > 1e-3 * ref["depth"].abs()
         r["median_depth_pixels_off_1e-3"] = float(dd.double().mean())

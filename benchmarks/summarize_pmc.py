@@ -132,16 +132,24 @@ def summary(d, tag):
         for issue_name, fk in targets:
           if fk and all(c in kernels[fk] for c in need):
             kk = kernels[fk]
-            # Issue cycles a launch NEEDS: 4 per wave64 VALU instruction, 32 per v_mfma_f32_32x32x16_f16 (the costs
-            # benchmarks/mfma_valu_overlap_probe.hip measures; the two classes share the SIMD's issue pipe and do not
-            # overlap).  SQ_INSTS_VALU (which includes the MFMAs) and SQ_INSTS_MFMA are exact instruction counts, so this
-            # is a property of the instruction stream and a LOWER bound of the busy cycles: instructions that hold the
-            # pipe longer (v_fma_mix*, v_exp, v_rcp, v_permlane32_swap: ~2 slots) are counted as one.  The busy counters
-            # themselves are kept next to it: 4 x SQ_ACTIVE_INST_VALU (quad-cycles) + SQ_VALU_MFMA_BUSY_CYCLES counts
-            # the issue cycles of an MFMA in both terms and can exceed the elapsed SIMD cycles by a few percent.
+            # Cycles a launch NEEDS on each of the two resources a SIMD has, priced with the constants
+            # benchmarks/issue_sweep_probe.hip measured in shader cycles (profiles/r6_issue_sweep.jsonl, round 6):
+            #   issue lane : 4 per wave64 VALU instruction (4.0 - 4.2 at 1, 2 and 3 waves per SIMD for every packed, converting,
+            #                VOP3 or transcendental-free form tried; plain VOP2 add / mul / and / xor on registers drop to 2.1 at
+            #                two waves and 1.4 at three -- for the share of the stream made of those this is an over-estimate)
+            #                + 10 per v_mfma_f32_32x32x16_f16 (what an MFMA holds the issue for: gap = 10.3 + 4 n once n > 6);
+            #   matrix lane: 32 per MFMA (back-to-back rate of the pipe; one chain or two, no difference).
+            # The lanes run side by side (up to six 4-cycle VALU instructions per MFMA cost 0.25 - 0.5 cycle each), so a launch
+            # needs max(issue lane, matrix lane).  Rounds 2 - 5 priced 4 VALU + 32 MFMA as ONE lane ("no overlap"): that
+            # probe put 8 fillers = 42 issue cycles into every 32-cycle gap and assumed a 2.4 GHz clock.
+            # SQ_INSTS_VALU (which includes the MFMAs) and SQ_INSTS_MFMA are exact instruction counts, so this is a property
+            # of the instruction stream.  The busy counters are kept next to it: 4 x SQ_ACTIVE_INST_VALU (quad-cycles)
+            # + SQ_VALU_MFMA_BUSY_CYCLES adds the matrix lane ON TOP of the issue lane and is not a utilisation.
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs -> elapsed cycles of one XCD x 1024 SIMDs = available cycles.
             valu_n = kk["SQ_INSTS_VALU"] - kk["SQ_INSTS_MFMA"]
-            issue = 4.0 * valu_n + 32.0 * kk["SQ_INSTS_MFMA"]
+            issue_lane = 4.0 * valu_n + 10.0 * kk["SQ_INSTS_MFMA"]
+            matrix_lane = 32.0 * kk["SQ_INSTS_MFMA"]
+            issue = max(issue_lane, matrix_lane)
             counters = 4.0 * kk["SQ_ACTIVE_INST_VALU"] + kk["SQ_VALU_MFMA_BUSY_CYCLES"]
             simd_cycles = kk["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
             j = {"method": issue_name, "K": K_OF.get(method, 0), "rays_per_launch": _rays_per_launch(method, kk.get("launches")),
@@ -150,7 +158,9 @@ def summary(d, tag):
                  "wait_any_frac_of_wave_cycles": (kk["SQ_WAIT_ANY"] / kk["SQ_WAVE_CYCLES"]) if kk.get("SQ_WAVE_CYCLES") else None,
                  "source": f"profiles/{tag}_{method}_pmc_sq.csv (rocprofv3 --pmc, own pass)",
                  "issue_cycles_per_launch": issue,
-                 "definition": "4 x (SQ_INSTS_VALU - SQ_INSTS_MFMA) + 32 x SQ_INSTS_MFMA",
+                 "definition": "max(4 x (SQ_INSTS_VALU - SQ_INSTS_MFMA) + 10 x SQ_INSTS_MFMA, 32 x SQ_INSTS_MFMA): issue lane vs matrix "
+                               "lane, constants of benchmarks/issue_sweep_probe.hip",
+                 "issue_lane_cycles_per_launch": issue_lane, "matrix_lane_cycles_per_launch": matrix_lane,
                  "valu_insts_per_launch": valu_n, "mfma_insts_per_launch": kk["SQ_INSTS_MFMA"],
                  "valu_active_quad_cycles": kk["SQ_ACTIVE_INST_VALU"], "mfma_busy_cycles": kk["SQ_VALU_MFMA_BUSY_CYCLES"],
                  "simd_cycles_per_launch": simd_cycles, "busy_frac": issue / simd_cycles,

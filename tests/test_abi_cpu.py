@@ -1,5 +1,6 @@
 """C-ABI surface: the library builds, loads, exports every symbol include/unerf.h declares, and
 validates arguments before touching the GPU.  No compute is launched here."""
+import threading
 import ctypes as C
 import os
 import re
@@ -184,3 +185,29 @@ def test_tight_tile_counts_are_only_offered_with_the_raw_projection(lib):
     z = torch.zeros(4, 3)
     with pytest.raises(ValueError, match="raw=True"):
         ops.splat_project(z, z, 1.0, torch.zeros(4, 4), torch.eye(4)[:3], 1.0, 1.0, 0.0, 0.0, 16, 16, opacity_logits=torch.zeros(4))
+
+
+def test_error_string_is_per_thread(lib):
+    """unerf_last_error() is thread-local: a call that fails in one thread leaves another thread's (empty or older) text
+    alone -- two threads fail DIFFERENT argument checks at the same time and each reads back its own message"""
+    h = lib.load()
+    seen, gate = {}, threading.Barrier(2)
+
+    def a():
+        gate.wait(timeout=30)
+        for _ in range(200):
+            rc = h.unerf_hashgrid_fwd(None, None, None, 10, 16, 19, None, None, None)
+            seen.setdefault("a", set()).add((rc, h.unerf_last_error()))
+
+    def b():
+        gate.wait(timeout=30)
+        for _ in range(200):
+            rc = h.unerf_composite_var(1, 1, None, None, 1, 1, 4, 48, 0.05, 1000.0, 0, None, 0, 32768, 7, None, None, 1, None)
+            seen.setdefault("b", set()).add((rc, h.unerf_last_error()))
+    ths = [threading.Thread(target=f) for f in (a, b)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert len(seen["a"]) == 1 and len(seen["b"]) == 1
+    (rca, ea), = seen["a"]
+    (rcb, eb), = seen["b"]
+    assert rca == -1 and b"null pointer" in ea and rcb == -1 and b"background=7" in eb

@@ -152,3 +152,17 @@ def test_parity_record_is_zero_for_identical_frames_and_well_conditioned():
     assert r1["d_ause_mse"] < r1["plain_target"]["d_ause_mse_mean"]
     assert 0 < r1["ause_mse_oracle"] < 0.6 < r1["plain_target"]["ause_mse_oracle"] + 0.1
     assert abs(rec["reference_arithmetics_gap"]["d_ause_mse"] - r1["d_ause_mse"]) < 1e-12     # same pair of frames here
+    # the plain target is GATED, relative to its floor: the two oracles' gap where the build is held against the oracle of
+    # its own arithmetic (2.5 x), noise of the build's RMS difference elsewhere (3 x)
+    pa, pf = rec["vs"]["autocast16"]["plain_gate"], r1["plain_gate"]
+    assert pa["floor"] == "reference arithmetics gap" and pa["ok"] and pa["d_ause_mse_mean"] == 0
+    assert pf["floor"].startswith("noise") and pf["ok"] and pf["d_ause_mse_bound"] >= 1e-3
+    # an image that is systematically off fails both targets (the plain target cannot see a wrong RANKING by itself -- on it
+    # every ranking is a random order, oracle/targets.py -- which is why the informative target carries the absolute gate)
+    bad = {k: v.clone() for k, v in got.items()}
+    bad["rgb"] = ref["rgb"] + 2e-3
+    rb = bench.parity_record(bad, ids, {"fp32": ref, "autocast16": got}, "f16")
+    assert rb["inside_gates"] is False and rb["vs"]["autocast16"]["plain_gate"]["ok"] is False
+    worse = {k: v.clone() for k, v in got.items()}
+    worse["rgb_std"] = ref["rgb_std"].flip(0).clone()
+    assert bench.parity_record(worse, ids, {"fp32": ref}, "f16")["inside_gates"] is False

@@ -186,6 +186,36 @@ def test_dropout_mask_generator_statistics():
     assert not np.array_equal(s0, O.mc_keep_mask(1235, 3, sidx[:100], 0, 64, p))        # and so do seeds
 
 
+@pytest.mark.parametrize("p", [0.5, 0.25, 0.1, 1.0 / 3.0, 0.75, 0.5 + 2.0 ** -9, 0.125, 2.0 ** -6])
+def test_dropout_mask_generator_at_other_rates_and_its_joint_structure(p):
+    """the statistics above are at p = 0.2 only, and a unit's K keep bits are a function of 16 bits of state (the
+    stepped halves are a 16-bit LCG).  Here, for thresholds at, next to and away from powers of two, on 2.56 M units x 8
+    passes: the keep rate of every pass, no PAIRWISE dependence between passes (what the mean and the variance over the K
+    passes -- the only statistics the renderer forms, mcdropout_models.py:116-126 -- are functions of) beyond sampling
+    noise, the variance of a unit's keep count over 8 passes within 0.5 % of Binomial(8, 1 - p)'s; and the third-order
+    structure a 16-bit state must have is BOUNDED, not absent: worst triple moment of centred keeps <= 1.2 % of
+    (q (1 - q))^1.5 (measured 0.2 - 0.8 %), total-variation distance of the keep-count histogram from the binomial
+    <= 0.8 % (measured 0.04 - 0.5 %).  DESIGN.md 4.3 records it."""
+    from math import comb
+    from oracle import nerf_oracle as O
+    n, K = 40000, 8
+    sidx = np.arange(n, dtype=np.int64) * 7 + 11
+    keeps = np.stack([O.mc_keep_mask(1234, k, sidx, 0, 64, p) for k in range(K)]).astype(np.float64)
+    N = n * 64
+    q = round((1.0 - p) * 65536.0) / 65536.0
+    assert np.abs(keeps.reshape(K, -1).mean(axis=1) - q).max() < 5.0 * np.sqrt(q * (1 - q) / N)
+    c = keeps - q
+    pair = max(abs((c[a] * c[b]).mean()) for a in range(K) for b in range(a + 1, K)) / (q * (1 - q))
+    assert pair < 6.0 / np.sqrt(N), pair
+    triple = max(abs((c[a] * c[b] * c[d]).mean()) for a in range(K) for b in range(a + 1, K) for d in range(b + 1, K))
+    assert triple / (q * (1 - q)) ** 1.5 < 1.2e-2
+    cnt = keeps.sum(axis=0).reshape(-1).astype(int)
+    hist = np.bincount(cnt, minlength=K + 1) / N
+    binom = np.array([comb(K, i) * q ** i * (1 - q) ** (K - i) for i in range(K + 1)])
+    assert 0.5 * np.abs(hist - binom).sum() < 8e-3
+    assert abs(cnt.var() / (K * q * (1 - q)) - 1.0) < 5e-3
+
+
 # ---- [REF] model glue run with a fake `self` (tests/golden/make_golden.py: golden_splat_get_outputs / golden_nerf_model_glue)
 
 

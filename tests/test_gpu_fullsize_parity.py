@@ -118,9 +118,11 @@ def test_full_size_trained_like_frame_in_the_reference_arithmetic(dev, method):
     from test_gpu_nerf_e2e import TIE_MARGIN_TRAINED_LIKE
     tie = TIE_MARGIN_TRAINED_LIKE   # densities up to e^12 (test_gpu_trained_like)
     rec16 = _gates(f"fullsize-trained-like-{method}-f16-vs-autocast", v(got["rgb"]), v(got["rgb_std"]), v(ref16["rgb"]), v(ref16["rgb_std"]),
-                   out=vd(got), ref=vd(ref16), diag=diag16, precision="f16", tie_margin=tie, ref_name="autocast(float16) oracle")
+                   out=vd(got), ref=vd(ref16), diag=diag16, precision="f16", tie_margin=tie, ref_name="autocast(float16) oracle",
+                   plain_other=(v(ref["rgb"]), v(ref["rgb_std"])))
     rec = _gates(f"fullsize-trained-like-{method}-f16", v(got["rgb"]), v(got["rgb_std"]), v(ref["rgb"]), v(ref["rgb_std"]),
-                 out=vd(got), ref=vd(ref), diag=diag, precision="f16", tie_margin=tie)
+                 out=vd(got), ref=vd(ref), diag=diag, precision="f16", tie_margin=tie,
+                 plain_other=(v(ref16["rgb"]), v(ref16["rgb_std"])))
     _img_close(got["rgb"], ref16["rgb"], 2e-4, 0, "rgb vs the autocast(fp16) oracle")
     _img_close(got["rgb"], ref["rgb"], 2e-4, 0, "rgb vs the fp32 oracle")
     _img_close(got["accumulation"], ref["accumulation"], 6e-4, 0, "accumulation", max_bad_frac=5e-3)   # densities up to e^12

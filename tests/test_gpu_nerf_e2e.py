@@ -105,21 +105,27 @@ def _depth_gates(rec, out, ref, margin=None, precision="f16x2", tie_margin=None)
 
 
 def _gates(name, out_rgb, out_std, ref_rgb, ref_std, out=None, ref=None, diag=None, precision="f16x2", tie_margin=None,
-           depth_ause_gate=1e-3, plain_gate=None, ref_name="fp32 oracle", depth_off_max=2e-2):
+           depth_ause_gate=1e-3, plain_other=None, ref_name="fp32 oracle", depth_off_max=1.6e-2):
     """The north-star parity gates: |dPSNR| <= 1e-4 dB and |dAUSE| <= 1e-3 against the same GT -- for the RGB image and,
     when the method returns `depth_std` (out / ref = the two output dicts), for the depth map too.  diag: the oracle's
     diagnostics dict (median margins) of the same render.
-    GT (oracle/targets.py): the INFORMATIVE target is gated.  The PLAIN target (rounds 1 - 4's gate) is recorded beside it
-    (`*_plain`) and gated only on request (plain_gate=True): it ranks near-tied rays -- on it the reference's own fp32 and
-    autocast(float16) arithmetics differ by 1e-3 .. 2.6e-2 (profiles/r5_exp_ause_oracle_gap.json), and the fp32-equivalent
-    kernels, 4e-5 from the oracle in rgb_std, by up to 1.4e-2 on a 2,000-pixel K = 4 image (rounds 1 - 4 passed it by
-    choosing image sizes; a change of the mask generator's stream re-drew the lottery)."""
+    GT (oracle/targets.py): the INFORMATIVE target carries the absolute 1e-4 dB / 1e-3 gates.  The PLAIN target (rounds
+    1 - 4's gate) ranks near-tied rays -- on it the reference's own fp32 and autocast(float16) arithmetics differ by
+    1e-3 .. 2.6e-2 (profiles/r5_exp_ause_oracle_gap.json) -- and is gated RELATIVE to what it can resolve
+    (targets.plain_gate): |dPSNR| <= 1e-4 dB as ever, and the mean |dAUSE| over 8 noise draws <= max(1e-3, slack x floor),
+    floor = the two reference arithmetics' own gap where the caller has both oracles (plain_other = (rgb, rgb_std) of the
+    OTHER oracle; 2.5 x, see
+    targets.PLAIN_SLACK), otherwise what unstructured noise of the build's RMS difference does (3 x).  The single-seed
+    numbers of rounds 1 - 5 stay in the record (`*_plain`).  depth_off_max: share of pixels whose median depth differs
+    from the oracle's by more than 1e-3 relative (all ties, see TIE_MARGIN): 1.6 %, the worst measured at the BASELINE size."""
     from oracle import targets
     rec = {"reference": ref_name, "precision": precision,
            "max_abs_rgb": (out_rgb - ref_rgb).abs().max().item(),
            "max_abs_rgb_std": (out_std - ref_std).abs().max().item()}
     rec.update(targets.gate_deltas(out_rgb, out_std, ref_rgb, ref_std, _gt_image_informative(ref_rgb, ref_std)))
     rec.update({k + "_plain": v for k, v in targets.gate_deltas(out_rgb, out_std, ref_rgb, ref_std, _gt_image(ref_rgb)).items()})
+    pg = targets.plain_gate(out_rgb, out_std, ref_rgb, ref_std, other=plain_other)
+    rec["plain_gate"] = pg
     depth = out is not None and ref is not None and "depth_std" in out and "depth_std" in ref
     if depth:
         _depth_gates(rec, out, ref, _margin_of(diag), precision, tie_margin)
@@ -127,10 +133,11 @@ def _gates(name, out_rgb, out_std, ref_rgb, ref_std, out=None, ref=None, diag=No
     assert rec["d_psnr"] <= 1e-4, f"|dPSNR| = {rec['d_psnr']:.2e} dB"
     for et in ("mse", "mae", "rmse"):
         assert rec[f"d_ause_{et}"] <= 1e-3, f"|dAUSE_{et}| = {rec[f'd_ause_{et}']:.2e}"
-    if plain_gate:
-        assert rec["d_psnr_plain"] <= 1e-4, f"plain target: |dPSNR| = {rec['d_psnr_plain']:.2e} dB"
-        for et in ("mse", "mae", "rmse"):
-            assert rec[f"d_ause_{et}_plain"] <= 1e-3, f"plain target: |dAUSE_{et}| = {rec[f'd_ause_{et}_plain']:.2e}"
+    assert pg["d_psnr_mean"] <= 1e-4, f"plain target: mean |dPSNR| = {pg['d_psnr_mean']:.2e} dB"
+    for et in ("mse", "mae", "rmse"):
+        assert pg[f"d_ause_{et}_mean"] <= pg[f"d_ause_{et}_bound"], \
+            (f"plain target: mean |dAUSE_{et}| over {pg['seeds']} draws = {pg[f'd_ause_{et}_mean']:.2e} > "
+             f"{pg[f'd_ause_{et}_bound']:.2e} (floor: {pg['floor']}, {pg[f'd_ause_{et}_floor']:.2e})")
     if depth:
         if "depth_flips" in rec:
             assert rec["depth_flip_worst_margin"] <= rec["tie_margin"], \
@@ -811,6 +818,10 @@ def test_reference_precision_f16_mode_meets_the_gates(dev, kind):
     v = lambda x: x.cpu().view(H, W, -1)
     _gates(f"f16-{kind}", v(out["rgb"]), v(out["rgb_std"]), v(ref[None]["rgb"]), v(ref[None]["rgb_std"]), out=out, ref=ref[None],
            diag=diag, precision="f16")
+    # and against the oracle of ITS arithmetic, the plain target within 2.5 x the two oracles' own gap on it
+    r16 = ref[torch.float16]
+    _gates(f"f16-{kind}-vs-autocast", v(out["rgb"]), v(out["rgb_std"]), v(r16["rgb"]), v(r16["rgb_std"]), precision="f16",
+           plain_other=(v(ref[None]["rgb"]), v(ref[None]["rgb_std"])), ref_name="autocast(float16) oracle")
     _img_close(out["rgb"], ref[torch.float16]["rgb"], 1e-4, 0, "rgb vs the autocast(fp16) oracle")
     _img_close(out["rgb"], ref[None]["rgb"], 1e-4, 0, "rgb vs the fp32 oracle")
     _img_close(out["accumulation"], ref[None]["accumulation"], 6e-4, 0, "accumulation")

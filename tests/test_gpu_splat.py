@@ -345,13 +345,14 @@ def test_depth_sort_is_rocprims(dev, N, H, W, monkeypatch):
     assert torch.equal(bins, bins2) and torch.equal(gids, gids2) and torch.equal(keys, keys2)
 
 
-@pytest.mark.parametrize("N", [1, 5, 1023, 1024, 1025, 4097, 1_000_003])
+@pytest.mark.parametrize("N", [1, 5, 1023, 1024, 1025, 4097, 1_000_003, 4096 * 1024, 4096 * 1024 + 1, 6_300_017])
 def test_count_intersects_scan(dev, N, monkeypatch):
-    """unerf_splat_count_intersects' own two-launch inclusive scan (block sums, then every block behind the sum of the blocks
-    before it) against torch.cumsum and against hipcub's scan (UNERF_SPLAT_SCAN=rocprim), ragged sizes included"""
+    """unerf_splat_count_intersects' own inclusive scan (block sums, then every block behind the sum of the blocks before it;
+    above 4,096 blocks = 4 M splats a one-workgroup middle step turns the block sums into their prefixes first, so the
+    work stays linear) against torch.cumsum and against hipcub's scan (UNERF_SPLAT_SCAN=rocprim), ragged sizes included"""
     from uncertainty_nerf_gs_amd import ops
     g = torch.Generator().manual_seed(N)
-    tiles = torch.randint(0, 60, (N,), generator=g, dtype=torch.int32).to(dev)
+    tiles = torch.randint(0, 60 if N < 2_000_000 else 30, (N,), generator=g, dtype=torch.int32).to(dev)
     want = torch.cumsum(tiles.long(), 0).to(torch.int32)
     c = ops.SplatCount(tiles)
     assert c.wait() == int(want[-1]) and torch.equal(c.cum, want)

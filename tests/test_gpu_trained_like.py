@@ -127,20 +127,21 @@ def test_trained_like_scene_end_to_end(dev, kind, precision):
         oracle = lambda ac, dg: O.laplace_outputs(sc, o, d, wsd, wsr, noise, autocast=ac, diagnostics=dg)
     sd.field.precision = precision
     ref = oracle(None, diag)
+    ref16 = oracle(torch.float16, diag16) if f16 else None
     out = render.render_rays(sd, o.to(dev), d.to(dev), **shade)
     assert all(torch.isfinite(v).all() for v in out.values())
     assert sd.overflow_rerenders == 0
     from test_gpu_nerf_e2e import _gates, TIE_MARGIN_TRAINED_LIKE
     v = lambda x: x.view(H, W, -1)
     rec = _gates(f"trained-like-{kind}-{precision}", v(out["rgb"].cpu()), v(out["rgb_std"].cpu()), v(ref["rgb"]), v(ref["rgb_std"]),
-                 out=out, ref=ref, diag=diag, precision=precision, tie_margin=TIE_MARGIN_TRAINED_LIKE)     # densities up to e^12: see TIE_MARGIN
+                 out=out, ref=ref, diag=diag, precision=precision, tie_margin=TIE_MARGIN_TRAINED_LIKE,     # densities up to e^12: see TIE_MARGIN
+                 plain_other=(v(ref16["rgb"]), v(ref16["rgb_std"])) if f16 else None)
     _close(out["rgb"], ref["rgb"], 0, 4e-4 if f16 else 2e-4, "rgb", max_bad_frac=5e-3)
     _close(out["accumulation"], ref["accumulation"], 0, 5e-4, "accumulation", max_bad_frac=5e-3)
     if f16:
-        ref16 = oracle(torch.float16, diag16)
         rec16 = _gates(f"trained-like-{kind}-f16-vs-autocast", v(out["rgb"].cpu()), v(out["rgb_std"].cpu()), v(ref16["rgb"]),
                        v(ref16["rgb_std"]), out=out, ref=ref16, diag=diag16, precision="f16", tie_margin=TIE_MARGIN_TRAINED_LIKE,
-                       ref_name="autocast(float16) oracle")
+                       ref_name="autocast(float16) oracle", plain_other=(v(ref["rgb"]), v(ref["rgb_std"])))
         _close(out["rgb"], ref16["rgb"], 0, 4e-4, "rgb vs the autocast(fp16) oracle", max_bad_frac=5e-3)
         # the plain target, for the record: this render against each oracle, and the two oracles against each other
         from oracle import targets

@@ -40,6 +40,18 @@ int unerf_check_launch(const char* what) {
 #ifndef UNERF_LAP_EXP2
 #define UNERF_LAP_EXP2 1         // LAPLACE: lap16_blob rows pre-scaled by +-log2(e), bare exp2 in the epilogue
 #endif
+#ifndef UNERF_RGB_SCALAR
+#define UNERF_RGB_SCALAR 0   // 1: the split-f16 kernels' fp32 colour layer as scalar fmas instead of v_pk_fma_f32
+#endif
+#ifndef UNERF_LAP_SCALAR_MOMENTS
+#define UNERF_LAP_SCALAR_MOMENTS 0   // 1: no packed-fp32 fma in the Laplace heads' moment sums
+#endif
+#ifndef UNERF_KPASS_FILL
+#define UNERF_KPASS_FILL 0   // 1: "f16" K-pass kernel with the mask arithmetic placed behind the MFMAs of a pass (round 6)
+#endif
+#ifndef UNERF_FIELD_BLEND_SCALAR
+#define UNERF_FIELD_BLEND_SCALAR 0   // 1: no packed-fp32 instruction in the matrix kernels' grid blend (same roundings)
+#endif
 #ifndef UNERF_TRUNK_RESIDENT
 #define UNERF_TRUNK_RESIDENT 1   // ... and its operands kept in registers across the passes (-3.5 %)
 #endif
@@ -1812,7 +1824,7 @@ __device__ __forceinline__ f32x16 mf_gather_feats(const FieldArgs& a, float px, 
             for (int k = 0; k < 8; ++k) c8[k] = cd[8 * q + k];
             // UNERF_FIELD_BLEND_FMA (experiments; 0 ships): 1 = fused lerps, 2 = fused lerps in the SCALAR form
             // in every kernel (no v_pk_fma_f32 in the blend), 3 = as 1 with two wait states behind every level's blend
-            float2 f = (PACKED && UNERF_FIELD_BLEND_FMA != 2) ? unerf_blend8<(UNERF_FIELD_BLEND_FMA != 0)>(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2])
+            float2 f = (PACKED && UNERF_FIELD_BLEND_FMA != 2 && !UNERF_FIELD_BLEND_SCALAR) ? unerf_blend8<(UNERF_FIELD_BLEND_FMA != 0)>(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2])
                               : unerf_blend8_scalar<(UNERF_FIELD_BLEND_FMA != 0)>(c8, of[3 * q], of[3 * q + 1], of[3 * q + 2]);
 #if UNERF_FIELD_BLEND_FMA == 3
             asm volatile("s_nop 1" : "+v"(f.x), "+v"(f.y));
@@ -2276,6 +2288,24 @@ __device__ __forceinline__ void mf16_apply_masks(f16x8& hi, f16x8& lo, const uin
     if (!F1) lo = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, lo) & m);
 }
 
+// UNERF_KPASS_FILL: the keep test of eight words in its two halves, so that the halves can sit in different MFMA shadows
+__device__ __forceinline__ void mf16_keep_sub(const uint32_t (&w)[8], uint32_t thr_pk, uint32_t (&d)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        d[q] = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(i16x2, w[q]), __builtin_bit_cast(i16x2, thr_pk)));
+}
+__device__ __forceinline__ void mf16_keep_sign(uint32_t (&d)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, d[q]) >> (short)15);
+}
+// the eight values exist HERE: an empty volatile statement the optimiser can neither sink into the loop latch (where it put the
+// mask steps, whose results only the next pass reads) nor hoist
+__device__ __forceinline__ void mf_pin8(uint32_t (&x)[8]) {
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+}
+// scheduling fence that LDS reads and scalar instructions may cross (the next layer's operand reads go up, nothing else moves)
+#define MF_FENCE() __builtin_amdgcn_sched_barrier(0x0104)
+
 // SITES = false: the reference's default Dropout placement (trunk + last head layer), every site test a compile-time
 // constant.  SITES = true: any other unerf_field_params.drop_sites (run-time site tests, and the words of the
 // UNERF_DROP_HEAD0 site recomputed per pass).  A separate instantiation: as run-time branches of the default kernel
@@ -2398,9 +2428,22 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             mf_mask_init(mk2, 0, h, base0, 1u);
             mf_mask_init(mk3, 1, h, base0, 1u);
         }
+        // UNERF_KPASS_FILL (F1, default sites): AND masks of the trunk for the pass about to run (am_t*), of the head for the
+        // running pass (am_h*).  The words are stepped and tested BEHIND the matrix instructions of a pass instead of in front
+        // of them: an MFMA holds the SIMD's issue for ~10 of its 32 cycles, five or six independent VALU instructions ride in
+        // its shadow for nothing (benchmarks/issue_sweep_probe.hip), and the mask arithmetic -- 96 of a pass' 216 VALU
+        // instructions -- depends on nothing the pass computes.  Same words, same tests, same bits.
+        constexpr bool FILL = UNERF_KPASS_FILL && F1 && DROP && !SITES && MODE == UNERF_FIELD_MCDROPOUT;
+        uint32_t am_t0[8], am_t1[8], am_h0[8], am_h1[8];
+        if (FILL) {
+            mf16_keep_sub(mk0, a.keep_pk, am_t0);
+            mf16_keep_sub(mk1, a.keep_pk, am_t1);
+            mf16_keep_sign(am_t0);
+            mf16_keep_sign(am_t1);
+        }
         for (int k = 0; k < passes; ++k) {
             asm volatile("" : "+v"(lane));
-            if (drop && k > 0) {
+            if (!FILL && drop && k > 0) {
                 mf_mask_step(mk0);
                 mf_mask_step(mk1);
                 mf_mask_step(mk2);
@@ -2419,7 +2462,11 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 f16x8 bhi = hhi[st], blo = hlo[st];
-                if (drop_trunk) mf16_apply_masks<F1>(bhi, blo, st < 2 ? mk0 : mk1, st & 1, a.keep_pk);
+                if (FILL) {
+                    const uint32_t (&am)[8] = st < 2 ? am_t0 : am_t1;
+                    const u32x4 m = {am[4 * (st & 1)], am[4 * (st & 1) + 1], am[4 * (st & 1) + 2], am[4 * (st & 1) + 3]};
+                    bhi = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, bhi) & m);
+                } else if (drop_trunk) mf16_apply_masks<F1>(bhi, blo, st < 2 ? mk0 : mk1, st & 1, a.keep_pk);
                 f16x8 a0, a1;
                 if (TRUNK_RESIDENT) {
                     a0 = ta0[st];
@@ -2439,6 +2486,15 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 }
             }
             if (FOLD) t = mf16_fold_rows(t);
+            if (FILL) {   // behind the trunk's four MFMAs: this pass' head words tested (first half), then stepped for the next pass
+                MF_FENCE();
+                mf16_keep_sub(mk2, a.keep_pk, am_h0);
+                mf16_keep_sub(mk3, a.keep_pk, am_h1);
+                mf_mask_step(mk2);
+                mf_mask_step(mk3);
+                mf_pin8(am_h0); mf_pin8(am_h1); mf_pin8(mk2); mf_pin8(mk3);
+                MF_FENCE();
+            }
             // colour 0: geo rows of t (registers 0..7 = one k-step) on top of the SH partial sum, ReLU
             f32x16 c0 = csh0, c1 = csh1;
             {
@@ -2455,6 +2511,13 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 f1_bad |= c0[0] != c0[0];
                 c0 = mf_relu(c0);
                 c1 = mf_relu(c1);
+            }
+            if (FILL) {   // behind colour 0's two MFMAs: the head masks' second half
+                MF_FENCE();
+                mf16_keep_sign(am_h0);
+                mf16_keep_sign(am_h1);
+                mf_pin8(am_h0); mf_pin8(am_h1);
+                MF_FENCE();
             }
             // colour 1: 64 -> 64, ReLU
             f32x16 d0 = mf16_bias(lds, 5, h), d1 = mf16_bias(lds, 6, h);
@@ -2486,6 +2549,13 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                 // select 1 on the fp32 accumulators, and 4 MFMAs (128 issue cycles) instead of 48 packed FMAs + the half
                 // exchange.  (Round 3 measured this form at -5 % and dropped it over ONE AUSE figure at 1.04e-3 -- a gate
                 // that the reference's own two arithmetics miss by more on that target)
+                if (FILL) {   // behind colour 1's last MFMAs: the trunk words stepped for the next pass
+                    MF_FENCE();
+                    mf_mask_step(mk0);
+                    mf_mask_step(mk1);
+                    mf_pin8(mk0); mf_pin8(mk1);
+                    MF_FENCE();
+                }
                 __builtin_amdgcn_s_setprio(1);
                 f32x16 o4;
 #pragma unroll
@@ -2495,9 +2565,22 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                     f16x8 bhi, blo;
                     mf16_split_relu(st < 2 ? d0 : d1, st & 1, bhi);
                     blo = bhi;
-                    if (drop_head1) mf16_apply_masks<true>(bhi, blo, st < 2 ? mk2 : mk3, st & 1, a.keep_pk);
+                    if (FILL) {
+                        const uint32_t (&am)[8] = st < 2 ? am_h0 : am_h1;
+                        const u32x4 m = {am[4 * (st & 1)], am[4 * (st & 1) + 1], am[4 * (st & 1) + 2], am[4 * (st & 1) + 3]};
+                        bhi = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, bhi) & m);
+                    } else if (drop_head1) mf16_apply_masks<true>(bhi, blo, st < 2 ? mk2 : mk3, st & 1, a.keep_pk);
                     const f16x8 aw = *reinterpret_cast<const f16x8*>(lds + UNERF_MFMA_BLOB_FLOATS + st * 256 + lane * 4);
                     o4 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, bhi, o4, 0, 0, 0);
+                }
+                if (FILL) {   // behind colour 2's four MFMAs: the next pass' trunk masks
+                    MF_FENCE();
+                    mf16_keep_sub(mk0, a.keep_pk, am_t0);
+                    mf16_keep_sub(mk1, a.keep_pk, am_t1);
+                    mf16_keep_sign(am_t0);
+                    mf16_keep_sign(am_t1);
+                    mf_pin8(am_t0); mf_pin8(am_t1);
+                    MF_FENCE();
                 }
                 // rows 0..2 = registers 0..2 of the h = 0 half: one v_permlane32_swap each hands them to both halves
 #pragma unroll
@@ -2547,8 +2630,17 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                         for (int c = 0; c < CG; ++c) {
 #pragma unroll
                             for (int q4 = 0; q4 < 4; ++q4) {
+#if UNERF_RGB_SCALAR
+                                // (round 6) the same four fused multiply-adds on scalar registers: packed-fp32 instructions
+                                // and the other wave's MFMAs exclude each other (benchmarks/issue_sweep_probe.hip)
+                                acc2[c0g + c].x = __builtin_fmaf(dv[4 * q4], wv[c][q4].x, acc2[c0g + c].x);
+                                acc2[c0g + c].y = __builtin_fmaf(dv[4 * q4 + 1], wv[c][q4].y, acc2[c0g + c].y);
+                                acc2[c0g + c].x = __builtin_fmaf(dv[4 * q4 + 2], wv[c][q4].z, acc2[c0g + c].x);
+                                acc2[c0g + c].y = __builtin_fmaf(dv[4 * q4 + 3], wv[c][q4].w, acc2[c0g + c].y);
+#else
                                 acc2[c0g + c] = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4], dv[4 * q4 + 1]}, unerf_v2f{wv[c][q4].x, wv[c][q4].y}, acc2[c0g + c]);
                                 acc2[c0g + c] = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4 + 2], dv[4 * q4 + 3]}, unerf_v2f{wv[c][q4].z, wv[c][q4].w}, acc2[c0g + c]);
+#endif
                             }
                         }
                     }
@@ -2867,8 +2959,18 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
                     // the high dword for both lanes, src1 low / high).  Spelled with vector types the compiler builds the
                     // two factor pairs with a v_mov each.  s_nop: a transcendental's result (p comes from v_exp / v_rcp)
                     // needs one wait state before a VALU instruction the compiler cannot see may read it.
+#if UNERF_LAP_SCALAR_MOMENTS
+                    // round 6: the same two sums as one add and one fma on their own registers (the same roundings as the
+                    // packed fma's two halves).  A packed-fp32 instruction cannot run beside an MFMA -- one behind an MFMA
+                    // waits for it and costs 18 cycles, the next MFMA waits for the packed instruction in turn
+                    // (benchmarks/issue_sweep_probe.hip) -- and at two or three waves per SIMD the other wave's head MFMAs
+                    // are always in flight; v_add_f32 / v_fmac_f32 issue in their shadow.
+                    s12.x += p;
+                    s12.y = __builtin_fmaf(p, p, s12.y);
+#else
                     pr.y = p;
                     asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(s12) : "v"(pr));
+#endif
                 }
             }
         }
@@ -2943,8 +3045,18 @@ __device__ __forceinline__ void mf16_lap_stream(const float* __restrict__ lap, c
                         const float e = UNERF_LAP_EXP2 ? __builtin_amdgcn_exp2f(acc[r]) : __expf(ACT == 1 ? -acc[r] : acc[r]);
                         p = ACT == 1 ? __builtin_amdgcn_rcpf(1.f + e) : e;
                     }
+#if UNERF_LAP_SCALAR_MOMENTS
+                    // round 6: the same two sums as one add and one fma on their own registers (the same roundings as the
+                    // packed fma's two halves).  A packed-fp32 instruction cannot run beside an MFMA -- one behind an MFMA
+                    // waits for it and costs 18 cycles, the next MFMA waits for the packed instruction in turn
+                    // (benchmarks/issue_sweep_probe.hip) -- and at two or three waves per SIMD the other wave's head MFMAs
+                    // are always in flight; v_add_f32 / v_fmac_f32 issue in their shadow.
+                    s12.x += p;
+                    s12.y = __builtin_fmaf(p, p, s12.y);
+#else
                     pr.y = p;
                     asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(s12) : "v"(pr));
+#endif
                 }
             }
         }

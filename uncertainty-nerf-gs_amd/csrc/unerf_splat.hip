@@ -476,6 +476,7 @@ extern "C" int unerf_splat_shade_inputs(int degree, const float* means3d, const 
 // ======================================================================================
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 #define SCAN_BLOCK 1024    // own_inclusive_scan: elements per workgroup
+#define SCAN_DIRECT_BLOCKS 4096   // up to this many blocks (4 M elements) every block re-sums the earlier blocks' sums itself
 #define TS_SEG 32          // one-pass tile sort (below): the prefix over chunks runs in 32 independent row segments
 #define TS_MAX_T1 12000    // tiles + 1 sentinel: the whole-key counters + 16 waves' digit counters must fit 64 KB of LDS (beyond: rocprim)
 struct TileSortPlan {
@@ -597,12 +598,43 @@ __global__ __launch_bounds__(256) void scan_sums_kernel(const int32_t* __restric
     if (threadIdx.x == 0) bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
+// Middle step for MANY blocks (own_inclusive_scan: nb > SCAN_DIRECT_BLOCKS): the block sums become their own exclusive prefix,
+// in place, by one workgroup -- each thread sums a contiguous run, the 1,024 run totals are scanned through LDS, each thread
+// rewrites its run.  Linear in nb: scan_apply_kernel's re-summing of every earlier block is nb^2 / 2 reads in total, fine at
+// the 1 M splats of the bench frame (0.5 M reads) and 50 M reads at 10 M splats.
+__global__ __launch_bounds__(1024) void scan_bsum_kernel(int32_t* __restrict__ bsum, int nb) {
+    __shared__ int32_t s_run[1024];
+    const int per = (nb + 1023) / 1024, b0 = threadIdx.x * per, b1 = min(b0 + per, nb);
+    int32_t tot = 0;
+    for (int b = b0; b < b1; ++b) tot += bsum[b];
+    s_run[threadIdx.x] = tot;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int32_t v = threadIdx.x >= d ? s_run[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_run[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int32_t run = s_run[threadIdx.x] - tot;
+    for (int b = b0; b < b1; ++b) {
+        const int32_t v = bsum[b];
+        bsum[b] = run;
+        run += v;
+    }
+}
+
+// PRE: bsum holds exclusive prefixes already (scan_bsum_kernel)
+template <bool PRE>
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ bsum,
                                                          int32_t* __restrict__ out) {
     __shared__ int32_t s_w[4], s_p[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int32_t before = 0;      // sum of the earlier blocks' sums
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += bsum[b];
+    if (PRE) {
+        before = (threadIdx.x & 63) == 0 && wv == 0 ? bsum[blockIdx.x] : 0;     // one lane carries it into the sum below
+    } else {
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += bsum[b];
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) before += __shfl_xor(before, m, 64);
     const int64_t e0 = (int64_t)blockIdx.x * SCAN_BLOCK + 4 * threadIdx.x;
@@ -635,7 +667,12 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 static void own_inclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* bsum, hipStream_t st) {
     const unsigned nb = blocks_for(n, SCAN_BLOCK);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, st, in, n, bsum);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, in, n, bsum, out);
+    if (nb > SCAN_DIRECT_BLOCKS) {
+        hipLaunchKernelGGL(scan_bsum_kernel, dim3(1), dim3(1024), 0, st, bsum, (int)nb);
+        hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nb), dim3(256), 0, st, in, n, bsum, out);
+    } else {
+        hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nb), dim3(256), 0, st, in, n, bsum, out);
+    }
 }
 static bool use_rocprim_scan() {
     const char* env = getenv("UNERF_SPLAT_SCAN");

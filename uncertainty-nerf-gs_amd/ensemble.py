@@ -86,7 +86,31 @@ def _image_keys(member: Dict[str, torch.Tensor]) -> Tuple[List[str], List[str]]:
     return img, [k for k in keys if k not in img]
 
 
-def aggregate_distributed(outputs, group=None, moments_fn: Optional[MomentsFn] = None):
+class _StageClock:
+    """per-stage device times of aggregate_distributed (events on the current stream; the collectives of a NCCL / RCCL
+    group make the current stream wait for them, so the event behind a collective is behind its data)"""
+
+    def __init__(self, sink: Optional[dict], device):
+        self.sink, self.marks = sink, []
+        self.on = sink is not None and torch.device(device).type == "cuda"
+        self.mark("start")
+
+    def mark(self, name: str) -> None:
+        if self.on:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, ev))
+
+    def finish(self) -> None:
+        if not self.on:
+            return
+        self.marks[-1][1].synchronize()
+        for (_, e0), (name, e1) in zip(self.marks[:-1], self.marks[1:]):
+            self.sink[name] = self.sink.get(name, 0.0) + e0.elapsed_time(e1)
+        self.sink["calls"] = self.sink.get("calls", 0) + 1
+
+
+def aggregate_distributed(outputs, group=None, moments_fn: Optional[MomentsFn] = None, stage_ms: Optional[dict] = None):
     """This rank's member outputs -> the ensemble outputs, identical on every rank.
     `outputs` is one member's dict ([H,W,C] per key) or a list of such dicts when a rank holds several
     members (M members over N < M GPUs; every rank must hold the same number).
@@ -107,6 +131,7 @@ def aggregate_distributed(outputs, group=None, moments_fn: Optional[MomentsFn] =
     P = H * W
     ml = len(members)
     # one packed [m_local, P, sum(C)] block per rank -> a single collective instead of one per key
+    clock = _StageClock(stage_ms, members[0][keys[0]].device)
     packed = torch.stack([torch.cat([m[k].reshape(P, -1) for k in keys], dim=-1) for m in members], dim=0).contiguous()
     Ctot = packed.shape[-1]
     edges = [pixel_slice(P, r, world) for r in range(world)]
@@ -114,8 +139,10 @@ def aggregate_distributed(outputs, group=None, moments_fn: Optional[MomentsFn] =
     # send block for destination r: this rank's members restricted to r's pixel rows, [m_local * (b_r - a_r), Ctot]
     send = torch.cat([packed[:, ar:br].reshape(-1, Ctot) for ar, br in edges], dim=0).contiguous()
     recv = torch.empty(world * ml * (b - a), Ctot, dtype=packed.dtype, device=packed.device)
+    clock.mark("pack")
     dist.all_to_all_single(recv, send, output_split_sizes=[ml * (b - a)] * world,
                            input_split_sizes=[ml * (br - ar) for ar, br in edges], group=group)
+    clock.mark("all_to_all")
     stack = recv.view(world * ml, b - a, Ctot)                      # [M, b-a, Ctot], member order = rank-major
     if b > a:
         m, v = moments_fn(stack.contiguous())
@@ -127,7 +154,9 @@ def aggregate_distributed(outputs, group=None, moments_fn: Optional[MomentsFn] =
     padded = torch.zeros(rows, 2 * Ctot, dtype=part.dtype, device=part.device)
     padded[: b - a] = part
     parts = [torch.empty_like(padded) for _ in range(world)]
+    clock.mark("moments")
     dist.all_gather(parts, padded, group=group)
+    clock.mark("all_gather")
     full = torch.cat([parts[r][: edges[r][1] - edges[r][0]] for r in range(world)], dim=0)
     mean, var, off = {}, {}, 0
     for k, c in zip(keys, widths):
@@ -145,7 +174,14 @@ def aggregate_distributed(outputs, group=None, moments_fn: Optional[MomentsFn] =
             mean[k], var[k] = sm[0, off:off + n].reshape(members[0][k].shape), sv[0, off:off + n].reshape(members[0][k].shape)
             off += n
     alea = {k: mean[k + "_var"] for k in ("rgb", "depth") if k + "_var" in mean}
-    return _finish(all_keys, mean, var, alea)
+    res = _finish(all_keys, mean, var, alea)
+    clock.mark("unpack")
+    clock.finish()
+    if stage_ms is not None:
+        stage_ms["bytes_all_to_all_sent_per_rank"] = int(send.numel() * send.element_size() * (world - 1) // max(world, 1))
+        stage_ms["bytes_all_gather_received_per_rank"] = int(padded.numel() * padded.element_size() * (world - 1))
+        stage_ms["packed_image_bytes_per_member"] = int(P * Ctot * packed.element_size())
+    return res
 
 
 class EnsemblePipeline:

@@ -7,6 +7,7 @@ stated), contiguous and on a HIP device; nothing is silently copied to or from t
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -826,11 +827,15 @@ class Workspace:
 
     def __init__(self):
         self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._streams: Dict[int, "torch.cuda.Stream"] = {}   # every stream a view was handed out on (see release)
 
     def get(self, tag: str, shape, device, dtype=torch.float32) -> torch.Tensor:
         n = 1
         for d in shape:
             n *= int(d)
+        if torch.device(device).type == "cuda":
+            st = torch.cuda.current_stream(device)
+            self._streams.setdefault(st.cuda_stream, st)
         key = (tag, dtype, str(device))
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < n:
@@ -845,13 +850,16 @@ class Workspace:
 
     def release(self) -> None:
         """drop every buffer (scene teardown; a scene that is rebuilt keeps its arena instead: models.invalidate()).
-        A buffer that a side stream may still be reading (render_camera(overlap=True) shades on its own stream) is
-        handed back to the allocator with that stream recorded on it."""
-        cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        Each buffer goes back to the allocator with every stream recorded on it that a view of this arena was ever handed
+        out on (`get` notes the caller's current stream: the frame's stream, and the sampling / shading side streams of
+        render_camera(overlap=True) when they take scratch), so the block is not reused under work still queued there."""
         for b in self._bufs.values():
-            if b.is_cuda and cur is not None:
-                b.record_stream(cur)
+            if b.is_cuda:
+                for st in self._streams.values():
+                    if st.device == b.device:
+                        b.record_stream(st)
         self._bufs.clear()
+        self._streams.clear()
 
 
 def _scratch(workspace: Optional["Workspace"], tag: str, shape, device) -> torch.Tensor:
@@ -1226,6 +1234,9 @@ class SplatCount:
     _owner: Dict = {}
 
     _events: Dict = {}
+    # slot allocation is the one piece of state threads share: two threads counting on one device would otherwise take the
+    # same ring word (and its event pair) and each could read the other's count
+    _lock = threading.Lock()
 
     def __init__(self, num_tiles_hit: torch.Tensor, defer_copy: bool = False):
         """defer_copy: only the scan is queued (and the point behind it marked on the caller's stream); the caller queues its
@@ -1243,22 +1254,23 @@ class SplatCount:
                                                                          ws0.numel(), _stream()))
             key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
             self._key = key
-            if key not in SplatCount._side:
-                SplatCount._side[key] = torch.cuda.Stream(device=self.dev)
-            if key not in SplatCount._pinned:
-                SplatCount._pinned[key] = torch.empty(SplatCount.RING, dtype=torch.int32, pin_memory=True)
-                SplatCount._next[key], SplatCount._owner[key] = 0, [None] * SplatCount.RING
-                # one (scan done, copy done) event pair per ring word, made once: an event is reusable once awaited
-                SplatCount._events[key] = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(SplatCount.RING)]
-            slot = SplatCount._next[key]
-            prev = SplatCount._owner[key][slot]
-            prev = prev() if prev is not None else None
-            if prev is not None and prev._value is None:
-                raise _l.UnerfError(f"SplatCount: {SplatCount.RING} counts started on this device without wait(): await them "
-                                    "before starting more")
             import weakref
-            SplatCount._owner[key][slot] = weakref.ref(self)
-            SplatCount._next[key] = (slot + 1) % SplatCount.RING
+            with SplatCount._lock:
+                if key not in SplatCount._side:
+                    SplatCount._side[key] = torch.cuda.Stream(device=self.dev)
+                if key not in SplatCount._pinned:
+                    SplatCount._pinned[key] = torch.empty(SplatCount.RING, dtype=torch.int32, pin_memory=True)
+                    SplatCount._next[key], SplatCount._owner[key] = 0, [None] * SplatCount.RING
+                    # one (scan done, copy done) event pair per ring word, made once: an event is reusable once awaited
+                    SplatCount._events[key] = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(SplatCount.RING)]
+                slot = SplatCount._next[key]
+                prev = SplatCount._owner[key][slot]
+                prev = prev() if prev is not None else None
+                if prev is not None and prev._value is None:
+                    raise _l.UnerfError(f"SplatCount: {SplatCount.RING} counts started on this device without wait(): await "
+                                        "them before starting more")
+                SplatCount._owner[key][slot] = weakref.ref(self)
+                SplatCount._next[key] = (slot + 1) % SplatCount.RING
             self._host = SplatCount._pinned[key][slot:slot + 1]
             self._ready, self._done = SplatCount._events[key][slot]
             self._ready.record(torch.cuda.current_stream())
