@@ -409,6 +409,16 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus})", file=sys.stderr)
         sys.exit(2)
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints a version banner through C stdio when a
+    # communicator is made, behind Python's own buffer -- so from here on file descriptor 1 IS stderr, and the line goes to a
+    # private duplicate of the real stdout at the very end (emit).
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(line):
+        print(json.dumps(line), file=real_stdout, flush=True)
+
     from uncertainty_nerf_gs_amd import lib
     lib.build_library()
     lib.require_gpu()
@@ -429,12 +439,12 @@ def main():
     if method == "splat":
         line = bench_splat(args, rank, world, dev, dist, args.steps, args.warmup)
         if rank == 0:
-            print(json.dumps(line))
+            emit(line)
     elif method == "ensemble":
         line = bench_ensemble(args, rank, world, dev, dist, args.steps, args.warmup)
         if rank == 0:
             line.update(comm)
-            print(json.dumps(line))
+            emit(line)
     else:
         K = args.mc_samples if method == "mcdropout" else 0
         rec = run_nerf(args, method, K, args.steps, args.warmup, rank, world, dev, dist, exact_check=not args.no_exact_check)
@@ -487,7 +497,7 @@ def main():
             line.update(comm)
             if subs is not None:
                 line["sub_records"] = subs
-            print(json.dumps(line))
+            emit(line)
     if dist is not None:
         dist.destroy_process_group()
 

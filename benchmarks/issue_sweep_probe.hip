@@ -8,9 +8,11 @@
 //   filler   = v_fma_f32, v_add_f32, v_pk_fma_f32, v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_mad_u16, v_pk_sub_i16 clamp,
 //              v_pk_max_i16, v_and_b32, v_max_i32, v_exp_f32 (eight destination registers in rotation, so no filler
 //              depends on one closer than eight behind it; none touches an MFMA register)
-//   waves    = 1, 2, 3, 4 per SIMD: 256-thread workgroups (one wave per SIMD) with 160 / 72 / 48 / 36 KiB of dynamic LDS, so a
-//              CU holds exactly 1 / 2 / 3 / 4 of them (4 x 40 KiB did NOT fit: the first run of this probe had three resident
-//              workgroups in its "4" column), and a grid of 256 x that many
+//   waves    = 1 ... 4 per SIMD asked for: 256-thread workgroups (one wave per SIMD) with 160 / 64 / 40 / 32 KiB of dynamic LDS
+//              and a grid of 256 x that many.  How many a CU really holds is MEASURED, not assumed: the MFMA-only variant
+//              runs 32.3 cycles per MFMA per SIMD whatever the occupancy, so resident = (its cycles per gap per wave) / 32.3; every row carries that figure (`resident_waves_per_simd`) and the
+//              cycles re-normalised with it.  (The LDS is handed out in coarse steps: 4 x 40 KiB, 4 x 36 KiB and 3 x 48 KiB
+//              all came out one workgroup short in earlier runs of this probe.)
 //   "valu"   = the same 16 x NF fillers with no MFMA (the VALU-only price at that occupancy)
 //
 // Units: shader cycles from s_memtime (NOT an assumed clock); the clock itself = d(s_memtime) / d(s_memrealtime) x 100 MHz.
@@ -178,12 +180,13 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> host(max_waves * 3);
     for (const Variant& v : kVariants) hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // keep the chip busy for a moment first so that the clock has settled before the first variant
-    for (int warm = 0; warm < 50; ++warm) hipLaunchKernelGGL(k_fma_2c_8, dim3(cus * 2), dim3(256), 72 * 1024, 0, out, iters);
+    for (int warm = 0; warm < 50; ++warm) hipLaunchKernelGGL(k_fma_2c_8, dim3(cus * 2), dim3(256), 64 * 1024, 0, out, iters);
     hipDeviceSynchronize();
+    double resident[5] = {0, 1, 2, 3, 4};
     for (const Variant& v : kVariants) {
         for (int wps = 1; wps <= 4; ++wps) {
             const int blocks = cus * wps;
-            static const int lds_kib[5] = {0, 160, 72, 48, 36};
+            static const int lds_kib[5] = {0, 160, 64, 40, 32};
             const size_t lds = (size_t)lds_kib[wps] * 1024;
             hipLaunchKernelGGL(v.fn, dim3(blocks), dim3(256), lds, 0, out, 20);
             hipMemset(out, 0, max_waves * 3 * sizeof(uint32_t));
@@ -195,9 +198,13 @@ int main(int argc, char** argv) {
                 cyc.push_back((double)host[3 * w] / ((double)iters * 16.0 * wps));
                 if (host[3 * w + 1]) clk.push_back((double)host[3 * w] / (double)host[3 * w + 1] * 0.1);
             }
-            printf("{\"filler\": \"%s\", \"kind\": \"%s\", \"fillers_per_gap\": %d, \"waves_per_simd\": %d, "
-                   "\"cycles_per_gap_per_simd\": %.2f, \"clock_ghz\": %.3f}\n",
-                   v.filler, v.kind, v.nf, wps, median(cyc), clk.empty() ? 0.0 : median(clk));
+            const double med = median(cyc);
+            // the first variant of the table is MFMA-only (fma, 1 chain, 0 fillers): its time per MFMA per SIMD is the pipe's 32.3
+            // cycles at every occupancy, so what it reads for `wps` asked waves tells how many were resident
+            if (&v == &kVariants[0]) resident[wps] = med * wps / 32.26;
+            printf("{\"filler\": \"%s\", \"kind\": \"%s\", \"fillers_per_gap\": %d, \"waves_per_simd_asked\": %d, "
+                   "\"resident_waves_per_simd\": %.2f, \"cycles_per_gap_per_simd\": %.2f, \"clock_ghz\": %.3f}\n",
+                   v.filler, v.kind, v.nf, wps, resident[wps], med * wps / resident[wps], clk.empty() ? 0.0 : median(clk));
         }
     }
     hipFree(out);

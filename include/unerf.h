@@ -38,7 +38,7 @@ extern "C" {
 const char* unerf_last_error(void);
 /* Library/ABI version (major*1000+minor).  A binding built against this header must find exactly UNERF_ABI_VERSION
  * (struct layouts and argument lists change with it; uncertainty-nerf-gs_amd/lib.py::load checks). */
-#define UNERF_ABI_VERSION 1410
+#define UNERF_ABI_VERSION 1420
 int unerf_version(void);
 
 /* Spacing function of the proposal sampler's initial sampler, passed behind every (near_plane, far_plane) pair:
@@ -86,8 +86,25 @@ int unerf_device_count(void);
  * of the distortion-free camera. */
 #define UNERF_UNDISTORT_ITERATIONS 10
 #define UNERF_UNDISTORT_EPS 1e-3f
+/* camera_type: nerfstudio's CameraType value of the camera (cameras.py: PERSPECTIVE = 1, FISHEYE = 2, EQUIRECTANGULAR = 3,
+ * ORTHOPHOTO = 8), as the reference's dataparsers hand it to `Cameras` (CAMERA_MODEL_TO_TYPE[meta["camera_model"]]:
+ * dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:237-239, sparse/sparse_nerfstudio_dataparser.py:277-279,
+ * nerfonthego, ood_mipnerf360, robustnerf alike).  Camera-frame direction of an (undistorted) image-plane coordinate (u, v)
+ * [UPSTREAM-RECALL nerfstudio 1.1.0 Cameras._generate_rays_from_coords]:
+ *   PERSPECTIVE      (u, v, -1)
+ *   FISHEYE          theta = clip(|(u, v)|, 0, pi):  (u sin(theta) / theta, v sin(theta) / theta, -cos(theta))
+ *                    (OPENCV_FISHEYE's k1..k4 act on (u, v) through the same undistortion as the perspective lens)
+ *   EQUIRECTANGULAR  theta = -pi u, phi = pi (0.5 - v):  (-sin(theta) sin(phi), cos(phi), -cos(theta) sin(phi));
+ *                    distortion parameters are ignored for this type, as upstream does
+ *   ORTHOPHOTO       (0, 0, -1) for every pixel, the ORIGIN moves instead: c2w (u, v, 0, 1)
+ * then rotated by c2w[:3,:3] and normalised (norm floored at 1e-7); pixel_area from the +1-pixel x / y neighbours as for
+ * the perspective camera.  The other CameraType values (omnidirectional stereo, VR180, FISHEYE624) are refused. */
+#define UNERF_CAMERA_PERSPECTIVE 1
+#define UNERF_CAMERA_FISHEYE 2
+#define UNERF_CAMERA_EQUIRECTANGULAR 3
+#define UNERF_CAMERA_ORTHOPHOTO 8
 int unerf_generate_rays(const float* c2w_host, float fx, float fy, float cx, float cy, const float* distortion_host,
-                        int H, int W, int64_t ray_start, int64_t count, float* origins, float* directions,
+                        int camera_type, int H, int W, int64_t ray_start, int64_t count, float* origins, float* directions,
                         float* pixel_area, void* stream);
 
 /* Oriented crop box (`obb_box` of Model.get_outputs_for_camera / get_outputs_for_camera_unc,

@@ -315,9 +315,18 @@ def radial_and_tangential_undistort(coords: torch.Tensor, distortion_params: tor
     return torch.stack([x, y], dim=-1)
 
 
-def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int, distortion=None):
-    """Cameras.generate_rays(keep_shape=True) for ONE perspective camera [UPSTREAM nerfstudio 1.1.0
-    Cameras._generate_rays_from_coords].  distortion: the camera's `distortion_params` (k1, k2, k3, k4, p1, p2) as the
+CAMERA_PERSPECTIVE, CAMERA_FISHEYE, CAMERA_EQUIRECTANGULAR, CAMERA_ORTHOPHOTO = 1, 2, 3, 8   # nerfstudio CameraType values
+
+
+def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int, distortion=None,
+                  camera_type: int = CAMERA_PERSPECTIVE):
+    """Cameras.generate_rays(keep_shape=True) for ONE camera [UPSTREAM-RECALL nerfstudio 1.1.0
+    Cameras._generate_rays_from_coords].  camera_type (CameraType value; the reference's parsers pass
+    CAMERA_MODEL_TO_TYPE[meta["camera_model"]] through, dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:237-239):
+    PERSPECTIVE (u, v, -1); FISHEYE theta = clip(|(u, v)|, 0, pi) -> (u sin(theta) / theta, v sin(theta) / theta, -cos(theta));
+    EQUIRECTANGULAR theta = -pi u, phi = pi (0.5 - v) -> (-sin(theta) sin(phi), cos(phi), -cos(theta) sin(phi)), no lens
+    undistortion ("do not apply distortion for equirectangular images"); ORTHOPHOTO (0, 0, -1) with the origin moved to
+    c2w (u, v, 0, 1).  distortion: the camera's `distortion_params` (k1, k2, k3, k4, p1, p2) as the
     reference's dataparsers pass them (dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:113-125, 248-274),
     or None; when any is non-zero the coordinate stack (pixel centre and its +1 x / y neighbours, y already negated) is
     undistorted before the rotation, as upstream does under `mask.any() and (distortion_params != 0).any()`.
@@ -331,11 +340,23 @@ def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
     coord_x = torch.stack([(x - cx + 1) / fx, -(y - cy) / fy], -1)
     coord_y = torch.stack([(x - cx) / fx, -(y - cy + 1) / fy], -1)
     cs = torch.stack([coord, coord_x, coord_y], dim=0)
-    if distortion is not None:
+    assert camera_type in (CAMERA_PERSPECTIVE, CAMERA_FISHEYE, CAMERA_EQUIRECTANGULAR, CAMERA_ORTHOPHOTO), camera_type
+    if distortion is not None and camera_type != CAMERA_EQUIRECTANGULAR:
         dp = torch.as_tensor(distortion, dtype=torch.float32).reshape(6)
         if bool((dp != 0).any()):
             cs = radial_and_tangential_undistort(cs, dp)
-    ds = torch.cat([cs, -torch.ones_like(cs[..., :1])], dim=-1)  # [3,H,W,3]
+    if camera_type == CAMERA_FISHEYE:
+        theta = torch.clip(torch.sqrt(torch.sum(cs ** 2, dim=-1)), 0.0, math.pi)
+        st = torch.sin(theta)
+        ds = torch.stack([cs[..., 0] * st / theta, cs[..., 1] * st / theta, -torch.cos(theta)], dim=-1)
+    elif camera_type == CAMERA_EQUIRECTANGULAR:
+        theta = -torch.pi * cs[..., 0]
+        phi = torch.pi * (0.5 - cs[..., 1])
+        ds = torch.stack([-torch.sin(theta) * torch.sin(phi), torch.cos(phi), -torch.cos(theta) * torch.sin(phi)], dim=-1)
+    elif camera_type == CAMERA_ORTHOPHOTO:
+        ds = torch.cat([torch.zeros_like(cs), -torch.ones_like(cs[..., :1])], dim=-1)
+    else:
+        ds = torch.cat([cs, -torch.ones_like(cs[..., :1])], dim=-1)  # [3,H,W,3]
     rot = c2w[:3, :3]
     ds = torch.sum(ds[..., None, :] * rot, dim=-1)
     norm = torch.maximum(torch.linalg.vector_norm(ds, dim=-1, keepdim=True), torch.tensor([1e-7]))
@@ -344,7 +365,11 @@ def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
     dx = torch.sqrt(torch.sum((directions - ds[1]) ** 2, dim=-1))
     dy = torch.sqrt(torch.sum((directions - ds[2]) ** 2, dim=-1))
     pixel_area = (dx * dy)[..., None]
-    origins = c2w[:3, 3].expand(H, W, 3).contiguous()
+    if camera_type == CAMERA_ORTHOPHOTO:   # grids = (u, v, 0, 1); origins = c2w @ grids
+        g = torch.cat([cs[0], torch.zeros_like(cs[0][..., :1]), torch.ones_like(cs[0][..., :1])], dim=-1)
+        origins = torch.matmul(c2w[:3, :4], g[..., None])[..., 0].contiguous()
+    else:
+        origins = c2w[:3, 3].expand(H, W, 3).contiguous()
     return origins, directions, pixel_area
 
 

@@ -27,7 +27,7 @@ def test_header_symbols_all_bound_and_exported(lib):
 
 def test_version_and_error_string(lib):
     h = lib.load()
-    assert h.unerf_version() == lib.ABI_VERSION == 1410
+    assert h.unerf_version() == lib.ABI_VERSION == 1420
     assert h.unerf_build_flags() & lib.BUILD_TRUNK_FOLD          # the shipped build folds the K-pass trunk-out slabs
     assert isinstance(h.unerf_last_error(), bytes)
 
@@ -51,11 +51,14 @@ def test_null_pointers_are_rejected_before_launch(lib):
 def test_bad_shapes_are_rejected(lib):
     h = lib.load()
     c2w = (C.c_float * 12)(*([0.0] * 12))
-    rc = h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, None, 4, 4, 10, 10, 1, 1, None, None)
+    rc = h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, None, 1, 4, 4, 10, 10, 1, 1, None, None)
     assert rc == -1 and b"outside" in h.unerf_last_error()
     lens = (C.c_float * 6)(-0.05, float("nan"), 0.0, 0.0, 0.0, 0.0)
-    rc = h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, lens, 4, 4, 0, 16, 1, 1, None, None)
+    rc = h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, lens, 1, 4, 4, 0, 16, 1, 1, None, None)
     assert rc == -1 and b"distortion[1]" in h.unerf_last_error()
+    for bad_type in (0, 4, 5, 6, 7, 9):   # omnidirectional stereo, VR180, FISHEYE624: not built, refused before any launch
+        rc = h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, None, bad_type, 4, 4, 0, 16, 1, 1, None, None)
+        assert rc == -1 and b"camera_type" in h.unerf_last_error()
     net = lib.DensityNet(1, 1, 7, 17, 1, 1, 1, 1, 16, None, 0)
     rc = h.unerf_proposal_density(1, 1, 1, 0, 4, 256, 0.05, 1000.0, 0, C.byref(net), 0.01, 1, 0, 0, None)
     assert rc == -1 and b"unsupported" in h.unerf_last_error()
@@ -78,7 +81,7 @@ def test_zero_counts_are_no_ops_and_oversized_inputs_are_refused(lib):
     launch, so this runs without a GPU); sample counters beyond 32 bits (the RNG counter / flat index) are refused."""
     h = lib.load()
     c2w = (C.c_float * 12)(*([0.0] * 12))
-    assert h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, None, 4, 4, 16, 0, None, None, None, None) == 0
+    assert h.unerf_generate_rays(c2w, 1.0, 1.0, 0.0, 0.0, None, 1, 4, 4, 16, 0, None, None, None, None) == 0
     assert h.unerf_moments(None, 8, 0, 3, None, None, None) == 0
     assert h.unerf_composite_var(None, None, None, None, None, 2, 0, 48, 0.05, 1000.0, 0, None, 0, 32768, 0, None, None, None, None) == 0
     assert h.unerf_composite_moments(None, None, None, 8, 0, 48, 0.05, 1000.0, 0, None, 0, 32768, 0, None, None, None, None, None) == 0

@@ -55,6 +55,36 @@ def _camera(H, W, theta=0.7):
                          fy=torch.tensor([0.9 * W]), cx=W / 2, cy=H / 2, height=H, width=W)
 
 
+@pytest.mark.parametrize("camera_type", [2, 3, 8])
+def test_model_renders_the_other_camera_models_through_the_same_path(dev, camera_type):
+    """A nerfstudio camera of type FISHEYE / EQUIRECTANGULAR / ORTHOPHOTO at Model.get_outputs_for_camera (what the reference's
+    nerfstudio-format parsers hand over when transforms.json says so: sparse_nerfstudio_dataparser.py:277-279): the frame
+    equals, bit for bit, the same model fed the bundle of ops.generate_rays(camera_type=...) -- whose rays the kernel test
+    holds against the oracle's restatement of Cameras._generate_rays_from_coords -- and differs from the pinhole frame."""
+    from types import SimpleNamespace
+    from uncertainty_nerf_gs_amd import ops, plugin, synthetic
+    t = synthetic.make_scene_tensors(seed=3, kind="active", log2T=14, prop_log2T=12)
+    cfg = _small_cfg(plugin.MODEL_CONFIGS["active-nerfacto"]())
+    model = cfg._target(cfg, num_train_data=4)
+    model.load_state_dict(_state_dict_from_tensors(t, "active"))
+    H, W = (32, 64) if camera_type == 3 else (40, 56)
+    f = 32.0 if camera_type == 3 else 0.5 * W
+    c2w = synthetic.orbit_c2w(0.7)
+    cam = SimpleNamespace(camera_to_worlds=c2w[None, :3], fx=torch.tensor([[f]]), fy=torch.tensor([[f]]), cx=torch.tensor([[W / 2]]),
+                          cy=torch.tensor([[H / 2]]), height=torch.tensor([[H]]), width=torch.tensor([[W]]),
+                          camera_type=torch.tensor([[camera_type]]), distortion_params=None)
+    with torch.cuda.device(dev):
+        model.to(dev)
+        out = model.get_outputs_for_camera(cam)
+        o, d, _ = ops.generate_rays(c2w[:3], f, f, W / 2, H / 2, H, W, dev, camera_type=camera_type)
+        want = model.get_outputs_for_camera_ray_bundle(SimpleNamespace(origins=o.view(H, W, 3), directions=d.view(H, W, 3)))
+        pin = model.get_outputs_for_camera(SimpleNamespace(**{**cam.__dict__, "camera_type": torch.tensor([[1]])}))
+    assert set(out) == set(want)
+    for k in want:
+        assert torch.equal(out[k], want[k]), k
+    assert torch.isfinite(out["rgb"]).all() and not torch.equal(out["rgb"], pin["rgb"])
+
+
 @pytest.mark.parametrize("kind,method", [("active", "active-nerfacto"), ("mcdropout", "nerfacto-mcdropout")])
 def test_model_from_checkpoint_equals_direct_pipeline(dev, kind, method):
     from uncertainty_nerf_gs_amd import plugin, render, synthetic

@@ -53,6 +53,39 @@ LENSES = [(-0.05, 0.02, 0.0, 0.0, 1e-3, -1e-3), (0.12, -0.03, 0.0, 0.0, 0.0, 0.0
           (0.0, 0.0, 0.0, 0.0, 2e-3, 0.0)]
 
 
+@pytest.mark.parametrize("camera_type,lens", [(2, None), (2, [0.05, -0.01, 0.002, -0.0004, 0.0, 0.0]), (3, None),
+                                              (3, [0.05, -0.01, 0.0, 0.0, 1e-3, -1e-3]), (8, None)])
+def test_generate_rays_of_the_other_camera_models_match_oracle(dev, camera_type, lens):
+    """FISHEYE (with and without OPENCV_FISHEYE's k1..k4), EQUIRECTANGULAR (lens parameters ignored, as upstream) and
+    ORTHOPHOTO (moving origins) rays of unerf_generate_rays against the oracle's restatement of
+    Cameras._generate_rays_from_coords [UPSTREAM-RECALL]; sin / cos differ between the device library and torch's CPU
+    kernels by a few ulp, so directions are compared to 2e-6 (perspective rays are exact: the test above)."""
+    from uncertainty_nerf_gs_amd import ops, synthetic
+    H, W = 37, 51
+    c2w = synthetic.orbit_c2w(1.3)
+    if camera_type == 3:      # equirect: fx = fy = H = W / 2, principal point at the centre
+        H, W = 32, 64
+        fx, fy, cx, cy = 32.0, 32.0, 32.0, 16.0
+    else:
+        fx, fy, cx, cy = 21.0, 22.0, 25.2, 18.4      # fisheye: |(u, v)| up to ~1.5 rad
+    o_ref, d_ref, pa_ref = O.generate_rays(c2w, fx, fy, cx, cy, H, W, distortion=lens, camera_type=camera_type)
+    o, d, pa = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, pixel_area=True, distortion=lens, camera_type=camera_type)
+    assert (d.cpu() - d_ref.reshape(-1, 3)).abs().max() <= 2e-6
+    assert (o.cpu() - o_ref.reshape(-1, 3)).abs().max() <= 1e-6
+    # (a pixel area is a product of two DIFFERENCES of unit vectors: the few-ulp sin / cos differences are amplified by the
+    # cancellation -- 8e-9 of 2e-3 measured)
+    assert (pa.cpu() - pa_ref.reshape(-1, 1)).abs().max() <= 2e-5 * max(float(pa_ref.max()), 1e-3) + 1e-9
+    assert abs(float(d.norm(dim=-1).mean()) - 1.0) < 1e-6
+    if camera_type == 3 and lens is not None:     # the same rays as without the lens
+        plain = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, pixel_area=True, camera_type=camera_type)
+        assert torch.equal(plain[1], d) and torch.equal(plain[2], pa)
+    if camera_type == 8:
+        assert float(pa.abs().max()) == 0.0 and float((d - d[0]).abs().max()) == 0.0 and float((o - o[0]).abs().max()) > 0.1
+    a, b = 333, 1111       # any row-major sub-range gives the same rays
+    o2, d2, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, ray_start=a, count=b - a, distortion=lens, camera_type=camera_type)
+    assert torch.equal(o2, o[a:b]) and torch.equal(d2, d[a:b])
+
+
 @pytest.mark.parametrize("lens", LENSES)
 def test_generate_rays_with_lens_distortion_matches_oracle(dev, lens):
     """Cameras.generate_rays with non-zero distortion_params (the reference's ns-process-data / OPENCV cameras,

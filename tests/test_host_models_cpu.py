@@ -225,8 +225,9 @@ def test_mcdropout_model_draws_fresh_masks_for_every_render():
 
 
 def test_cameras_the_ray_kernel_does_not_model_are_refused():
-    """unerf_generate_rays restates Cameras.generate_rays for one perspective camera (with its OPENCV lens parameters); a
-    fisheye camera or a camera batch must not render silently wrong rays"""
+    """unerf_generate_rays restates Cameras.generate_rays for one perspective / fisheye / equirectangular / orthophoto camera
+    (with its OPENCV lens parameters); any other CameraType, a non-pinhole camera at a splat model, or a camera batch must
+    not render silently wrong rays"""
     from types import SimpleNamespace
     base = dict(camera_to_worlds=torch.eye(4)[None, :3], fx=torch.tensor([[50.0]]), fy=torch.tensor([[50.0]]),
                 cx=torch.tensor([[8.0]]), cy=torch.tensor([[6.0]]), height=torch.tensor([[12]]), width=torch.tensor([[16]]))
@@ -239,7 +240,13 @@ def test_cameras_the_ray_kernel_does_not_model_are_refused():
     assert "distortion" not in cam
     with pytest.raises(ValueError, match="expected 6 values"):
         M._camera_args(SimpleNamespace(**base, distortion_params=torch.tensor([[0.1, 0, 0, 0]])))
-    with pytest.raises(NotImplementedError, match="camera_type 2"):
-        M._camera_args(SimpleNamespace(**base, camera_type=torch.tensor([[2]])))
+    for ct in (2, 3, 8):     # FISHEYE, EQUIRECTANGULAR, ORTHOPHOTO travel to the ray kernel ...
+        _, cam = M._camera_args(SimpleNamespace(**base, camera_type=torch.tensor([[ct]])))
+        assert cam["camera_type"] == ct
+        with pytest.raises(NotImplementedError, match="pinhole"):     # ... but not to gsplat's projection
+            M._camera_args(SimpleNamespace(**base, camera_type=torch.tensor([[ct]])), lens=False)
+    for ct in (4, 5, 6, 7, 9):
+        with pytest.raises(NotImplementedError, match=f"camera_type {ct}"):
+            M._camera_args(SimpleNamespace(**base, camera_type=torch.tensor([[ct]])))
     with pytest.raises(ValueError, match="one camera"):
         M._camera_args(SimpleNamespace(**dict(base, camera_to_worlds=torch.eye(4)[None, :3].repeat(3, 1, 1))))

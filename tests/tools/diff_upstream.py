@@ -209,7 +209,7 @@ def _renderers():
     return out
 
 
-@row("L0.9 Cameras.generate_rays (perspective; plain and OPENCV-distorted)", ["nerfstudio"])
+@row("L0.9 Cameras.generate_rays (perspective plain / OPENCV-distorted; fisheye, equirectangular, orthophoto)", ["nerfstudio"])
 def _rays():
     from nerfstudio.cameras.cameras import Cameras, CameraType
     from oracle import nerf_oracle as O
@@ -222,6 +222,18 @@ def _rays():
                       distortion_params=torch.tensor(dist)[None] if dist else None, camera_type=CameraType.PERSPECTIVE)
         rb = cam.generate_rays(camera_indices=0, keep_shape=True)
         o, d, pa = O.generate_rays(c2w, 70.0, 68.0, W / 2 - 0.7, H / 2 + 0.4, H, W, distortion=dist)
+        out[f"{name}_origins"] = _maxdiff(o, rb.origins)
+        out[f"{name}_directions"] = _maxdiff(d, rb.directions)
+        out[f"{name}_pixel_area"] = _maxdiff(pa, rb.pixel_area)
+    # the other camera models the ray kernel restates (round 6): FISHEYE with OPENCV_FISHEYE's k1..k4, EQUIRECTANGULAR
+    # (fx = fy = H = W / 2), ORTHOPHOTO
+    for name, ct, dist, (h, w, f) in (("fisheye", CameraType.FISHEYE, [0.05, -0.01, 0.002, -0.0004, 0.0, 0.0], (48, 64, 25.0)),
+                                      ("equirectangular", CameraType.EQUIRECTANGULAR, None, (32, 64, 32.0)),
+                                      ("orthophoto", CameraType.ORTHOPHOTO, None, (48, 64, 40.0))):
+        cam = Cameras(camera_to_worlds=c2w[:3, :4][None], fx=f, fy=f, cx=w / 2, cy=h / 2, width=w, height=h,
+                      distortion_params=torch.tensor(dist)[None] if dist else None, camera_type=ct)
+        rb = cam.generate_rays(camera_indices=0, keep_shape=True)
+        o, d, pa = O.generate_rays(c2w, f, f, w / 2, h / 2, h, w, distortion=dist, camera_type=int(ct.value))
         out[f"{name}_origins"] = _maxdiff(o, rb.origins)
         out[f"{name}_directions"] = _maxdiff(d, rb.directions)
         out[f"{name}_pixel_area"] = _maxdiff(pa, rb.pixel_area)

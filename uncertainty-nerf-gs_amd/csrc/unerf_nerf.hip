@@ -41,10 +41,18 @@ int unerf_check_launch(const char* what) {
 #define UNERF_LAP_EXP2 1         // LAPLACE: lap16_blob rows pre-scaled by +-log2(e), bare exp2 in the epilogue
 #endif
 #ifndef UNERF_RGB_SCALAR
-#define UNERF_RGB_SCALAR 0   // 1: the split-f16 kernels' fp32 colour layer as scalar fmas instead of v_pk_fma_f32
+#define UNERF_RGB_SCALAR 2   // the split-f16 kernels' fp32 colour layer as scalar fmas instead of v_pk_fma_f32: 1 every mode, 2 ACTIVE only
 #endif
 #ifndef UNERF_LAP_SCALAR_MOMENTS
-#define UNERF_LAP_SCALAR_MOMENTS 0   // 1: no packed-fp32 fma in the Laplace heads' moment sums
+#define UNERF_LAP_SCALAR_MOMENTS 1   // 1: no packed-fp32 fma in the Laplace heads' moment sums (-1.4 % Laplace field kernel, same box)
+#endif
+#ifndef UNERF_LAP_NO_FENCE
+#define UNERF_LAP_NO_FENCE 0         // 1 (with scalar moments only: no inline assembly left in the heads): no scheduling fences
+#endif
+#if UNERF_LAP_NO_FENCE && UNERF_LAP_SCALAR_MOMENTS
+#define LAP_FENCE() ((void)0)
+#else
+#define LAP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 #ifndef UNERF_KPASS_FILL
 #define UNERF_KPASS_FILL 0   // 1: "f16" K-pass kernel with the mask arithmetic placed behind the MFMAs of a pass (round 6)
@@ -212,7 +220,8 @@ struct RayGenArgs {
     float T[3];
     float fx, fy, cx, cy;
     float k1, k2, k3, k4, p1, p2;   // OPENCV lens parameters, nerfstudio's order
-    int distorted;                  // any of the six != 0
+    int distorted;                  // any of the six != 0 (and the camera type takes lens parameters)
+    int camera_type;                // UNERF_CAMERA_*
     int H, W;
     int64_t start, count;
     float* o;
@@ -253,10 +262,28 @@ __device__ __forceinline__ void raygen_undistort(const RayGenArgs& a, float& u, 
 
 __device__ __forceinline__ void raygen_dir(const RayGenArgs& a, float u, float v, float& dx, float& dy, float& dz) {
     if (a.distorted) raygen_undistort(a, u, v);
-    // sum_c dir[c] * R[r][c], dir = (u, v, -1); torch.sum over 3 elements left to right
-    float x = (u * a.R[0] + v * a.R[1]) + (-1.f) * a.R[2];
-    float y = (u * a.R[3] + v * a.R[4]) + (-1.f) * a.R[5];
-    float z = (u * a.R[6] + v * a.R[7]) + (-1.f) * a.R[8];
+    // camera-frame direction (include/unerf.h: camera_type), uniform branch; PERSPECTIVE keeps the exact (u, v, -1)
+    float cxd = u, cyd = v, czd = -1.f;
+    if (a.camera_type == UNERF_CAMERA_FISHEYE) {
+        float theta = sqrtf(u * u + v * v);
+        theta = fminf(fmaxf(theta, 0.f), 3.14159265358979323846f);
+        const float st = sinf(theta);
+        cxd = u * st / theta;     // 0 / 0 at the exact principal point, as upstream
+        cyd = v * st / theta;
+        czd = -cosf(theta);
+    } else if (a.camera_type == UNERF_CAMERA_EQUIRECTANGULAR) {
+        const float theta = -3.14159265358979323846f * u, phi = 3.14159265358979323846f * (0.5f - v);
+        cxd = -sinf(theta) * sinf(phi);
+        cyd = cosf(phi);
+        czd = -cosf(theta) * sinf(phi);
+    } else if (a.camera_type == UNERF_CAMERA_ORTHOPHOTO) {
+        cxd = 0.f;
+        cyd = 0.f;
+    }
+    // sum_c dir[c] * R[r][c]; torch.sum over 3 elements left to right
+    float x = (cxd * a.R[0] + cyd * a.R[1]) + czd * a.R[2];
+    float y = (cxd * a.R[3] + cyd * a.R[4]) + czd * a.R[5];
+    float z = (cxd * a.R[6] + cyd * a.R[7]) + czd * a.R[8];
     float n = fmaxf(sqrtf((x * x + y * y) + z * z), 1e-7f);
     dx = x / n;
     dy = y / n;
@@ -274,9 +301,15 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a) {
     float v2 = -(y - a.cy + 1.f) / a.fy;
     float d0x, d0y, d0z, d1x, d1y, d1z, d2x, d2y, d2z;
     raygen_dir(a, u0, v0, d0x, d0y, d0z);
-    a.o[n * 3 + 0] = a.T[0];
-    a.o[n * 3 + 1] = a.T[1];
-    a.o[n * 3 + 2] = a.T[2];
+    if (a.camera_type == UNERF_CAMERA_ORTHOPHOTO) {   // the origin moves over the image plane: c2w (u, v, 0, 1)
+        a.o[n * 3 + 0] = (u0 * a.R[0] + v0 * a.R[1]) + a.T[0];
+        a.o[n * 3 + 1] = (u0 * a.R[3] + v0 * a.R[4]) + a.T[1];
+        a.o[n * 3 + 2] = (u0 * a.R[6] + v0 * a.R[7]) + a.T[2];
+    } else {
+        a.o[n * 3 + 0] = a.T[0];
+        a.o[n * 3 + 1] = a.T[1];
+        a.o[n * 3 + 2] = a.T[2];
+    }
     a.d[n * 3 + 0] = d0x;
     a.d[n * 3 + 1] = d0y;
     a.d[n * 3 + 2] = d0z;
@@ -292,9 +325,12 @@ __global__ __launch_bounds__(256) void raygen_kernel(RayGenArgs a) {
 }
 
 extern "C" int unerf_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, const float* distortion,
-                                   int H, int W, int64_t ray_start, int64_t count, float* origins, float* directions,
-                                   float* pixel_area, void* stream) {
+                                   int camera_type, int H, int W, int64_t ray_start, int64_t count, float* origins,
+                                   float* directions, float* pixel_area, void* stream) {
     UNERF_REQUIRE(c2w && (count == 0 || (origins && directions)), "generate_rays: null pointer");
+    UNERF_REQUIRE(camera_type == UNERF_CAMERA_PERSPECTIVE || camera_type == UNERF_CAMERA_FISHEYE ||
+                      camera_type == UNERF_CAMERA_EQUIRECTANGULAR || camera_type == UNERF_CAMERA_ORTHOPHOTO,
+                  "generate_rays: camera_type %d is not built (PERSPECTIVE 1, FISHEYE 2, EQUIRECTANGULAR 3, ORTHOPHOTO 8)", camera_type);
     UNERF_REQUIRE(H > 0 && W > 0 && ray_start >= 0 && count >= 0 && ray_start + count <= (int64_t)H * W,
                   "generate_rays: ray range [%lld,+%lld) outside %dx%d", (long long)ray_start, (long long)count, H, W);
     if (count == 0) return UNERF_OK;
@@ -306,7 +342,8 @@ extern "C" int unerf_generate_rays(const float* c2w, float fx, float fy, float c
     a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.H = H; a.W = W;
     a.k1 = a.k2 = a.k3 = a.k4 = a.p1 = a.p2 = 0.f;
     a.distorted = 0;
-    if (distortion) {
+    a.camera_type = camera_type;
+    if (distortion && camera_type != UNERF_CAMERA_EQUIRECTANGULAR) {   // upstream: "do not apply distortion for equirectangular images"
         for (int i = 0; i < 6; ++i) {
             UNERF_REQUIRE(std::isfinite(distortion[i]), "generate_rays: distortion[%d] is not finite", i);
             a.distorted |= distortion[i] != 0.f;
@@ -2630,17 +2667,17 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
                         for (int c = 0; c < CG; ++c) {
 #pragma unroll
                             for (int q4 = 0; q4 < 4; ++q4) {
-#if UNERF_RGB_SCALAR
-                                // (round 6) the same four fused multiply-adds on scalar registers: packed-fp32 instructions
-                                // and the other wave's MFMAs exclude each other (benchmarks/issue_sweep_probe.hip)
-                                acc2[c0g + c].x = __builtin_fmaf(dv[4 * q4], wv[c][q4].x, acc2[c0g + c].x);
-                                acc2[c0g + c].y = __builtin_fmaf(dv[4 * q4 + 1], wv[c][q4].y, acc2[c0g + c].y);
-                                acc2[c0g + c].x = __builtin_fmaf(dv[4 * q4 + 2], wv[c][q4].z, acc2[c0g + c].x);
-                                acc2[c0g + c].y = __builtin_fmaf(dv[4 * q4 + 3], wv[c][q4].w, acc2[c0g + c].y);
-#else
-                                acc2[c0g + c] = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4], dv[4 * q4 + 1]}, unerf_v2f{wv[c][q4].x, wv[c][q4].y}, acc2[c0g + c]);
-                                acc2[c0g + c] = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4 + 2], dv[4 * q4 + 3]}, unerf_v2f{wv[c][q4].z, wv[c][q4].w}, acc2[c0g + c]);
-#endif
+                                // (round 6) UNERF_RGB_SCALAR: the same four fused multiply-adds on scalar registers (1: every
+                                // mode, 2: ACTIVE only -- measured -1.8 % there and +0.7 % in the K-pass kernel, same box)
+                                if constexpr (UNERF_RGB_SCALAR == 1 || (UNERF_RGB_SCALAR == 2 && MODE == UNERF_FIELD_ACTIVE)) {
+                                    acc2[c0g + c].x = __builtin_fmaf(dv[4 * q4], wv[c][q4].x, acc2[c0g + c].x);
+                                    acc2[c0g + c].y = __builtin_fmaf(dv[4 * q4 + 1], wv[c][q4].y, acc2[c0g + c].y);
+                                    acc2[c0g + c].x = __builtin_fmaf(dv[4 * q4 + 2], wv[c][q4].z, acc2[c0g + c].x);
+                                    acc2[c0g + c].y = __builtin_fmaf(dv[4 * q4 + 3], wv[c][q4].w, acc2[c0g + c].y);
+                                } else {
+                                    acc2[c0g + c] = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4], dv[4 * q4 + 1]}, unerf_v2f{wv[c][q4].x, wv[c][q4].y}, acc2[c0g + c]);
+                                    acc2[c0g + c] = __builtin_elementwise_fma(unerf_v2f{dv[4 * q4 + 2], dv[4 * q4 + 3]}, unerf_v2f{wv[c][q4].z, wv[c][q4].w}, acc2[c0g + c]);
+                                }
                             }
                         }
                     }
@@ -2932,7 +2969,7 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
         f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
         // the fences keep each row block's MFMAs and its activations (with the inline-asm packed fma, whose hazards
         // the compiler does not model) as separate scheduling regions: without them the kernel is 1.3 % faster and wrong
-        __builtin_amdgcn_sched_barrier(0);
+        LAP_FENCE();
 #pragma unroll
         for (int st = 0; st < 4; ++st) {  // cur[2 st] = hi, cur[2 st + 1] = lo of k-step st
             if (!F1) {
@@ -2974,7 +3011,7 @@ __device__ __forceinline__ void mf16_lap_head(const float* __restrict__ lap, int
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        LAP_FENCE();
         if (b + 1 < LAP_BLOCKS) {
 #pragma unroll
             for (int i = 0; i < 8; i += (F1 ? 2 : 1)) cur[i] = nxt[i];
@@ -3023,7 +3060,7 @@ __device__ __forceinline__ void mf16_lap_stream(const float* __restrict__ lap, c
         float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
         f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
         if (b == 0) s12 = unerf_v2f{0.f, 0.f};
-        __builtin_amdgcn_sched_barrier(0);   // (see mf16_lap_head: the inline-asm packed fma and its operands stay in one region)
+        LAP_FENCE();   // (see mf16_lap_head: the inline-asm packed fma and its operands stay in one region)
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             if (!F1) {
@@ -3060,7 +3097,7 @@ __device__ __forceinline__ void mf16_lap_stream(const float* __restrict__ lap, c
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        LAP_FENCE();
         if (b == LAP_BLOCKS - 1) {
             sum1[hd] = s12.x + __shfl_xor(s12.x, 32, 64);
             sum2[hd] = s12.y + __shfl_xor(s12.y, 32, 64);

@@ -83,6 +83,18 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
                 raise UnerfError("hipcc failed:\n" + res.stdout + res.stderr)
+            # the listing of what was just built: no MFMA may read a VGPR within two wait states of the VALU instruction that
+            # writes it (the compiler guarantees that for its own instructions, nobody does for inline assembly: isa_check.py)
+            if not os.environ.get("UNERF_SKIP_ISA_CHECK"):
+                from . import isa_check
+                try:
+                    isa_check.check_library(tmp, verbose=verbose)
+                except isa_check.IsaHazard as e:
+                    os.remove(tmp)
+                    raise UnerfError(f"libunerf: refused by the ISA check -- {e}")
+                except (FileNotFoundError, subprocess.CalledProcessError) as e:
+                    import warnings
+                    warnings.warn(f"libunerf: ISA check skipped ({e})")
             os.replace(tmp, LIB_PATH)
             with open(stamp, "w") as f:
                 f.write(digest)
@@ -128,10 +140,13 @@ class FieldParams(C.Structure):
     ]
 
 
-ABI_VERSION = 1410                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
+ABI_VERSION = 1420                                # include/unerf.h: UNERF_ABI_VERSION (struct layouts / argument lists)
 FIELD_ACTIVE, FIELD_MCDROPOUT, FIELD_LAPLACE = 0, 1, 2
 SPACING_PIECEWISE, SPACING_UNIFORM = 0, 1         # include/unerf.h: UNERF_SPACING_*
 BG_LAST_SAMPLE, BG_NONE, BG_COLOR = 0, 1, 2       # include/unerf.h: UNERF_BG_*
+# include/unerf.h: UNERF_CAMERA_* = nerfstudio's CameraType values of the camera models the ray kernel restates
+CAMERA_PERSPECTIVE, CAMERA_FISHEYE, CAMERA_EQUIRECTANGULAR, CAMERA_ORTHOPHOTO = 1, 2, 3, 8
+CAMERA_TYPES = (CAMERA_PERSPECTIVE, CAMERA_FISHEYE, CAMERA_EQUIRECTANGULAR, CAMERA_ORTHOPHOTO)
 RASTER_NO_CULL = 1                                # include/unerf.h: UNERF_RASTER_NO_CULL
 BUILD_TRUNK_FOLD, BUILD_LAP_EXP2 = 1, 2   # include/unerf.h: UNERF_BUILD_*
 DROP_TRUNK, DROP_HEAD0, DROP_HEAD1, DROP_HEADIN = 1, 2, 4, 8     # include/unerf.h: UNERF_DROP_*
@@ -145,7 +160,7 @@ SIGNATURES = {
     "unerf_version": (_i, []),
     "unerf_build_flags": (_i, []),
     "unerf_device_count": (_i, []),
-    "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _fp, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "unerf_generate_rays": (_i, [_fp, _f, _f, _f, _f, _fp, _i, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "unerf_ray_box_bins": (_i, [_vp, _vp, _i64, _fp, _fp, _f, _f, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "unerf_ray_planes_bins": (_i, [_vp, _vp, _i64, _f, _f, _i, _vp, _i, _vp, _vp]),
     "unerf_hashgrid_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),

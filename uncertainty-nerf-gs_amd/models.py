@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import fields as F
+from . import lib as _lib
 from . import ops, render, splat
 from .render import NerfSceneDev
 
@@ -42,24 +43,31 @@ def _scalar(v) -> float:
 
 
 def _camera_args(camera, lens: bool = True) -> Tuple[torch.Tensor, Dict[str, Any]]:
-    """[UPSTREAM Cameras.generate_rays] is restated (unerf_generate_rays) for ONE perspective camera, with the OPENCV lens
-    parameters `distortion_params` = (k1, k2, k3, k4, p1, p2) the reference's dataparsers attach to it
-    (dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:248-274: every `ns-process-data images` scene) --
-    one eval image at a time is what the reference's eval loops hand over.  Anything else a nerfstudio `Cameras` can
-    describe (fisheye / equirectangular / ... types, camera batches) would silently render the wrong rays, so it is
-    refused here.  lens=False (the splat models): the parameters are not looked at, as upstream Splatfacto.get_outputs
-    never reads them (its datamanager undistorts the images instead)."""
+    """[UPSTREAM Cameras.generate_rays] is restated (unerf_generate_rays) for ONE camera of type PERSPECTIVE, FISHEYE,
+    EQUIRECTANGULAR or ORTHOPHOTO (what CAMERA_MODEL_TO_TYPE maps a transforms.json camera_model to, as the reference's
+    parsers pass it on: dataparsers/sparse_mipnerf360/sparse_mipnerf360_dataparser.py:237-239), with the OPENCV lens
+    parameters `distortion_params` = (k1, k2, k3, k4, p1, p2) the dataparsers attach to it (:248-274: every
+    `ns-process-data images` scene) -- one eval image at a time is what the reference's eval loops hand over.  Anything
+    else a nerfstudio `Cameras` can describe (omnidirectional stereo, VR180, FISHEYE624, camera batches) would silently
+    render the wrong rays, so it is refused here.  lens=False (the splat models): perspective only -- gsplat's projection
+    is a pinhole -- and the lens parameters are not looked at, as upstream Splatfacto.get_outputs never reads them (its
+    datamanager undistorts the images instead)."""
     c2w = camera.camera_to_worlds
     if c2w.dim() == 3 and c2w.shape[0] != 1:
         raise ValueError(f"get_outputs_for_camera takes one camera, got a batch of {c2w.shape[0]}")
     ctype = getattr(camera, "camera_type", None)
     if ctype is not None:
         v = int(torch.as_tensor(ctype).reshape(-1)[0]) if torch.is_tensor(ctype) else int(getattr(ctype, "value", ctype))
-        if v != 1:      # nerfstudio CameraType.PERSPECTIVE = 1
-            raise NotImplementedError(f"camera_type {v}: only perspective cameras (CameraType.PERSPECTIVE = 1) are built")
+        if v not in (_lib.CAMERA_TYPES if lens else (_lib.CAMERA_PERSPECTIVE,)):
+            raise NotImplementedError(f"camera_type {v}: " + ("the ray kernel restates PERSPECTIVE 1, FISHEYE 2, EQUIRECTANGULAR 3 "
+                                      "and ORTHOPHOTO 8" if lens else "the splat models project through a pinhole (PERSPECTIVE 1) only"))
+    else:
+        v = _lib.CAMERA_PERSPECTIVE
     c2w = c2w[0] if c2w.dim() == 3 else c2w
     args = dict(fx=_scalar(camera.fx), fy=_scalar(camera.fy), cx=_scalar(camera.cx), cy=_scalar(camera.cy),
                 H=int(_scalar(camera.height)), W=int(_scalar(camera.width)))
+    if v != _lib.CAMERA_PERSPECTIVE:
+        args["camera_type"] = v
     dist_params = getattr(camera, "distortion_params", None) if lens else None
     if dist_params is not None:
         dp = torch.as_tensor(dist_params).detach().cpu().to(torch.float32).reshape(-1)

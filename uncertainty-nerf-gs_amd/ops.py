@@ -93,9 +93,11 @@ def _host_distortion(distortion):
 
 
 def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int, device,
-                  ray_start: int = 0, count: Optional[int] = None, pixel_area: bool = False, distortion=None):
+                  ray_start: int = 0, count: Optional[int] = None, pixel_area: bool = False, distortion=None,
+                  camera_type: int = _l.CAMERA_PERSPECTIVE):
     """-> origins [count,3], directions [count,3], (pixel_area [count,1] | None)
-    distortion: the camera's 6 OPENCV lens parameters (include/unerf.h: unerf_generate_rays) or None"""
+    distortion: the camera's 6 OPENCV lens parameters (include/unerf.h: unerf_generate_rays) or None
+    camera_type: nerfstudio CameraType value (lib.CAMERA_*: perspective, fisheye, equirectangular, orthophoto)"""
     lib = _l.load()
     count = H * W - ray_start if count is None else count
     o = torch.empty(count, 3, device=device, dtype=torch.float32)
@@ -103,7 +105,7 @@ def generate_rays(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
     pa = torch.empty(count, 1, device=device, dtype=torch.float32) if pixel_area else None
     dist = _host_distortion(distortion)
     with _ctx(o.device):
-        _run("generate_rays", lambda: lib.unerf_generate_rays(_host12(c2w), fx, fy, cx, cy, dist, H, W, ray_start, count,
+        _run("generate_rays", lambda: lib.unerf_generate_rays(_host12(c2w), fx, fy, cx, cy, dist, int(camera_type), H, W, ray_start, count,
                                                               _p(o), _p(d), _p(pa), _stream()))
     return o, d, pa
 

@@ -273,13 +273,14 @@ def render_rays(scene: NerfSceneDev, origins: torch.Tensor, directions: torch.Te
 
 
 def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int,
-                  rays_per_launch: int = 1 << 20, overlap: bool = False, obb=None, distortion=None,
+                  rays_per_launch: int = 1 << 20, overlap: bool = False, obb=None, distortion=None, camera_type: int = 1,
                   **shade_kw) -> Dict[str, torch.Tensor]:
     """get_outputs_for_camera: generate the H*W rays on device, render them in row-major launch
     groups, return images [H,W,C].  With `overlap`, sampling (group g+1) and shading (group g) run on
     two streams.  obb = (world_to_box [3,4], S [3]): the oriented crop box of `obb_box` (see crop_bins).
     distortion = the camera's `distortion_params` (k1, k2, k3, k4, p1, p2) or None: the rays are bent as
-    Cameras.generate_rays bends them (unerf_generate_rays)."""
+    Cameras.generate_rays bends them (unerf_generate_rays).  camera_type: nerfstudio's CameraType value (perspective 1,
+    fisheye 2, equirectangular 3, orthophoto 8: include/unerf.h)."""
     _l.require_gpu()
     total = H * W
     dev = scene.device
@@ -294,7 +295,8 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
 
         def group(gi: int, flag=None):
             start = starts[gi]
-            o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start), distortion=distortion)
+            o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start), distortion=distortion,
+                                        camera_type=camera_type)
             return render_rays(scene, o, d, ray_offset=start, total_rays=total, clip=clip, image_width=W,
                                init_bins=crop_bins(scene, o, d, obb), nonfinite_flag=flag, **shade_kw)
 
@@ -315,7 +317,8 @@ def render_camera(scene: NerfSceneDev, c2w: torch.Tensor, fx: float, fy: float, 
             s_shade.wait_stream(cur)
             for gi, start in enumerate(starts):
                 with torch.cuda.stream(s_samp):
-                    o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start), distortion=distortion)
+                    o, d, _ = ops.generate_rays(c2w, fx, fy, cx, cy, H, W, dev, start, min(rpl, total - start), distortion=distortion,
+                                        camera_type=camera_type)
                     sb, pds, feats = sampling_stage(scene, o, d, clip, start, image_width=W,
                                                     init_bins=crop_bins(scene, o, d, obb), scratch=False)
                     ev = torch.cuda.Event()
