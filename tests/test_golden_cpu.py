@@ -195,7 +195,7 @@ def test_dropout_mask_generator_at_other_rates_and_its_joint_structure(p):
     noise, the variance of a unit's keep count over 8 passes within 0.5 % of Binomial(8, 1 - p)'s; and the third-order
     structure a 16-bit state must have is BOUNDED, not absent: worst triple moment of centred keeps <= 1.2 % of
     (q (1 - q))^1.5 (measured 0.2 - 0.8 %), total-variation distance of the keep-count histogram from the binomial
-    <= 0.8 % (measured 0.04 - 0.5 %).  DESIGN.md 4.3 records it."""
+    <= 0.8 % (measured 0.04 - 0.5 %).  DESIGN.md 4.2 records it."""
     from math import comb
     from oracle import nerf_oracle as O
     n, K = 40000, 8
