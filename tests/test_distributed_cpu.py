@@ -64,7 +64,13 @@ def _worker(rank, world, port, tag, ret, per_rank=1):
     else:  # rank-major member order: rank r holds members r*per_rank .. r*per_rank+per_rank-1
         member = [_member(g, tag, rank * per_rank + i) for i in range(per_rank)]
     if per_rank == 1:
-        out = ensemble.aggregate_distributed(member, moments_fn=_torch_moments)
+        stages = {}      # bench.py's per-stage record: on CPU tensors no device times, but the byte counts of the exchange
+        out = ensemble.aggregate_distributed(member, moments_fn=_torch_moments, stage_ms=stages)
+        P, C = member["rgb"].shape[0] * member["rgb"].shape[1], stages["packed_image_bytes_per_member"] // (member["rgb"].shape[0] * member["rgb"].shape[1])
+        assert stages["packed_image_bytes_per_member"] == P * C and C % 4 == 0
+        # every rank sends (world - 1) / world of its packed image and receives world - 1 reduced (mean, var) slices
+        assert abs(stages["bytes_all_to_all_sent_per_rank"] - P * C * (world - 1) // world) <= C
+        assert stages["bytes_all_gather_received_per_rank"] == (world - 1) * 2 * C * (-(-P // world))
     else:  # the same through the EnsemblePipeline surface (fake members that return the golden images)
         pipe = ensemble.EnsemblePipeline([_FakeMember(m) for m in member], moments_fn=_torch_moments)
         out = pipe.get_ensemble_outputs_for_camera_ray_bundle("camera")
