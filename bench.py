@@ -601,7 +601,11 @@ def ensemble_exchange_record(pipe, cam, M, world, dev, dist, frame_ms):
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
-            tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            # an explicit master store of our own with a short timeout: under a launcher that sets TORCHELASTIC_USE_AGENT_STORE
+            # (torchrun at --nproc-per-node 1) an init_method URL makes rank 0 a CLIENT of a store nobody hosts -- ten minutes
+            from datetime import timedelta
+            store = tdist.TCPStore("127.0.0.1", port, 1, is_master=True, timeout=timedelta(seconds=60))
+            tdist.init_process_group("nccl", store=store, rank=0, world_size=1, device_id=dev, timeout=timedelta(seconds=120))
             own_group = True
         outs = [m.get_outputs_for_camera(cam) for m in pipe.models]
         st = {}

