@@ -2239,9 +2239,10 @@ __device__ __forceinline__ f32x16 mf16_mac(const float* lds, int slab, int lane,
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
     return acc;
 }
-// two row blocks against one B operand, the two accumulator chains interleaved: an MFMA whose SrcC is the result of
-// the MFMA right before it issues 16 cycles late (benchmarks/mfma_data_probe.hip: 48 instead of 32 cycles per
-// instruction in a single dependent chain), an independent MFMA in between hides that
+// two row blocks against one B operand, the two accumulator chains interleaved.  (Round 2 read benchmarks/mfma_data_probe.hip
+// as "an MFMA whose SrcC is the result of the MFMA right before it issues 16 cycles late"; round 6's hand-written sweep,
+// benchmarks/issue_sweep_probe.hip, measures 32.3 cycles per MFMA on ONE chain as on two at every occupancy.  The interleave
+// costs nothing and stays.)
 // LOZ: the activations are half values already (tcnn's half grid features): their lo residual is zero and the W_hi x lo
 // product is dropped
 template <bool F1 = false, bool LOZ = false>
@@ -2635,11 +2636,11 @@ void field_kernel_mfma16(FieldArgs a, uint32_t num_tiles, FastDiv div_s) {
             }
             __builtin_amdgcn_s_setprio(1);
             // colour 2: 64 -> 3 on the VALU in fp32 (weights pre-scaled by the dropout scale when masks are on).
-            // MFMA and VALU instructions share one issue pipe on gfx950 and never overlap
-            // (benchmarks/mfma_valu_overlap_probe.hip: 32 cycles per f16 MFMA + 4 per VALU instruction, additive at
-            // every occupancy and instruction order), so a layer belongs where it costs fewer of those cycles: as four
-            // more k-steps on the matrix pipe this one took 12 MFMAs + 48 split instructions (576 cycles, 29 of 32
-            // output rows wasted), as packed fp32 FMAs it takes 48 + the half-to-half exchange (~240 cycles).
+            // A SIMD has an issue lane (4 cycles per VALU instruction, ~10 per f16 MFMA) beside its matrix lane (32 per MFMA:
+            // benchmarks/issue_sweep_probe.hip), and these kernels are bound by the issue lane, so a layer belongs
+            // where it costs fewer ISSUE cycles: as four more k-steps on the matrix pipe this one took 12 MFMAs + 48 split
+            // instructions (~310 issue cycles, 29 of 32 output rows wasted), as packed fp32 FMAs it takes 48 + the half-to-half
+            // exchange (~220).  (Rounds 2 - 5 argued the same choice from "MFMA and VALU never overlap, 32 + 4 cycles".)
             {
                 const float4* wq = reinterpret_cast<const float4*>(lds + MF_H2_OFF + h * 48);
                 // Per 32-unit block the 12 weight quads (3 channels x 4) are read into an array FIRST and the 24 packed FMAs
