@@ -52,7 +52,7 @@ def gt_image_informative(ref_rgb: torch.Tensor, ref_std: torch.Tensor, seed: int
 PLAIN_SEEDS = tuple(range(123, 131))   # noise draws of the plain target the relative gate averages over (bench.parity_record's)
 PLAIN_DRAWS = 4                        # perturbation draws per seed of the one-oracle floor
 # VERDICT r5 item 2 asked for 1.25 x the two oracles' gap.  Measured on MI355X over the 75 gated cases of the suite
-# (profiles/r6_parity_report.jsonl): 73 sit below 0.95 of that bound (most below 0.5), and the two that do not are both
+# (profiles/r6_01_parity_report.jsonl, with that factor): 73 sit below 0.95 of that bound (most below 0.5), and the two that do not are both
 # nerfacto-mcdropout "f16" on the trained-like scene -- 1.94 x the gap at the BASELINE size against the autocast oracle.  The
 # kernel's f16 arithmetic is A member of the reference's arithmetic family, not the oracle's emulation of it: it rounds the
 # same operands to f16 but keeps the last layer's outputs in fp32 and carries the dropout scale in the weights, where
