@@ -8,11 +8,12 @@
 //   filler   = v_fma_f32, v_add_f32, v_pk_fma_f32, v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_mad_u16, v_pk_sub_i16 clamp,
 //              v_pk_max_i16, v_and_b32, v_max_i32, v_exp_f32 (eight destination registers in rotation, so no filler
 //              depends on one closer than eight behind it; none touches an MFMA register)
-//   waves    = 1 ... 4 per SIMD asked for: 256-thread workgroups (one wave per SIMD) with 160 / 64 / 40 / 32 KiB of dynamic LDS
+//   waves    = 1 ... 4 per SIMD asked for: 256-thread workgroups (one wave per SIMD) with 160 / 64 / 32 / 16 KiB of dynamic LDS
 //              and a grid of 256 x that many.  How many a CU really holds is MEASURED, not assumed: the MFMA-only variant
 //              runs 32.3 cycles per MFMA per SIMD whatever the occupancy, so resident = (its cycles per gap per wave) / 32.3; every row carries that figure (`resident_waves_per_simd`) and the
-//              cycles re-normalised with it.  (The LDS is handed out in coarse steps: 4 x 40 KiB, 4 x 36 KiB and 3 x 48 KiB
-//              all came out one workgroup short in earlier runs of this probe.)
+//              cycles re-normalised with it.  (Asking for 3 gave 2 resident workgroups per CU and asking for 4 gave 3, at every
+//              LDS size tried from 48 down to 16 KiB per workgroup and with 104 VGPRs per lane: whatever caps it, it is not the
+//              LDS; the table therefore has columns for 1, 2, 2 and 3 waves per SIMD.)
 //   "valu"   = the same 16 x NF fillers with no MFMA (the VALU-only price at that occupancy)
 //
 // Units: shader cycles from s_memtime (NOT an assumed clock); the clock itself = d(s_memtime) / d(s_memrealtime) x 100 MHz.
@@ -186,7 +187,7 @@ int main(int argc, char** argv) {
     for (const Variant& v : kVariants) {
         for (int wps = 1; wps <= 4; ++wps) {
             const int blocks = cus * wps;
-            static const int lds_kib[5] = {0, 160, 64, 40, 32};
+            static const int lds_kib[5] = {0, 160, 64, 32, 16};
             const size_t lds = (size_t)lds_kib[wps] * 1024;
             hipLaunchKernelGGL(v.fn, dim3(blocks), dim3(256), lds, 0, out, 20);
             hipMemset(out, 0, max_waves * 3 * sizeof(uint32_t));
